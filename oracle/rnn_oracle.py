@@ -1,0 +1,550 @@
+"""CPU oracle for the `train.py -m RNN` hot path  --  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference (rdevooght/sequence-based-recommendations) ships no
+tests, golden vectors or fixtures for this path, and Theano/Lasagne (which hold the
+arithmetic) cannot be installed here (no network, python2-only code).  This file is a
+float64 NumPy restatement of the algorithm, with hand-derived BPTT; it is cross-checked
+against an independent torch-autograd restatement (oracle/torch_ref.py) and against
+central finite differences (tests/test_oracle.py).  Nothing in the product path may
+import it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  "[3P]" marks semantics that live in Theano/Lasagne (not vendored
+in the reference): Lasagne `master` (>=0.2.dev1, no commit pinned by the reference,
+Dockerfile:12-13) and Theano >=0.8.2 (requirements.txt:1); those are restated from
+their published formulas and anchored on the reference's call sites.
+
+Conventions
+-----------
+B batch, T max_length, F indices per step, H hidden units, G gates (LSTM 4, GRU 3,
+Vanilla 1), N items.  Parameter lists are in Lasagne `get_all_param_values` order
+(neural_networks/rnn_base.py:470-479, sparse_lstm.py:240-279, :660-676).
+"""
+import numpy as np
+
+GRAD_CLIP = 100.0  # recurrent_layers.py:19 (`-g` is never forwarded, command_parser.py:40)
+
+CELL_GATES = {"LSTM": 4, "GRU": 3, "Vanilla": 1}
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _clip(x):
+    # theano.gradient.grad_clip: identity forward, clamps the incoming gradient [3P]
+    return np.clip(x, -GRAD_CLIP, GRAD_CLIP)
+
+
+# --------------------------------------------------------------------------------------
+# Parameter creation (Lasagne init laws [3P]; order = get_all_param_values)
+# --------------------------------------------------------------------------------------
+def recurrent_param_shapes(cell, n_in, H):
+    """Per-layer parameter (name, shape) list in Lasagne creation order.
+
+    LSTM: sparse_lstm.py:240-279 (ingate, forgetgate, cell, outgate triples, then the
+    three peepholes, cell_init, hid_init).  GRU: sparse_lstm.py:660-676 (updategate,
+    resetgate, hidden_update triples, hid_init).  Vanilla: sparse_lstm.py:1030-1042.
+    """
+    if cell == "LSTM":
+        names = []
+        for g in ("ingate", "forgetgate", "cell", "outgate"):
+            names += [("W_in_to_" + g, (n_in, H)), ("W_hid_to_" + g, (H, H)), ("b_" + g, (H,))]
+        names += [("W_cell_to_ingate", (H,)), ("W_cell_to_forgetgate", (H,)),
+                  ("W_cell_to_outgate", (H,)), ("cell_init", (1, H)), ("hid_init", (1, H))]
+        return names
+    if cell == "GRU":
+        names = []
+        for g in ("updategate", "resetgate", "hidden_update"):
+            names += [("W_in_to_" + g, (n_in, H)), ("W_hid_to_" + g, (H, H)), ("b_" + g, (H,))]
+        names += [("hid_init", (1, H))]
+        return names
+    if cell == "Vanilla":
+        return [("W_in_to_hidden_update", (n_in, H)), ("W_hid_to_hidden_update", (H, H)),
+                ("b_hidden_update", (H,)), ("hid_init", (1, H))]
+    raise ValueError("Unknown layer type")  # recurrent_layers.py:90
+
+
+def model_param_shapes(cell, layers, n_items, n_in0=None):
+    """Whole-model list: layer 0 (index input, input_size = n_items + n_optional,
+    rnn_one_hot.py:48-49), dense layers >= 1 (recurrent_layers.py:94-104), then the
+    output DenseLayer/BlackoutLayer W (H_last, N), b (N,) (rnn_one_hot.py:65,
+    rnn_sampling.py:131)."""
+    if n_in0 is None:
+        n_in0 = n_items
+    shapes = []
+    n_in = n_in0
+    for li, H in enumerate(layers):
+        for name, shp in recurrent_param_shapes(cell, n_in, H):
+            shapes.append(("l%d." % li + name, shp))
+        n_in = H
+    shapes += [("out.W", (layers[-1], n_items)), ("out.b", (n_items,))]
+    return shapes
+
+
+def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dtype=np.float64):
+    """Lasagne default initialisers [3P]: Gate W_in/W_hid/W_cell Normal(std=0.1),
+    b Constant(0), cell_init/hid_init Constant(0) (sparse_lstm.py:156-162); output W
+    GlorotUniform(gain) = U(+-gain*sqrt(6/(fan_in+fan_out))), b 0 (rnn_sampling.py:131)."""
+    out = []
+    for name, shp in model_param_shapes(cell, layers, n_items, n_in0):
+        base = name.split(".")[1]
+        if name == "out.W":
+            lim = last_layer_init * np.sqrt(6.0 / (shp[0] + shp[1]))
+            a = rng.uniform(-lim, lim, size=shp)
+        elif base.startswith("W_"):
+            a = rng.normal(0.0, 0.1, size=shp)
+        else:
+            a = np.zeros(shp)
+        out.append(a.astype(dtype))
+    return out
+
+
+def split_params(params, cell, layers):
+    """Split the flat Lasagne-ordered list into per-layer dicts + output (W, b)."""
+    per = []
+    pos = 0
+    for H in layers:
+        names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
+        per.append(dict(zip(names, params[pos:pos + len(names)])))
+        pos += len(names)
+    W_out, b_out = params[pos], params[pos + 1]
+    assert pos + 2 == len(params)
+    return per, W_out, b_out
+
+
+def stacked(layer, cell):
+    """Stacked matrices exactly as the reference stacks them.
+    LSTM [i,f,c,o] (sparse_lstm.py:348-360); GRU **[r,u,c]** although parameters are
+    created update-first (sparse_lstm.py:737-749); Vanilla single (sparse_lstm.py:1099-1105)."""
+    if cell == "LSTM":
+        order = ("ingate", "forgetgate", "cell", "outgate")
+    elif cell == "GRU":
+        order = ("resetgate", "updategate", "hidden_update")
+    else:
+        order = ("hidden_update",)
+    W_in = np.concatenate([layer["W_in_to_" + g] for g in order], axis=1)
+    W_hid = np.concatenate([layer["W_hid_to_" + g] for g in order], axis=1)
+    b = np.concatenate([layer["b_" + g] for g in order], axis=0)
+    return W_in, W_hid, b, order
+
+
+# --------------------------------------------------------------------------------------
+# Recurrent layers: forward (with cache) and hand-derived backward
+# --------------------------------------------------------------------------------------
+def input_projection(layer, cell, inp, index_input):
+    """x~ = W_in_stacked[idx].sum(-2) + b for index input (sparse_lstm.py:368, :755,
+    :1111) or dot(x, W_in_stacked) + b for dense layers (Lasagne LSTMLayer/GRULayer
+    precompute_input [3P]).  inp: (B,T,F) int or (B,T,D) float.  Returns (T,B,G*H)."""
+    W_in, _, b, _ = stacked(layer, cell)
+    if index_input:
+        x = W_in[inp, :].sum(axis=-2) + b          # (B,T,GH)
+    else:
+        x = inp @ W_in + b
+    return np.transpose(x, (1, 0, 2))              # dimshuffle(1,0,2): sparse_lstm.py:343
+
+
+def recurrent_forward(layer, cell, xt, mask):
+    """Scan over T (sparse_lstm.py:474-481 LSTM, :843-850 GRU, :1190-1197 Vanilla).
+
+    xt (T,B,G*H) precomputed input; mask (B,T).  Returns hid_out (T,B,H) and a cache.
+    Masked steps copy the previous state (sparse_lstm.py:417-425, :798-805, :1145-1152).
+    """
+    T, B, _ = xt.shape
+    _, W_hid, _, _ = stacked(layer, cell)
+    H = W_hid.shape[0]
+    m = np.transpose(mask, (1, 0)).astype(bool)    # (T,B)
+    h = np.repeat(layer["hid_init"], B, axis=0)    # T.dot(ones, hid_init): :438-445
+    hs = np.zeros((T + 1, B, H)); hs[0] = h
+    cache = {"cell": cell, "xt": xt, "m": m, "hs": hs}
+    if cell == "LSTM":
+        c = np.repeat(layer["cell_init"], B, axis=0)
+        cs = np.zeros((T + 1, B, H)); cs[0] = c
+        gi = np.zeros((T, B, H)); gf = np.zeros((T, B, H)); gg = np.zeros((T, B, H))
+        go = np.zeros((T, B, H)); cn = np.zeros((T, B, H))
+        p_i, p_f, p_o = layer["W_cell_to_ingate"], layer["W_cell_to_forgetgate"], layer["W_cell_to_outgate"]
+        for t in range(T):
+            a = xt[t] + h @ W_hid                                    # :383
+            i = sigmoid(a[:, 0 * H:1 * H] + c * p_i)                 # :397-402
+            f = sigmoid(a[:, 1 * H:2 * H] + c * p_f)
+            g = np.tanh(a[:, 2 * H:3 * H])
+            c_new = f * c + i * g                                    # :407
+            o = sigmoid(a[:, 3 * H:4 * H] + c_new * p_o)             # :409-411
+            h_new = o * np.tanh(c_new)                               # :414
+            gi[t], gf[t], gg[t], go[t], cn[t] = i, f, g, o, c_new
+            mt = m[t][:, None]
+            c = np.where(mt, c_new, c); h = np.where(mt, h_new, h)   # :422-423
+            cs[t + 1] = c; hs[t + 1] = h
+        cache.update(cs=cs, gi=gi, gf=gf, gg=gg, go=go, cn=cn)
+    elif cell == "GRU":
+        gr = np.zeros((T, B, H)); gu = np.zeros((T, B, H)); gc = np.zeros((T, B, H)); hic = np.zeros((T, B, H))
+        for t in range(T):
+            hi = h @ W_hid                                           # :766
+            r = sigmoid(hi[:, 0:H] + xt[t][:, 0:H])                  # :780-783
+            u = sigmoid(hi[:, H:2 * H] + xt[t][:, H:2 * H])
+            q = xt[t][:, 2 * H:] + r * hi[:, 2 * H:]                 # :786-788
+            cc = np.tanh(q)
+            h_new = (1 - u) * h + u * cc                             # :795
+            gr[t], gu[t], gc[t], hic[t] = r, u, cc, hi[:, 2 * H:]
+            h = np.where(m[t][:, None], h_new, h)                    # :803
+            hs[t + 1] = h
+        cache.update(gr=gr, gu=gu, gc=gc, hic=hic)
+    else:  # Vanilla
+        hn = np.zeros((T, B, H))
+        for t in range(T):
+            h_new = np.tanh(xt[t] + h @ W_hid)                       # :1122-1143
+            hn[t] = h_new
+            h = np.where(m[t][:, None], h_new, h)                    # :1150
+            hs[t + 1] = h
+        cache.update(hn=hn)
+    return hs[1:], cache
+
+
+def recurrent_backward(layer, cell, cache, dhid_out):
+    """Hand-derived BPTT of recurrent_forward (the reference gets it from theano.grad
+    through scan [3P]); grad_clip nodes clamp the gradient at: LSTM gates
+    (sparse_lstm.py:386-388); GRU input_n, hid_input, hidden_update (:768-772, :789-791);
+    Vanilla input_n, hid_input, hidden_update (:1125-1128, :1140).
+
+    dhid_out (T,B,H): gradient wrt every hid_out[t] (only [-1] is non-zero for the last
+    layer, only_return_final: sparse_lstm.py:485-486).
+    Returns dict: dxt (T,B,G*H), dW_hid, peepholes / inits grads.
+    """
+    xt, m, hs = cache["xt"], cache["m"], cache["hs"]
+    T, B, GH = xt.shape
+    _, W_hid, _, _ = stacked(layer, cell)
+    H = W_hid.shape[0]
+    dW_hid = np.zeros_like(W_hid)
+    dxt = np.zeros_like(xt)
+    dh = np.zeros((B, H))
+    out = {}
+    if cell == "LSTM":
+        cs = cache["cs"]
+        p_i, p_f, p_o = layer["W_cell_to_ingate"], layer["W_cell_to_forgetgate"], layer["W_cell_to_outgate"]
+        dp_i = np.zeros(H); dp_f = np.zeros(H); dp_o = np.zeros(H)
+        dc = np.zeros((B, H))
+        for t in range(T - 1, -1, -1):
+            dh = dh + dhid_out[t]
+            mt = m[t][:, None]
+            i, f, g, o, c_new = cache["gi"][t], cache["gf"][t], cache["gg"][t], cache["go"][t], cache["cn"][t]
+            c_prev, h_prev = cs[t], hs[t]
+            dh_new = np.where(mt, dh, 0.0); dh_pass = np.where(mt, 0.0, dh)
+            dc_new = np.where(mt, dc, 0.0); dc_pass = np.where(mt, 0.0, dc)
+            tc = np.tanh(c_new)
+            do = dh_new * tc
+            dz_o = do * o * (1 - o)
+            dc_new = dc_new + dh_new * o * (1 - tc * tc) + dz_o * p_o
+            di = dc_new * g; df = dc_new * c_prev; dg = dc_new * i
+            dz_i = di * i * (1 - i); dz_f = df * f * (1 - f); da_c = dg * (1 - g * g)
+            dp_o += (dz_o * c_new).sum(0); dp_i += (dz_i * c_prev).sum(0); dp_f += (dz_f * c_prev).sum(0)
+            da = _clip(np.concatenate([dz_i, dz_f, da_c, dz_o], axis=1))
+            dW_hid += h_prev.T @ da
+            dxt[t] = da
+            dc = dc_pass + dc_new * f + dz_i * p_i + dz_f * p_f
+            dh = dh_pass + da @ W_hid.T
+        out.update(dp_i=dp_i, dp_f=dp_f, dp_o=dp_o, dcell_init=dc.sum(0, keepdims=True))
+    elif cell == "GRU":
+        for t in range(T - 1, -1, -1):
+            dh = dh + dhid_out[t]
+            mt = m[t][:, None]
+            r, u, cc, hic = cache["gr"][t], cache["gu"][t], cache["gc"][t], cache["hic"][t]
+            h_prev = hs[t]
+            dh_new = np.where(mt, dh, 0.0); dh_pass = np.where(mt, 0.0, dh)
+            du = dh_new * (cc - h_prev)
+            dcc = dh_new * u
+            dq = _clip(dcc * (1 - cc * cc))
+            dr = dq * hic
+            dz_r = dr * r * (1 - r); dz_u = du * u * (1 - u)
+            dxi = _clip(np.concatenate([dz_r, dz_u, dq], axis=1))
+            dhi = _clip(np.concatenate([dz_r, dz_u, dq * r], axis=1))
+            dW_hid += h_prev.T @ dhi
+            dxt[t] = dxi
+            dh = dh_pass + dh_new * (1 - u) + dhi @ W_hid.T
+    else:
+        for t in range(T - 1, -1, -1):
+            dh = dh + dhid_out[t]
+            mt = m[t][:, None]
+            hn = cache["hn"][t]
+            dh_new = np.where(mt, dh, 0.0); dh_pass = np.where(mt, 0.0, dh)
+            dq = _clip(dh_new * (1 - hn * hn))
+            dxi = _clip(dq); dhi = _clip(dq)
+            dW_hid += hs[t].T @ dhi
+            dxt[t] = dxi
+            dh = dh_pass + dhi @ W_hid.T
+    out.update(dxt=dxt, dW_hid=dW_hid, dhid_init=dh.sum(0, keepdims=True))
+    return out
+
+
+def layer_grads_to_list(layer, cell, inp, index_input, bw):
+    """Map stacked gradients back to the Lasagne per-gate parameter order; returns
+    (list of grads for this layer, d_input (B,T,D) or None for index input).
+    Index-input gradient = AdvancedIncSubtensor: duplicates accumulate [3P]."""
+    W_in, W_hid, b, order = stacked(layer, cell)
+    H = W_hid.shape[0]
+    dxt = bw["dxt"]                                   # (T,B,GH)
+    dx_bt = np.transpose(dxt, (1, 0, 2))              # (B,T,GH)
+    if index_input:
+        dW_in = np.zeros_like(W_in)
+        dflat = dx_bt.reshape(-1, dx_bt.shape[-1])
+        for f in range(inp.shape[-1]):               # sum(axis=-2) fans the grad out to every f
+            np.add.at(dW_in, inp[..., f].reshape(-1), dflat)
+        d_inp = None
+    else:
+        flat_in = inp.reshape(-1, inp.shape[-1])
+        dW_in = flat_in.T @ dx_bt.reshape(-1, dx_bt.shape[-1])
+        d_inp = dx_bt @ W_in.T
+    db = dxt.sum(axis=(0, 1))
+    g = {}
+    for k, name in enumerate(order):
+        g["W_in_to_" + name] = dW_in[:, k * H:(k + 1) * H]
+        g["W_hid_to_" + name] = bw["dW_hid"][:, k * H:(k + 1) * H]
+        g["b_" + name] = db[k * H:(k + 1) * H]
+    if cell == "LSTM":
+        g["W_cell_to_ingate"] = bw["dp_i"]; g["W_cell_to_forgetgate"] = bw["dp_f"]
+        g["W_cell_to_outgate"] = bw["dp_o"]; g["cell_init"] = bw["dcell_init"]
+    g["hid_init"] = bw["dhid_init"]
+    names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
+    return [g[n] for n in names], d_inp
+
+
+# --------------------------------------------------------------------------------------
+# Whole-network forward / backward
+# --------------------------------------------------------------------------------------
+def network_forward(params, cell, layers, X, mask):
+    """recurrent_layers.py:57-68: layer 0 index-input, later layers dense; only the
+    last layer returns its final step (sparse_lstm.py:485-486: hid_out[-1], valid
+    because X is left-aligned and masked steps copy state).  Returns h_last (B,H), caches."""
+    per, W_out, b_out = split_params(params, cell, layers)
+    caches = []
+    inp = X
+    for li, layer in enumerate(per):
+        xt = input_projection(layer, cell, inp, index_input=(li == 0))
+        hid, cache = recurrent_forward(layer, cell, xt, mask)
+        cache["inp"] = inp
+        caches.append(cache)
+        inp = np.transpose(hid, (1, 0, 2))            # (B,T,H) dimshuffle back: :489
+    h_last = caches[-1]["hs"][-1]
+    return h_last, caches
+
+
+def network_backward(params, cell, layers, caches, dh_last):
+    per, _, _ = split_params(params, cell, layers)
+    grads = [None] * len(per)
+    T, B, _ = caches[-1]["xt"].shape
+    dhid = np.zeros((T, B, layers[-1])); dhid[-1] = dh_last
+    for li in range(len(per) - 1, -1, -1):
+        bw = recurrent_backward(per[li], cell, caches[li], dhid)
+        gl, d_inp = layer_grads_to_list(per[li], cell, caches[li]["inp"], li == 0, bw)
+        grads[li] = gl
+        if li > 0:
+            dhid = np.transpose(d_inp, (1, 0, 2))
+    flat = []
+    for gl in grads:
+        flat += gl
+    return flat
+
+
+# --------------------------------------------------------------------------------------
+# Output layers + costs
+# --------------------------------------------------------------------------------------
+def softmax_rows(a):
+    e = np.exp(a - a.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def cce_cost_and_grads(h, W_out, b_out, target, target_popularity, regularization=0.0):
+    """rnn_one_hot.py:65-77: DenseLayer(N, softmax) [3P]; cost = mean(CCE / pop);
+    +reg*sum(b^2) if reg>0, +|reg|*sum|b| if reg<0 (bias only).
+    Returns cost, logits, (dh, dW_out, db_out)."""
+    B = h.shape[0]
+    logits = h @ W_out + b_out
+    p = softmax_rows(logits)
+    nll = -np.log(p[np.arange(B), target])
+    cost = (nll / target_popularity).mean()
+    dlog = p.copy(); dlog[np.arange(B), target] -= 1.0
+    dlog /= (target_popularity[:, None] * B)
+    db = dlog.sum(0)
+    if regularization > 0.0:
+        cost += regularization * (b_out ** 2).sum()
+        db = db + 2.0 * regularization * b_out
+    elif regularization < 0.0:
+        cost -= regularization * np.abs(b_out).sum()
+        db = db - regularization * np.sign(b_out)
+    return cost, logits, (dlog @ W_out.T, h.T @ dlog, db)
+
+
+def sampled_activation(h, W_out, b_out, target, samples):
+    """BlackoutLayer.get_output_for, non-deterministic branch (sparse_lstm.py:42-54):
+    output_cells = concat(targets, samples); a = h . W[:, cells] + b[cells]."""
+    cells = np.concatenate([target, samples])
+    return h @ W_out[:, cells] + b_out[cells], cells
+
+
+def sampled_loss_rows(a, B, loss):
+    """Per-row loss and d loss / d a for the sampled heads; row b's positive is column b
+    (targets = np.arange(batch_size), rnn_sampling.py:137), negatives are columns >= B.
+    Blackout rnn_sampling.py:68-72; BPR :80-84; TOP1 :86-91 (last_layer_tanh is False
+    from the CLI, command_parser.py:120-121)."""
+    rows = np.arange(B)
+    if loss == "Blackout":
+        p = softmax_rows(a)
+        L = -np.log(p[rows, rows]) - np.log(1 - p[:, B:]).sum(axis=1)
+        dLdp = np.zeros_like(p)
+        dLdp[rows, rows] = -1.0 / p[rows, rows]
+        dLdp[:, B:] += 1.0 / (1 - p[:, B:])
+        da = p * (dLdp - (dLdp * p).sum(axis=1, keepdims=True))
+    elif loss == "BPR":
+        diff = a[:, B:] - a[rows, rows][:, None]
+        S = diff.shape[1]
+        L = -np.log(sigmoid(-diff)).mean(axis=1)          # softplus(diff)
+        dd = sigmoid(diff) / S
+        da = np.zeros_like(a)
+        da[:, B:] = dd
+        da[rows, rows] -= dd.sum(axis=1)
+    elif loss == "TOP1":
+        neg = a[:, B:]
+        diff = neg - a[rows, rows][:, None]
+        S = diff.shape[1]
+        s1 = sigmoid(diff); s2 = sigmoid(neg ** 2)
+        L = (s1 + s2).mean(axis=1)
+        d1 = s1 * (1 - s1) / S
+        da = np.zeros_like(a)
+        da[:, B:] = d1 + s2 * (1 - s2) * 2 * neg / S
+        da[rows, rows] -= d1.sum(axis=1)
+    else:
+        raise ValueError("Unknown loss function")         # rnn_sampling.py:54
+    return L, da
+
+
+def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, loss):
+    """rnn_sampling.py:131-137: cost = mean(loss_rows / target_popularity).  The
+    gradient wrt W[:, cells] is an AdvancedIncSubtensor: duplicate cells accumulate [3P]."""
+    B = h.shape[0]
+    a, cells = sampled_activation(h, W_out, b_out, target, samples)
+    L, da = sampled_loss_rows(a, B, loss)
+    cost = (L / target_popularity).mean()
+    da = da / (target_popularity[:, None] * B)
+    dW = np.zeros_like(W_out); db = np.zeros_like(b_out)
+    np.add.at(dW.T, cells, (h.T @ da).T)
+    np.add.at(db, cells, da.sum(0))
+    dh = da @ W_out[:, cells].T
+    return cost, a, (dh, dW, db)
+
+
+def cost_and_grads(params, cfg, batch):
+    """cost + gradient list (Lasagne parameter order) for one batch = the symbolic part
+    of RNNBase._compile_train_function (rnn_base.py:175-186) before the updates."""
+    cell, layers = cfg["cell"], cfg["layers"]
+    per, W_out, b_out = split_params(params, cell, layers)
+    h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"])
+    if cfg["loss"] == "CCE":
+        cost, act, (dh, dW, db) = cce_cost_and_grads(h, W_out, b_out, batch["target"], batch["pop"],
+                                                     cfg.get("regularization", 0.0))
+    else:
+        cost, act, (dh, dW, db) = sampled_cost_and_grads(h, W_out, b_out, batch["target"], batch["samples"],
+                                                         batch["pop"], cfg["loss"])
+    grads = network_backward(params, cell, layers, caches, dh) + [dW, db]
+    return cost, grads, {"h": h, "act": act}
+
+
+# --------------------------------------------------------------------------------------
+# Updaters (update_manager.py:24-82 -> lasagne.updates.* [3P], dense over every param)
+# --------------------------------------------------------------------------------------
+class Updater(object):
+    def __init__(self, name, learning_rate, rho=0.9, beta1=0.9, beta2=0.999):
+        self.name, self.lr, self.rho, self.b1, self.b2 = name, learning_rate, rho, beta1, beta2
+        self.state = None
+        self.t = 0
+
+    def apply(self, params, grads):
+        n = self.name
+        if self.state is None:
+            self.state = [[np.zeros_like(p), np.zeros_like(p)] for p in params]
+        if n == "adam":                                  # lasagne.updates.adam, eps 1e-8
+            self.t += 1
+            a_t = self.lr * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        for p, g, st in zip(params, grads, self.state):
+            if n == "adagrad":                           # eps 1e-6
+                st[0] += g * g
+                p -= self.lr * g / np.sqrt(st[0] + 1e-6)
+            elif n == "rmsprop":                         # eps 1e-6
+                st[0][...] = self.rho * st[0] + (1 - self.rho) * g * g
+                p -= self.lr * g / np.sqrt(st[0] + 1e-6)
+            elif n == "adadelta":                        # eps 1e-6
+                st[0][...] = self.rho * st[0] + (1 - self.rho) * g * g
+                upd = g * np.sqrt(st[1] + 1e-6) / np.sqrt(st[0] + 1e-6)
+                p -= self.lr * upd
+                st[1][...] = self.rho * st[1] + (1 - self.rho) * upd * upd
+            elif n == "nesterov":                        # sgd + apply_nesterov_momentum
+                st[0][...] = self.rho * st[0] - self.lr * g
+                p += self.rho * st[0] - self.lr * g
+            elif n == "adam":
+                st[0][...] = self.b1 * st[0] + (1 - self.b1) * g
+                st[1][...] = self.b2 * st[1] + (1 - self.b2) * g * g
+                p -= a_t * st[0] / (np.sqrt(st[1]) + 1e-8)
+            else:
+                raise ValueError("Unknown update option")  # update_manager.py:22
+
+
+def train_function(params, cfg, updater, batch):
+    """One call of the compiled train function (rnn_base.py:185,290): cost of the
+    batch *before* the update, parameters mutated in place."""
+    cost, grads, _ = cost_and_grads(params, cfg, batch)
+    updater.apply(params, grads)
+    return cost
+
+
+# --------------------------------------------------------------------------------------
+# Test / predict path (rnn_base.py:132-159, :188-213; rnn_sampling.py:140-157)
+# --------------------------------------------------------------------------------------
+def predict_scores(params, cfg, X, mask):
+    """predict_function output (rnn_base.py:188-194): one-hot head = softmax
+    probabilities (DenseLayer nonlinearity, rnn_one_hot.py:65); sampling head = raw
+    full activations (BlackoutLayer deterministic branch, sparse_lstm.py:37-40)."""
+    cell, layers = cfg["cell"], cfg["layers"]
+    _, W_out, b_out = split_params(params, cell, layers)
+    h, _ = network_forward(params, cell, layers, X, mask)
+    logits = h @ W_out + b_out
+    return (softmax_rows(logits) if cfg["loss"] == "CCE" else logits), logits
+
+
+def topk_ordered(scores_row, k):
+    """np.argpartition(-out, range(k))[:k] (rnn_base.py:159,207): the k best ids in
+    descending score order (ties: unspecified in the reference; fixtures avoid them)."""
+    return np.argpartition(-scores_row, range(k))[:k]
+
+
+def test_function(params, cfg, X, mask, exclude_ids, k=10):
+    """test_function (rnn_base.py:196-211 / rnn_sampling.py:140-157): softmax
+    probabilities * (1 - exclude) then ordered top-k, one row at a time."""
+    cell, layers = cfg["cell"], cfg["layers"]
+    _, logits = predict_scores(params, cfg, X, mask)
+    p = softmax_rows(logits)
+    out = []
+    for b in range(p.shape[0]):
+        row = p[b].copy()
+        row[np.asarray(exclude_ids[b], dtype=np.int64)] *= 0.0
+        out.append(topk_ordered(row, k))
+    return np.array(out)
+
+
+# --------------------------------------------------------------------------------------
+# Host-side batch packing restated literally (loop form) for checking the host mirror
+# --------------------------------------------------------------------------------------
+def prepare_input_one_hot(sequences, max_length, n_items, item_popularity, diversity_bias):
+    """RNNOneHot._prepare_input (rnn_one_hot.py:83-106), no optional features (F=1):
+    X left-aligned zero-padded, mask, Y first target, pop = popularity[y]**db,
+    exclude one-hot of the seen items (unused by train_function)."""
+    B = len(sequences)
+    X = np.zeros((B, max_length, 1), dtype=np.int32)
+    mask = np.zeros((B, max_length))
+    Y = np.zeros((B,), dtype=np.int32)
+    pop = np.zeros((B,))
+    exclude = np.zeros((B, n_items), dtype=np.float32)
+    for i, (user_id, in_seq, target) in enumerate(sequences):
+        X[i, :len(in_seq), 0] = [it[0] for it in in_seq]
+        mask[i, :len(in_seq)] = 1
+        Y[i] = target[0][0]
+        pop[i] = item_popularity[target[0][0]] ** diversity_bias
+        exclude[i, [j[0] for j in in_seq]] = 1
+    return X, mask.astype(np.float32), Y, pop.astype(np.float32), exclude
