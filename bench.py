@@ -1,0 +1,222 @@
+"""bench.py -- user-sequences/sec of training on MovieLens-1M-shaped synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): `train.py -m RNN --r_t GRU --r_l 128
+--max_length 200 -b 256 --loss CCE --u_m adam`: 1-layer GRU-128, full softmax over N=3706 items,
+batch 256 sequences of length 200 PER GPU (weak scaling: the global batch is 256*N, every rank holds
+256 rows, gradients are all-reduced over RCCL and every rank applies the identical Adam step).
+A "step" = one full train_function call (gather -> GRU -> softmax/CCE -> BPTT -> scatter -> Adam)
+on one resident batch.  Inputs live in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel of the step, measured live with HIP events (ring of per-step
+                  event sets inside libsbr_rnn.so, read back after the timed region)
+  cpu_baseline -- the torch-CPU float32 port of the same step (oracle/torch_ref.py; Theano/Lasagne
+                  cannot run here) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (cell, layers, n_items, loss, n_samples)
+    "c2": ("GRU", [128], 3706, "CCE", 0),        # BASELINE.json configs[1] -- the metric's config
+    "c1": ("LSTM", [20], 3706, "CCE", 0),        # configs[0]: the reference's own CPU-runnable case
+    "c4": ("LSTM", [256], 26744, "CCE", 0),      # configs[3] shape (per-GPU part)
+    "c3": ("LSTM", [256], 100000, "Blackout", 32),
+}
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact f32
+HBM_PEAK_GBS = 8000.0             # HBM3E spec
+
+
+def zipf_items(rng, n_items, size, perm):
+    """item ids ~ Zipf(alpha=1.0) over N through a fixed permutation."""
+    w = 1.0 / np.arange(1, n_items + 1)
+    cdf = np.cumsum(w / w.sum())
+    return perm[np.minimum(np.searchsorted(cdf, rng.random(size)), n_items - 1)].astype(np.int32)
+
+
+def synth_batches(n_batches, B, T, n_items, n_samples, lengths_mode, seed):
+    rng = np.random.default_rng(seed)
+    perm = np.random.default_rng(1234).permutation(n_items)
+    out = []
+    for _ in range(n_batches):
+        if lengths_mode == "full":
+            lens = np.full(B, T, dtype=np.int32)
+        else:   # "ml1m": L ~ clip(lognormal(4.6, 0.9), 2, T)
+            lens = np.clip(rng.lognormal(4.6, 0.9, size=B), 2, T).astype(np.int32)
+        X = np.zeros((B, T, 1), dtype=np.int32)
+        ids = zipf_items(rng, n_items, B * T, perm).reshape(B, T)
+        m = np.arange(T)[None, :] < lens[:, None]
+        X[:, :, 0] = np.where(m, ids, 0)
+        out.append(dict(X=X, lengths=lens, mask=m.astype(np.float32), target=zipf_items(rng, n_items, B, perm),
+                        samples=rng.integers(0, n_items, size=max(n_samples, 1)).astype(np.int32),
+                        pop=np.ones(B, dtype=np.float32)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--lengths", default="full", choices=["full", "ml1m"])
+    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU per step")
+    ap.add_argument("--max_length", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from oracle import rnn_oracle as O          # parameter init law + the cpu_baseline leg only
+    from sbr_amd.engine import RNNEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cell, layers, n_items, loss, n_samples = CONFIGS[args.config]
+    B, T = args.batch, args.max_length
+    Bg = B * world
+    eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=Bg, local_batch=B,
+                    row_offset=rank * B, loss=loss, n_samples=n_samples, updater="adam", learning_rate=1e-3)
+    params = O.init_params(cell, layers, n_items, np.random.default_rng(42), dtype=np.float32)   # Lasagne init law
+    eng.set_all_param_values(params)
+
+    # synthetic batches, resident in HBM before the timed region
+    nb = 8
+    host_batches = synth_batches(nb, B, T, n_items, n_samples, args.lengths, seed=1235 + rank)
+    dev = eng.device
+    dev_batches = []
+    for hb in host_batches:
+        d = dict(X=torch.from_numpy(hb["X"]).to(dev), lengths=torch.from_numpy(hb["lengths"]).to(dev),
+                 target=torch.from_numpy(hb["target"]).to(dev), samples=torch.from_numpy(hb["samples"]).to(dev),
+                 pop=torch.from_numpy(hb["pop"]).to(dev))
+        dev_batches.append(d)
+    grads, split = eng.section("grads")
+
+    def step(i):
+        d = dev_batches[i % nb]
+        tgt = d["target"]
+        if world > 1 and loss != "CCE":      # sampled heads need every rank's targets (rnn_sampling.py:137)
+            allt = [torch.empty_like(tgt) for _ in range(world)]
+            dist.all_gather(allt, tgt)
+            tgt = torch.cat(allt)
+        eng.set_batch_device(d["X"], d["lengths"], tgt, d["samples"] if loss != "CCE" else None, d["pop"], B)
+        if world == 1:
+            eng.train_step(sync=False)
+            return
+        eng._check(eng.lib.sbr_zero_grads(eng.h))
+        eng._check(eng.lib.sbr_forward(eng.h))
+        eng._check(eng.lib.sbr_loss_backward_output(eng.h))
+        # output-layer gradients are final here: reduce them while BPTT runs (separate RCCL stream)
+        w1 = dist.all_reduce(grads[split:], async_op=True)
+        eng._check(eng.lib.sbr_backward_recurrent(eng.h))
+        w2 = dist.all_reduce(grads[:split], async_op=True)
+        w1.wait(); w2.wait()
+        eng.apply_update()
+
+    for i in range(args.warmup):
+        step(i)
+    eng.enable_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    cost = eng.read_cost()
+    if not np.isfinite(cost):
+        raise ValueError("Cost is NaN")            # rnn_base.py:291-292
+
+    phases = eng.phase_times() if world == 1 else None
+    ms_per_step = dt / args.steps * 1e3
+    value = Bg * args.steps / dt
+
+    result = {
+        "metric": "user-sequences/sec training (ML-1M shape, seq200 b256) at 1/2/4/8 GPUs",
+        "value": round(value, 1), "unit": "user-sequences/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: train.py -m RNN --r_t %s --r_l %s --max_length %d -b %d --loss %s --u_m adam, "
+                               "N=%d items, Zipf(1.0) ids, lengths=%s, %d rows per GPU"
+                               % (args.config, cell, "-".join(map(str, layers)), T, B, loss, n_items, args.lengths, B),
+                   "global_batch": Bg, "seq_len": T, "parallelism": "dp%d" % world, "last_cost": round(cost, 5)},
+    }
+
+    if rank == 0 and phases is not None:
+        G = {"LSTM": 4, "GRU": 3, "Vanilla": 1}[cell]
+        H = layers[0]
+        Ltot = float(np.mean([hb["lengths"].sum() for hb in host_batches]))     # valid (t,row) positions per step
+        rec_flops = 2.0 * Ltot * H * G * H                                        # per recurrent kernel launch
+        row_bytes = G * H * 4.0
+        kernels = {
+            "gather": {"bound": "hbm", "alg": Ltot * (row_bytes * 2 + 4), "unit": "GB/s"},       # read row + write xt
+            "rec_fwd": {"bound": "mfma", "alg": rec_flops, "unit": "TFLOP/s"},
+            "rec_bwd": {"bound": "mfma", "alg": rec_flops, "unit": "TFLOP/s"},
+            "scatter": {"bound": "hbm", "alg": Ltot * (row_bytes * 2 + 4), "unit": "GB/s"},      # read dxt + add row
+        }
+        for k, v in kernels.items():
+            us = phases[k]
+            peak = HBM_PEAK_GBS if v["bound"] == "hbm" else F32_MFMA_PEAK_TFLOPS
+            ach = (v["alg"] / (us * 1e-6)) / (1e9 if v["bound"] == "hbm" else 1e12) if us > 0 else 0.0
+            v.update(us=round(us, 2), achieved=round(ach, 3), peak=peak, frac=round(ach / peak, 5))
+            del v["alg"]
+        dom = max(("gather", "rec_fwd", "rec_bwd", "scatter"), key=lambda k: phases[k])
+        d = kernels[dom]
+        result["roofline"] = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                              "unit": d["unit"], "frac": d["frac"], "traffic": None, "launch_us": d["us"]}
+        result["phases_us"] = {k: round(v, 2) for k, v in phases.items()}
+        result["kernels"] = kernels
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_ref as R
+        torch.set_num_threads(os.cpu_count() or 1)
+        cfg = dict(cell=cell, layers=layers, loss=loss, regularization=0.0)
+        tr = R.TorchTrainer(params, cfg, O.recurrent_param_shapes, updater="adam", lr=1e-3)
+        hb = host_batches[0]
+        cb = dict(X=hb["X"], mask=hb["mask"], target=hb["target"], samples=hb["samples"], pop=hb["pop"])
+        tr.train_function(cb)                      # warm-up
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            tr.train_function(cb)
+        cdt = (time.perf_counter() - t0) / args.cpu_steps
+        result["cpu_baseline"] = {"value": round(B / cdt, 1), "unit": "user-sequences/s", "cores": torch.get_num_threads(),
+                                  "kind": "port", "sample": "%d train steps of the same %s workload (B=%d, T=%d), torch-CPU "
+                                  "float32 port of the reference path (Theano/Lasagne not installable), %.2f s/step"
+                                  % (args.cpu_steps, args.config, B, T, cdt)}
+    if rank == 0:
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/* sbr_rnn.h -- C-ABI of libsbr_rnn.so: the MI355X (gfx950) engine for the
+ * `train.py -m RNN` training hot path of rdevooght/sequence-based-recommendations.
+ *
+ * The reference has no FFI for this path: its seam is three Theano-compiled callables
+ * plus a parameter list, all owned by RNNBase (neural_networks/rnn_base.py):
+ *     train_function(*theano_inputs) -> cost        built :185, called :290
+ *     test_function(theano_inputs, k) -> ids[k]     built :196-211, called :361
+ *     predict_function(X, mask) -> scores (1,N)     built :188-194, called :151
+ *     lasagne.layers.get/set_all_param_values       :476, :515
+ * Each entry point below cites the reference interface it replaces.  Plain pointers and
+ * sizes only; no torch types.  All functions return 0 on success or a negative
+ * sbr_status; sbr_last_error() gives the message (thread-local).  Nothing throws across
+ * the ABI.  A handle is not thread-safe (one stream, one host thread per rank), which
+ * matches the reference's single-threaded synchronous calls (rnn_base.py:285-300).
+ *
+ * Memory: the caller may hand in a device arena (e.g. a torch tensor's data_ptr(), so
+ * that torch.distributed/RCCL can all-reduce the gradient section in place); with
+ * arena == NULL the library hipMallocs its own.
+ */
+#ifndef SBR_RNN_H
+#define SBR_RNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBR_MAX_LAYERS 4
+#define SBR_ABI_VERSION 1
+
+typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
+               SBR_EUNSUPPORTED = -5 } sbr_status;
+
+/* --r_t (recurrent_layers.py:9) */
+typedef enum { SBR_CELL_LSTM = 0, SBR_CELL_GRU = 1, SBR_CELL_VANILLA = 2 } sbr_cell;
+/* --loss (command_parser.py:43, :116-121) */
+typedef enum { SBR_LOSS_CCE = 0, SBR_LOSS_BLACKOUT = 1, SBR_LOSS_BPR = 2, SBR_LOSS_TOP1 = 3 } sbr_loss;
+/* --u_m (update_manager.py:4) */
+typedef enum { SBR_UPD_ADAGRAD = 0, SBR_UPD_ADADELTA = 1, SBR_UPD_RMSPROP = 2, SBR_UPD_NESTEROV = 3,
+               SBR_UPD_ADAM = 4 } sbr_updater;
+
+/* Everything RNNBase.__init__/prepare_model fixes (rnn_base.py:61-109, rnn_one_hot.py:37-78,
+ * rnn_sampling.py:93-137, recurrent_layers.py:18-26, update_manager.py:24-82). */
+typedef struct sbr_config {
+    int32_t abi_version;            /* SBR_ABI_VERSION */
+    int32_t cell;                   /* sbr_cell */
+    int32_t n_layers;               /* --r_l "100-50" -> 2 */
+    int32_t layers[SBR_MAX_LAYERS]; /* hidden units per layer */
+    int32_t n_items;                /* N: output units (data/stats, data_handling.py:94) */
+    int32_t input_size;             /* rows of layer-0 W_in = N + n_optional_features (rnn_one_hot.py:48-49) */
+    int32_t n_feat;                 /* F indices per step: 1, or 2 with --rf (rnn_base.py:615-642) */
+    int32_t max_length;             /* T (--max_length) */
+    int32_t batch_size;             /* global batch B: the mean in the cost (rnn_one_hot.py:71) */
+    int32_t local_batch;            /* rows this rank holds per step (== batch_size on one GPU) */
+    int32_t row_offset;             /* first global row of this rank (sampled heads: positive column) */
+    int32_t loss;                   /* sbr_loss */
+    int32_t n_samples;              /* S = effective_sampling (rnn_sampling.py:102-106); 0 for CCE */
+    int32_t updater;                /* sbr_updater */
+    float learning_rate;            /* --u_l */
+    float rho;                      /* --u_rho (adadelta/rmsprop rho, nesterov momentum) */
+    float beta1, beta2;             /* --u_b1 --u_b2 */
+    float regularization;           /* -r: >0 L2, <0 L1, on b_out only (rnn_one_hot.py:73-77) */
+    float grad_clip;                /* 100 (recurrent_layers.py:19); <=0 disables */
+    int32_t flags;                  /* SBR_FLAG_* */
+} sbr_config;
+
+#define SBR_FLAG_SIMPLE_REC  1   /* triage: per-step VALU recurrent kernels instead of the MFMA persistent ones */
+#define SBR_FLAG_SIMPLE_GEMM 2   /* triage: naive GEMM instead of the MFMA tiled one */
+
+typedef struct sbr_handle sbr_handle;
+
+const char* sbr_last_error(void);
+int sbr_abi_version(void);
+
+/* Bytes of device arena a handle for this config needs (params + grads + optimizer state +
+ * activations saved for BPTT + workspaces). */
+int sbr_arena_bytes(const sbr_config* cfg, size_t* bytes);
+
+/* Replaces RNNBase.prepare_model + _compile_*_function (rnn_base.py:106-109, :175-213).
+ * arena: device pointer of >= sbr_arena_bytes() bytes, 256-B aligned, or NULL (library
+ * allocates).  stream: hipStream_t every launch goes to (NULL = default stream).
+ * Parameters start as zeros: call sbr_set_params. */
+int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes, void* stream, sbr_handle** out);
+void sbr_destroy(sbr_handle* h);
+
+/* lasagne.layers.get_all_param_values / set_all_param_values (rnn_base.py:476, :515):
+ * n arrays in Lasagne order and shape (float32, C-contiguous, host memory); LSTM layer:
+ * 12 gate arrays, 3 peepholes, cell_init, hid_init; GRU: 9 gate arrays, hid_init; then
+ * out.W (H,N), out.b (N,)  (sparse_lstm.py:240-279, :660-676). */
+int sbr_num_params(const sbr_handle* h);
+int sbr_param_shape(const sbr_handle* h, int i, int64_t dims[2], int* ndim);
+int sbr_set_params(sbr_handle* h, int n, const float* const* host_arrays);
+int sbr_get_params(sbr_handle* h, int n, float* const* host_arrays);
+/* Same layout, gradients of the last forward/backward (parity tests). */
+int sbr_get_grads(sbr_handle* h, int n, float* const* host_arrays);
+
+/* Flat device sections (float32).  The gradient section carries one extra trailing float:
+ * the batch cost, so that one all-reduce sums gradients and cost across ranks.
+ * which: 0 params, 1 grads(+cost), 2 optimizer state.  split_floats (grads only): offset of
+ * the output-layer gradients, which are complete after sbr_loss_backward_output and can be
+ * all-reduced while sbr_backward_recurrent runs. */
+int sbr_section(sbr_handle* h, int which, void** dev_ptr, size_t* n_floats, size_t* split_floats);
+
+/* The per-call inputs of train_function (rnn_one_hot.py:61,106; rnn_sampling.py:128,194):
+ * X int32 (B,T,F) left-aligned; lengths int32 (B,) = mask.sum(1) (masks are prefix masks,
+ * rnn_one_hot.py:100-101); target int32 (Bg,) -- all GLOBAL rows for the sampled heads
+ * (Blackout's softmax spans every target, rnn_sampling.py:68-72,137), local rows for CCE;
+ * samples int32 (S,) or NULL; target_popularity float (B,) local rows (pop**db,
+ * rnn_one_hot.py:103).  `exclude` (B,N) is never materialised (unused by train_function,
+ * rnn_base.py:185 on_unused_input='ignore').  on_device != 0: pointers are device memory. */
+int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* lengths, const int32_t* target,
+                  const int32_t* samples, const float* target_popularity, int n_rows, int on_device);
+
+/* train_function(*batch) -> cost (rnn_base.py:290): zero grads, forward, loss, backward,
+ * update.  cost_host may be NULL (cost stays on device: sbr_read_cost). */
+int sbr_train_step(sbr_handle* h, float* cost_host);
+/* The same in phases (data-parallel: all-reduce the gradient section between them). */
+int sbr_zero_grads(sbr_handle* h);
+int sbr_forward(sbr_handle* h);
+int sbr_loss_backward_output(sbr_handle* h);
+int sbr_backward_recurrent(sbr_handle* h);
+int sbr_apply_update(sbr_handle* h);
+int sbr_read_cost(sbr_handle* h, float* cost_host);
+
+/* predict_function(X, mask) (rnn_base.py:188-194) on the current batch: scores (rows,N);
+ * softmax probabilities for CCE (DenseLayer softmax, rnn_one_hot.py:65), raw activations
+ * for the sampled heads (sparse_lstm.py:37-40).  probs != 0 forces softmax (test function of
+ * the sampled heads, rnn_sampling.py:144).  out_host (rows*N floats) may be NULL. */
+int sbr_predict_scores(sbr_handle* h, int probs, float* out_host);
+/* test_function(theano_inputs, k) (rnn_base.py:196-211): ordered top-k ids per row of
+ * softmax * (1 - exclude) where exclude = the row's own input items when exclude_seen
+ * (interactions_are_unique, rnn_base.py:200-201).  Ties break to the lowest id. */
+int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_host);
+
+/* Named device buffers for parity tests: "h_last" (rows,Hp), "logits", "xt0", "hs0" ... */
+int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr, size_t* n_floats);
+/* Copy n_floats from a device pointer to host (tests without torch). */
+int sbr_copy_to_host(sbr_handle* h, const void* dev_ptr, float* host, size_t n_floats);
+int sbr_synchronize(sbr_handle* h);
+
+/* Per-phase device time of the last sbr_train_step in microseconds (hipEvents on the
+ * handle's stream): gather, rec_fwd, output, rec_bwd, wgrad, scatter, update, total. */
+#define SBR_N_PHASES 8
+int sbr_enable_timing(sbr_handle* h, int on);
+int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBR_RNN_H */

@@ -178,4 +178,4 @@ class TorchTrainer(object):
                 else:  # adagrad
                     m.addcmul_(g, g)
                     p.sub_(self.lr * g / (m + 1e-6).sqrt())
-        return float(cost)
+        return float(cost.detach())

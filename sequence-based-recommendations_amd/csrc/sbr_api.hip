@@ -1,0 +1,581 @@
+// C-ABI of libsbr_rnn.so (see include/sbr_rnn.h): arena layout, Lasagne <-> device parameter
+// layout conversion, and the orchestration of one training / prediction step.
+// The host side mirrors what RNNBase does around its Theano functions
+// (neural_networks/rnn_base.py:175-213, :285-300, :470-515); the arithmetic lives in the kernels.
+#include "sbr_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+static thread_local std::string g_err;
+void sbr_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+}
+extern "C" const char* sbr_last_error(void) { return g_err.c_str(); }
+extern "C" int sbr_abi_version(void) { return SBR_ABI_VERSION; }
+
+#define CHECK_ARG(cond, ...) do { if (!(cond)) { sbr_set_error(__VA_ARGS__); return SBR_EINVAL; } } while (0)
+#define SBR_LAUNCH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Layout
+// ---------------------------------------------------------------------------------------
+int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
+    char buf[256];
+#define LFAIL(...) do { snprintf(buf, sizeof(buf), __VA_ARGS__); err = buf; return SBR_EINVAL; } while (0)
+    if (cfg.abi_version != SBR_ABI_VERSION) LFAIL("abi_version %d != %d", cfg.abi_version, SBR_ABI_VERSION);
+    if (cfg.cell < 0 || cfg.cell > 2) LFAIL("Unknown layer type %d", cfg.cell);                  // recurrent_layers.py:90
+    if (cfg.loss < 0 || cfg.loss > 3) LFAIL("Unknown loss for the RNN model (%d)", cfg.loss);     // command_parser.py:123
+    if (cfg.updater < 0 || cfg.updater > 4) LFAIL("Unknown update option %d", cfg.updater);       // update_manager.py:22
+    if (cfg.n_layers < 1 || cfg.n_layers > SBR_MAX_LAYERS) LFAIL("n_layers must be in [1,%d]", SBR_MAX_LAYERS);
+    for (int l = 0; l < cfg.n_layers; ++l)
+        if (cfg.layers[l] < 1 || cfg.layers[l] > 1024) LFAIL("layer %d size %d out of range [1,1024]", l, cfg.layers[l]);
+    if (cfg.n_items < 1 || cfg.input_size < cfg.n_items) LFAIL("need n_items >= 1 and input_size >= n_items");
+    if (cfg.n_feat < 1 || cfg.n_feat > 8) LFAIL("n_feat must be in [1,8]");
+    if (cfg.max_length < 1) LFAIL("max_length must be >= 1");
+    if (cfg.batch_size < 1 || cfg.local_batch < 1 || cfg.local_batch > cfg.batch_size) LFAIL("need 1 <= local_batch <= batch_size");
+    if (cfg.row_offset < 0 || cfg.row_offset + cfg.local_batch > cfg.batch_size) LFAIL("row_offset/local_batch outside the global batch");
+    if (cfg.loss != SBR_LOSS_CCE && cfg.n_samples < 1) LFAIL("sampled losses need n_samples >= 1");
+    if (cfg.learning_rate <= 0.0f) LFAIL("learning_rate must be > 0");
+#undef LFAIL
+    lay = Layout();
+    lay.cfg = cfg;
+    lay.L = cfg.n_layers; lay.G = sbr_gates(cfg.cell); lay.T = cfg.max_length;
+    lay.B = cfg.local_batch; lay.Bp = (cfg.local_batch + 15) / 16 * 16;
+    lay.N = cfg.n_items; lay.F = cfg.n_feat; lay.Bg = cfg.batch_size;
+    lay.S = cfg.loss == SBR_LOSS_CCE ? 0 : cfg.n_samples;
+    lay.C = lay.Bg + lay.S;
+    const int G = lay.G, T = lay.T, Bp = lay.Bp;
+
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += sbr_align(n); return o; };
+    for (int l = 0; l < lay.L; ++l) {
+        LayerLayout& y = lay.layer[l];
+        y.H = cfg.layers[l]; y.Hp = sbr_pad_hidden(y.H); y.G = G;
+        y.n_in = l == 0 ? cfg.input_size : cfg.layers[l - 1];
+        y.n_in_p = l == 0 ? cfg.input_size : lay.layer[l - 1].Hp;
+        y.p_Win = take((size_t)y.n_in_p * G * y.Hp);
+        y.p_b = take((size_t)G * y.Hp);
+        y.p_Whid = take((size_t)y.Hp * G * y.Hp);
+        y.p_peep = take((size_t)3 * y.Hp);
+        y.p_cinit = take(y.Hp);
+        y.p_hinit = take(y.Hp);
+    }
+    lay.HLp = lay.layer[lay.L - 1].Hp;
+    lay.p_split = off;
+    lay.p_WoutT = take((size_t)lay.N * lay.HLp);
+    lay.p_bout = take(lay.N);
+    lay.n_params = off;
+    lay.n_state_arrays = (cfg.updater == SBR_UPD_ADAM || cfg.updater == SBR_UPD_ADADELTA) ? 2 : 1;
+
+    lay.s_params = 0;
+    lay.s_grads = sbr_align(lay.n_params);
+    lay.s_state = lay.s_grads + sbr_align(lay.n_params + 1);
+    lay.s_act = lay.s_state + lay.n_state_arrays * sbr_align(lay.n_params);
+    // NB: state arrays are addressed as s_state + k*n_params; n_params is already 64-aligned.
+
+    off = 0;
+    size_t maxrec = 0;
+    for (int l = 0; l < lay.L; ++l) {
+        LayerLayout& y = lay.layer[l];
+        const size_t tb = (size_t)T * Bp, tb1 = (size_t)(T + 1) * Bp;
+        y.a_xt = take(tb * G * y.Hp);
+        y.a_hs = take(tb1 * y.Hp);
+        y.a_cs = cfg.cell == SBR_CELL_LSTM ? take(tb1 * y.Hp) : 0;
+        for (int k = 0; k < 4; ++k) y.a_g[k] = cfg.cell == SBR_CELL_VANILLA ? 0 : take(tb * y.Hp);
+        y.a_dxt = take(tb * G * y.Hp);
+        y.a_dhi = cfg.cell == SBR_CELL_GRU ? take(tb * G * y.Hp) : y.a_dxt;
+        y.a_dhext = l < lay.L - 1 ? take(tb * y.Hp) : 0;
+        y.a_part = take((size_t)(Bp / 16) * (G * y.Hp + 5 * y.Hp));
+        maxrec = std::max(maxrec, (size_t)y.Hp * G * y.Hp);
+        if (l > 0) maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp);
+    }
+    lay.a_logits = take((size_t)Bp * lay.N);
+    lay.a_dhlast = take((size_t)Bp * lay.HLp);
+    lay.a_rowcost = take(Bp);
+    if (lay.S > 0) {
+        lay.a_Wc = take((size_t)lay.C * lay.HLp); lay.a_bc = take(lay.C);
+        lay.a_act = take((size_t)Bp * lay.C);
+        lay.a_dWc = take((size_t)lay.C * lay.HLp); lay.a_dbc = take(lay.C);
+    }
+    lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
+    lay.a_ws = take(lay.ws_floats);
+    lay.a_X = take((size_t)Bp * T * lay.F);
+    lay.a_len = take(Bp);
+    lay.a_tgt = take(std::max(lay.Bg, Bp));
+    lay.a_smp = take(std::max(lay.S, 1));
+    lay.a_cells = take(std::max(lay.C, 1));
+    lay.a_pop = take(Bp);
+    lay.a_topk = take((size_t)Bp * 64);
+    lay.s_end = lay.s_act + off;
+    return SBR_OK;
+}
+
+void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out) {
+    out.clear();
+    const int cell = lay.cfg.cell;
+    static const char* lstm_g[4] = {"ingate", "forgetgate", "cell", "outgate"};       // sparse_lstm.py:240-254
+    static const char* gru_g[3] = {"updategate", "resetgate", "hidden_update"};       // sparse_lstm.py:660-668
+    static const char* van_g[1] = {"hidden_update"};
+    const char* const* gn = cell == SBR_CELL_LSTM ? lstm_g : (cell == SBR_CELL_GRU ? gru_g : van_g);
+    for (int l = 0; l < lay.L; ++l) {
+        const LayerLayout& y = lay.layer[l];
+        char pre[16]; snprintf(pre, sizeof(pre), "l%d.", l);
+        for (int g = 0; g < lay.G; ++g) {
+            out.push_back({std::string(pre) + "W_in_to_" + gn[g], l, 0, g, y.n_in, y.H, 2});
+            out.push_back({std::string(pre) + "W_hid_to_" + gn[g], l, 1, g, y.H, y.H, 2});
+            out.push_back({std::string(pre) + "b_" + gn[g], l, 2, g, y.H, 1, 1});
+        }
+        if (cell == SBR_CELL_LSTM) {
+            out.push_back({std::string(pre) + "W_cell_to_ingate", l, 3, 0, y.H, 1, 1});
+            out.push_back({std::string(pre) + "W_cell_to_forgetgate", l, 3, 1, y.H, 1, 1});
+            out.push_back({std::string(pre) + "W_cell_to_outgate", l, 3, 2, y.H, 1, 1});
+            out.push_back({std::string(pre) + "cell_init", l, 4, 0, 1, y.H, 2});
+        }
+        out.push_back({std::string(pre) + "hid_init", l, 5, 0, 1, y.H, 2});
+    }
+    out.push_back({"out.W", lay.L - 1, 6, 0, lay.layer[lay.L - 1].H, lay.N, 2});
+    out.push_back({"out.b", lay.L - 1, 7, 0, lay.N, 1, 1});
+}
+
+// position of Lasagne gate g (creation order) inside the stacked matrices:
+// LSTM [i,f,c,o] = creation order (sparse_lstm.py:348-360); GRU stacks [reset, update, hidden]
+// although it creates update first (sparse_lstm.py:737-749).
+static inline int stacked_pos(int cell, int g) { return cell == SBR_CELL_GRU ? (g == 0 ? 1 : (g == 1 ? 0 : 2)) : g; }
+
+// copy one Lasagne array <-> its place in a host image of a parameter-shaped section
+static void convert_param(const Layout& lay, const ParamDesc& d, float* image, float* arr, bool to_image) {
+    const LayerLayout& y = lay.layer[d.layer];
+    const int GHp = y.G * y.Hp;
+    auto mv = [&](size_t io, size_t ao) { if (to_image) image[io] = arr[ao]; else arr[ao] = image[io]; };
+    const int gp = stacked_pos(lay.cfg.cell, d.gate);
+    switch (d.kind) {
+        case 0: for (int64_t r = 0; r < d.d0; ++r) for (int64_t c = 0; c < d.d1; ++c) mv(y.p_Win + r * GHp + gp * y.Hp + c, r * d.d1 + c); break;
+        case 1: for (int64_t r = 0; r < d.d0; ++r) for (int64_t c = 0; c < d.d1; ++c) mv(y.p_Whid + r * GHp + gp * y.Hp + c, r * d.d1 + c); break;
+        case 2: for (int64_t c = 0; c < d.d0; ++c) mv(y.p_b + gp * y.Hp + c, c); break;
+        case 3: for (int64_t c = 0; c < d.d0; ++c) mv(y.p_peep + d.gate * y.Hp + c, c); break;
+        case 4: for (int64_t c = 0; c < d.d1; ++c) mv(y.p_cinit + c, c); break;
+        case 5: for (int64_t c = 0; c < d.d1; ++c) mv(y.p_hinit + c, c); break;
+        case 6: for (int64_t k = 0; k < d.d0; ++k) for (int64_t n = 0; n < d.d1; ++n) mv(lay.p_WoutT + n * lay.HLp + k, k * d.d1 + n); break;
+        case 7: for (int64_t n = 0; n < d.d0; ++n) mv(lay.p_bout + n, n); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// create / destroy / parameters
+// ---------------------------------------------------------------------------------------
+extern "C" int sbr_arena_bytes(const sbr_config* cfg, size_t* bytes) {
+    CHECK_ARG(cfg && bytes, "null argument");
+    Layout lay; std::string err;
+    if (sbr_build_layout(*cfg, lay, err) != SBR_OK) { sbr_set_error("%s", err.c_str()); return SBR_EINVAL; }
+    *bytes = lay.s_end * sizeof(float);
+    return SBR_OK;
+}
+
+extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes, void* stream, sbr_handle** out) {
+    CHECK_ARG(cfg && out, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        sbr_set_error("no HIP device visible: libsbr_rnn.so has no CPU path");
+        return SBR_EHIP;
+    }
+    sbr_handle* h = new sbr_handle();
+    std::string err;
+    if (sbr_build_layout(*cfg, h->lay, err) != SBR_OK) { sbr_set_error("%s", err.c_str()); delete h; return SBR_EINVAL; }
+    const size_t need = h->lay.s_end * sizeof(float);
+    h->stream = (hipStream_t)stream;
+    if (arena) {
+        if (arena_bytes < need || ((uintptr_t)arena & 255)) {
+            sbr_set_error("arena too small (%zu < %zu bytes) or not 256-byte aligned", arena_bytes, need);
+            delete h; return SBR_EINVAL;
+        }
+        h->arena = (float*)arena; h->own_arena = false;
+    } else {
+        void* p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) { sbr_set_error("hipMalloc(%zu) failed", need); delete h; return SBR_ENOMEM; }
+        h->arena = (float*)p; h->own_arena = true;
+    }
+    sbr_param_descs(h->lay, h->descs);
+    h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
+    memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
+    // parameters, gradients, optimizer state and batch buffers start as zeros
+    // (activations too: one-off, keeps every later GEMM operand finite)
+    hipError_t e = hipMemsetAsync(h->arena, 0, h->lay.s_end * sizeof(float), h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { sbr_set_error("arena initialisation failed: %s", hipGetErrorString(e)); sbr_destroy(h); return SBR_EHIP; }
+    *out = h;
+    return SBR_OK;
+}
+
+extern "C" void sbr_destroy(sbr_handle* h) {
+    if (!h) return;
+    for (int r = 0; r < sbr_handle::kRing; ++r)
+        for (int i = 0; i < SBR_N_PHASES; ++i) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    if (h->own_arena && h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+extern "C" int sbr_num_params(const sbr_handle* h) { return h ? (int)h->descs.size() : SBR_EINVAL; }
+
+extern "C" int sbr_param_shape(const sbr_handle* h, int i, int64_t dims[2], int* ndim) {
+    CHECK_ARG(h && dims && ndim && i >= 0 && i < (int)h->descs.size(), "bad parameter index %d", i);
+    const ParamDesc& d = h->descs[i];
+    dims[0] = d.d0; dims[1] = d.ndim == 2 ? d.d1 : 1; *ndim = d.ndim;
+    return SBR_OK;
+}
+
+extern "C" int sbr_set_params(sbr_handle* h, int n, const float* const* arrays) {
+    CHECK_ARG(h && arrays && n == (int)h->descs.size(), "expected %d parameter arrays, got %d", h ? (int)h->descs.size() : -1, n);
+    std::vector<float> image(h->lay.n_params, 0.0f);     // padding stays exactly zero
+    for (int i = 0; i < n; ++i) {
+        CHECK_ARG(arrays[i], "parameter array %d is NULL", i);
+        convert_param(h->lay, h->descs[i], image.data(), const_cast<float*>(arrays[i]), true);
+    }
+    SBR_HIP(hipMemcpyAsync(h->P(0), image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    h->fwd_done = false;
+    return SBR_OK;
+}
+
+static int get_section(sbr_handle* h, const float* dev, int n, float* const* arrays) {
+    CHECK_ARG(h && arrays && n == (int)h->descs.size(), "expected %d parameter arrays, got %d", h ? (int)h->descs.size() : -1, n);
+    std::vector<float> image(h->lay.n_params);
+    SBR_HIP(hipMemcpyAsync(image.data(), dev, image.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        CHECK_ARG(arrays[i], "parameter array %d is NULL", i);
+        convert_param(h->lay, h->descs[i], image.data(), arrays[i], false);
+    }
+    return SBR_OK;
+}
+extern "C" int sbr_get_params(sbr_handle* h, int n, float* const* arrays) { return get_section(h, h ? h->P(0) : nullptr, n, arrays); }
+extern "C" int sbr_get_grads(sbr_handle* h, int n, float* const* arrays) { return get_section(h, h ? h->Gd(0) : nullptr, n, arrays); }
+
+extern "C" int sbr_section(sbr_handle* h, int which, void** dev_ptr, size_t* n_floats, size_t* split_floats) {
+    CHECK_ARG(h && dev_ptr && n_floats, "null argument");
+    const Layout& y = h->lay;
+    if (split_floats) *split_floats = y.p_split;
+    switch (which) {
+        case 0: *dev_ptr = h->P(0); *n_floats = y.n_params; return SBR_OK;
+        case 1: *dev_ptr = h->Gd(0); *n_floats = y.n_params + 1; return SBR_OK;
+        case 2: *dev_ptr = h->St(0, 0); *n_floats = y.n_state_arrays * y.n_params; return SBR_OK;
+    }
+    sbr_set_error("unknown section %d", which);
+    return SBR_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------
+extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* lengths, const int32_t* target,
+                             const int32_t* samples, const float* pop, int n_rows, int on_device) {
+    CHECK_ARG(h && X && lengths, "null X / lengths");
+    const Layout& y = h->lay;
+    CHECK_ARG(n_rows >= 1 && n_rows <= y.B, "n_rows %d outside [1,%d]", n_rows, y.B);
+    const int n_tgt = y.S > 0 ? y.Bg : n_rows;
+    if (!on_device) {   // the reference would raise IndexError inside Theano for bad ids; check on host
+        for (size_t i = 0; i < (size_t)n_rows * y.T * y.F; ++i)
+            CHECK_ARG(X[i] >= 0 && X[i] < y.cfg.input_size, "input index %d out of range [0,%d)", X[i], y.cfg.input_size);
+        for (int i = 0; i < n_rows; ++i) CHECK_ARG(lengths[i] >= 0 && lengths[i] <= y.T, "length %d outside [0,%d]", lengths[i], y.T);
+        if (target) for (int i = 0; i < n_tgt; ++i) CHECK_ARG(target[i] >= 0 && target[i] < y.N, "target %d out of range", target[i]);
+        if (samples) for (int i = 0; i < y.S; ++i) CHECK_ARG(samples[i] >= 0 && samples[i] < y.N, "sample %d out of range", samples[i]);
+    }
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    hipStream_t s = h->stream;
+    if (n_rows < y.Bp) {   // padded rows: index 0, length 0, popularity 1
+        SBR_HIP(hipMemsetAsync(h->A(y.a_X), 0, (size_t)y.Bp * y.T * y.F * sizeof(int), s));
+        SBR_HIP(hipMemsetAsync(h->A(y.a_len), 0, (size_t)y.Bp * sizeof(int), s));
+        SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
+    }
+    SBR_HIP(hipMemcpyAsync(h->A(y.a_X), X, (size_t)n_rows * y.T * y.F * sizeof(int), kind, s));
+    SBR_HIP(hipMemcpyAsync(h->A(y.a_len), lengths, (size_t)n_rows * sizeof(int), kind, s));
+    if (target) SBR_HIP(hipMemcpyAsync(h->A(y.a_tgt), target, (size_t)n_tgt * sizeof(int), kind, s));
+    if (samples && y.S > 0) SBR_HIP(hipMemcpyAsync(h->A(y.a_smp), samples, (size_t)y.S * sizeof(int), kind, s));
+    if (pop) SBR_HIP(hipMemcpyAsync(h->A(y.a_pop), pop, (size_t)n_rows * sizeof(float), kind, s));
+    else SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
+    if (!on_device) SBR_HIP(hipStreamSynchronize(s));   // caller's host arrays may be freed on return
+    h->n_rows = n_rows; h->have_batch = true; h->fwd_done = false;
+    return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// step phases
+// ---------------------------------------------------------------------------------------
+static RecArgs rec_args(sbr_handle* h, int l) {
+    const Layout& y = h->lay; const LayerLayout& ly = y.layer[l];
+    RecArgs a; memset(&a, 0, sizeof(a));
+    a.cell = y.cfg.cell; a.T = y.T; a.Bp = y.Bp; a.H = ly.H; a.Hp = ly.Hp; a.G = y.G;
+    a.clip = y.cfg.grad_clip;
+    a.len = (const int*)h->A(y.a_len);
+    a.xt = h->A(ly.a_xt); a.Whid = h->P(ly.p_Whid); a.peep = h->P(ly.p_peep);
+    a.cinit = h->P(ly.p_cinit); a.hinit = h->P(ly.p_hinit);
+    a.hs = h->A(ly.a_hs); a.cs = h->A(ly.a_cs);
+    for (int k = 0; k < 4; ++k) a.g[k] = h->A(ly.a_g[k]);
+    a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
+    return a;
+}
+static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
+static inline bool simple_gemm(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_GEMM; }
+static inline void mark(sbr_handle* h, int i) {
+    if (h->timing && h->ev[h->ring_cur][i]) (void)hipEventRecord(h->ev[h->ring_cur][i], h->stream);
+}
+
+extern "C" int sbr_zero_grads(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    SBR_HIP(hipMemsetAsync(h->Gd(0), 0, (h->lay.n_params + 1) * sizeof(float), h->stream));
+    return SBR_OK;
+}
+
+extern "C" int sbr_forward(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    if (!h->have_batch) { sbr_set_error("sbr_forward: no batch set"); return SBR_ESTATE; }
+    const Layout& y = h->lay; hipStream_t s = h->stream;
+    for (int l = 0; l < y.L; ++l) {
+        const LayerLayout& ly = y.layer[l];
+        const int GHp = y.G * ly.Hp;
+        if (l == 0) {
+            SBR_LAUNCH(launch_gather_xt(s, h->P(ly.p_Win), h->P(ly.p_b), (const int*)h->A(y.a_X), h->A(ly.a_xt), y.T, y.Bp,
+                                        y.F, GHp, h->n_rows));
+            mark(h, 1);
+        } else {   // dense layers: xt = hid_out(l-1) . W_in + b  (Lasagne precompute_input [3P], recurrent_layers.py:94-104)
+            const LayerLayout& lo = y.layer[l - 1];
+            SBR_LAUNCH(launch_gemm(s, h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp, lo.Hp, 1, h->P(ly.p_Win), GHp, 1, h->A(ly.a_xt), GHp,
+                                   y.T * y.Bp, GHp, lo.Hp, h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
+        }
+        SBR_LAUNCH(launch_rec_forward(s, rec_args(h, l), simple_rec(h)));
+    }
+    mark(h, 2);
+    h->fwd_done = true;
+    return SBR_OK;
+}
+
+static float* h_last(sbr_handle* h) {   // hid_out[-1] (sparse_lstm.py:485-486) = slot T of the top layer
+    const Layout& y = h->lay; const LayerLayout& ly = y.layer[y.L - 1];
+    return h->A(ly.a_hs) + (size_t)y.T * y.Bp * ly.Hp;
+}
+
+extern "C" int sbr_loss_backward_output(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    if (!h->fwd_done) { sbr_set_error("sbr_loss_backward_output: call sbr_forward first"); return SBR_ESTATE; }
+    const Layout& y = h->lay; hipStream_t s = h->stream;
+    const int R = h->n_rows, Hp = y.HLp, N = y.N;
+    const bool sg = simple_gemm(h);
+    float* hl = h_last(h);
+    float* ws = h->A(y.a_ws);
+    const int* tgt = (const int*)h->A(y.a_tgt);
+    SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));
+    if (y.cfg.loss == SBR_LOSS_CCE) {
+        float* lg = h->A(y.a_logits);
+        // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
+        SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, N, R, N, Hp, nullptr, nullptr, 0, sg));
+        SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->A(y.a_pop), h->A(y.a_rowcost), R, N, y.Bg));
+        SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
+        // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
+        const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
+        SBR_LAUNCH(launch_colsum_bias(s, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr()));
+        // dW_out^T [N][Hp] = dlogits^T . h ;  dh = dlogits . W_out^T
+        SBR_LAUNCH(launch_gemm(s, lg, 1, N, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws, y.ws_floats, sg));
+        SBR_LAUNCH(launch_gemm(s, lg, N, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
+    } else {
+        const int C = y.C;
+        int* cells = (int*)h->A(y.a_cells);
+        float *Wc = h->A(y.a_Wc), *bc = h->A(y.a_bc), *act = h->A(y.a_act), *dWc = h->A(y.a_dWc), *dbc = h->A(y.a_dbc);
+        SBR_LAUNCH(launch_build_cells(s, tgt, (const int*)h->A(y.a_smp), y.Bg, y.S, cells));
+        SBR_LAUNCH(launch_gather_rows(s, h->P(y.p_WoutT), h->P(y.p_bout), cells, C, Hp, Wc, bc));
+        SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, Wc, 1, Hp, act, C, R, C, Hp, nullptr, nullptr, 0, sg));
+        SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->A(y.a_pop), h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
+                                       y.cfg.loss, y.Bg));
+        SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
+        SBR_LAUNCH(launch_colsum_bias(s, act, R, C, C, dbc, nullptr, 0.0f, nullptr));
+        SBR_LAUNCH(launch_gemm(s, act, 1, C, hl, Hp, 1, dWc, Hp, C, Hp, R, nullptr, nullptr, 0, sg));
+        SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
+        SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
+    }
+    mark(h, 3);
+    return SBR_OK;
+}
+
+extern "C" int sbr_backward_recurrent(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    if (!h->fwd_done) { sbr_set_error("sbr_backward_recurrent: call sbr_forward first"); return SBR_ESTATE; }
+    const Layout& y = h->lay; hipStream_t s = h->stream;
+    const bool sg = simple_gemm(h);
+    float* ws = h->A(y.a_ws);
+    const int TB = y.T * y.Bp;
+    for (int l = y.L - 1; l >= 0; --l) {
+        const LayerLayout& ly = y.layer[l];
+        const int GHp = y.G * ly.Hp;
+        RecArgs a = rec_args(h, l);
+        a.dh_last = l == y.L - 1 ? h->A(y.a_dhlast) : nullptr;
+        a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
+        SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
+        if (l == 0) mark(h, 4);
+        SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, y.Bp / 16, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+                                              h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
+        // dW_hid [Hp][G*Hp] = sum over (t,row) of hs[t]^T . dhi[t]   (hs slot t = h_{t-1})
+        SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
+                               y.ws_floats, sg));
+        if (l == 0) {
+            mark(h, 5);
+            SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_X), a.len, y.T, y.Bp, y.F, GHp));
+            mark(h, 6);
+        } else {
+            const LayerLayout& lo = y.layer[l - 1];
+            const float* xin = h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp;     // input at step t = h^{l-1}_t = slot t+1
+            SBR_LAUNCH(launch_gemm(s, xin, 1, lo.Hp, a.dxt, GHp, 1, h->Gd(ly.p_Win), GHp, lo.Hp, GHp, TB, nullptr, ws,
+                                   y.ws_floats, sg));
+            SBR_LAUNCH(launch_gemm(s, a.dxt, GHp, 1, h->P(ly.p_Win), 1, GHp, h->A(lo.a_dhext), lo.Hp, TB, lo.Hp, GHp, nullptr,
+                                   nullptr, 0, sg));
+        }
+    }
+    return SBR_OK;
+}
+
+extern "C" int sbr_apply_update(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    const Layout& y = h->lay;
+    h->step_count += 1;
+    float* s1 = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+    SBR_LAUNCH(launch_update(h->stream, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, y.n_params, y.cfg.learning_rate,
+                             y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count));
+    mark(h, 7);
+    h->fwd_done = false;
+    return SBR_OK;
+}
+
+extern "C" int sbr_read_cost(sbr_handle* h, float* cost_host) {
+    CHECK_ARG(h && cost_host, "null argument");
+    SBR_HIP(hipMemcpyAsync(cost_host, h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    return SBR_OK;
+}
+
+extern "C" int sbr_train_step(sbr_handle* h, float* cost_host) {
+    CHECK_ARG(h, "null handle");
+    int rc;
+    if (h->timing) h->ring_cur = h->ring_used % sbr_handle::kRing;
+    mark(h, 0);
+    if ((rc = sbr_zero_grads(h)) != SBR_OK) return rc;
+    if ((rc = sbr_forward(h)) != SBR_OK) return rc;
+    if ((rc = sbr_loss_backward_output(h)) != SBR_OK) return rc;
+    if ((rc = sbr_backward_recurrent(h)) != SBR_OK) return rc;
+    // train_function returns the cost of the batch BEFORE the update (rnn_base.py:290)
+    if ((rc = sbr_apply_update(h)) != SBR_OK) return rc;
+    if (h->timing) h->ring_used += 1;
+    if (cost_host) return sbr_read_cost(h, cost_host);
+    return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// predict / top-k
+// ---------------------------------------------------------------------------------------
+static int full_scores(sbr_handle* h, int do_softmax) {
+    const Layout& y = h->lay;
+    int rc;
+    if (!h->fwd_done && (rc = sbr_forward(h)) != SBR_OK) return rc;
+    float* lg = h->A(y.a_logits);
+    SBR_LAUNCH(launch_gemm(h->stream, h_last(h), y.HLp, 1, h->P(y.p_WoutT), 1, y.HLp, lg, y.N, h->n_rows, y.N, y.HLp, nullptr,
+                           nullptr, 0, simple_gemm(h)));
+    SBR_LAUNCH(launch_softmax_rows(h->stream, lg, h->P(y.p_bout), h->n_rows, y.N, do_softmax));
+    return SBR_OK;
+}
+
+extern "C" int sbr_predict_scores(sbr_handle* h, int probs, float* out_host) {
+    CHECK_ARG(h, "null handle");
+    if (!h->have_batch) { sbr_set_error("sbr_predict_scores: no batch set"); return SBR_ESTATE; }
+    const Layout& y = h->lay;
+    const int rc = full_scores(h, (probs || y.cfg.loss == SBR_LOSS_CCE) ? 1 : 0);
+    if (rc != SBR_OK) return rc;
+    if (out_host) {
+        SBR_HIP(hipMemcpyAsync(out_host, h->A(y.a_logits), (size_t)h->n_rows * y.N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        SBR_HIP(hipStreamSynchronize(h->stream));
+    }
+    return SBR_OK;
+}
+
+extern "C" int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_host) {
+    CHECK_ARG(h && ids_host, "null argument");
+    if (!h->have_batch) { sbr_set_error("sbr_topk: no batch set"); return SBR_ESTATE; }
+    const Layout& y = h->lay;
+    CHECK_ARG(k >= 1 && k <= 64 && k <= y.N, "k=%d outside [1,min(64,N)]", k);
+    // softmax is monotone: ranking the biased logits == ranking softmax(logits)*(1-exclude)
+    // (rnn_base.py:200-207) whenever at least k items are not excluded.
+    const int rc = full_scores(h, 0);
+    if (rc != SBR_OK) return rc;
+    float* lg = h->A(y.a_logits);
+    if (exclude_seen)
+        SBR_LAUNCH(launch_exclude_seen(h->stream, lg, (const int*)h->A(y.a_X), (const int*)h->A(y.a_len), h->n_rows, y.T, y.F, y.N));
+    int* ids = (int*)h->A(y.a_topk);
+    SBR_LAUNCH(launch_topk(h->stream, lg, h->n_rows, y.N, k, ids));
+    SBR_HIP(hipMemcpyAsync(ids_host, ids, (size_t)h->n_rows * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// debug / timing
+// ---------------------------------------------------------------------------------------
+extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr, size_t* n_floats) {
+    CHECK_ARG(h && name && dev_ptr && n_floats, "null argument");
+    const Layout& y = h->lay;
+    const std::string nm(name);
+    const size_t tb = (size_t)y.T * y.Bp;
+    if (nm == "h_last") { *dev_ptr = h_last(h); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
+    if (nm == "logits") { *dev_ptr = h->A(y.a_logits); *n_floats = (size_t)y.Bp * y.N; return SBR_OK; }
+    if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
+    if (nm == "rowcost") { *dev_ptr = h->A(y.a_rowcost); *n_floats = y.Bp; return SBR_OK; }
+    if (nm == "act" && y.S > 0) { *dev_ptr = h->A(y.a_act); *n_floats = (size_t)y.Bp * y.C; return SBR_OK; }
+    for (int l = 0; l < y.L; ++l) {
+        const LayerLayout& ly = y.layer[l];
+        const std::string sfx = std::to_string(l);
+        if (nm == "xt" + sfx) { *dev_ptr = h->A(ly.a_xt); *n_floats = tb * y.G * ly.Hp; return SBR_OK; }
+        if (nm == "hs" + sfx) { *dev_ptr = h->A(ly.a_hs); *n_floats = (tb + y.Bp) * ly.Hp; return SBR_OK; }
+        if (nm == "dxt" + sfx) { *dev_ptr = h->A(ly.a_dxt); *n_floats = tb * y.G * ly.Hp; return SBR_OK; }
+        if (nm == "dhi" + sfx) { *dev_ptr = h->A(ly.a_dhi); *n_floats = tb * y.G * ly.Hp; return SBR_OK; }
+    }
+    sbr_set_error("unknown debug buffer '%s'", name);
+    return SBR_EINVAL;
+}
+
+extern "C" int sbr_copy_to_host(sbr_handle* h, const void* dev_ptr, float* host, size_t n_floats) {
+    CHECK_ARG(h && dev_ptr && host, "null argument");
+    SBR_HIP(hipMemcpyAsync(host, dev_ptr, n_floats * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    return SBR_OK;
+}
+
+extern "C" int sbr_synchronize(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    return SBR_OK;
+}
+
+extern "C" int sbr_enable_timing(sbr_handle* h, int on) {
+    CHECK_ARG(h, "null handle");
+    if (on)
+        for (int r = 0; r < sbr_handle::kRing; ++r)
+            for (int i = 0; i < SBR_N_PHASES; ++i) if (!h->ev[r][i]) SBR_HIP(hipEventCreate(&h->ev[r][i]));
+    h->timing = on != 0; h->ring_used = 0; h->ring_cur = 0;
+    return SBR_OK;
+}
+
+// mean over the (up to 64 most recent) train steps recorded since sbr_enable_timing(h, 1)
+extern "C" int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]) {
+    CHECK_ARG(h && us, "null argument");
+    if (!h->timing || h->ring_used == 0) { sbr_set_error("no timed train step recorded"); return SBR_ESTATE; }
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    const int n = std::min(h->ring_used, (int)sbr_handle::kRing);
+    for (int i = 0; i < SBR_N_PHASES; ++i) us[i] = 0.f;
+    for (int r = 0; r < n; ++r)
+        for (int i = 0; i < SBR_N_PHASES - 1; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[r][i], h->ev[r][i + 1]) != hipSuccess) ms = 0.f;
+            us[i] += ms * 1000.f / n;
+        }
+    for (int i = 0; i < SBR_N_PHASES - 1; ++i) us[SBR_N_PHASES - 1] += us[i];
+    return SBR_OK;
+}

@@ -1,0 +1,162 @@
+// Internal declarations shared by the HIP translation units of libsbr_rnn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/sbr_rnn.h"
+
+#define SBR_ALIGN_FLOATS 64   // every carved buffer starts on a 256-byte boundary
+
+static inline size_t sbr_align(size_t n_floats) { return (n_floats + SBR_ALIGN_FLOATS - 1) / SBR_ALIGN_FLOATS * SBR_ALIGN_FLOATS; }
+static inline int sbr_gates(int cell) { return cell == SBR_CELL_LSTM ? 4 : (cell == SBR_CELL_GRU ? 3 : 1); }
+// Hidden size padded for the MFMA tiling: 16/32/64/128 (W_hid register-resident kernels are
+// instantiated for those), above that the next multiple of 64 (streamed-W kernels).
+static inline int sbr_pad_hidden(int H) {
+    if (H <= 16) return 16;
+    if (H <= 32) return 32;
+    if (H <= 64) return 64;
+    if (H <= 128) return 128;
+    return (H + 63) / 64 * 64;
+}
+
+// ---------------------------------------------------------------------------------------
+// Parameter / activation layout in the device arena (all float32, offsets in floats)
+// ---------------------------------------------------------------------------------------
+struct LayerLayout {
+    int H, Hp, G;
+    int n_in;        // logical rows of W_in (input_size for layer 0, H of the layer below otherwise)
+    int n_in_p;      // stored rows (== n_in for layer 0, Hp of the layer below otherwise)
+    // parameter section offsets (the gradient section mirrors them exactly)
+    size_t p_Win;    // [n_in_p][G*Hp]   item-major rows, gate-major inside a row
+    size_t p_b;      // [G*Hp]
+    size_t p_Whid;   // [Hp][G*Hp]
+    size_t p_peep;   // [3][Hp]          LSTM only (i, f, o)
+    size_t p_cinit;  // [Hp]             LSTM only
+    size_t p_hinit;  // [Hp]
+    // activation offsets (activation section)
+    size_t a_xt;     // [T][Bp][G*Hp]    precomputed input (gather or dense GEMM)
+    size_t a_hs;     // [T+1][Bp][Hp]    slot 0 = hid_init, slot t+1 = h_t
+    size_t a_cs;     // [T+1][Bp][Hp]    LSTM cell states
+    size_t a_g[4];   // [T][Bp][Hp]      LSTM i,f,g,o / GRU r,u,c~,hid_c
+    size_t a_dxt;    // [T][Bp][G*Hp]    grad wrt xt (= grad wrt gates for LSTM/Vanilla)
+    size_t a_dhi;    // [T][Bp][G*Hp]    GRU only: grad wrt hid_input
+    size_t a_dhext;  // [T][Bp][Hp]      grad arriving from the layer above (layers below the top)
+    size_t a_part;   // [nblk][G*Hp + 5*Hp] per-workgroup partial sums: bias, peepholes, inits
+};
+
+struct Layout {
+    sbr_config cfg;
+    int L, G, T, B, Bp, N, F, Bg, S, C;   // C = Bg + S sampled columns
+    int HLp;                              // padded width of the top layer
+    LayerLayout layer[SBR_MAX_LAYERS];
+    size_t p_WoutT, p_bout;               // [N][HLp], [N]
+    size_t n_params;                      // floats in the parameter section
+    size_t p_split;                       // == p_WoutT : output-layer part starts here
+    size_t n_state_arrays;                // optimizer state arrays of n_params floats each (1 or 2)
+    // arena sections (float offsets from the arena base)
+    size_t s_params, s_grads, s_state, s_act, s_end;
+    // misc activation-section buffers
+    size_t a_logits;                      // [Bp][N]
+    size_t a_dhlast;                      // [Bp][HLp]
+    size_t a_rowcost;                     // [Bp]
+    size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
+    size_t a_ws; size_t ws_floats;        // split-K workspace
+    size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
+};
+
+int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err);
+
+struct ParamDesc { std::string name; int layer; int kind; int gate; int64_t d0, d1; int ndim; };
+// kind: 0 W_in, 1 W_hid, 2 b, 3 peephole(i,f,o by gate 0..2), 4 cell_init, 5 hid_init, 6 out.W, 7 out.b
+void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out);
+
+struct sbr_handle {
+    Layout lay;
+    float* arena; bool own_arena;
+    hipStream_t stream;
+    std::vector<ParamDesc> descs;
+    int n_rows;          // rows of the current batch (<= local_batch)
+    int64_t step_count;  // adam t
+    bool have_batch, fwd_done;
+    bool timing;
+    // ring of per-step event sets, read back after the timed region (no per-step sync)
+    static const int kRing = 64;
+    hipEvent_t ev[kRing][SBR_N_PHASES];
+    int ring_used;       // train steps recorded since timing was enabled
+    int ring_cur;        // set used by the step in flight
+    float* P(size_t off) const { return arena + lay.s_params + off; }
+    float* Gd(size_t off) const { return arena + lay.s_grads + off; }
+    float* St(int k, size_t off) const { return arena + lay.s_state + (size_t)k * lay.n_params + off; }
+    float* A(size_t off) const { return arena + lay.s_act + off; }
+    float* cost_ptr() const { return arena + lay.s_grads + lay.n_params; }
+};
+
+void sbr_set_error(const char* fmt, ...);
+#define SBR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Kernel launchers (each returns hipGetLastError())
+// ---------------------------------------------------------------------------------------
+// K1: xt[t][b][:] = sum_f W_in[X[b][t][f]][:] + bias         (sparse_lstm.py:368,:755,:1111)
+hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, const int* X, float* xt,
+                            int T, int Bp, int F, int GHp, int n_rows_in);
+// K6: dWin[X[b][t][f]][:] += dxt[t][b][:] for t < len[b]     (AdvancedIncSubtensor grad [3P])
+hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, const int* X, const int* len,
+                               int T, int Bp, int F, int GHp);
+
+struct RecArgs {
+    int cell, T, Bp, H, Hp, G;
+    float clip;
+    const int* len;         // [Bp]
+    const float* xt;        // [T][Bp][G*Hp]
+    const float* Whid;      // [Hp][G*Hp]
+    const float* peep;      // [3][Hp]
+    const float* cinit;     // [Hp]
+    const float* hinit;     // [Hp]
+    float* hs; float* cs; float* g[4];
+    // backward only
+    const float* dh_last;   // [Bp][Hp] grad wrt the final hidden state (top layer) or NULL
+    const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
+    float* dxt; float* dhi; // dhi == dxt for LSTM/Vanilla
+    float* part;            // [nblk][G*Hp + 5*Hp]
+};
+hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
+hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple);
+// sums the per-workgroup partials into bias / peephole / init gradients
+hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk, int G, int Hp, int cell,
+                                      float* db, float* dpeep, float* dcinit, float* dhinit);
+
+// Generic f32 GEMM on v_mfma_f32_16x16x4_f32:  C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n])
+// A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], C row-major with leading dim ldc.
+// ws: split-K workspace of ws_floats floats (may be NULL -> no split).
+hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                       float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
+                       bool simple);
+
+// full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N) in, dlogits out in place
+hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
+                              float* rowcost, int rows, int N, int Bglobal);
+hipError_t launch_softmax_rows(hipStream_t s, float* logits, const float* bout, int rows, int N, int do_softmax);
+// db[n] = sum_rows d[r][n] + reg term ; cost += reg term
+hipError_t launch_colsum_bias(hipStream_t s, const float* d, int rows, int N, long ld, float* db, const float* b,
+                              float reg, float* cost);
+hipError_t launch_sum_cost(hipStream_t s, const float* rowcost, int rows, float* cost);
+// sampled heads (sparse_lstm.py:42-54, rnn_sampling.py:68-91,137)
+hipError_t launch_build_cells(hipStream_t s, const int* target, const int* samples, int Bg, int S, int* cells);
+hipError_t launch_gather_rows(hipStream_t s, const float* W, const float* b, const int* cells, int C, int Hp,
+                              float* Wc, float* bc);
+hipError_t launch_sampled_loss(hipStream_t s, float* act, const float* bc, const float* pop, float* rowcost, int rows,
+                               int Bg, int S, int row_offset, int loss, int Bglobal);
+hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float* dWc, const float* dbc,
+                                const int* cells, int C, int Hp);
+// optimizers (lasagne.updates.* [3P], update_manager.py:24-82)
+hipError_t launch_update(hipStream_t s, int updater, float* p, const float* g, float* s0, float* s1, size_t n,
+                         float lr, float rho, float b1, float b2, long t);
+// top-k (rnn_base.py:196-211)
+hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F,
+                               int N);
+hipError_t launch_topk(hipStream_t s, float* scores, int rows, int N, int k, int* ids);
+hipError_t launch_fill(hipStream_t s, float* p, float v, size_t n);

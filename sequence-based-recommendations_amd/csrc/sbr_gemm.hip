@@ -1,0 +1,161 @@
+// Generic float32 GEMM on v_mfma_f32_16x16x4_f32 (exact f32: bitwise an fmaf chain) for gfx950.
+// Used for the dense pieces of the hot path: output projection logits = h.W_out (K7), its
+// backward pair (K9), the split-K weight gradients dW_hid = hs^T.dhi / dW_in = x^T.dxt that run
+// after the BPTT chain, and the layer>=2 input projections (K15).
+//
+//   C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n]),  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+//
+// Workgroup = 256 threads = 4 waves, 64x64 output tile, BK = 16; each wave owns a 32x32
+// sub-tile = 2x2 MFMA tiles.  Global -> registers -> LDS with the next K-tile prefetched into
+// registers while the MFMAs of the current one run.  Split-K over grid.z writes partial slabs
+// that a second kernel sums in fixed order (deterministic).
+#include "sbr_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDT 68   // LDS row stride (floats): 64 + 4 keeps 16-B alignment and breaks the 64-float bank period
+
+struct GemmArgs {
+    const float* A; long sam, sak;
+    const float* B; long sbk, sbn;
+    float* C; long ldc;
+    int M, N, K;
+    const float* bias;
+    int kchunk;      // K range per grid.z slice (multiple of BK)
+    float* ws;       // split-K slabs [z][M][N] (NULL when gridDim.z == 1)
+};
+
+__global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int j = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    // thread -> element mapping for the global loads: 4 elements per thread per operand,
+    // contiguous along whichever dimension has unit stride
+    const bool a_kfast = g.sak == 1;
+    const int a_m = a_kfast ? (tid >> 2) : ((tid & 15) << 2);
+    const int a_k = a_kfast ? ((tid & 3) << 2) : (tid >> 4);
+    const bool b_nfast = g.sbn == 1;
+    const int b_n = b_nfast ? ((tid & 15) << 2) : (tid >> 2);
+    const int b_k = b_nfast ? (tid >> 4) : ((tid & 3) << 2);
+
+    float ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + a_m + (a_kfast ? 0 : e), k = k0 + a_k + (a_kfast ? e : 0);
+            ra[e] = (m < g.M && k < kend) ? g.A[(long)m * g.sam + (long)k * g.sak] : 0.0f;
+            const int n = n0 + b_n + (b_nfast ? e : 0), kb = k0 + b_k + (b_nfast ? 0 : e);
+            rb[e] = (n < g.N && kb < kend) ? g.B[(long)kb * g.sbk + (long)n * g.sbn] : 0.0f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            As[(a_k + (a_kfast ? e : 0)) * LDT + a_m + (a_kfast ? 0 : e)] = ra[e];
+            Bs[(b_k + (b_nfast ? 0 : e)) * LDT + b_n + (b_nfast ? e : 0)] = rb[e];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+
+    if (kbeg < kend) {
+        load_tile(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            __syncthreads();               // previous tile's MFMA reads are done
+            store_tile();
+            __syncthreads();
+            if (k0 + BK < kend) load_tile(k0 + BK);
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[a] = As[(ks * 4 + q) * LDT + wm * 32 + a * 16 + j];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[b] = Bs[(ks * 4 + q) * LDT + wn * 32 + b * 16 + j];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    float* out = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const long ld = g.ws ? g.N : g.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 32 + b * 16 + j;
+            if (n >= g.N) continue;
+            const float bv = (!g.ws && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + a * 16 + q * 4 + r;
+                if (m < g.M) out[(long)m * ld + n] = acc[a][b][r] + bv;
+            }
+        }
+}
+
+__global__ void gemm_splitk_reduce(const float* ws, int nsplit, int M, int N, float* C, long ldc, const float* bias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    float s = 0.0f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * M * N + i];
+    const int m = i / N, n = i % N;
+    C[(long)m * ldc + n] = s + (bias ? bias[n] : 0.0f);
+}
+
+// triage: one thread per output element
+__global__ void gemm_naive(GemmArgs g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)g.M * g.N) return;
+    const int m = i / g.N, n = i % g.N;
+    float s = 0.0f;
+    for (int k = 0; k < g.K; ++k) s = fmaf(g.A[(long)m * g.sam + (long)k * g.sak], g.B[(long)k * g.sbk + (long)n * g.sbn], s);
+    g.C[(long)m * g.ldc + n] = s + (g.bias ? g.bias[n] : 0.0f);
+}
+
+hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
+                       long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, K, nullptr};
+    if (simple) {
+        const size_t n = (size_t)M * N;
+        gemm_naive<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g);
+        return hipGetLastError();
+    }
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    int nsplit = 1;
+    if (ws && K >= 8 * BK) {
+        nsplit = 1024 / (tm * tn);
+        nsplit = min(nsplit, K / (4 * BK));
+        nsplit = (int)min((size_t)nsplit, ws_floats / ((size_t)M * N));
+        nsplit = max(nsplit, 1);
+    }
+    int kchunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+    if (kchunk <= 0) kchunk = BK;
+    nsplit = max(1, (K + kchunk - 1) / kchunk);
+    g.kchunk = kchunk;
+    g.ws = nsplit > 1 ? ws : nullptr;
+    gemm_f32_mfma<<<dim3(tn, tm, nsplit), 256, 0, s>>>(g);
+    if (nsplit > 1) {
+        const size_t n = (size_t)M * N;
+        gemm_splitk_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(ws, nsplit, M, N, C, ldc, bias);
+    }
+    return hipGetLastError();
+}

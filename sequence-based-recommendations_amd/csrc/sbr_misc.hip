@@ -1,0 +1,414 @@
+// HBM-bound and small kernels of the hot path (gfx950, wave64): embedding-bag gather (K1) and
+// its scatter-add gradient (K6), softmax / cross-entropy (K8), sampled heads (K10-K12),
+// optimizers (K13), test-path exclusion + top-k (K14).
+#include "sbr_common.h"
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// block-wide reductions (256 threads = 4 waves)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s = fmaxf(s, red[w]);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 embedding-bag gather: xt[t][b][:] = sum_f W_in[X[b][t][f]][:] + bias
+// (sparse_lstm.py:368 / :755 / :1111).  One 16-byte piece per thread: a row of G*Hp floats is
+// read by G*Hp/4 consecutive lanes (coalesced 16 B/lane), written the same way.
+// ---------------------------------------------------------------------------------------
+__global__ void gather_xt_kernel(const f32x4* __restrict__ Win, const f32x4* __restrict__ bias,
+                                 const int* __restrict__ X, f32x4* __restrict__ xt, int T, int Bp, int F, int R4) {
+    const size_t total = (size_t)T * Bp * R4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int f4 = (int)(i % R4);
+        const size_t pos = i / R4;
+        const int b = (int)(pos % Bp), t = (int)(pos / Bp);
+        f32x4 v = bias[f4];
+        const int* ids = X + ((size_t)b * T + t) * F;
+        for (int f = 0; f < F; ++f) v += Win[(size_t)ids[f] * R4 + f4];
+        xt[i] = v;
+    }
+}
+
+hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, const int* X, float* xt, int T, int Bp,
+                            int F, int GHp, int) {
+    const int R4 = GHp / 4;
+    const size_t total = (size_t)T * Bp * R4;
+    const int grid = (int)min((size_t)256 * 16, (total + 255) / 256);
+    gather_xt_kernel<<<grid, 256, 0, s>>>((const f32x4*)Win, (const f32x4*)bias, X, (f32x4*)xt, T, Bp, F, R4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K6 scatter-add: dWin[X[b][t][f]][:] += dxt[t][b][:] for t < len[b]; duplicates accumulate
+// (gradient of the advanced-indexing gather [3P]).  float atomics in L2 (round 1).
+// ---------------------------------------------------------------------------------------
+__global__ void scatter_rows_kernel(float* __restrict__ dWin, const f32x4* __restrict__ dxt, const int* __restrict__ X,
+                                    const int* __restrict__ len, int T, int Bp, int F, int R4) {
+    const size_t total = (size_t)T * Bp * R4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int f4 = (int)(i % R4);
+        const size_t pos = i / R4;
+        const int b = (int)(pos % Bp), t = (int)(pos / Bp);
+        if (t >= len[b]) continue;
+        const f32x4 v = dxt[i];
+        const int* ids = X + ((size_t)b * T + t) * F;
+        for (int f = 0; f < F; ++f) {
+            float* dst = dWin + ((size_t)ids[f] * R4 + f4) * 4;
+            atomicAdd(dst + 0, v[0]); atomicAdd(dst + 1, v[1]); atomicAdd(dst + 2, v[2]); atomicAdd(dst + 3, v[3]);
+        }
+    }
+}
+
+hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, const int* X, const int* len, int T,
+                               int Bp, int F, int GHp) {
+    const int R4 = GHp / 4;
+    const size_t total = (size_t)T * Bp * R4;
+    const int grid = (int)min((size_t)256 * 16, (total + 255) / 256);
+    scatter_rows_kernel<<<grid, 256, 0, s>>>(dWin, (const f32x4*)dxt, X, len, T, Bp, F, R4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K8 full softmax + categorical cross-entropy, forward and backward fused, one workgroup per
+// row (rnn_one_hot.py:65-71): in: raw h.W_out; out (in place): dcost/dlogits.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_cce_kernel(float* __restrict__ logits, const float* __restrict__ bout,
+                                                          const int* __restrict__ target, const float* __restrict__ pop,
+                                                          float* __restrict__ rowcost, int N, int Bglobal) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    float* x = logits + (size_t)r * N;
+    float mx = -INFINITY;
+    for (int n = threadIdx.x; n < N; n += 256) { const float v = x[n] + bout[n]; x[n] = v; mx = fmaxf(mx, v); }
+    mx = block_max(mx, red);
+    float se = 0.0f;
+    for (int n = threadIdx.x; n < N; n += 256) se += expf(x[n] - mx);
+    se = block_sum(se, red);
+    const int y = target[r];
+    const float scale = 1.0f / (pop[r] * (float)Bglobal);
+    const float xy = x[y];
+    __syncthreads();
+    const float inv = 1.0f / se;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float p = expf(x[n] - mx) * inv;
+        x[n] = (p - (n == y ? 1.0f : 0.0f)) * scale;
+    }
+    if (threadIdx.x == 0) rowcost[r] = (logf(se) + mx - xy) * scale;
+}
+
+hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
+                              float* rowcost, int rows, int N, int Bglobal) {
+    if (rows <= 0) return hipSuccess;
+    softmax_cce_kernel<<<rows, 256, 0, s>>>(logits, bout, target, pop, rowcost, N, Bglobal);
+    return hipGetLastError();
+}
+
+// predict path: x += b, optional softmax (rnn_base.py:188-194, rnn_sampling.py:144)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ logits, const float* __restrict__ bout, int N,
+                                                           int do_softmax) {
+    __shared__ float red[4];
+    float* x = logits + (size_t)blockIdx.x * N;
+    float mx = -INFINITY;
+    for (int n = threadIdx.x; n < N; n += 256) { const float v = x[n] + bout[n]; x[n] = v; mx = fmaxf(mx, v); }
+    if (!do_softmax) return;
+    mx = block_max(mx, red);
+    float se = 0.0f;
+    for (int n = threadIdx.x; n < N; n += 256) se += expf(x[n] - mx);
+    se = block_sum(se, red);
+    const float inv = 1.0f / se;
+    for (int n = threadIdx.x; n < N; n += 256) x[n] = expf(x[n] - mx) * inv;
+}
+
+hipError_t launch_softmax_rows(hipStream_t s, float* logits, const float* bout, int rows, int N, int do_softmax) {
+    if (rows <= 0) return hipSuccess;
+    softmax_rows_kernel<<<rows, 256, 0, s>>>(logits, bout, N, do_softmax);
+    return hipGetLastError();
+}
+
+// db[n] = sum_r d[r][n] (+ d reg/db); rnn_one_hot.py:73-77 regularises the output bias only
+__global__ void colsum_bias_kernel(const float* __restrict__ d, int rows, int N, long ld, float* __restrict__ db,
+                                   const float* __restrict__ b, float reg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += d[(size_t)r * ld + n];
+    if (reg > 0.0f) s += 2.0f * reg * b[n];
+    else if (reg < 0.0f) s -= reg * (b[n] > 0.0f ? 1.0f : (b[n] < 0.0f ? -1.0f : 0.0f));
+    db[n] = s;
+}
+// cost += reg * sum(b^2)  or  |reg| * sum|b|   (single workgroup, fixed order)
+__global__ void __launch_bounds__(256) reg_cost_kernel(const float* __restrict__ b, int N, float reg, float* cost) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int n = threadIdx.x; n < N; n += 256) s += reg > 0.0f ? b[n] * b[n] : fabsf(b[n]);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *cost += fabsf(reg) * s;
+}
+
+hipError_t launch_colsum_bias(hipStream_t s, const float* d, int rows, int N, long ld, float* db, const float* b,
+                              float reg, float* cost) {
+    colsum_bias_kernel<<<(N + 255) / 256, 256, 0, s>>>(d, rows, N, ld, db, b, reg);
+    if (reg != 0.0f && cost) reg_cost_kernel<<<1, 256, 0, s>>>(b, N, reg, cost);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) sum_cost_kernel(const float* __restrict__ rowcost, int rows, float* cost) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += 256) s += rowcost[r];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *cost = s;
+}
+hipError_t launch_sum_cost(hipStream_t s, const float* rowcost, int rows, float* cost) {
+    sum_cost_kernel<<<1, 256, 0, s>>>(rowcost, rows, cost);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Sampled heads (BlackoutLayer, sparse_lstm.py:42-54; losses rnn_sampling.py:68-91)
+// ---------------------------------------------------------------------------------------
+__global__ void build_cells_kernel(const int* target, const int* samples, int Bg, int S, int* cells) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < Bg + S) cells[c] = c < Bg ? target[c] : samples[c - Bg];   // T.concatenate((targets, output_cells)) :50
+}
+hipError_t launch_build_cells(hipStream_t s, const int* target, const int* samples, int Bg, int S, int* cells) {
+    build_cells_kernel<<<(Bg + S + 255) / 256, 256, 0, s>>>(target, samples, Bg, S, cells);
+    return hipGetLastError();
+}
+
+// W_out is stored item-major [N][Hp], so W[:, cells] (sparse_lstm.py:52) is a coalesced row gather
+__global__ void gather_rows_kernel(const f32x4* __restrict__ W, const float* __restrict__ b, const int* __restrict__ cells,
+                                   int C, int R4, f32x4* __restrict__ Wc, float* __restrict__ bc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * R4) return;
+    const int c = i / R4, f4 = i % R4;
+    Wc[i] = W[(size_t)cells[c] * R4 + f4];
+    if (f4 == 0) bc[c] = b[cells[c]];
+}
+hipError_t launch_gather_rows(hipStream_t s, const float* W, const float* b, const int* cells, int C, int Hp, float* Wc,
+                              float* bc) {
+    const int R4 = Hp / 4;
+    gather_rows_kernel<<<(C * R4 + 255) / 256, 256, 0, s>>>((const f32x4*)W, b, cells, C, R4, (f32x4*)Wc, bc);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float sigmf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// one workgroup per local row r; act row (C = Bg+S columns) in: h.Wc^T, out: dcost/dact
+__global__ void __launch_bounds__(256) sampled_loss_kernel(float* __restrict__ act, const float* __restrict__ bc,
+                                                           const float* __restrict__ pop, float* __restrict__ rowcost,
+                                                           int Bg, int S, int row_offset, int loss, int Bglobal) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, C = Bg + S, pos = row_offset + r;
+    float* a = act + (size_t)r * C;
+    const float scale = 1.0f / (pop[r] * (float)Bglobal);
+    for (int c = threadIdx.x; c < C; c += 256) a[c] += bc[c];       // + b[output_cells] :54
+    __syncthreads();
+    const float apos = a[pos];
+    float L;
+    if (loss == SBR_LOSS_BLACKOUT) {                                  // rnn_sampling.py:68-72
+        float mx = -INFINITY;
+        for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, a[c]);
+        mx = block_max(mx, red);
+        float se = 0.0f;
+        for (int c = threadIdx.x; c < C; c += 256) se += expf(a[c] - mx);
+        se = block_sum(se, red);
+        const float inv = 1.0f / se;
+        const float ppos = expf(apos - mx) * inv;
+        // sum_k dLdp_k p_k  and  sum of -log(1-p) over the negatives
+        float dot = 0.0f, lneg = 0.0f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float p = expf(a[c] - mx) * inv;
+            if (c >= Bg) { dot += p / (1.0f - p); lneg -= logf(1.0f - p); }
+        }
+        dot = block_sum(dot, red) - 1.0f;                             // positive: (-1/p_pos) * p_pos
+        lneg = block_sum(lneg, red);
+        L = -logf(ppos) + lneg;
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float p = expf(a[c] - mx) * inv;
+            float dldp = 0.0f;
+            if (c >= Bg) dldp = 1.0f / (1.0f - p);
+            if (c == pos) dldp += -1.0f / p;
+            a[c] = p * (dldp - dot) * scale;
+        }
+    } else {
+        float lsum = 0.0f, dpos = 0.0f;
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (c == pos) continue;                                   // written after the reduction
+            float da = 0.0f;
+            if (c >= Bg) {
+                const float v = a[c], diff = v - apos;
+                if (loss == SBR_LOSS_BPR) {                           // :80-84  -log(sigmoid(-diff)) = softplus(diff)
+                    lsum += fmaxf(diff, 0.0f) + log1pf(expf(-fabsf(diff)));
+                    const float dd = sigmf(diff) / (float)S;
+                    da = dd; dpos += dd;
+                } else {                                              // TOP1 :86-91
+                    const float s1 = sigmf(diff), s2 = sigmf(v * v);
+                    lsum += s1 + s2;
+                    const float d1 = s1 * (1.0f - s1) / (float)S;
+                    da = d1 + s2 * (1.0f - s2) * 2.0f * v / (float)S; dpos += d1;
+                }
+            }
+            a[c] = da * scale;
+        }
+        lsum = block_sum(lsum, red);
+        dpos = block_sum(dpos, red);
+        L = lsum / (float)S;
+        if (threadIdx.x == 0) a[pos] = -dpos * scale;
+    }
+    if (threadIdx.x == 0) rowcost[r] = L * scale;
+}
+
+hipError_t launch_sampled_loss(hipStream_t s, float* act, const float* bc, const float* pop, float* rowcost, int rows,
+                               int Bg, int S, int row_offset, int loss, int Bglobal) {
+    if (rows <= 0) return hipSuccess;
+    sampled_loss_kernel<<<rows, 256, 0, s>>>(act, bc, pop, rowcost, Bg, S, row_offset, loss, Bglobal);
+    return hipGetLastError();
+}
+
+// dW_out^T[cells[c]][:] += dWc[c][:], db_out[cells[c]] += dbc[c]; duplicates accumulate [3P]
+__global__ void scatter_cells_kernel(float* __restrict__ dW, float* __restrict__ db, const float* __restrict__ dWc,
+                                     const float* __restrict__ dbc, const int* __restrict__ cells, int C, int Hp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * Hp) return;
+    const int c = i / Hp, k = i % Hp;
+    atomicAdd(&dW[(size_t)cells[c] * Hp + k], dWc[i]);
+    if (k == 0) atomicAdd(&db[cells[c]], dbc[c]);
+}
+hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float* dWc, const float* dbc, const int* cells,
+                                int C, int Hp) {
+    scatter_cells_kernel<<<(C * Hp + 255) / 256, 256, 0, s>>>(dW, db, dWc, dbc, cells, C, Hp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K13 optimizers: lasagne.updates.{adagrad,adadelta,rmsprop,nesterov_momentum,adam} [3P]
+// (update_manager.py:24-82), applied densely to the whole flat parameter section.
+// ---------------------------------------------------------------------------------------
+__global__ void update_kernel(int updater, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s0,
+                              float* __restrict__ s1, size_t n, float lr, float rho, float b1, float b2, float a_t) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i];
+        if (updater == SBR_UPD_ADAGRAD) {                 // eps 1e-6
+            const float acc = s0[i] + gi * gi;
+            s0[i] = acc; pi -= lr * gi / sqrtf(acc + 1e-6f);
+        } else if (updater == SBR_UPD_RMSPROP) {          // eps 1e-6
+            const float acc = rho * s0[i] + (1.0f - rho) * gi * gi;
+            s0[i] = acc; pi -= lr * gi / sqrtf(acc + 1e-6f);
+        } else if (updater == SBR_UPD_ADADELTA) {         // eps 1e-6
+            const float acc = rho * s0[i] + (1.0f - rho) * gi * gi;
+            const float upd = gi * sqrtf(s1[i] + 1e-6f) / sqrtf(acc + 1e-6f);
+            s0[i] = acc; pi -= lr * upd;
+            s1[i] = rho * s1[i] + (1.0f - rho) * upd * upd;
+        } else if (updater == SBR_UPD_NESTEROV) {         // sgd + apply_nesterov_momentum
+            const float v = rho * s0[i] - lr * gi;
+            s0[i] = v; pi += rho * v - lr * gi;
+        } else {                                          // adam, eps 1e-8
+            const float m = b1 * s0[i] + (1.0f - b1) * gi;
+            const float v = b2 * s1[i] + (1.0f - b2) * gi * gi;
+            s0[i] = m; s1[i] = v;
+            pi -= a_t * m / (sqrtf(v) + 1e-8f);
+        }
+        p[i] = pi;
+    }
+}
+
+hipError_t launch_update(hipStream_t s, int updater, float* p, const float* g, float* s0, float* s1, size_t n, float lr,
+                         float rho, float b1, float b2, long t) {
+    float a_t = 0.0f;
+    if (updater == SBR_UPD_ADAM)
+        a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    const int grid = (int)min((size_t)256 * 16, (n + 255) / 256);
+    update_kernel<<<grid, 256, 0, s>>>(updater, p, g, s0, s1, n, lr, rho, b1, b2, a_t);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K14 test path: exclude seen items, ordered top-k (rnn_base.py:196-211)
+// ---------------------------------------------------------------------------------------
+__global__ void exclude_seen_kernel(float* __restrict__ scores, const int* __restrict__ X, const int* __restrict__ len,
+                                    int rows, int T, int F, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * T) return;
+    const int r = i / T, t = i % T;
+    if (t < len[r]) scores[(size_t)r * N + X[((size_t)r * T + t) * F]] = -INFINITY;   // exclude[i, item ids] = 1
+}
+hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F, int N) {
+    if (rows <= 0) return hipSuccess;
+    exclude_seen_kernel<<<(rows * T + 255) / 256, 256, 0, s>>>(scores, X, len, rows, T, F, N);
+    return hipGetLastError();
+}
+
+// k rounds of arg-max per row; ties -> lowest id; destroys the row (winners set to -inf)
+__global__ void __launch_bounds__(256) topk_kernel(float* __restrict__ scores, int N, int k, int* __restrict__ ids) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    float* x = scores + (size_t)blockIdx.x * N;
+    for (int it = 0; it < k; ++it) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int n = threadIdx.x; n < N; n += 256) {
+            const float v = x[n];
+            if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = bv; ri[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+            ids[(size_t)blockIdx.x * k + it] = bi;
+            if (bi < N) x[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_topk(hipStream_t s, float* scores, int rows, int N, int k, int* ids) {
+    if (rows <= 0) return hipSuccess;
+    topk_kernel<<<rows, 256, 0, s>>>(scores, N, k, ids);
+    return hipGetLastError();
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+hipError_t launch_fill(hipStream_t s, float* p, float v, size_t n) {
+    const int grid = (int)min((size_t)256 * 16, (n + 255) / 256);
+    fill_kernel<<<grid, 256, 0, s>>>(p, v, n);
+    return hipGetLastError();
+}

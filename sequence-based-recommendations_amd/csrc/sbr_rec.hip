@@ -1,0 +1,593 @@
+// Recurrent forward / BPTT kernels for gfx950 (CDNA4, wave64).
+//
+// Math follows the reference's scan step functions (neural_networks/sparse_lstm.py:377-425
+// LSTM, :764-805 GRU, :1120-1152 Vanilla); the backward is the hand-derived BPTT pinned by
+// oracle/rnn_oracle.py (the reference obtains it from theano.grad through scan).
+//
+// Design (one workgroup = one 16-row tile of the batch for ALL T steps, no inter-workgroup sync):
+//   * v_mfma_f32_16x16x4_f32 computes D[unit][row] = sum_k W_hid[k][unit] * h[row][k]:
+//     the A operand is a W_hid fragment (register-resident for Hp <= 128: one 16-unit tile x G
+//     gates x Hp/4 k-steps per wave = 96 VGPRs for GRU-128), the B operand is h_{t-1} read from
+//     LDS (written by all waves at the end of the previous step, double-buffered: one
+//     __syncthreads per step).  k is permuted (lane group q owns k in [q*Hp/4, (q+1)*Hp/4)) so a
+//     lane's B values are contiguous in LDS (ds_read_b128).
+//   * With D[unit][row], the accumulator layout gives every lane 4 CONSECUTIVE hidden units of
+//     ONE batch row -> xt loads, state, and all saved-activation stores are 16-byte accesses in
+//     the natural [t][row][unit] layout; gate math stays in registers (c_t, h_t never leave the
+//     wave except h_t -> LDS for the next step's B operand).
+//   * Rows are left-aligned (rnn_one_hot.py:90-101): steps t >= len(row) copy state
+//     (sparse_lstm.py:422-423); steps beyond the tile's longest row skip the MFMA work.
+#include "sbr_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CELL_LSTM 0
+#define CELL_GRU 1
+#define CELL_VANILLA 2
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float clipf(float x, float c) { return c > 0.0f ? fminf(fmaxf(x, -c), c) : x; }
+template <int CELL> struct Gates { static constexpr int G = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1); };
+
+// ---------------------------------------------------------------------------------------
+// Scalar cell math shared by the MFMA kernels and the triage ("simple") kernels
+// ---------------------------------------------------------------------------------------
+// Forward: a[g] = (h_prev . W_hid)[g], x[g] = xt[g].  Updates h/c in place (masked rows copy),
+// writes the values saved for BPTT into sv[0..3].
+template <int CELL>
+__device__ __forceinline__ void cell_forward(const float* x, const float* a, bool m, float& h, float& c,
+                                             float pi, float pf, float po, float* sv) {
+    if (CELL == CELL_LSTM) {
+        float i = sigm(x[0] + a[0] + c * pi);                 // sparse_lstm.py:397-402
+        float f = sigm(x[1] + a[1] + c * pf);
+        float g = tanhf(x[2] + a[2]);
+        float cn = f * c + i * g;                             // :407
+        float o = sigm(x[3] + a[3] + cn * po);                // :409-411
+        float hn = o * tanhf(cn);                             // :414
+        sv[0] = i; sv[1] = f; sv[2] = g; sv[3] = o;
+        c = m ? cn : c; h = m ? hn : h;                       // :422-423
+    } else if (CELL == CELL_GRU) {
+        float r = sigm(a[0] + x[0]);                          // :780-783
+        float u = sigm(a[1] + x[1]);
+        float cc = tanhf(x[2] + r * a[2]);                    // :786-792
+        float hn = (1.0f - u) * h + u * cc;                   // :795
+        sv[0] = r; sv[1] = u; sv[2] = cc; sv[3] = a[2];
+        h = m ? hn : h;                                       // :803
+    } else {
+        float hn = tanhf(x[0] + a[0]);                        // :1133-1143
+        h = m ? hn : h;                                       // :1150
+    }
+}
+
+// Backward of one step for one (row, unit).  In: dh, dc = grads wrt h_t, c_t; saved values.
+// Out: dxi[g], dhi[g] (grad wrt xt and wrt hid_input, both clipped), dh/dc updated to the part
+// that flows to step t-1 WITHOUT the dhi.W^T term (added by the caller); peephole partials.
+template <int CELL>
+__device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, float& dc, const float* sv, float hprev,
+                                              float cprev, float cnew, float hnew, float pi, float pf, float po,
+                                              float* dxi, float* dhi, float* dpeep) {
+    float dhn = m ? dh : 0.0f, dhp = m ? 0.0f : dh;
+    if (CELL == CELL_LSTM) {
+        float i = sv[0], f = sv[1], g = sv[2], o = sv[3];
+        float dcn = m ? dc : 0.0f, dcp = m ? 0.0f : dc;
+        float tc = tanhf(cnew);
+        float dzo = dhn * tc * o * (1.0f - o);
+        dcn += dhn * o * (1.0f - tc * tc) + dzo * po;
+        float dzi = dcn * g * i * (1.0f - i);
+        float dzf = dcn * cprev * f * (1.0f - f);
+        float dac = dcn * i * (1.0f - g * g);
+        dpeep[0] = dzi * cprev; dpeep[1] = dzf * cprev; dpeep[2] = dzo * cnew;
+        dxi[0] = dhi[0] = clipf(dzi, clip); dxi[1] = dhi[1] = clipf(dzf, clip);
+        dxi[2] = dhi[2] = clipf(dac, clip); dxi[3] = dhi[3] = clipf(dzo, clip);
+        dc = dcp + dcn * f + dzi * pi + dzf * pf;
+        dh = dhp;
+    } else if (CELL == CELL_GRU) {
+        float r = sv[0], u = sv[1], cc = sv[2], hic = sv[3];
+        float du = dhn * (cc - hprev);
+        float dq = clipf(dhn * u * (1.0f - cc * cc), clip);
+        float dzr = dq * hic * r * (1.0f - r);
+        float dzu = du * u * (1.0f - u);
+        dxi[0] = clipf(dzr, clip); dxi[1] = clipf(dzu, clip); dxi[2] = clipf(dq, clip);
+        dhi[0] = dxi[0]; dhi[1] = dxi[1]; dhi[2] = clipf(dq * r, clip);
+        dh = dhp + dhn * (1.0f - u);
+    } else {
+        float dq = clipf(dhn * (1.0f - hnew * hnew), clip);
+        dxi[0] = dhi[0] = clipf(dq, clip);
+        dh = dhp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA persistent forward.  KS_RES > 0: Hp = 4*KS_RES compile-time, W_hid fragments in VGPRs.
+// KS_RES == 0: runtime Hp, fragments streamed from L2 every step.  NT unit tiles per wave.
+// ---------------------------------------------------------------------------------------
+template <int CELL, int NT, int KS_RES>
+__global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(RecArgs a) {
+    constexpr int G = Gates<CELL>::G;
+    const int Hp = KS_RES > 0 ? 4 * KS_RES : a.Hp;
+    const int KS = Hp / 4, GHp = G * Hp, LDH = Hp + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][16][LDH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + j;
+    const int T = a.T, Bp = a.Bp;
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    // register-resident A fragments: W[n][g][kk] = W_hid[q*KS+kk][g*Hp + tile*16 + j]
+    float W[NT][G][KS_RES > 0 ? KS_RES : 1];
+    if (KS_RES > 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int kk = 0; kk < KS_RES; ++kk)
+                    W[n][g][kk] = a.Whid[(size_t)(q * KS + kk) * GHp + g * Hp + (wave * NT + n) * 16 + j];
+    }
+
+    f32x4 h[NT], c[NT], pi[NT], pf[NT], po[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int u0 = (wave * NT + n) * 16 + q * 4;
+        h[n] = *(const f32x4*)&a.hinit[u0];
+        c[n] = f32x4{0, 0, 0, 0}; pi[n] = c[n]; pf[n] = c[n]; po[n] = c[n];
+        if (CELL == CELL_LSTM) {
+            c[n] = *(const f32x4*)&a.cinit[u0];
+            pi[n] = *(const f32x4*)&a.peep[u0]; pf[n] = *(const f32x4*)&a.peep[Hp + u0];
+            po[n] = *(const f32x4*)&a.peep[2 * Hp + u0];
+            *(f32x4*)&a.cs[(size_t)row * Hp + u0] = c[n];
+        }
+        *(f32x4*)&a.hs[(size_t)row * Hp + u0] = h[n];
+        *(f32x4*)&smem[j * LDH + u0] = h[n];
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        if (t < tmax) {                                           // workgroup-uniform
+            f32x4 x[NT][G];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    x[n][g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4];
+            const float* hb = smem + (t & 1) * 16 * LDH + j * LDH + q * KS;
+            f32x4 acc[NT][G];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[n][g] = f32x4{0, 0, 0, 0};
+            if (KS_RES > 0) {
+                f32x4 hv[KS_RES / 4 > 0 ? KS_RES / 4 : 1];
+#pragma unroll
+                for (int k4 = 0; k4 < KS_RES / 4; ++k4) hv[k4] = *(const f32x4*)&hb[4 * k4];
+#pragma unroll
+                for (int kk = 0; kk < KS_RES; ++kk)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+                            acc[n][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][g][kk], hv[kk >> 2][kk & 3], acc[n][g], 0, 0, 0);
+            } else {
+                for (int kc = 0; kc < KS; kc += 4) {
+                    const f32x4 hv = *(const f32x4*)&hb[kc];
+                    const float* wrow = a.Whid + (size_t)(q * KS + kc) * GHp + wave * NT * 16 + j;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int g = 0; g < G; ++g)
+                                acc[n][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[(size_t)kk * GHp + g * Hp + n * 16], hv[kk],
+                                                                                 acc[n][g], 0, 0, 0);
+                }
+            }
+            const bool m = t < mylen;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int u0 = (wave * NT + n) * 16 + q * 4;
+                f32x4 sv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xs[G], as[G], s[4];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) { xs[g] = x[n][g][e]; as[g] = acc[n][g][e]; }
+                    float hh = h[n][e], cc = c[n][e];
+                    cell_forward<CELL>(xs, as, m, hh, cc, pi[n][e], pf[n][e], po[n][e], s);
+                    h[n][e] = hh; c[n][e] = cc;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
+                }
+                if (CELL != CELL_VANILLA) {
+                    const size_t o = ((size_t)t * Bp + row) * Hp + u0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][o] = sv[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int u0 = (wave * NT + n) * 16 + q * 4;
+            const size_t o = ((size_t)(t + 1) * Bp + row) * Hp + u0;
+            *(f32x4*)&a.hs[o] = h[n];
+            if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c[n];
+        }
+        if (t + 1 < tmax) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                *(f32x4*)&smem[((t + 1) & 1) * 16 * LDH + j * LDH + (wave * NT + n) * 16 + q * 4] = h[n];
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA persistent backward (BPTT).  D[unit k][row] = sum_j W_hid[k][j] * dhi[row][j]:
+// A = W_hid rows of the wave's unit tile (JS_RES > 0: register resident, JS = G*Hp/4 j-steps),
+// B = this step's dhi tile in LDS.  dxt/dhi rows are streamed out for the scatter-add and the
+// split-K weight-gradient GEMM (dW_hid = hs_prev^T . dhi), which run after the chain.
+// ---------------------------------------------------------------------------------------
+template <int CELL, int NT, int KS_RES>
+__global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(RecArgs a, int dbuf) {
+    constexpr int G = Gates<CELL>::G;
+    constexpr int JS_RES = G * KS_RES;
+    const int Hp = KS_RES > 0 ? 4 * KS_RES : a.Hp;
+    const int GHp = G * Hp, JS = GHp / 4, LDB = GHp + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [dbuf ? 2 : 1][16][LDB]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + j;
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    // A fragments: Wb[n][jj] = W_hid[tile*16 + j][q*JS + jj]
+    float Wb[NT][JS_RES > 0 ? JS_RES : 1];
+    if (KS_RES > 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j4 = 0; j4 < JS_RES / 4; ++j4) {
+                const f32x4 w = *(const f32x4*)&a.Whid[(size_t)((wave * NT + n) * 16 + j) * GHp + q * JS + 4 * j4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Wb[n][4 * j4 + e] = w[e];
+            }
+    }
+
+    f32x4 dh[NT], dc[NT], pi[NT], pf[NT], po[NT];
+    f32x4 sdb[NT][G], sdp[NT][3];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int u0 = (wave * NT + n) * 16 + q * 4;
+        const f32x4 z = f32x4{0, 0, 0, 0};
+        dh[n] = a.dh_last ? *(const f32x4*)&a.dh_last[(size_t)row * Hp + u0] : z;
+        dc[n] = z; pi[n] = z; pf[n] = z; po[n] = z;
+        if (CELL == CELL_LSTM) {
+            pi[n] = *(const f32x4*)&a.peep[u0]; pf[n] = *(const f32x4*)&a.peep[Hp + u0];
+            po[n] = *(const f32x4*)&a.peep[2 * Hp + u0];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) sdb[n][g] = z;
+        sdp[n][0] = z; sdp[n][1] = z; sdp[n][2] = z;
+    }
+
+    for (int t = T - 1; t >= 0; --t) {
+        if (a.dh_ext) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                dh[n] += *(const f32x4*)&a.dh_ext[((size_t)t * Bp + row) * Hp + (wave * NT + n) * 16 + q * 4];
+        }
+        if (t >= tmax) {                                          // whole tile masked: zero rows
+            const f32x4 z = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const size_t o = ((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4;
+                    *(f32x4*)&a.dxt[o] = z;
+                    if (CELL == CELL_GRU) *(f32x4*)&a.dhi[o] = z;
+                }
+            continue;
+        }
+        const bool m = t < mylen;
+        float* lds = smem + (dbuf ? (t & 1) : 0) * 16 * LDB;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int u0 = (wave * NT + n) * 16 + q * 4;
+            const size_t o = ((size_t)t * Bp + row) * Hp + u0;
+            const size_t o1 = ((size_t)(t + 1) * Bp + row) * Hp + u0;
+            f32x4 sv[4], hprev, cprev, cnew, hnew;
+            const f32x4 z = f32x4{0, 0, 0, 0};
+            sv[0] = sv[1] = sv[2] = sv[3] = z; cprev = z; cnew = z; hnew = z;
+            hprev = *(const f32x4*)&a.hs[o];
+            if (CELL != CELL_VANILLA) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = *(const f32x4*)&a.g[k][o];
+            }
+            if (CELL == CELL_LSTM) { cprev = *(const f32x4*)&a.cs[o]; cnew = *(const f32x4*)&a.cs[o1]; }
+            if (CELL == CELL_VANILLA) hnew = *(const f32x4*)&a.hs[o1];
+            f32x4 vxi[G], vhi[G];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s[4] = {sv[0][e], sv[1][e], sv[2][e], sv[3][e]};
+                float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+                float dhh = dh[n][e], dcc = dc[n][e];
+                cell_backward<CELL>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[n][e], pf[n][e],
+                                    po[n][e], dxi, dhi, dp);
+                dh[n][e] = dhh; dc[n][e] = dcc;
+#pragma unroll
+                for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[n][g][e] += dxi[g]; }
+                sdp[n][0][e] += dp[0]; sdp[n][1][e] += dp[1]; sdp[n][2][e] += dp[2];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const size_t og = ((size_t)t * Bp + row) * GHp + g * Hp + u0;
+                *(f32x4*)&a.dxt[og] = vxi[g];
+                if (CELL == CELL_GRU) *(f32x4*)&a.dhi[og] = vhi[g];
+                *(f32x4*)&lds[j * LDB + g * Hp + u0] = vhi[g];
+            }
+        }
+        __syncthreads();
+        const float* db = lds + j * LDB + q * JS;
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { acc[n][0] = f32x4{0, 0, 0, 0}; acc[n][1] = f32x4{0, 0, 0, 0}; }
+        if (KS_RES > 0) {
+#pragma unroll
+            for (int j4 = 0; j4 < JS_RES / 4; ++j4) {
+                const f32x4 bv = *(const f32x4*)&db[4 * j4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[n][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wb[n][4 * j4 + e], bv[e], acc[n][e & 1], 0, 0, 0);
+            }
+        } else {
+            for (int j4 = 0; j4 < JS / 4; ++j4) {
+                const f32x4 bv = *(const f32x4*)&db[4 * j4];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 w = *(const f32x4*)&a.Whid[(size_t)((wave * NT + n) * 16 + j) * GHp + q * JS + 4 * j4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[n][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], bv[e], acc[n][e & 1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dh[n] += acc[n][0] + acc[n][1];
+        if (!dbuf) __syncthreads();
+    }
+
+    // per-workgroup partial sums -> part[block][ G*Hp | dpi | dpf | dpo | dcinit | dhinit ]
+    float* part = a.part + (size_t)blockIdx.x * (GHp + 5 * Hp);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int u0 = (wave * NT + n) * 16 + q * 4;
+        f32x4 v[G + 5];
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[g] = sdb[n][g];
+        v[G] = sdp[n][0]; v[G + 1] = sdp[n][1]; v[G + 2] = sdp[n][2]; v[G + 3] = dc[n]; v[G + 4] = dh[n];
+#pragma unroll
+        for (int k = 0; k < G + 5; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = v[k][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+                v[k][e] = s;
+            }
+        if (j == 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) *(f32x4*)&part[g * Hp + u0] = v[g];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) *(f32x4*)&part[GHp + k * Hp + u0] = v[G + k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Triage ("simple") kernels: one launch per time step, one thread per (row, unit), plain FMAs.
+// Same scalar cell math, none of the MFMA/LDS machinery (SBR_FLAG_SIMPLE_REC).
+// ---------------------------------------------------------------------------------------
+template <int CELL>
+__global__ void rec_fwd_step_simple(RecArgs a, int t) {
+    constexpr int G = Gates<CELL>::G;
+    const int Hp = a.Hp, GHp = G * Hp, Bp = a.Bp;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Bp * Hp) return;
+    const int row = idx / Hp, k = idx % Hp;
+    const size_t o0 = ((size_t)t * Bp + row) * Hp, o1 = ((size_t)(t + 1) * Bp + row) * Hp;
+    float h, c = 0.f;
+    if (t == 0) {
+        h = a.hinit[k]; a.hs[(size_t)row * Hp + k] = h;
+        if (CELL == CELL_LSTM) { c = a.cinit[k]; a.cs[(size_t)row * Hp + k] = c; }
+    } else {
+        h = a.hs[o0 + k];
+        if (CELL == CELL_LSTM) c = a.cs[o0 + k];
+    }
+    float acc[G], x[G], s[4];
+    for (int g = 0; g < G; ++g) {
+        float v = 0.f;
+        for (int kk = 0; kk < Hp; ++kk) {
+            const float hv = t == 0 ? a.hinit[kk] : a.hs[o0 + kk];
+            v = fmaf(hv, a.Whid[(size_t)kk * GHp + g * Hp + k], v);
+        }
+        acc[g] = v; x[g] = a.xt[((size_t)t * Bp + row) * GHp + g * Hp + k];
+    }
+    float pi = 0.f, pf = 0.f, po = 0.f;
+    if (CELL == CELL_LSTM) { pi = a.peep[k]; pf = a.peep[Hp + k]; po = a.peep[2 * Hp + k]; }
+    cell_forward<CELL>(x, acc, t < a.len[row], h, c, pi, pf, po, s);
+    if (CELL != CELL_VANILLA)
+        for (int q = 0; q < 4; ++q) a.g[q][o0 + k] = s[q];
+    a.hs[o1 + k] = h;
+    if (CELL == CELL_LSTM) a.cs[o1 + k] = c;
+}
+
+// elementwise part of one backward step; dhstate/dcstate [Bp][Hp] carry dh, dc between launches
+template <int CELL>
+__global__ void rec_bwd_elem_simple(RecArgs a, int t, float* dhstate, float* dcstate) {
+    constexpr int G = Gates<CELL>::G;
+    const int Hp = a.Hp, GHp = G * Hp, Bp = a.Bp;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Bp * Hp) return;
+    const int row = idx / Hp, k = idx % Hp;
+    const size_t o0 = ((size_t)t * Bp + row) * Hp + k, o1 = ((size_t)(t + 1) * Bp + row) * Hp + k;
+    float dh = dhstate[idx], dc = dcstate[idx];
+    if (t == a.T - 1) { dh = a.dh_last ? a.dh_last[idx] : 0.f; dc = 0.f; }
+    if (a.dh_ext) dh += a.dh_ext[o0];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CELL != CELL_VANILLA)
+        for (int q = 0; q < 4; ++q) s[q] = a.g[q][o0];
+    float cprev = 0.f, cnew = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
+    if (CELL == CELL_LSTM) { cprev = a.cs[o0]; cnew = a.cs[o1]; pi = a.peep[k]; pf = a.peep[Hp + k]; po = a.peep[2 * Hp + k]; }
+    float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+    cell_backward<CELL>(t < a.len[row], a.clip, dh, dc, s, a.hs[o0], cprev, cnew, a.hs[o1], pi, pf, po, dxi, dhi, dp);
+    for (int g = 0; g < G; ++g) {
+        const size_t og = ((size_t)t * Bp + row) * GHp + g * Hp + k;
+        a.dxt[og] = dxi[g];
+        if (CELL == CELL_GRU) a.dhi[og] = dhi[g];
+        atomicAdd(&a.part[g * Hp + k], dxi[g]);
+    }
+    if (CELL == CELL_LSTM) {
+        atomicAdd(&a.part[GHp + k], dp[0]); atomicAdd(&a.part[GHp + Hp + k], dp[1]); atomicAdd(&a.part[GHp + 2 * Hp + k], dp[2]);
+    }
+    dhstate[idx] = dh; dcstate[idx] = dc;
+}
+
+template <int CELL>
+__global__ void rec_bwd_matvec_simple(RecArgs a, int t, float* dhstate, float* dcstate) {
+    constexpr int G = Gates<CELL>::G;
+    const int Hp = a.Hp, GHp = G * Hp, Bp = a.Bp;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Bp * Hp) return;
+    const int row = idx / Hp, k = idx % Hp;
+    const float* d = a.dhi + ((size_t)t * Bp + row) * GHp;
+    float v = 0.f;
+    for (int jj = 0; jj < GHp; ++jj) v = fmaf(d[jj], a.Whid[(size_t)k * GHp + jj], v);
+    const float dh = dhstate[idx] + v;
+    dhstate[idx] = dh;
+    if (t == 0) {   // init-state gradients: column sums over rows
+        atomicAdd(&a.part[GHp + 4 * Hp + k], dh);
+        if (CELL == CELL_LSTM) atomicAdd(&a.part[GHp + 3 * Hp + k], dcstate[idx]);
+    }
+}
+
+__global__ void rec_reduce_partials(const float* part, int nblk, int G, int Hp, float* db, float* dpeep,
+                                    float* dcinit, float* dhinit) {
+    const int GHp = G * Hp, n = GHp + 5 * Hp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + e];   // fixed order: deterministic
+    if (e < GHp) { db[e] = s; return; }
+    const int k = (e - GHp) / Hp, u = (e - GHp) % Hp;
+    if (k < 3) { if (dpeep) dpeep[k * Hp + u] = s; }
+    else if (k == 3) { if (dcinit) dcinit[u] = s; }
+    else dhinit[u] = s;
+}
+
+hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk, int G, int Hp, int cell, float* db,
+                                      float* dpeep, float* dcinit, float* dhinit) {
+    const int n = G * Hp + 5 * Hp;
+    const bool lstm = cell == SBR_CELL_LSTM;
+    rec_reduce_partials<<<(n + 255) / 256, 256, 0, s>>>(part, nblk, G, Hp, db, lstm ? dpeep : nullptr,
+                                                        lstm ? dcinit : nullptr, dhinit);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------
+template <int CELL>
+static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) {
+    const int Hp = a.Hp;
+    if (simple) {
+        const int n = a.Bp * Hp, blk = 256, grid = (n + blk - 1) / blk;
+        for (int t = 0; t < a.T; ++t) rec_fwd_step_simple<CELL><<<grid, blk, 0, s>>>(a, t);
+        return hipGetLastError();
+    }
+    const int nblk = a.Bp / 16;
+    const size_t lds = 2 * 16 * (size_t)(Hp + 4) * sizeof(float);
+#define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
+        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        KERNEL<<<GRID, BLOCK, LDS, s>>>(__VA_ARGS__); } while (0)
+#define FWD_RES(KS) LAUNCH_DYN((rec_fwd_mfma<CELL, 1, KS>), nblk, (Hp / 16) * 64, lds, a)
+    if (Hp == 16) FWD_RES(4);
+    else if (Hp == 32) FWD_RES(8);
+    else if (Hp == 64) FWD_RES(16);
+    else if (Hp == 128) FWD_RES(32);
+    else {
+        const int tiles = Hp / 16;
+        if (tiles <= 16) LAUNCH_DYN((rec_fwd_mfma<CELL, 1, 0>), nblk, tiles * 64, lds, a);
+        else if (tiles <= 32) LAUNCH_DYN((rec_fwd_mfma<CELL, 2, 0>), nblk, (tiles / 2) * 64, lds, a);
+        else if (tiles <= 64) LAUNCH_DYN((rec_fwd_mfma<CELL, 4, 0>), nblk, (tiles / 4) * 64, lds, a);
+        else return hipErrorInvalidValue;
+    }
+#undef FWD_RES
+    return hipGetLastError();
+}
+
+hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple) {
+    switch (a.cell) {
+        case SBR_CELL_LSTM: return launch_fwd_cell<CELL_LSTM>(s, a, simple);
+        case SBR_CELL_GRU: return launch_fwd_cell<CELL_GRU>(s, a, simple);
+        default: return launch_fwd_cell<CELL_VANILLA>(s, a, simple);
+    }
+}
+
+template <int CELL>
+static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) {
+    const int Hp = a.Hp, G = Gates<CELL>::G, GHp = G * Hp;
+    const int nblk = a.Bp / 16;
+    if (simple) {
+        // part block 0 accumulates (atomics); other blocks stay zero
+        hipError_t e = hipMemsetAsync(a.part, 0, (size_t)nblk * (GHp + 5 * Hp) * sizeof(float), s);
+        if (e != hipSuccess) return e;
+        float* st = nullptr;   // dh/dc carry: reuse the tail of the dhi/dxt-independent scratch: allocate ad hoc
+        e = hipMalloc(&st, (size_t)2 * a.Bp * Hp * sizeof(float));
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(st, 0, (size_t)2 * a.Bp * Hp * sizeof(float), s);
+        const int n = a.Bp * Hp, blk = 256, grid = (n + blk - 1) / blk;
+        for (int t = a.T - 1; t >= 0; --t) {
+            rec_bwd_elem_simple<CELL><<<grid, blk, 0, s>>>(a, t, st, st + (size_t)a.Bp * Hp);
+            rec_bwd_matvec_simple<CELL><<<grid, blk, 0, s>>>(a, t, st, st + (size_t)a.Bp * Hp);
+        }
+        e = hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(st);
+        return e;
+    }
+    const size_t one = 16 * (size_t)(GHp + 4) * sizeof(float);
+    const int dbuf = (2 * one <= 150 * 1024) ? 1 : 0;
+    const size_t lds = dbuf ? 2 * one : one;
+#define BWD_RES(KS) LAUNCH_DYN((rec_bwd_mfma<CELL, 1, KS>), nblk, (Hp / 16) * 64, lds, a, dbuf)
+    if (Hp == 16) BWD_RES(4);
+    else if (Hp == 32) BWD_RES(8);
+    else if (Hp == 64) BWD_RES(16);
+    else if (Hp == 128) BWD_RES(32);
+    else {
+        const int tiles = Hp / 16;
+        if (tiles <= 16) LAUNCH_DYN((rec_bwd_mfma<CELL, 1, 0>), nblk, tiles * 64, lds, a, dbuf);
+        else if (tiles <= 32) LAUNCH_DYN((rec_bwd_mfma<CELL, 2, 0>), nblk, (tiles / 2) * 64, lds, a, dbuf);
+        else if (tiles <= 64) LAUNCH_DYN((rec_bwd_mfma<CELL, 4, 0>), nblk, (tiles / 4) * 64, lds, a, dbuf);
+        else return hipErrorInvalidValue;
+    }
+#undef BWD_RES
+    return hipGetLastError();
+}
+
+hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple) {
+    switch (a.cell) {
+        case SBR_CELL_LSTM: return launch_bwd_cell<CELL_LSTM>(s, a, simple);
+        case SBR_CELL_GRU: return launch_bwd_cell<CELL_GRU>(s, a, simple);
+        default: return launch_bwd_cell<CELL_VANILLA>(s, a, simple);
+    }
+}

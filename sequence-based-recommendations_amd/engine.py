@@ -1,0 +1,343 @@
+"""ctypes binding of libsbr_rnn.so + `RNNEngine`, the object that stands where the
+reference keeps its three Theano callables and the Lasagne parameter list
+(neural_networks/rnn_base.py:185 train_function, :196-211 test_function, :188-194
+predict_function, :476/:515 get/set_all_param_values).
+
+There is NO CPU path here: if the HIP library is missing or no GPU is visible the
+constructor raises.  PyTorch is used for plumbing only (device arena allocation, current
+stream, torch.distributed all-reduce of the gradient section in data-parallel runs).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
+
+SBR_MAX_LAYERS = 4
+SBR_ABI_VERSION = 1
+SBR_N_PHASES = 8
+PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
+
+CELLS = {"LSTM": 0, "GRU": 1, "Vanilla": 2}                     # --r_t, recurrent_layers.py:9
+LOSSES = {"CCE": 0, "Blackout": 1, "BPR": 2, "TOP1": 3}          # --loss, command_parser.py:43
+UPDATERS = {"adagrad": 0, "adadelta": 1, "rmsprop": 2, "nesterov": 3, "adam": 4}   # --u_m
+FLAG_SIMPLE_REC = 1
+FLAG_SIMPLE_GEMM = 2
+
+
+class SbrConfig(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("cell", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("layers", ctypes.c_int32 * SBR_MAX_LAYERS), ("n_items", ctypes.c_int32),
+                ("input_size", ctypes.c_int32), ("n_feat", ctypes.c_int32), ("max_length", ctypes.c_int32),
+                ("batch_size", ctypes.c_int32), ("local_batch", ctypes.c_int32), ("row_offset", ctypes.c_int32),
+                ("loss", ctypes.c_int32), ("n_samples", ctypes.c_int32), ("updater", ctypes.c_int32),
+                ("learning_rate", ctypes.c_float), ("rho", ctypes.c_float), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("regularization", ctypes.c_float), ("grad_clip", ctypes.c_float),
+                ("flags", ctypes.c_int32)]
+
+
+# every symbol include/sbr_rnn.h declares (tests check the library exports all of them)
+EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create", "sbr_destroy", "sbr_num_params",
+           "sbr_param_shape", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
+           "sbr_train_step", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
+           "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
+           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times"]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libsbr_rnn.so (import torch first so one HIP runtime serves both)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("HIP extension %s is missing: build it with __graft_entry__.build() "
+                           "(there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
+    lib.sbr_last_error.restype = ctypes.c_char_p
+    vp, i32p, f32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
+    lib.sbr_arena_bytes.argtypes = [ctypes.POINTER(SbrConfig), ctypes.POINTER(ctypes.c_size_t)]
+    lib.sbr_create.argtypes = [ctypes.POINTER(SbrConfig), vp, ctypes.c_size_t, vp, ctypes.POINTER(vp)]
+    lib.sbr_destroy.argtypes = [vp]
+    lib.sbr_destroy.restype = None
+    lib.sbr_num_params.argtypes = [vp]
+    lib.sbr_param_shape.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+    for fn in (lib.sbr_set_params, lib.sbr_get_params, lib.sbr_get_grads):
+        fn.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.sbr_section.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t),
+                                ctypes.POINTER(ctypes.c_size_t)]
+    lib.sbr_set_batch.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int]
+    lib.sbr_train_step.argtypes = [vp, f32p]
+    for fn in (lib.sbr_zero_grads, lib.sbr_forward, lib.sbr_loss_backward_output, lib.sbr_backward_recurrent,
+               lib.sbr_apply_update, lib.sbr_synchronize):
+        fn.argtypes = [vp]
+    lib.sbr_read_cost.argtypes = [vp, f32p]
+    lib.sbr_predict_scores.argtypes = [vp, ctypes.c_int, vp]
+    lib.sbr_topk.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.sbr_debug_buffer.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    lib.sbr_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.sbr_enable_timing.argtypes = [vp, ctypes.c_int]
+    lib.sbr_phase_times.argtypes = [vp, f32p]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+class SbrError(RuntimeError):
+    pass
+
+
+def mask_to_lengths(mask):
+    """The reference's masks are prefix masks (rnn_one_hot.py:100-101: mask[i, :len] = 1);
+    the engine takes lengths.  Anything else is rejected loudly."""
+    mask = np.asarray(mask)
+    lengths = (mask != 0).sum(axis=1).astype(np.int32)
+    if not np.array_equal(mask != 0, np.arange(mask.shape[1])[None, :] < lengths[:, None]):
+        raise ValueError("mask must be a left-aligned prefix mask (rows of ones followed by zeros)")
+    return lengths
+
+
+class RNNEngine(object):
+    """Device-resident model + optimizer state behind the reference's callables.
+
+    train_function / test_function / predict_function take the same tuples the Theano
+    functions take (rnn_one_hot.py:61,106; rnn_sampling.py:128,194); `exclude` is accepted
+    and ignored in training exactly like the reference (rnn_base.py:185
+    on_unused_input='ignore') and derived on the device for the test path.
+    """
+
+    def __init__(self, cell="GRU", layers=(50,), n_items=None, max_length=30, batch_size=16, loss="CCE",
+                 n_samples=0, updater="adam", learning_rate=0.001, rho=0.9, beta1=0.9, beta2=0.999,
+                 regularization=0.0, grad_clip=100.0, input_size=None, n_feat=1, local_batch=None, row_offset=0,
+                 flags=0, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("RNNEngine needs a HIP device (MI355X); there is no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        if cell not in CELLS:
+            raise ValueError("Unknown layer type")                      # recurrent_layers.py:90
+        if loss not in LOSSES:
+            raise ValueError("Unknown loss for the RNN model")          # command_parser.py:123
+        if updater not in UPDATERS:
+            raise ValueError("Unknown update option")                   # update_manager.py:22
+        layers = [int(h) for h in layers]
+        cfg = SbrConfig()
+        cfg.abi_version = SBR_ABI_VERSION
+        cfg.cell = CELLS[cell]
+        cfg.n_layers = len(layers)
+        for i, hsz in enumerate(layers[:SBR_MAX_LAYERS]):
+            cfg.layers[i] = hsz
+        cfg.n_items = int(n_items)
+        cfg.input_size = int(input_size if input_size is not None else n_items)
+        cfg.n_feat = int(n_feat)
+        cfg.max_length = int(max_length)
+        cfg.batch_size = int(batch_size)
+        cfg.local_batch = int(local_batch if local_batch is not None else batch_size)
+        cfg.row_offset = int(row_offset)
+        cfg.loss = LOSSES[loss]
+        cfg.n_samples = int(n_samples) if loss != "CCE" else 0
+        cfg.updater = UPDATERS[updater]
+        cfg.learning_rate, cfg.rho, cfg.beta1, cfg.beta2 = learning_rate, rho, beta1, beta2
+        cfg.regularization = regularization
+        cfg.grad_clip = grad_clip
+        cfg.flags = int(flags)
+        if len(layers) > SBR_MAX_LAYERS:
+            raise ValueError("at most %d recurrent layers" % SBR_MAX_LAYERS)
+        self.cfg = cfg
+        self.cell, self.layers, self.loss = cell, layers, loss
+        self.n_items, self.max_length = cfg.n_items, cfg.max_length
+        self.batch_size, self.local_batch, self.n_feat = cfg.batch_size, cfg.local_batch, cfg.n_feat
+        self.n_samples = cfg.n_samples
+
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        nbytes = ctypes.c_size_t()
+        self._check(self.lib.sbr_arena_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)))
+        self.arena_bytes = nbytes.value
+        with torch.cuda.device(self.device):
+            self.arena = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=self.device)
+            self.stream = torch.cuda.current_stream(self.device)
+            handle = ctypes.c_void_p()
+            self._check(self.lib.sbr_create(ctypes.byref(cfg), ctypes.c_void_p(self.arena.data_ptr()),
+                                            ctypes.c_size_t(self.arena.numel() * 4),
+                                            ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
+        self.h = handle
+        self.n_params = self.lib.sbr_num_params(self.h)
+        self.param_shapes = []
+        for i in range(self.n_params):
+            dims = (ctypes.c_int64 * 2)()
+            nd = ctypes.c_int()
+            self._check(self.lib.sbr_param_shape(self.h, i, dims, ctypes.byref(nd)))
+            self.param_shapes.append(tuple(int(d) for d in dims[:nd.value]))
+        self._sections = {}
+
+    # ---------------------------------------------------------------- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.sbr_last_error().decode("utf-8", "replace")
+            if rc == -1:
+                raise ValueError(msg)
+            raise SbrError("libsbr_rnn error %d: %s" % (rc, msg))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sbr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ptr_array(self, arrays):
+        arr = (ctypes.c_void_p * len(arrays))()
+        for i, a in enumerate(arrays):
+            arr[i] = a.ctypes.data
+        return arr
+
+    def section(self, which):
+        """torch view of a flat arena section: 'params', 'grads' (last element = cost), 'state'.
+        Returns (tensor, split) where split = first float of the output-layer part."""
+        if which not in self._sections:
+            idx = {"params": 0, "grads": 1, "state": 2}[which]
+            ptr, n, split = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+            self._check(self.lib.sbr_section(self.h, idx, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(split)))
+            off = (ptr.value - self.arena.data_ptr()) // 4
+            self._sections[which] = (self.arena[off:off + n.value], split.value)
+        return self._sections[which]
+
+    # ---------------------------------------------------------------- parameters
+    def set_all_param_values(self, values):
+        """lasagne.layers.set_all_param_values(l_out, values) (rnn_base.py:515)."""
+        if len(values) != self.n_params:
+            raise ValueError("mismatch: got %d values to set %d parameters" % (len(values), self.n_params))
+        arrays = []
+        for v, shp in zip(values, self.param_shapes):
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+            if a.shape != shp:
+                raise ValueError("mismatch: parameter has shape %r but value to set has shape %r" % (shp, a.shape))
+            arrays.append(a)
+        self._check(self.lib.sbr_set_params(self.h, len(arrays), self._ptr_array(arrays)))
+
+    def _get(self, fn):
+        arrays = [np.empty(shp, dtype=np.float32) for shp in self.param_shapes]
+        self._check(fn(self.h, len(arrays), self._ptr_array(arrays)))
+        return arrays
+
+    def get_all_param_values(self):
+        """lasagne.layers.get_all_param_values(l_out) (rnn_base.py:476)."""
+        return self._get(self.lib.sbr_get_params)
+
+    def get_all_grad_values(self):
+        return self._get(self.lib.sbr_get_grads)
+
+    # ---------------------------------------------------------------- batches
+    def set_batch(self, X, mask=None, target=None, samples=None, target_popularity=None, lengths=None):
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.int32))
+        if X.ndim == 2:
+            X = X[:, :, None]
+        n_rows = X.shape[0]
+        if X.shape[1] != self.max_length or X.shape[2] != self.n_feat:
+            raise ValueError("X must have shape (rows, %d, %d), got %r" % (self.max_length, self.n_feat, X.shape))
+        if lengths is None:
+            lengths = mask_to_lengths(mask)
+        lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int32))
+        tgt = None if target is None else np.ascontiguousarray(np.asarray(target, dtype=np.int32))
+        smp = None if samples is None else np.ascontiguousarray(np.asarray(samples, dtype=np.int32))
+        pop = None if target_popularity is None else np.ascontiguousarray(np.asarray(target_popularity, dtype=np.float32))
+        if tgt is not None:
+            need = self.batch_size if self.loss != "CCE" else n_rows
+            if tgt.shape[0] != need:
+                raise ValueError("target must have %d entries, got %d" % (need, tgt.shape[0]))
+        if self.loss != "CCE" and smp is not None and smp.shape[0] != self.n_samples:
+            raise ValueError("samples must have %d entries" % self.n_samples)
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        self._check(self.lib.sbr_set_batch(self.h, p(X), p(lengths), p(tgt), p(smp), p(pop), n_rows, 0))
+        return n_rows
+
+    def set_batch_device(self, X, lengths, target, samples, target_popularity, n_rows):
+        """Same, inputs already resident in HBM (torch int32/float32 tensors on this device)."""
+        dp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        self._check(self.lib.sbr_set_batch(self.h, dp(X), dp(lengths), dp(target), dp(samples), dp(target_popularity),
+                                           int(n_rows), 1))
+
+    # ---------------------------------------------------------------- the reference's callables
+    def train_function(self, X, mask, target, *rest):
+        """cost = train_function(X, mask, target, [samples,] target_popularity, exclude)."""
+        if self.loss == "CCE":
+            pop = rest[0] if len(rest) > 0 else None
+            samples = None
+        else:
+            samples = rest[0]
+            pop = rest[1] if len(rest) > 1 else None
+        self.set_batch(X, mask, target, samples, pop)
+        return self.train_step(sync=True)
+
+    def train_step(self, sync=True):
+        if sync:
+            cost = ctypes.c_float()
+            self._check(self.lib.sbr_train_step(self.h, ctypes.byref(cost)))
+            return float(cost.value)
+        self._check(self.lib.sbr_train_step(self.h, None))
+        return None
+
+    def forward_backward(self):
+        """Gradients without the update (parity tests, data-parallel)."""
+        for fn in (self.lib.sbr_zero_grads, self.lib.sbr_forward, self.lib.sbr_loss_backward_output,
+                   self.lib.sbr_backward_recurrent):
+            self._check(fn(self.h))
+        return self.read_cost()
+
+    def apply_update(self):
+        self._check(self.lib.sbr_apply_update(self.h))
+
+    def read_cost(self):
+        cost = ctypes.c_float()
+        self._check(self.lib.sbr_read_cost(self.h, ctypes.byref(cost)))
+        return float(cost.value)
+
+    def predict_function(self, X, mask):
+        """scores (rows, N): softmax probabilities for CCE, raw activations for sampled heads."""
+        n = self.set_batch(X, mask)
+        out = np.empty((n, self.n_items), dtype=np.float32)
+        self._check(self.lib.sbr_predict_scores(self.h, 0, ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def test_probabilities(self, X, mask):
+        n = self.set_batch(X, mask)
+        out = np.empty((n, self.n_items), dtype=np.float32)
+        self._check(self.lib.sbr_predict_scores(self.h, 1, ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def test_function(self, theano_inputs, k=10, exclude_seen=True):
+        """ids = test_function(theano_inputs, k) (rnn_base.py:205-209): ordered top-k of
+        softmax * (1 - exclude), for every row (the reference feeds one row at a time)."""
+        X, mask = theano_inputs[0], theano_inputs[1]
+        n = self.set_batch(X, mask)
+        ids = np.empty((n, k), dtype=np.int32)
+        self._check(self.lib.sbr_topk(self.h, int(k), 1 if exclude_seen else 0, ctypes.c_void_p(ids.ctypes.data)))
+        return ids
+
+    # ---------------------------------------------------------------- debug / timing
+    def debug_buffer(self, name):
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self.lib.sbr_debug_buffer(self.h, name.encode(), ctypes.byref(ptr), ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        self._check(self.lib.sbr_copy_to_host(self.h, ptr, ctypes.c_void_p(out.ctypes.data), n.value))
+        return out
+
+    def synchronize(self):
+        self._check(self.lib.sbr_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.sbr_enable_timing(self.h, 1 if on else 0))
+
+    def phase_times(self):
+        us = (ctypes.c_float * SBR_N_PHASES)()
+        self._check(self.lib.sbr_phase_times(self.h, us))
+        return dict(zip(PHASE_NAMES, [float(v) for v in us]))

@@ -1,0 +1,112 @@
+"""Shared helpers for the GPU parity tests and tools/gpu_diag.py: build a seeded model + batch,
+run the HIP engine and the CPU oracle on the same inputs, return per-quantity relative errors."""
+import numpy as np
+
+from oracle import rnn_oracle as O
+
+
+def make_batch(rng, B, T, N, S=0, F=1, n_in0=None, full=False, Bg=None):
+    n_in0 = n_in0 or N
+    lens = rng.integers(1, T + 1, size=B)
+    if full:
+        lens[:] = T
+    else:
+        lens[0] = T
+        if B > 1:
+            lens[1] = 1
+    X = np.zeros((B, T, F), dtype=np.int32)
+    mask = np.zeros((B, T), dtype=np.float32)
+    for b in range(B):
+        X[b, :lens[b], 0] = rng.integers(0, N, size=lens[b])
+        mask[b, :lens[b]] = 1
+        if F > 1:
+            X[b, :lens[b], 1] = rng.integers(N, n_in0, size=lens[b])
+    if B > 2:
+        X[2, :lens[2], 0] = 0          # pad id 0 is a real item; duplicates accumulate
+    return dict(X=X, mask=mask, target=rng.integers(0, N, size=Bg or B).astype(np.int32),
+                samples=rng.integers(0, N, size=max(S, 1)).astype(np.int32),
+                pop=rng.uniform(0.5, 2.0, size=B).astype(np.float32))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=0.3, popscale=1.0):
+    rng = np.random.default_rng(seed)
+    params = O.init_params(cell, layers, N, rng, n_in0=N + n_opt)
+    for p in params:                      # move every parameter (biases, inits, peepholes) off zero
+        p += rng.normal(0, scale, size=p.shape)
+    params = [p.astype(np.float32).astype(np.float64) for p in params]
+    batch = make_batch(rng, B, T, N, S=S, F=F, n_in0=N + n_opt, full=full)
+    batch["pop"] = (batch["pop"] * popscale).astype(np.float32)
+    cfg = dict(cell=cell, layers=list(layers), loss=loss, regularization=0.0)
+    return params, cfg, batch
+
+
+def engine_for(cfg, N, B, T, S=0, F=1, n_opt=0, updater="adam", lr=0.01, flags=0, reg=0.0, local_batch=None,
+               row_offset=0):
+    from sbr_amd.engine import RNNEngine
+    return RNNEngine(cell=cfg["cell"], layers=cfg["layers"], n_items=N, max_length=T, batch_size=B, loss=cfg["loss"],
+                     n_samples=S, updater=updater, learning_rate=lr, rho=0.9, beta1=0.9, beta2=0.999,
+                     regularization=reg, input_size=N + n_opt, n_feat=F, flags=flags, local_batch=local_batch,
+                     row_offset=row_offset)
+
+
+def oracle_batch(batch):
+    ob = dict(batch)
+    ob["pop"] = batch["pop"].astype(np.float64)
+    return ob
+
+
+def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
+                 reg=0.0, steps=2, popscale=1.0):
+    """Returns dict of relative errors (engine float32 vs oracle float64)."""
+    params, cfg, batch = build_case(cell, layers, loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, full=full,
+                                    popscale=popscale)
+    cfg["regularization"] = reg
+    eng = engine_for(cfg, N, B, T, S=S, F=F, n_opt=n_opt, updater=updater, flags=flags, reg=reg)
+    out = {}
+    try:
+        eng.set_all_param_values(params)
+        back = eng.get_all_param_values()
+        out["param_roundtrip"] = max(rel_err(a, b) for a, b in zip(back, params))
+        smp = batch["samples"] if loss != "CCE" else None
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], smp, batch["pop"])
+        cost = eng.forward_backward()
+        ocost, ograds, aux = O.cost_and_grads(params, cfg, oracle_batch(batch))
+        Hp = eng.debug_buffer("h_last").size // (((B + 15) // 16) * 16)
+        hl = eng.debug_buffer("h_last").reshape(-1, Hp)[:B, :layers[-1]]
+        out["h_last"] = rel_err(hl, aux["h"])
+        out["cost"] = abs(cost - ocost) / (abs(ocost) + 1e-12)
+        grads = eng.get_all_grad_values()
+        names = [n for n, _ in O.model_param_shapes(cell, layers, N, N + n_opt)]
+        worst = 0.0
+        for n, g, og in zip(names, grads, ograds):
+            e = rel_err(g, og) if np.abs(og).max() > 0 else float(np.abs(g).max())
+            out["grad:" + n] = e
+            worst = max(worst, e)
+        out["grad_worst"] = worst
+        # a few optimizer steps on the same batch
+        upd = O.Updater(updater, 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+        oparams = [p.copy() for p in params]
+        costs_e, costs_o = [], []
+        for _ in range(steps):
+            costs_o.append(O.train_function(oparams, cfg, upd, oracle_batch(batch)))
+            costs_e.append(eng.train_step(sync=True))
+        new = eng.get_all_param_values()
+        out["params_after_%d_steps" % steps] = max(rel_err(a, b) for a, b in zip(new, oparams))
+        out["cost_after_steps"] = abs(costs_e[-1] - costs_o[-1]) / (abs(costs_o[-1]) + 1e-12)
+        # predict / top-k on the updated model
+        scores = eng.predict_function(batch["X"], batch["mask"])
+        oscores, ologits = O.predict_scores(oparams, cfg, batch["X"], batch["mask"])
+        out["predict_scores"] = rel_err(scores, oscores)
+        k = min(5, N - T) if N - T >= 1 else 1
+        ids = eng.test_function((batch["X"], batch["mask"]), k=k)
+        excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
+        oids = O.test_function(oparams, cfg, batch["X"], batch["mask"], excl, k=k)
+        out["topk_mismatch"] = float((ids != oids).sum())
+    finally:
+        eng.close()
+    return out
