@@ -73,13 +73,20 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="sequences per GPU per step")
     ap.add_argument("--max_length", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="max timed CPU-baseline steps")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
     args = ap.parse_args()
 
+    def log(*a):
+        print("[bench %6.1fs]" % (time.perf_counter() - T0), *a, file=sys.stderr, flush=True)
+    T0 = time.perf_counter()
     import torch
     import torch.distributed as dist
     from oracle import rnn_oracle as O          # parameter init law + the cpu_baseline leg only
     from sbr_amd.engine import RNNEngine
+    from sbr_amd.parallel import DataParallel
+    log("imports done")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,31 +118,24 @@ def main():
                  target=torch.from_numpy(hb["target"]).to(dev), samples=torch.from_numpy(hb["samples"]).to(dev),
                  pop=torch.from_numpy(hb["pop"]).to(dev))
         dev_batches.append(d)
-    grads, split = eng.section("grads")
+    dp = DataParallel(eng, dist)
+    log("engine ready, arena %.1f MB" % (eng.arena_bytes / 1e6))
 
     def step(i):
         d = dev_batches[i % nb]
         tgt = d["target"]
         if world > 1 and loss != "CCE":      # sampled heads need every rank's targets (rnn_sampling.py:137)
-            allt = [torch.empty_like(tgt) for _ in range(world)]
-            dist.all_gather(allt, tgt)
-            tgt = torch.cat(allt)
+            tgt = dp.gather_targets(tgt)
         eng.set_batch_device(d["X"], d["lengths"], tgt, d["samples"] if loss != "CCE" else None, d["pop"], B)
         if world == 1:
-            eng.train_step(sync=False)
-            return
-        eng._check(eng.lib.sbr_zero_grads(eng.h))
-        eng._check(eng.lib.sbr_forward(eng.h))
-        eng._check(eng.lib.sbr_loss_backward_output(eng.h))
-        # output-layer gradients are final here: reduce them while BPTT runs (separate RCCL stream)
-        w1 = dist.all_reduce(grads[split:], async_op=True)
-        eng._check(eng.lib.sbr_backward_recurrent(eng.h))
-        w2 = dist.all_reduce(grads[:split], async_op=True)
-        w1.wait(); w2.wait()
-        eng.apply_update()
+            eng.train_step(sync=False)       # one C call: zero grads, fwd, loss, BPTT, scatter, Adam
+        else:
+            dp.train_step()                  # same phases with the RCCL all-reduces in between
 
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    log("warmup done")
     eng.enable_timing(True)
     torch.cuda.synchronize()
     if world > 1:
@@ -151,6 +151,7 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
     cost = eng.read_cost()
     if not np.isfinite(cost):
         raise ValueError("Cost is NaN")            # rnn_base.py:291-292
@@ -197,20 +198,26 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref as R
-        torch.set_num_threads(os.cpu_count() or 1)
+        ncores = os.cpu_count() or 1
+        nthr = args.cpu_threads or min(ncores, 32)
+        torch.set_num_threads(nthr)
         cfg = dict(cell=cell, layers=layers, loss=loss, regularization=0.0)
         tr = R.TorchTrainer(params, cfg, O.recurrent_param_shapes, updater="adam", lr=1e-3)
         hb = host_batches[0]
         cb = dict(X=hb["X"], mask=hb["mask"], target=hb["target"], samples=hb["samples"], pop=hb["pop"])
-        tr.train_function(cb)                      # warm-up
         t0 = time.perf_counter()
-        for _ in range(args.cpu_steps):
+        tr.train_function(cb)                      # warm-up (also bounds the sample if the host is slow)
+        warm = time.perf_counter() - t0
+        log("cpu baseline warm-up step %.2f s on %d threads (%d host cores)" % (warm, nthr, ncores))
+        n, t0 = 0, time.perf_counter()
+        while n < args.cpu_steps and (n == 0 or time.perf_counter() - t0 + warm < args.cpu_seconds):
             tr.train_function(cb)
-        cdt = (time.perf_counter() - t0) / args.cpu_steps
-        result["cpu_baseline"] = {"value": round(B / cdt, 1), "unit": "user-sequences/s", "cores": torch.get_num_threads(),
-                                  "kind": "port", "sample": "%d train steps of the same %s workload (B=%d, T=%d), torch-CPU "
-                                  "float32 port of the reference path (Theano/Lasagne not installable), %.2f s/step"
-                                  % (args.cpu_steps, args.config, B, T, cdt)}
+            n += 1
+        cdt = (time.perf_counter() - t0) / n
+        result["cpu_baseline"] = {"value": round(B / cdt, 1), "unit": "user-sequences/s", "cores": nthr,
+                                  "kind": "port", "sample": "%d train step(s) of the same %s workload (B=%d, T=%d): torch-CPU "
+                                  "float32 port of the reference path (Theano/Lasagne not installable), %.2f s/step, "
+                                  "%d threads of %d host cores" % (n, args.config, B, T, cdt, nthr, ncores)}
     if rank == 0:
         print(json.dumps(result))
     eng.close()

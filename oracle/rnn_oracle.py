@@ -352,18 +352,22 @@ def softmax_rows(a):
     return e / e.sum(axis=1, keepdims=True)
 
 
-def cce_cost_and_grads(h, W_out, b_out, target, target_popularity, regularization=0.0):
+def cce_cost_and_grads(h, W_out, b_out, target, target_popularity, regularization=0.0, Bglobal=None):
     """rnn_one_hot.py:65-77: DenseLayer(N, softmax) [3P]; cost = mean(CCE / pop);
     +reg*sum(b^2) if reg>0, +|reg|*sum|b| if reg<0 (bias only).
-    Returns cost, logits, (dh, dW_out, db_out)."""
-    B = h.shape[0]
+    Returns cost, logits, (dh, dW_out, db_out).  Bglobal (data-parallel restatement): h holds
+    R of the Bglobal rows; the returned cost/grads are this shard's share (shares sum to the
+    full-batch values, including the regulariser's)."""
+    R = h.shape[0]
+    B = Bglobal or R
     logits = h @ W_out + b_out
     p = softmax_rows(logits)
-    nll = -np.log(p[np.arange(B), target])
-    cost = (nll / target_popularity).mean()
-    dlog = p.copy(); dlog[np.arange(B), target] -= 1.0
+    nll = -np.log(p[np.arange(R), target])
+    cost = (nll / target_popularity).sum() / B
+    dlog = p.copy(); dlog[np.arange(R), target] -= 1.0
     dlog /= (target_popularity[:, None] * B)
     db = dlog.sum(0)
+    regularization = regularization * R / B
     if regularization > 0.0:
         cost += regularization * (b_out ** 2).sum()
         db = db + 2.0 * regularization * b_out
@@ -380,49 +384,55 @@ def sampled_activation(h, W_out, b_out, target, samples):
     return h @ W_out[:, cells] + b_out[cells], cells
 
 
-def sampled_loss_rows(a, B, loss):
+def sampled_loss_rows(a, B, loss, row_offset=0):
     """Per-row loss and d loss / d a for the sampled heads; row b's positive is column b
     (targets = np.arange(batch_size), rnn_sampling.py:137), negatives are columns >= B.
     Blackout rnn_sampling.py:68-72; BPR :80-84; TOP1 :86-91 (last_layer_tanh is False
-    from the CLI, command_parser.py:120-121)."""
-    rows = np.arange(B)
+    from the CLI, command_parser.py:120-121).
+    Data-parallel restatement: `a` may hold only the rows [row_offset, row_offset+R) of the
+    global batch of B rows (all B+S columns); the formulas are unchanged."""
+    R = a.shape[0]
+    cols = row_offset + np.arange(R)          # positive column of each local row
+    rows = np.arange(R)
     if loss == "Blackout":
         p = softmax_rows(a)
-        L = -np.log(p[rows, rows]) - np.log(1 - p[:, B:]).sum(axis=1)
+        L = -np.log(p[rows, cols]) - np.log(1 - p[:, B:]).sum(axis=1)
         dLdp = np.zeros_like(p)
-        dLdp[rows, rows] = -1.0 / p[rows, rows]
+        dLdp[rows, cols] = -1.0 / p[rows, cols]
         dLdp[:, B:] += 1.0 / (1 - p[:, B:])
         da = p * (dLdp - (dLdp * p).sum(axis=1, keepdims=True))
     elif loss == "BPR":
-        diff = a[:, B:] - a[rows, rows][:, None]
+        diff = a[:, B:] - a[rows, cols][:, None]
         S = diff.shape[1]
         L = -np.log(sigmoid(-diff)).mean(axis=1)          # softplus(diff)
         dd = sigmoid(diff) / S
         da = np.zeros_like(a)
         da[:, B:] = dd
-        da[rows, rows] -= dd.sum(axis=1)
+        da[rows, cols] -= dd.sum(axis=1)
     elif loss == "TOP1":
         neg = a[:, B:]
-        diff = neg - a[rows, rows][:, None]
+        diff = neg - a[rows, cols][:, None]
         S = diff.shape[1]
         s1 = sigmoid(diff); s2 = sigmoid(neg ** 2)
         L = (s1 + s2).mean(axis=1)
         d1 = s1 * (1 - s1) / S
         da = np.zeros_like(a)
         da[:, B:] = d1 + s2 * (1 - s2) * 2 * neg / S
-        da[rows, rows] -= d1.sum(axis=1)
+        da[rows, cols] -= d1.sum(axis=1)
     else:
         raise ValueError("Unknown loss function")         # rnn_sampling.py:54
     return L, da
 
 
-def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, loss):
+def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, loss, row_offset=0):
     """rnn_sampling.py:131-137: cost = mean(loss_rows / target_popularity).  The
-    gradient wrt W[:, cells] is an AdvancedIncSubtensor: duplicate cells accumulate [3P]."""
-    B = h.shape[0]
+    gradient wrt W[:, cells] is an AdvancedIncSubtensor: duplicate cells accumulate [3P].
+    `target` always lists the targets of ALL B rows of the global batch; h may hold only the
+    rows [row_offset, row_offset+R) (data-parallel shard: its share of cost and grads)."""
+    B = target.shape[0]
     a, cells = sampled_activation(h, W_out, b_out, target, samples)
-    L, da = sampled_loss_rows(a, B, loss)
-    cost = (L / target_popularity).mean()
+    L, da = sampled_loss_rows(a, B, loss, row_offset)
+    cost = (L / target_popularity).sum() / B
     da = da / (target_popularity[:, None] * B)
     dW = np.zeros_like(W_out); db = np.zeros_like(b_out)
     np.add.at(dW.T, cells, (h.T @ da).T)
@@ -439,10 +449,10 @@ def cost_and_grads(params, cfg, batch):
     h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"])
     if cfg["loss"] == "CCE":
         cost, act, (dh, dW, db) = cce_cost_and_grads(h, W_out, b_out, batch["target"], batch["pop"],
-                                                     cfg.get("regularization", 0.0))
+                                                     cfg.get("regularization", 0.0), batch.get("Bglobal"))
     else:
         cost, act, (dh, dW, db) = sampled_cost_and_grads(h, W_out, b_out, batch["target"], batch["samples"],
-                                                         batch["pop"], cfg["loss"])
+                                                         batch["pop"], cfg["loss"], batch.get("row_offset", 0))
     grads = network_backward(params, cell, layers, caches, dh) + [dW, db]
     return cost, grads, {"h": h, "act": act}
 

@@ -293,6 +293,19 @@ class RNNEngine(object):
             self._check(fn(self.h))
         return self.read_cost()
 
+    # phases of one step (data-parallel: all-reduce the gradient section between them)
+    def zero_grads(self):
+        self._check(self.lib.sbr_zero_grads(self.h))
+
+    def forward(self):
+        self._check(self.lib.sbr_forward(self.h))
+
+    def loss_backward_output(self):
+        self._check(self.lib.sbr_loss_backward_output(self.h))
+
+    def backward_recurrent(self):
+        self._check(self.lib.sbr_backward_recurrent(self.h))
+
     def apply_update(self):
         self._check(self.lib.sbr_apply_update(self.h))
 

@@ -1,0 +1,412 @@
+"""Host-side mirror of the reference's RNN model classes, Python 3, with the Theano/Lasagne
+graph replaced by the HIP engine (engine.RNNEngine).  Same class names, constructor arguments,
+methods, filenames and checkpoint layout as neural_networks/rnn_base.py (RNNBase),
+rnn_one_hot.py (RNNOneHot) and rnn_sampling.py (RNNSampling), so `train.py -m RNN` code that
+holds one of these objects keeps working:
+
+    prepare_model(dataset) / train(dataset, ...) / top_k_recommendations(sequence, ...) /
+    save(filename) / load(filename) / load_last(save_dir)
+
+Only what the RNN hot path needs is here; `--mf/--uf` (feature tables the
+reference never loads), `--r_bi`, `--r_emb` raise NotImplementedError in this round.
+"""
+import glob
+import os
+import pickle
+import random
+import re
+import sys
+from bisect import bisect
+from time import time
+
+import numpy as np
+
+from .options import Adagrad, RecurrentLayers, SelectTargets, SequenceNoise
+
+MAX_LENGTH = 200      # rnn_base.py:24
+BATCH_SIZE = 10       # rnn_base.py:32
+
+
+class RNNBase(object):
+    """rnn_base.py:58-642 minus everything Theano: the engine owns parameters and math."""
+
+    def __init__(self, sequence_noise=None, recurrent_layer=None, updater=None, target_selection=None,
+                 interactions_are_unique=True, other_features=None, use_ratings_features=True, movies_features=None,
+                 use_movies_features=True, users_features=None, use_users_features=True, max_length=MAX_LENGTH,
+                 batch_size=BATCH_SIZE):
+        self.other_features, self.movies_features, self.users_features = other_features, movies_features, users_features
+        self.use_ratings_features = use_ratings_features
+        self.use_movies_features = use_movies_features
+        self.use_users_features = use_users_features
+        self.max_length, self.batch_size = max_length, batch_size
+        self.sequence_noise = sequence_noise if sequence_noise is not None else SequenceNoise()
+        self.recurrent_layer = recurrent_layer if recurrent_layer is not None else RecurrentLayers()
+        self.updater = updater if updater is not None else Adagrad()
+        self.target_selection = target_selection if target_selection is not None else SelectTargets()
+        self.interactions_are_unique = interactions_are_unique
+        if self.use_movies_features or self.use_users_features:
+            # the reference dereferences feature tables that are always None (rnn_base.py:27-29,572,607)
+            raise NotImplementedError("movie/user features (--mf/--uf) are unusable in the reference and unsupported here")
+        if self.recurrent_layer.bidirectional or self.recurrent_layer.embedding_size > 0:
+            raise NotImplementedError("--r_bi / --r_emb are not part of the round-1 hot path")
+        self._input_type = "int32"
+        self.name = "RNN base"
+        self.metrics = {"recall": {"direction": 1}, "sps": {"direction": 1}, "user_coverage": {"direction": 1},
+                        "item_coverage": {"direction": 1}, "ndcg": {"direction": 1},
+                        "blockbuster_share": {"direction": -1}}
+        self.engine = None
+
+    # ------------------------------------------------------------------ model construction
+    def _n_optional_features(self):
+        return 10 if self.use_ratings_features else 0       # rating one-hot on a scale of ten (rnn_base.py:590-605)
+
+    def _input_size(self):
+        return 2 if self.use_ratings_features else 1        # indices per step (rnn_base.py:615-622)
+
+    def _engine_kwargs(self):
+        raise NotImplementedError
+
+    def prepare_model(self, dataset):
+        """Must be called before train, load or top_k_recommendations (rnn_base.py:106-109)."""
+        from .engine import RNNEngine
+        self.n_items = dataset.n_items
+        kw = dict(cell=self.recurrent_layer.layer_type, layers=self.recurrent_layer.layers, n_items=self.n_items,
+                  max_length=self.max_length, batch_size=self.batch_size, grad_clip=float(self.recurrent_layer.grad_clip),
+                  input_size=self.n_items + self._n_optional_features(), n_feat=self._input_size())
+        kw.update(self.updater.engine_kwargs())
+        kw.update(self._engine_kwargs())
+        self.engine = RNNEngine(**kw)
+        self._init_parameters()
+
+    def _init_parameters(self, seed=None):
+        """Lasagne initialisers [3P]: gate weights and peepholes Normal(std 0.1), biases and initial
+        states 0, output W GlorotUniform(gain), output b 0."""
+        rng = np.random.RandomState(seed)
+        values = []
+        last = len(self.engine.param_shapes) - 2
+        for i, shp in enumerate(self.engine.param_shapes):
+            if i == last:
+                lim = getattr(self, "last_layer_init", 1.0) * np.sqrt(6.0 / (shp[0] + shp[1]))
+                values.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+            elif i > last:
+                values.append(np.zeros(shp, dtype=np.float32))
+            else:
+                values.append(None)
+        # recurrent part: which arrays are weights is decided by the Lasagne order
+        cell = self.recurrent_layer.layer_type
+        per_layer = {"LSTM": 17, "GRU": 10, "Vanilla": 4}[cell]
+        n_gate = {"LSTM": 12, "GRU": 9, "Vanilla": 3}[cell]
+        for i in range(last):
+            shp = self.engine.param_shapes[i]
+            k = i % per_layer
+            is_weight = (k < n_gate and k % 3 != 2) or (cell == "LSTM" and 12 <= k < 15)
+            values[i] = (rng.normal(0.0, 0.1, size=shp) if is_weight else np.zeros(shp)).astype(np.float32)
+        self.engine.set_all_param_values(values)
+
+    # ------------------------------------------------------------------ filenames (rnn_base.py:111-130)
+    def _common_filename(self, epochs):
+        filename = ("ml" + str(self.max_length) + "_bs" + str(self.batch_size) + "_ne" + str(epochs) + "_" +
+                    self.recurrent_layer.name + "_" + self.updater.name + "_" + self.target_selection.name)
+        if self.sequence_noise.name != "":
+            filename += "_" + self.sequence_noise.name
+        if not self.interactions_are_unique:
+            filename += "_ri"
+        if not (self.use_ratings_features or self.use_movies_features or self.use_users_features):
+            filename += "_nf"
+        if self.use_ratings_features:
+            filename += "_rf"
+        if self.use_movies_features:
+            filename += "_mf"
+        if self.use_users_features:
+            filename += "_uf"
+        return filename
+
+    def _get_model_filename(self, epochs):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ features (rnn_base.py:590-642)
+    def _get_features(self, item, user_id=None):
+        """[item_id] (+ [n_items + rating bucket] with --rf): rating one-hot index round(r*2)-1."""
+        item_id, rating = item
+        if self.use_ratings_features:
+            return [item_id, self.n_items + (int(round(rating * 2)) - 1) % 10]
+        return [item_id]
+
+    def _pack(self, sequences):
+        """Common part of _prepare_input: X left-aligned zero-padded (pad id 0 is a real item, the
+        mask alone marks validity), mask, first target, popularity**db (rnn_one_hot.py:83-106)."""
+        B, T, F = len(sequences), self.max_length, self._input_size()
+        X = np.zeros((B, T, F), dtype=np.int32)
+        mask = np.zeros((B, T), dtype=np.float32)
+        Y = np.zeros((B,), dtype=np.int32)
+        pop = np.zeros((B,), dtype=np.float32)
+        for i, (user_id, in_seq, target) in enumerate(sequences):
+            n = len(in_seq)
+            if n:
+                X[i, :n, :] = np.array([self._get_features(x, user_id) for x in in_seq], dtype=np.int32)
+            mask[i, :n] = 1
+            Y[i] = target[0][0]
+            pop[i] = self.dataset.item_popularity[target[0][0]] ** self.diversity_bias
+        return X, mask, Y, pop
+
+    def set_dataset(self, dataset):
+        self.dataset = dataset
+        self.target_selection.set_dataset(dataset)
+
+    # ------------------------------------------------------------------ batches (rnn_base.py:373-420)
+    def _gen_mini_batch(self, sequence_generator, test=False, max_reuse_sequence=np.inf):
+        while True:
+            j = 0
+            sequences = []
+            batch_size = 1 if test else self.batch_size
+            while j < batch_size:
+                sequence, user_id = next(sequence_generator)
+                if not test:
+                    k = int(min(batch_size - j, len(sequence) - 2, max_reuse_sequence))
+                    seq_lengths = sorted(random.sample(range(2, len(sequence)), k))
+                else:
+                    seq_lengths = [int(len(sequence) / 2)]
+                skipped = 0
+                for l in seq_lengths:
+                    target = self.target_selection(sequence[l:], test=test)
+                    if len(target) == 0:
+                        skipped += 1
+                        continue
+                    start = max(0, l - self.max_length)
+                    sequences.append([user_id, sequence[start:l], target])
+                j += len(seq_lengths) - skipped
+            if test:
+                yield self._prepare_input(sequences), [i[0] for i in sequence[seq_lengths[0]:]]
+            else:
+                yield self._prepare_input(sequences)
+
+    # ------------------------------------------------------------------ the compiled-function seam
+    def train_function(self, *batch):
+        return self.engine.train_function(*batch)
+
+    def test_function(self, theano_inputs, k=10):
+        """ordered top-k ids of the (single) row (rnn_base.py:205-209)."""
+        return self.engine.test_function(theano_inputs, k=k, exclude_seen=self.interactions_are_unique)[0]
+
+    def predict_function(self, X, mask):
+        return self.engine.predict_function(X, mask)
+
+    def top_k_recommendations(self, sequence, user_id=None, k=10, exclude=None):
+        """rnn_base.py:132-159: last max_length items -> scores -> viewed/excluded to -inf -> top k."""
+        if exclude is None:
+            exclude = []
+        seq = sequence[-min(self.max_length, len(sequence)):]
+        X = np.zeros((1, self.max_length, self._input_size()), dtype=np.int32)
+        X[0, :len(seq), :] = np.array([self._get_features(x, user_id) for x in seq], dtype=np.int32)
+        mask = np.zeros((1, self.max_length), dtype=np.float32)
+        mask[0, :len(seq)] = 1
+        output = self.predict_function(X, mask)[0]
+        if self.interactions_are_unique:
+            output[[i[0] for i in sequence]] = -np.inf
+        output[exclude] = -np.inf
+        return list(np.argpartition(-output, range(k))[:k])
+
+    # ------------------------------------------------------------------ training loop (rnn_base.py:215-356)
+    def get_pareto_front(self, metrics, metrics_names):
+        costs = np.zeros((len(metrics[metrics_names[0]]), len(metrics_names)))
+        for i, m in enumerate(metrics_names):
+            costs[:, i] = np.array(metrics[m]) * self.metrics[m]["direction"]
+        is_efficient = np.ones(costs.shape[0], dtype=bool)
+        for i, c in enumerate(costs):
+            if is_efficient[i]:
+                is_efficient[is_efficient] = np.any(costs[is_efficient] >= c, axis=1)
+        return np.where(is_efficient)[0].tolist()
+
+    def train(self, dataset, max_time=np.inf, progress=2.0, time_based_progress=False, autosave="All", save_dir="",
+              min_iterations=0, max_iter=np.inf, max_progress_interval=np.inf, load_last_model=False,
+              early_stopping=None, validation_metrics=("sps",)):
+        self.set_dataset(dataset)
+        validation_metrics = list(validation_metrics)
+        if len(set(validation_metrics) & set(self.metrics.keys())) < len(validation_metrics):
+            raise ValueError("Incorrect validation metrics. Metrics must be chosen among: " + ", ".join(self.metrics.keys()))
+        iterations, epochs_offset = 0, 0
+        if load_last_model:
+            epochs_offset = self.load_last(save_dir)
+        batch_generator = self._gen_mini_batch(self.sequence_noise(dataset.training_set()))
+        start_time = time()
+        next_save = int(progress)
+        train_costs, current_train_cost, epochs = [], [], []
+        metrics = {name: [] for name in self.metrics.keys()}
+        filename = {}
+        try:
+            while time() - start_time < max_time and iterations < max_iter:
+                try:
+                    batch = next(batch_generator)
+                    cost = self.train_function(*batch)
+                    if np.isnan(cost):
+                        raise ValueError("Cost is NaN")
+                except StopIteration:
+                    break
+                current_train_cost.append(cost)
+                iterations += 1
+                progress_indicator = int(time() - start_time) if time_based_progress else iterations
+                if progress_indicator >= next_save:
+                    if progress_indicator >= min_iterations:
+                        epochs.append(epochs_offset + dataset.training_set.epochs)
+                        train_costs.append(np.mean(current_train_cost))
+                        current_train_cost = []
+                        metrics = self._compute_validation_metrics(metrics)
+                        self._print_progress(iterations, epochs[-1], start_time, train_costs, metrics, validation_metrics)
+                        run_nb = len(metrics[list(self.metrics.keys())[0]]) - 1
+                        if autosave == "All":
+                            filename[run_nb] = save_dir + self._get_model_filename(round(epochs[-1], 3))
+                            self.save(filename[run_nb])
+                        elif autosave == "Best":
+                            pareto_runs = self.get_pareto_front(metrics, validation_metrics)
+                            if run_nb in pareto_runs:
+                                filename[run_nb] = save_dir + self._get_model_filename(round(epochs[-1], 3))
+                                self.save(filename[run_nb])
+                                for run in [r for r in filename if r not in pareto_runs]:
+                                    try:
+                                        os.remove(filename[run])
+                                    except OSError:
+                                        print("Warning : Previous model could not be deleted")
+                                    del filename[run]
+                        if early_stopping is not None:
+                            if all([early_stopping(epochs, metrics[m]) for m in validation_metrics]):
+                                break
+                    if isinstance(progress, int):
+                        next_save += min(progress, max_progress_interval)
+                    else:
+                        next_save += min(max_progress_interval, next_save * (progress - 1))
+        except KeyboardInterrupt:
+            print("Training interrupted")
+        if not metrics[validation_metrics[0]]:
+            return {}, time() - start_time, None
+        best_run = int(np.argmax(np.array(metrics[validation_metrics[0]]) * self.metrics[validation_metrics[0]]["direction"]))
+        # the reference raises KeyError here when the best run was not saved (--save None): return None instead
+        return ({m: metrics[m][best_run] for m in self.metrics.keys()}, time() - start_time, filename.get(best_run))
+
+    def _compute_validation_metrics(self, metrics):
+        from .data import Evaluator
+        ev = Evaluator(self.dataset, k=10)
+        for batch_input, goal in self._gen_mini_batch(self.dataset.validation_set(epochs=1), test=True):
+            ev.add_instance(goal, self.test_function(batch_input))
+        metrics["recall"].append(ev.average_recall())
+        metrics["sps"].append(ev.sps())
+        metrics["ndcg"].append(ev.average_ndcg())
+        metrics["user_coverage"].append(ev.user_coverage())
+        metrics["item_coverage"].append(ev.item_coverage())
+        metrics["blockbuster_share"].append(ev.blockbuster_share())
+        return metrics
+
+    def _print_progress(self, iterations, epochs, start_time, train_costs, metrics, validation_metrics):
+        print(self.name, iterations, "batchs, ", epochs, " epochs in", time() - start_time, "s")
+        print("Last train cost : ", train_costs[-1])
+        for m in self.metrics:
+            print(m, ": ", metrics[m][-1])
+            if m in validation_metrics:
+                d = self.metrics[m]["direction"]
+                print("Best ", m, ": ", max(np.array(metrics[m]) * d) * d)
+        print("-----------------")
+        # machine-readable line on stderr (rnn_base.py:434)
+        print(iterations, epochs, time() - start_time, train_costs[-1],
+              " ".join(map(str, [metrics[m][-1] for m in self.metrics])), file=sys.stderr)
+
+    # ------------------------------------------------------------------ checkpoints (rnn_base.py:470-515)
+    def save(self, filename):
+        """pickle of get_all_param_values(l_out): a plain list of float arrays in Lasagne order.
+        Protocol 2 so that a Python-2 reference install can load it."""
+        print("Save model in " + filename)
+        d = os.path.dirname(filename)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        param = self.engine.get_all_param_values()
+        with open(filename, "wb") as f:
+            pickle.dump(param, f, protocol=2)
+
+    def load_last(self, save_dir):
+        def extract_number_of_epochs(filename):
+            m = re.search(r"_ne([0-9]+(\.[0-9]+)?)_", filename)
+            return float(m.group(1))
+        files = glob.glob(save_dir + self._get_model_filename("*"))
+        if len(files) == 0:
+            print("No previous model, starting from scratch")
+            return 0
+        last_batch = np.amax(np.array([extract_number_of_epochs(f) for f in files]))
+        last_model = save_dir + self._get_model_filename(last_batch)
+        print("Starting from model " + last_model)
+        self.load(last_model)
+        return last_batch
+
+    def load(self, filename):
+        """Reads reference checkpoints too (py2 cPickle protocol 2 -> encoding='latin1')."""
+        with open(filename, "rb") as f:
+            param = pickle.load(f, encoding="latin1")
+        self.engine.set_all_param_values([np.asarray(i, dtype=np.float32) for i in param])
+
+
+class RNNOneHot(RNNBase):
+    """RNN + full softmax + categorical cross-entropy, `--loss CCE` (rnn_one_hot.py:13-106)."""
+
+    def __init__(self, diversity_bias=0.0, regularization=0.0, **kwargs):
+        super(RNNOneHot, self).__init__(**kwargs)
+        self.diversity_bias = np.float64(diversity_bias)     # np.cast[floatX]: the filename prints it as a float
+        self.regularization = regularization
+        self.name = "RNN with categorical cross entropy"
+
+    def _engine_kwargs(self):
+        return dict(loss="CCE", regularization=float(self.regularization))
+
+    def _get_model_filename(self, epochs):
+        return "rnn_cce_db" + str(self.diversity_bias) + "_r" + str(self.regularization) + "_" + self._common_filename(epochs)
+
+    def _prepare_input(self, sequences):
+        """(X, mask, Y, pop, exclude) as rnn_one_hot.py:83-106 returns them, except that `exclude`
+        (B,N) float -- built every batch and never used by train_function in the reference -- is
+        None: the engine derives the exclusion from X on the device."""
+        X, mask, Y, pop = self._pack(sequences)
+        return (X, mask, Y, pop, None)
+
+
+class RNNSampling(RNNBase):
+    """RNN + sampled output losses Blackout / BPR / TOP1 (rnn_sampling.py:14-194)."""
+
+    def __init__(self, loss_function="Blackout", sampling=32, last_layer_tanh=False, last_layer_init=1.0,
+                 diversity_bias=0.0, sampling_bias=0.0, **kwargs):
+        super(RNNSampling, self).__init__(**kwargs)
+        if last_layer_tanh:
+            raise NotImplementedError("last_layer_tanh is not reachable from the reference CLI (command_parser.py:120-121)")
+        self.last_layer_init, self.last_layer_tanh = last_layer_init, last_layer_tanh
+        self.diversity_bias, self.sampling, self.sampling_bias = diversity_bias, sampling, sampling_bias
+        if loss_function is None:
+            loss_function = "Blackout"
+        if loss_function not in ("BPR", "TOP1", "Blackout"):
+            raise ValueError("Unknown loss function")
+        self.loss_function_name = loss_function
+        self.name = "RNN with sampling loss"
+
+    def prepare_model(self, dataset):
+        n_items = dataset.n_items                            # rnn_sampling.py:102-106
+        self.effective_sampling = int(self.sampling * n_items) if self.sampling < 1 else int(self.sampling)
+        super(RNNSampling, self).prepare_model(dataset)
+
+    def _engine_kwargs(self):
+        return dict(loss=self.loss_function_name, n_samples=self.effective_sampling)
+
+    def _get_model_filename(self, epochs):
+        filename = "rnn_sampling_" + self.loss_function_name + "_"
+        if self.sampling_bias > 0.0:
+            filename += "p" + str(self.sampling_bias)
+        filename += "s" + str(self.sampling) + "_ini" + str(self.last_layer_init) + "_db" + str(self.diversity_bias)
+        return filename + "_" + self._common_filename(epochs)
+
+    def _popularity_sample(self):
+        if not hasattr(self, "_cumsum"):
+            self._cumsum = np.cumsum(np.power(self.dataset.item_popularity, self.sampling_bias))
+        return bisect(self._cumsum, random.uniform(0, self._cumsum[-1]))
+
+    def _prepare_input(self, sequences):
+        """(X, mask, Y, samples, pop, exclude) as rnn_sampling.py:165-194; the S negatives are shared
+        by the batch, drawn with replacement and NOT filtered against the targets."""
+        X, mask, Y, pop = self._pack(sequences)
+        if self.sampling_bias > 0:
+            samples = np.array([self._popularity_sample() for _ in range(self.effective_sampling)], dtype=np.int32)
+        else:
+            samples = np.random.choice(self.n_items, self.effective_sampling).astype(np.int32)
+        return (X, mask, Y, samples, pop, None)

@@ -1,0 +1,57 @@
+"""Data-parallel training step: the batch rows (independent user sub-sequences, the cost is their
+mean: rnn_one_hot.py:71) are sharded over ranks, one process per GPU; every rank computes its
+share of cost and gradients (already scaled by 1/B_global inside the engine), the flat gradient
+section is summed with an all-reduce (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the
+CPU tests), and every rank applies the identical optimizer step to its replica.
+
+Overlap: the output-layer gradients (W_out, b_out + the cost scalar that rides at the end of the
+section) are final after `loss_backward_output`, so their all-reduce is launched asynchronously
+and runs on RCCL's stream while the BPTT chain of `backward_recurrent` executes; the recurrent
+part follows.  The sampled heads need the targets of ALL rows on every rank (Blackout's softmax
+spans every target column, rnn_sampling.py:68-72,137): `gather_targets` all-gathers B int32.
+
+`engine` is anything with the RNNEngine phase methods -- the CPU tests pass an oracle-backed
+stand-in, production passes engine.RNNEngine.
+"""
+
+
+class DataParallel(object):
+    def __init__(self, engine, dist=None, group=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.engine, self.dist, self.group = engine, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.grads, self.split = engine.section("grads")
+
+    @staticmethod
+    def shard(batch_size, world, rank):
+        """rows [lo, hi) of the global batch owned by `rank` (contiguous, sizes differ by <= 1)."""
+        base, extra = divmod(batch_size, world)
+        lo = rank * base + min(rank, extra)
+        return lo, lo + base + (1 if rank < extra else 0)
+
+    def gather_targets(self, local_target):
+        """all ranks' targets in global row order (equal shard sizes)."""
+        if self.world == 1:
+            return local_target
+        import torch
+        parts = [torch.empty_like(local_target) for _ in range(self.world)]
+        self.dist.all_gather(parts, local_target, group=self.group)
+        return torch.cat(parts)
+
+    def train_step(self):
+        """One step on the batch already set on the engine; returns nothing (cost: read_cost())."""
+        e = self.engine
+        if self.world == 1:
+            e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()
+            return
+        e.zero_grads()
+        e.forward()
+        e.loss_backward_output()
+        w_out = self.dist.all_reduce(self.grads[self.split:], group=self.group, async_op=True)
+        e.backward_recurrent()
+        w_rec = self.dist.all_reduce(self.grads[:self.split], group=self.group, async_op=True)
+        w_out.wait()
+        w_rec.wait()
+        e.apply_update()

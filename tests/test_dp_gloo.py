@@ -1,0 +1,108 @@
+"""world_size-2 data-parallel step on CPU (gloo): parallel.DataParallel drives an oracle-backed
+stand-in engine per rank; after the all-reduce both replicas must hold exactly the parameters of
+the unsharded single-process step (cost mean over the GLOBAL batch, sampled heads see every rank's
+targets, the bias regulariser is added once)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import rnn_oracle as O
+import parity_util as PU
+
+
+class OracleEngine(object):
+    """RNNEngine's phase interface on top of the CPU oracle (flat float64 gradient section with the
+    cost as trailing element and the output-layer part last, like the arena of libsbr_rnn.so)."""
+
+    def __init__(self, params, cfg, updater, Bglobal, row_offset):
+        self.params, self.cfg, self.Bglobal, self.row_offset = params, cfg, Bglobal, row_offset
+        self.upd = O.Updater(updater, 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+        self.sizes = [p.size for p in params]
+        self.flat = torch.zeros(sum(self.sizes) + 1, dtype=torch.float64)
+        self.split = sum(self.sizes[:-2])
+
+    def section(self, which):
+        assert which == "grads"
+        return self.flat, self.split
+
+    def set_batch(self, batch):
+        self.batch = dict(batch, Bglobal=self.Bglobal, row_offset=self.row_offset)
+
+    def zero_grads(self):
+        self.flat.zero_()
+
+    def forward(self):
+        self.cost, self.g, _ = O.cost_and_grads(self.params, self.cfg, self.batch)
+
+    def loss_backward_output(self):
+        o = self.split
+        for g in self.g[-2:]:
+            self.flat[o:o + g.size] = torch.from_numpy(g.reshape(-1)); o += g.size
+        self.flat[-1] = self.cost
+
+    def backward_recurrent(self):
+        o = 0
+        for g in self.g[:-2]:
+            self.flat[o:o + g.size] = torch.from_numpy(np.ascontiguousarray(g).reshape(-1)); o += g.size
+
+    def apply_update(self):
+        grads, o = [], 0
+        for p in self.params:
+            grads.append(self.flat[o:o + p.size].numpy().reshape(p.shape).copy()); o += p.size
+        self.upd.apply(self.params, grads)
+
+    def read_cost(self):
+        return float(self.flat[-1])
+
+
+def _worker(rank, world, port, loss, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbr_amd.parallel import DataParallel
+    B, T, N, S = 6, 5, 17, 4
+    params, cfg, batch = PU.build_case("GRU", [6], loss, N, B, T, S=S, seed=11)
+    cfg["regularization"] = 0.03 if loss == "CCE" else 0.0
+    lo, hi = DataParallel.shard(B, world, rank)
+    eng = OracleEngine([p.copy() for p in params], cfg, "adam", B, lo)
+    dp = DataParallel(eng, dist)
+    ob = PU.oracle_batch(batch)
+    local_t = torch.from_numpy(ob["target"][lo:hi])
+    tgt = dp.gather_targets(local_t).numpy() if loss != "CCE" else ob["target"][lo:hi]
+    costs = []
+    for _ in range(2):
+        eng.set_batch(dict(X=ob["X"][lo:hi], mask=ob["mask"][lo:hi], target=tgt, samples=ob["samples"], pop=ob["pop"][lo:hi]))
+        dp.train_step()
+        costs.append(eng.read_cost())
+    np.savez(out % rank, costs=np.array(costs), **{"p%d" % i: p for i, p in enumerate(eng.params)})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss", ["CCE", "Blackout", "BPR"])
+def test_two_rank_step_equals_single_process(tmp_path, loss):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(2, port, loss, out), nprocs=2, join=True)
+    B, T, N, S = 6, 5, 17, 4
+    params, cfg, batch = PU.build_case("GRU", [6], loss, N, B, T, S=S, seed=11)
+    cfg["regularization"] = 0.03 if loss == "CCE" else 0.0
+    upd = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+    ref_costs = [O.train_function(params, cfg, upd, PU.oracle_batch(batch)) for _ in range(2)]
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert np.allclose(r0["costs"], ref_costs, rtol=1e-12) and np.allclose(r1["costs"], ref_costs, rtol=1e-12)
+    for i, p in enumerate(params):
+        assert np.allclose(r0["p%d" % i], p, rtol=1e-10, atol=1e-14)
+        assert np.array_equal(r0["p%d" % i], r1["p%d" % i])          # replicas stay identical
+
+
+def test_shard_covers_the_batch():
+    from sbr_amd.parallel import DataParallel
+    for B, W in ((256, 8), (10, 4), (7, 2)):
+        spans = [DataParallel.shard(B, W, r) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == B
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -1,0 +1,84 @@
+"""Golden vectors (tests/golden/*.npz, made by tools/make_golden.py from the pinned oracle):
+CPU: the oracle still reproduces them;  GPU: the HIP engine, driven through the C-ABI, matches them
+(logits/hidden state <= 1e-3 relative as BASELINE.json's north_star states, gradients and updated
+parameters <= 1e-4, top-k ids bit-exact) without importing the oracle at all."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+TOL_LOGITS = 1e-3      # north_star: "within 1e-3 relative on logits"
+TOL_GRADS = 1e-4       # grads / updated params <= 1e-4 relative (float32 engine vs float64 oracle)
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    n = int(z["n_params"])
+    return z, [z["p%d" % i] for i in range(n)], [z["g%d" % i] for i in range(n)], [z["q%d" % i] for i in range(n)]
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_fixtures_exist():
+    assert len(GOLD) >= 8
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_oracle_reproduces_golden(path):
+    from oracle import rnn_oracle as O
+    z, p0, g, q = load(path)
+    cfg = dict(cell=str(z["cell"]), layers=[int(h) for h in z["layers"]], loss=str(z["loss"]), regularization=0.0)
+    batch = dict(X=z["X"], mask=z["mask"], target=z["target"], samples=z["samples"], pop=z["pop"].astype(np.float64))
+    params = [p.astype(np.float64) for p in p0]
+    cost, grads, aux = O.cost_and_grads(params, cfg, batch)
+    assert abs(cost - float(z["cost"])) <= 1e-12 * abs(cost)
+    for a, b in zip(grads, g):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-15)
+    upd = O.Updater(str(z["updater"]), 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+    for _ in range(3):
+        O.train_function(params, cfg, upd, batch)
+    for a, b in zip(params, q):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_engine_matches_golden(path):
+    from sbr_amd.engine import RNNEngine
+    z, p0, g, q = load(path)
+    cell, layers, loss = str(z["cell"]), [int(h) for h in z["layers"]], str(z["loss"])
+    N, B, T, S, F, n_opt = (int(z[k]) for k in ("N", "B", "T", "S", "F", "n_opt"))
+    eng = RNNEngine(cell=cell, layers=layers, n_items=N, max_length=T, batch_size=B, loss=loss, n_samples=S,
+                    updater=str(z["updater"]), learning_rate=0.01, rho=0.9, beta1=0.9, beta2=0.999,
+                    input_size=N + n_opt, n_feat=F)
+    try:
+        eng.set_all_param_values(p0)
+        smp = z["samples"] if loss != "CCE" else None
+        eng.set_batch(z["X"], z["mask"], z["target"], smp, z["pop"])
+        cost = eng.forward_backward()
+        assert abs(cost - float(z["cost"])) <= 1e-5 * abs(float(z["cost"]))
+        Bp = (B + 15) // 16 * 16
+        hl = eng.debug_buffer("h_last").reshape(Bp, -1)[:B, :layers[-1]]
+        assert rel(hl, z["h_last"]) <= TOL_LOGITS
+        if loss == "CCE":
+            pass    # "logits" now holds dlogits; the logits themselves are checked through predict below
+        else:
+            C = B + S
+            # activations were overwritten by their gradient; rerun forward only for them is covered by cost/h_last
+            assert C > 0
+        for i, (a, b) in enumerate(zip(eng.get_all_grad_values(), g)):
+            assert rel(a, b) <= TOL_GRADS or np.abs(b).max() < 1e-12, ("grad", i, rel(a, b))
+        costs = [eng.train_step(sync=True) for _ in range(3)]
+        assert np.allclose(costs, z["costs3"], rtol=1e-4)
+        for i, (a, b) in enumerate(zip(eng.get_all_param_values(), q)):
+            assert rel(a, b) <= TOL_GRADS, ("param", i, rel(a, b))
+        scores = eng.predict_function(z["X"], z["mask"])
+        assert rel(scores, z["scores"]) <= TOL_LOGITS
+        ids = eng.test_function((z["X"], z["mask"]), k=z["topk"].shape[1])
+        assert np.array_equal(ids, z["topk"])          # bit-exact item ids
+    finally:
+        eng.close()

@@ -1,0 +1,169 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs (sizes the oracle finishes in seconds), plus size-independent properties at
+BASELINE.json's full sizes.  Tolerances: logits / hidden state 1e-3 relative (north_star), gradients
+and updated parameters 1e-4 relative, top-k ids exact."""
+import numpy as np
+import pytest
+
+import parity_util as PU
+
+pytestmark = pytest.mark.gpu
+
+
+def check(r, steps=2, tol_h=1e-4, tol_g=1e-4):
+    assert r["param_roundtrip"] == 0.0
+    assert r["h_last"] <= tol_h, r
+    assert r["cost"] <= 1e-5, r
+    assert r["grad_worst"] <= tol_g, {k: v for k, v in r.items() if k.startswith("grad")}
+    assert r["params_after_%d_steps" % steps] <= 1e-3, r
+    assert r["predict_scores"] <= 1e-3, r
+    assert r["topk_mismatch"] == 0, r
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+@pytest.mark.parametrize("H", [4, 20, 50, 128])          # Hp = 16, 32, 64, 128: register-resident W_hid kernels
+def test_one_layer_cce(cell, H):
+    check(PU.compare_step(cell, [H], "CCE", N=61, B=37, T=9))
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_streamed_whid_kernels(cell):                      # Hp = 192: W_hid fragments streamed from L2
+    check(PU.compare_step(cell, [160], "CCE", N=61, B=21, T=8), tol_h=2e-4)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_triage_kernels_agree(cell):                       # SBR_FLAG_SIMPLE_REC | SBR_FLAG_SIMPLE_GEMM
+    check(PU.compare_step(cell, [12], "CCE", N=23, B=5, T=7, flags=3))
+
+
+@pytest.mark.parametrize("loss", ["Blackout", "BPR", "TOP1"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_sampled_heads(cell, loss):
+    check(PU.compare_step(cell, [16], loss, N=40, B=6, T=5, S=7))
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_two_layer_stack(cell):                            # recurrent_layers.py:57-68: dense layers above layer 0
+    check(PU.compare_step(cell, [20, 12], "CCE", N=30, B=6, T=6))
+
+
+def test_rating_feature_two_indices_per_step():            # --rf: F=2, input_size = N + 10
+    check(PU.compare_step("LSTM", [8], "CCE", N=19, B=4, T=5, F=2, n_opt=10))
+
+
+@pytest.mark.parametrize("updater", ["adagrad", "adadelta", "rmsprop", "nesterov", "adam"])
+def test_updaters(updater):
+    check(PU.compare_step("GRU", [8], "CCE", N=19, B=4, T=5, updater=updater, steps=3), steps=3)
+
+
+@pytest.mark.parametrize("reg", [0.05, -0.05])
+def test_bias_regularisation(reg):                         # rnn_one_hot.py:73-77
+    check(PU.compare_step("GRU", [8], "CCE", N=19, B=4, T=5, reg=reg))
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_gradient_clip_active(cell):                       # tiny popularity -> gate gradients beyond +-100
+    check(PU.compare_step(cell, [8], "CCE", N=19, B=4, T=5, popscale=1e-4))
+
+
+def test_ragged_and_edge_lengths():
+    # rows of length 1 and T, a row whose items are all id 0 (== the pad id), B not a multiple of 16
+    check(PU.compare_step("GRU", [16], "CCE", N=33, B=17, T=11, seed=5))
+    check(PU.compare_step("LSTM", [16], "CCE", N=33, B=1, T=3, seed=6))
+
+
+def test_bench_shape_one_step():                           # BASELINE configs[1] with a shorter T for the oracle
+    check(PU.compare_step("GRU", [128], "CCE", N=3706, B=256, T=20, steps=1), steps=1)
+
+
+def test_full_size_properties():
+    """Config 2 at full size (GRU-128, N=3706, B=256, T=200): properties that need no oracle."""
+    from sbr_amd.engine import RNNEngine
+    rng = np.random.default_rng(0)
+    N, B, T, H = 3706, 256, 200, 128
+    eng = RNNEngine(cell="GRU", layers=[H], n_items=N, max_length=T, batch_size=B, loss="CCE", updater="adam")
+    try:
+        params, cfg, batch = PU.build_case("GRU", [H], "CCE", N, B, T, seed=1, scale=0.0)
+        eng.set_all_param_values(params)
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], None, batch["pop"])
+        c1 = eng.forward_backward()
+        g1 = eng.get_all_grad_values()
+        # (1) softmax gradient rows sum to zero -> d cost / d b_out sums to ~0
+        assert abs(g1[-1].sum()) <= 1e-5
+        # (2) W_in rows of items that never occur in a valid position get exactly zero gradient
+        seen = np.zeros(N, dtype=bool)
+        m = batch["mask"].astype(bool)
+        seen[np.unique(batch["X"][:, :, 0][m])] = True
+        for gi in (0, 3, 6):
+            assert np.all(g1[gi][~seen] == 0.0) and np.abs(g1[gi][seen]).max() > 0
+        # (3) padding content is ignored: garbage ids behind the mask change nothing
+        X2 = batch["X"].copy()
+        X2[:, :, 0][~m] = rng.integers(0, N, size=(~m).sum())
+        eng.set_batch(X2, batch["mask"], batch["target"], None, batch["pop"])
+        c2 = eng.forward_backward()
+        g2 = eng.get_all_grad_values()
+        assert abs(c1 - c2) <= 1e-6 * abs(c1)
+        assert all(np.allclose(a, b, rtol=1e-4, atol=1e-7) for a, b in zip(g1, g2))
+        # (4) row permutation invariance of the cost (mean over rows)
+        perm = rng.permutation(B)
+        eng.set_batch(batch["X"][perm], batch["mask"][perm], batch["target"][perm], None, batch["pop"][perm])
+        c3 = eng.forward_backward()
+        assert abs(c1 - c3) <= 1e-5 * abs(c1)
+        # (5) untrained model: cost ~ log(N) (uniform softmax), and a few Adam steps reduce it
+        costs = [eng.train_step(sync=True) for _ in range(5)]
+        assert abs(costs[0] - c3) <= 1e-5 * abs(c3) and costs[-1] < costs[0]
+        assert abs(c1 - np.log(N)) < 0.5
+        # (6) top-k ids are valid, distinct and never a seen item
+        ids = eng.test_function((batch["X"], batch["mask"]), k=10)
+        for b in range(B):
+            assert len(set(ids[b])) == 10 and ids[b].min() >= 0 and ids[b].max() < N
+            assert not set(ids[b]) & set(batch["X"][b, :int(batch["mask"][b].sum()), 0])
+    finally:
+        eng.close()
+
+
+def test_error_behaviour():
+    from sbr_amd.engine import RNNEngine
+    eng = RNNEngine(cell="GRU", layers=[8], n_items=10, max_length=4, batch_size=2)
+    try:
+        with pytest.raises(ValueError, match="mismatch"):
+            eng.set_all_param_values([np.zeros(3)])
+        X = np.zeros((2, 4, 1), dtype=np.int32); X[0, 0, 0] = 10            # id out of range
+        with pytest.raises(ValueError, match="out of range"):
+            eng.set_batch(X, np.ones((2, 4), np.float32), np.zeros(2, np.int32), None, np.ones(2, np.float32))
+        with pytest.raises(ValueError, match="prefix"):
+            eng.set_batch(np.zeros((2, 4, 1), np.int32), np.array([[0, 1, 1, 1], [1, 1, 1, 1]], np.float32))
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("loss", ["CCE", "Blackout"])
+def test_virtual_ranks_sum_to_the_unsharded_step(loss):
+    """Data-parallel by construction: two engines holding rows [0,B/2) and [B/2,B) of the same global
+    batch produce gradient sections whose SUM equals the single-engine gradients ("N
+    virtual ranks on one GPU"); cost shares add up; identical updates follow."""
+    import torch
+    N, B, T, S = 50, 32, 9, 6
+    params, cfg, batch = PU.build_case("GRU", [16], loss, N, B, T, S=S, seed=4)
+    smp = batch["samples"] if loss != "CCE" else None
+    full = PU.engine_for(cfg, N, B, T, S=S)
+    halves = [PU.engine_for(cfg, N, B, T, S=S, local_batch=B // 2, row_offset=r * (B // 2)) for r in range(2)]
+    try:
+        for e in [full] + halves:
+            e.set_all_param_values(params)
+        full.set_batch(batch["X"], batch["mask"], batch["target"], smp, batch["pop"])
+        c_full = full.forward_backward()
+        g_full = full.section("grads")[0].clone()
+        total = torch.zeros_like(g_full)
+        for r, e in enumerate(halves):
+            sl = slice(r * (B // 2), (r + 1) * (B // 2))
+            tgt = batch["target"] if loss != "CCE" else batch["target"][sl]
+            e.set_batch(batch["X"][sl], batch["mask"][sl], tgt, smp, batch["pop"][sl])
+            e.forward_backward()
+            total += e.section("grads")[0]
+        assert abs(float(total[-1]) - c_full) <= 1e-5 * abs(c_full)
+        err = float((total - g_full).abs().max() / g_full.abs().max())
+        assert err <= 1e-5, err
+    finally:
+        for e in [full] + halves:
+            e.close()

@@ -1,0 +1,215 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares (no compute calls without a GPU), the option surface / filenames follow the reference's
+grammar, and the vectorised batch packing equals the oracle's literal loop restatement."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import rnn_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "sequence-based-recommendations_amd", "libsbr_rnn.so")
+HEADER = os.path.join(ROOT, "include", "sbr_rnn.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    import sbr_amd.engine as E
+    return E.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    import sbr_amd.engine as E
+    src = open(HEADER).read()
+    declared = set(re.findall(r"\b(sbr_[a-z_]+)\s*\(", src))
+    assert declared == set(E.EXPORTS), declared ^ set(E.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sbr_abi_version() == E.SBR_ABI_VERSION
+
+
+def _cfg(E, **kw):
+    c = E.SbrConfig()
+    c.abi_version = E.SBR_ABI_VERSION
+    c.cell, c.n_layers = E.CELLS["GRU"], 1
+    c.layers[0] = 128
+    c.n_items = c.input_size = 3706
+    c.n_feat, c.max_length, c.batch_size, c.local_batch = 1, 200, 256, 256
+    c.loss, c.updater, c.learning_rate = E.LOSSES["CCE"], E.UPDATERS["adam"], 1e-3
+    c.rho, c.beta1, c.beta2, c.grad_clip = 0.9, 0.9, 0.999, 100.0
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_arena_size_and_config_validation(lib):
+    import sbr_amd.engine as E
+    n = ctypes.c_size_t()
+    assert lib.sbr_arena_bytes(ctypes.byref(_cfg(E)), ctypes.byref(n)) == 0
+    # params+grads+2 adam arrays (~4 x 7.8 MB) + saved activations (~0.5 GB at B=256, T=200)
+    assert 300e6 < n.value < 1.5e9
+    bad = _cfg(E, cell=7)
+    assert lib.sbr_arena_bytes(ctypes.byref(bad), ctypes.byref(n)) == -1
+    assert b"Unknown layer type" in lib.sbr_last_error()
+    bad = _cfg(E, loss=E.LOSSES["BPR"], n_samples=0)
+    assert lib.sbr_arena_bytes(ctypes.byref(bad), ctypes.byref(n)) == -1
+    bad = _cfg(E, local_batch=300)
+    assert lib.sbr_arena_bytes(ctypes.byref(bad), ctypes.byref(n)) == -1
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sbr_amd.engine import RNNEngine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        RNNEngine(cell="GRU", layers=[8], n_items=10)
+
+
+def test_mask_to_lengths_rejects_non_prefix_masks():
+    from sbr_amd.engine import mask_to_lengths
+    m = np.array([[1, 1, 0, 0], [1, 1, 1, 1], [0, 0, 0, 0]], dtype=np.float32)
+    assert list(mask_to_lengths(m)) == [2, 4, 0]
+    with pytest.raises(ValueError):
+        mask_to_lengths(np.array([[1, 0, 1, 0]]))
+
+
+class FakeDataset(object):
+    n_items = 50
+    item_popularity = np.arange(1, 51, dtype=np.float64)
+
+
+def _model(cls, **kw):
+    from sbr_amd import options as Opt
+    common = dict(use_ratings_features=False, use_movies_features=False, use_users_features=False,
+                  recurrent_layer=Opt.RecurrentLayers("GRU", [128]), updater=Opt.Adam(), max_length=200, batch_size=256)
+    common.update(kw)
+    m = cls(**common)
+    m.n_items = FakeDataset.n_items
+    m.set_dataset(FakeDataset())
+    return m
+
+
+def test_checkpoint_filename_grammar():
+    # SURVEY 8(a14) example: rnn_cce_db0.0_r0.0_ml200_bs256_ne1.234_GRU_gc100_h128_Ua_lr0.001_b10.9_b20.999_nt1_nf
+    from sbr_amd.models import RNNOneHot, RNNSampling
+    from sbr_amd import options as Opt
+    m = _model(RNNOneHot)
+    assert m._get_model_filename(1.234) == "rnn_cce_db0.0_r0.0_ml200_bs256_ne1.234_GRU_gc100_h128_Ua_lr0.001_b10.9_b20.999_nt1_nf"
+    s = _model(RNNSampling, loss_function="BPR", sampling=32.0, recurrent_layer=Opt.RecurrentLayers("LSTM", [100, 50]),
+               updater=Opt.Adagrad(0.1), use_ratings_features=True, interactions_are_unique=False)
+    assert s._get_model_filename("*") == "rnn_sampling_BPR_s32.0_ini1.0_db0.0_ml200_bs256_ne*_gc100_h100-50_Ug_lr0.1_nt1_ri_rf"
+    assert Opt.RecurrentLayers("LSTM", [20], bidirectional=True).name == "bLSTM_gc100_h20"
+    assert Opt.SelectTargets(n_targets=3, shuffle=True, bias=0.5).name == "nt3_tb0.5_shufT"
+    assert Opt.SequenceNoise(dropout=0.1, swap=0.2).name == "do0.1_sw0.2"
+    assert Opt.NesterovMomentum(0.5, 0.8).name == "Un_lr0.5_m0.8" and Opt.RMSProp(1.0, 0.9).name == "Ur_lr1.0_rho0.9"
+
+
+def test_cli_defaults_match_the_reference_parser():
+    from sbr_amd import options as Opt
+    a = Opt.command_parser(Opt.predictor_command_parser, Opt.training_command_parser, argv=[])
+    # command_parser.py:37,65; recurrent_layers.py:9-10; update_manager.py:4-5; train.py:19,23
+    assert (a.batch_size, a.max_length, a.recurrent_layer_type, a.r_l) == (16, 30, "GRU", "50")
+    assert (a.update_manager, a.u_l, a.loss, a.sampling, a.save, a.progress) == ("adam", 0.001, "CCE", 32.0, "Best", "2.")
+    assert Opt.num("2.") == 2.0 and isinstance(Opt.num("5"), int)
+
+
+def test_prepare_input_matches_the_literal_restatement():
+    from sbr_amd.models import RNNOneHot, RNNSampling
+    rng = np.random.default_rng(0)
+    seqs = []
+    for b in range(6):
+        n = int(rng.integers(1, 9))
+        in_seq = [[int(rng.integers(0, 50)), float(rng.integers(1, 11)) / 2] for _ in range(n)]
+        seqs.append(["u%d" % b, in_seq, [[int(rng.integers(0, 50)), 4.0]]])
+    m = _model(RNNOneHot, diversity_bias=0.5, max_length=8, batch_size=6)
+    X, mask, Y, pop, excl = m._prepare_input(seqs)
+    oX, omask, oY, opop, oexcl = O.prepare_input_one_hot(seqs, 8, 50, FakeDataset.item_popularity, 0.5)
+    assert np.array_equal(X, oX) and np.array_equal(mask, omask) and np.array_equal(Y, oY)
+    assert np.allclose(pop, opop, rtol=1e-6) and excl is None
+    s = _model(RNNSampling, loss_function="TOP1", sampling=7, max_length=8, batch_size=6)
+    s.effective_sampling = 7
+    X2, mask2, Y2, samples, pop2, _ = s._prepare_input(seqs)
+    assert np.array_equal(X2, oX) and samples.shape == (7,) and samples.dtype == np.int32 and samples.max() < 50
+    r = _model(RNNOneHot, use_ratings_features=True, max_length=8, batch_size=6)
+    Xr = r._prepare_input(seqs)[0]
+    assert Xr.shape == (6, 8, 2)
+    b, t = 0, 0
+    assert Xr[b, t, 1] == 50 + int(round(seqs[b][1][t][1] * 2)) - 1      # rnn_base.py:590-605
+
+
+def test_gen_mini_batch_policy():
+    # rnn_base.py:396-415: distinct sorted split points in [2, len), inputs truncated to max_length
+    from sbr_amd.models import RNNOneHot
+    m = _model(RNNOneHot, max_length=5, batch_size=7)
+
+    def gen():
+        while True:
+            yield [[i % 50, 3.0] for i in range(12)], "7"
+    X, mask, Y, pop, _ = next(m._gen_mini_batch(gen()))
+    assert X.shape == (7, 5, 1)
+    lens = mask.sum(1).astype(int)
+    assert lens.min() >= 2 and lens.max() <= 5
+    for b in range(7):                                       # target = the item right after the input window
+        last = X[b, lens[b] - 1, 0]
+        assert Y[b] == (last + 1) % 50
+    (bi, goal) = next(m._gen_mini_batch(gen(), test=True))   # test mode: split in the middle, goal = the rest
+    assert bi[0].shape == (1, 5, 1) and goal == [i % 50 for i in range(6, 12)]
+
+
+def test_save_load_roundtrip_layout(tmp_path):
+    # checkpoints are plain pickled lists of arrays in Lasagne order, protocol 2 (rnn_base.py:470-479)
+    import pickle
+    from sbr_amd.models import RNNOneHot
+
+    class FakeEngine(object):
+        def __init__(self):
+            self.vals = [np.full(s, i, dtype=np.float32) for i, (n, s) in enumerate(O.model_param_shapes("GRU", [4], 9))]
+
+        def get_all_param_values(self):
+            return self.vals
+
+        def set_all_param_values(self, v):
+            self.vals = v
+    m = _model(RNNOneHot)
+    m.engine = FakeEngine()
+    fn = str(tmp_path / "models" / m._get_model_filename(0.5))
+    m.save(fn)
+    raw = pickle.load(open(fn, "rb"))
+    assert isinstance(raw, list) and len(raw) == 12 and raw[0].shape == (9, 4) and raw[-2].shape == (4, 9)
+    m.engine.vals = None
+    assert m.load_last(str(tmp_path / "models") + "/") == 0.5
+    assert len(m.engine.vals) == 12 and m.engine.vals[3][0, 0] == 3.0
+
+
+def test_evaluator_metrics():
+    from sbr_amd.data import Evaluator
+    ev = Evaluator(FakeDataset(), k=3)
+    ev.add_instance([5, 7, 9], [7, 1, 5, 9])
+    ev.add_instance([2], [3, 4, 6])
+    assert ev.sps() == 0.5 and ev.user_coverage() == 0.5 and ev.item_coverage() == 2
+    assert abs(ev.average_recall() - (2 / 3) / 2) < 1e-12 and abs(ev.average_precision() - (2 / 3) / 2) < 1e-12
+    dcg = 1 / np.log2(2) + 1 / np.log2(4); mx = 1 / np.log2(2) + 1 / np.log2(3) + 1 / np.log2(4)
+    assert abs(ev.average_ndcg() - (dcg / mx) / 2) < 1e-12
+
+
+def test_data_handler_reads_the_preprocess_format(tmp_path):
+    from sbr_amd.data import DataHandler
+    d = tmp_path / "ds" / "data"
+    d.mkdir(parents=True)
+    (d / "train_set_sequences").write_text("0 1 4.0 2 3.5 3 5.0\n1 2 1.0 0 2.0\n")
+    (d / "val_set_sequences").write_text("2 3 4.0 1 4.0 0 1.0 2 2.0\n")
+    (d / "test_set_sequences").write_text("3 0 4.0 1 4.0\n")
+    (d / "train_set_triplets").write_text("0 1 4.0\n0 2 3.5\n0 3 5.0\n1 2 1.0\n1 0 2.0\n")
+    (d / "stats").write_text("set n_users n_items n_interactions longest_sequence\nFull 4 4 11 4\nTrain 2 4 5 3\nVal 1 4 4 4\nTest 1 2 2 2\n")
+    dh = DataHandler(str(tmp_path / "ds") + "/")
+    assert (dh.n_users, dh.n_items, dh.training_set.n_interactions) == (4, 4, 5)
+    assert list(dh.item_popularity) == [1, 1, 2, 1]
+    seqs = list(dh.training_set(epochs=1))
+    assert seqs[0] == ([[1, 4.0], [2, 3.5], [3, 5.0]], "0") and seqs[1][1] == "1"
