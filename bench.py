@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="max timed CPU-baseline steps")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU-baseline sample")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the port scales to ~16 threads on the GPU box")
     args = ap.parse_args()
 
     def log(*a):
@@ -199,7 +199,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref as R
         ncores = os.cpu_count() or 1
-        nthr = args.cpu_threads or min(ncores, 32)
+        nthr = args.cpu_threads or min(ncores, 16)
         torch.set_num_threads(nthr)
         cfg = dict(cell=cell, layers=layers, loss=loss, regularization=0.0)
         tr = R.TorchTrainer(params, cfg, O.recurrent_param_shapes, updater="adam", lr=1e-3)

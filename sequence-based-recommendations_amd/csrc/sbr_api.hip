@@ -102,6 +102,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         lay.a_act = take((size_t)Bp * lay.C);
         lay.a_dWc = take((size_t)lay.C * lay.HLp); lay.a_dbc = take(lay.C);
     }
+    lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
     lay.a_X = take((size_t)Bp * T * lay.F);
@@ -111,6 +112,9 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_cells = take(std::max(lay.C, 1));
     lay.a_pop = take(Bp);
     lay.a_topk = take((size_t)Bp * 64);
+    lay.a_scnt = take((size_t)cfg.input_size + 1); lay.a_soff = take((size_t)cfg.input_size + 1);
+    lay.a_scur = take((size_t)cfg.input_size + 1);
+    lay.a_sid = take((size_t)T * Bp * lay.F); lay.a_spos = take((size_t)T * Bp * lay.F);
     lay.s_end = lay.s_act + off;
     return SBR_OK;
 }
@@ -202,6 +206,12 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     sbr_param_descs(h->lay, h->descs);
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
+    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        sbr_set_error("side stream creation failed"); sbr_destroy(h); return SBR_EHIP;
+    }
     // parameters, gradients, optimizer state and batch buffers start as zeros
     // (activations too: one-off, keeps every later GEMM operand finite)
     hipError_t e = hipMemsetAsync(h->arena, 0, h->lay.s_end * sizeof(float), h->stream);
@@ -215,6 +225,9 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (!h) return;
     for (int r = 0; r < sbr_handle::kRing; ++r)
         for (int i = 0; i < SBR_N_PHASES; ++i) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -368,6 +381,15 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     float* ws = h->A(y.a_ws);
     const int* tgt = (const int*)h->A(y.a_tgt);
     SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));
+    if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
+        // batch-only work for the embedding scatter-add: side stream, joins before the reduce kernel
+        SBR_HIP(hipEventRecord(h->ev_fork, s));
+        SBR_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        SBR_LAUNCH(launch_scatter_sort(h->side, (const int*)h->A(y.a_X), (const int*)h->A(y.a_len), y.T, y.Bp, y.F,
+                                       y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
+                                       (int*)h->A(y.a_sid), (int*)h->A(y.a_spos)));
+        SBR_HIP(hipEventRecord(h->ev_join, h->side));
+    }
     if (y.cfg.loss == SBR_LOSS_CCE) {
         float* lg = h->A(y.a_logits);
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
@@ -376,7 +398,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
-        SBR_LAUNCH(launch_colsum_bias(s, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr()));
+        SBR_LAUNCH(launch_colsum_bias(s, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
         // dW_out^T [N][Hp] = dlogits^T . h ;  dh = dlogits . W_out^T
         SBR_LAUNCH(launch_gemm(s, lg, 1, N, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws, y.ws_floats, sg));
         SBR_LAUNCH(launch_gemm(s, lg, N, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
@@ -390,7 +412,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->A(y.a_pop), h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
                                        y.cfg.loss, y.Bg));
         SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
-        SBR_LAUNCH(launch_colsum_bias(s, act, R, C, C, dbc, nullptr, 0.0f, nullptr));
+        SBR_LAUNCH(launch_colsum_bias(s, act, R, C, C, dbc, nullptr, 0.0f, nullptr, h->A(y.a_csum)));
         SBR_LAUNCH(launch_gemm(s, act, 1, C, hl, Hp, 1, dWc, Hp, C, Hp, R, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
@@ -421,7 +443,13 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                y.ws_floats, sg));
         if (l == 0) {
             mark(h, 5);
-            SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_X), a.len, y.T, y.Bp, y.F, GHp));
+            if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
+                SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_X), a.len, y.T, y.Bp, y.F, GHp));
+            } else {
+                SBR_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+                SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp));
+            }
             mark(h, 6);
         } else {
             const LayerLayout& lo = y.layer[l - 1];

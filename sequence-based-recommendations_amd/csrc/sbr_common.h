@@ -63,7 +63,9 @@ struct Layout {
     size_t a_rowcost;                     // [Bp]
     size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
     size_t a_ws; size_t ws_floats;        // split-K workspace
+    size_t a_csum;                        // [16][max(N,C)] column-sum partials
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
+    size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
 };
 
 int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err);
@@ -76,6 +78,8 @@ struct sbr_handle {
     Layout lay;
     float* arena; bool own_arena;
     hipStream_t stream;
+    hipStream_t side;            // batch-only preprocessing (scatter sort) overlapped with the chain
+    hipEvent_t ev_fork, ev_join;
     std::vector<ParamDesc> descs;
     int n_rows;          // rows of the current batch (<= local_batch)
     int64_t step_count;  // adam t
@@ -106,6 +110,12 @@ hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, 
 // K6: dWin[X[b][t][f]][:] += dxt[t][b][:] for t < len[b]     (AdvancedIncSubtensor grad [3P])
 hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, const int* X, const int* len,
                                int T, int Bp, int F, int GHp);
+// counting sort of the valid (position, id) pairs by id (depends on the batch only), then one wave per
+// chunk of 32 sorted entries reduces the dxt rows of equal id in registers
+hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
+                               int* offs, int* cur, int* sid, int* spos);
+hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
+                                 const int* offs, int n_ids, int max_entries, int GHp);
 
 struct RecArgs {
     int cell, T, Bp, H, Hp, G;
@@ -142,7 +152,7 @@ hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, c
 hipError_t launch_softmax_rows(hipStream_t s, float* logits, const float* bout, int rows, int N, int do_softmax);
 // db[n] = sum_rows d[r][n] + reg term ; cost += reg term
 hipError_t launch_colsum_bias(hipStream_t s, const float* d, int rows, int N, long ld, float* db, const float* b,
-                              float reg, float* cost);
+                              float reg, float* cost, float* ws /* >= 16*N floats */);
 hipError_t launch_sum_cost(hipStream_t s, const float* rowcost, int rows, float* cost);
 // sampled heads (sparse_lstm.py:42-54, rnn_sampling.py:68-91,137)
 hipError_t launch_build_cells(hipStream_t s, const int* target, const int* samples, int Bg, int S, int* cells);

@@ -26,6 +26,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CELL_VANILLA 2
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms used by the MFMA kernels (1 ulp-class hardware transcendentals; the
+// libm forms above cost ~25 VALU instructions each and sat on the per-step critical path)
+__device__ __forceinline__ float sigm_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {   // 2*sigmoid(2x) - 1, abs error ~1 ulp(1.0)
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
+}
+template <bool FAST> __device__ __forceinline__ float sg(float x) { return FAST ? sigm_fast(x) : sigm(x); }
+template <bool FAST> __device__ __forceinline__ float th(float x) { return FAST ? tanh_fast(x) : tanhf(x); }
 __device__ __forceinline__ float clipf(float x, float c) { return c > 0.0f ? fminf(fmaxf(x, -c), c) : x; }
 template <int CELL> struct Gates { static constexpr int G = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1); };
 
@@ -34,27 +44,27 @@ template <int CELL> struct Gates { static constexpr int G = CELL == CELL_LSTM ? 
 // ---------------------------------------------------------------------------------------
 // Forward: a[g] = (h_prev . W_hid)[g], x[g] = xt[g].  Updates h/c in place (masked rows copy),
 // writes the values saved for BPTT into sv[0..3].
-template <int CELL>
+template <int CELL, bool FAST = false>
 __device__ __forceinline__ void cell_forward(const float* x, const float* a, bool m, float& h, float& c,
                                              float pi, float pf, float po, float* sv) {
     if (CELL == CELL_LSTM) {
-        float i = sigm(x[0] + a[0] + c * pi);                 // sparse_lstm.py:397-402
-        float f = sigm(x[1] + a[1] + c * pf);
-        float g = tanhf(x[2] + a[2]);
+        float i = sg<FAST>(x[0] + a[0] + c * pi);             // sparse_lstm.py:397-402
+        float f = sg<FAST>(x[1] + a[1] + c * pf);
+        float g = th<FAST>(x[2] + a[2]);
         float cn = f * c + i * g;                             // :407
-        float o = sigm(x[3] + a[3] + cn * po);                // :409-411
-        float hn = o * tanhf(cn);                             // :414
+        float o = sg<FAST>(x[3] + a[3] + cn * po);            // :409-411
+        float hn = o * th<FAST>(cn);                          // :414
         sv[0] = i; sv[1] = f; sv[2] = g; sv[3] = o;
         c = m ? cn : c; h = m ? hn : h;                       // :422-423
     } else if (CELL == CELL_GRU) {
-        float r = sigm(a[0] + x[0]);                          // :780-783
-        float u = sigm(a[1] + x[1]);
-        float cc = tanhf(x[2] + r * a[2]);                    // :786-792
+        float r = sg<FAST>(a[0] + x[0]);                      // :780-783
+        float u = sg<FAST>(a[1] + x[1]);
+        float cc = th<FAST>(x[2] + r * a[2]);                 // :786-792
         float hn = (1.0f - u) * h + u * cc;                   // :795
         sv[0] = r; sv[1] = u; sv[2] = cc; sv[3] = a[2];
         h = m ? hn : h;                                       // :803
     } else {
-        float hn = tanhf(x[0] + a[0]);                        // :1133-1143
+        float hn = th<FAST>(x[0] + a[0]);                     // :1133-1143
         h = m ? hn : h;                                       // :1150
     }
 }
@@ -62,7 +72,7 @@ __device__ __forceinline__ void cell_forward(const float* x, const float* a, boo
 // Backward of one step for one (row, unit).  In: dh, dc = grads wrt h_t, c_t; saved values.
 // Out: dxi[g], dhi[g] (grad wrt xt and wrt hid_input, both clipped), dh/dc updated to the part
 // that flows to step t-1 WITHOUT the dhi.W^T term (added by the caller); peephole partials.
-template <int CELL>
+template <int CELL, bool FAST = false>
 __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, float& dc, const float* sv, float hprev,
                                               float cprev, float cnew, float hnew, float pi, float pf, float po,
                                               float* dxi, float* dhi, float* dpeep) {
@@ -70,7 +80,7 @@ __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, flo
     if (CELL == CELL_LSTM) {
         float i = sv[0], f = sv[1], g = sv[2], o = sv[3];
         float dcn = m ? dc : 0.0f, dcp = m ? 0.0f : dc;
-        float tc = tanhf(cnew);
+        float tc = th<FAST>(cnew);
         float dzo = dhn * tc * o * (1.0f - o);
         dcn += dhn * o * (1.0f - tc * tc) + dzo * po;
         float dzi = dcn * g * i * (1.0f - i);
@@ -98,15 +108,28 @@ __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, flo
 }
 
 // ---------------------------------------------------------------------------------------
+// LDS tile layout shared by both MFMA kernels: 16 rows (batch rows of the tile) x K values, K split
+// in 4 chunks (one per MFMA k-lane-group q).  Chunk stride CH = multiple of 64 floats and row
+// stride 4*CH+4 make every ds_read_b128 of the B operand conflict-free (rows land on distinct
+// 16-byte slots of the 256-byte bank row for each of the instruction's four 16-lane groups).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_chunk(int kper) { return (kper + 63) / 64 * 64; }
+
+// ---------------------------------------------------------------------------------------
 // MFMA persistent forward.  KS_RES > 0: Hp = 4*KS_RES compile-time, W_hid fragments in VGPRs.
 // KS_RES == 0: runtime Hp, fragments streamed from L2 every step.  NT unit tiles per wave.
+// Per step: [B operand: ds_read_b128] -> [G*Hp/4 MFMAs per tile] -> [gate math in registers]
+// -> [16-B stores of h_t and the activations BPTT needs] -> [prefetch xt of step t+1] ->
+// [h_t -> LDS] -> one __syncthreads.  The xt prefetch is issued BEFORE the barrier so that its
+// HBM latency hides under the barrier wait and the next step's MFMA phase.
 // ---------------------------------------------------------------------------------------
 template <int CELL, int NT, int KS_RES>
 __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(RecArgs a) {
     constexpr int G = Gates<CELL>::G;
     const int Hp = KS_RES > 0 ? 4 * KS_RES : a.Hp;
-    const int KS = Hp / 4, GHp = G * Hp, LDH = Hp + 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][16][LDH]
+    const int KS = Hp / 4, GHp = G * Hp;
+    const int CH = lds_chunk(KS), ROW = 4 * CH + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][16][ROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * 16 + j;
@@ -130,9 +153,11 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
     }
 
     f32x4 h[NT], c[NT], pi[NT], pf[NT], po[NT];
+    int wofs[NT];          // where this lane's 4 units live inside an LDS row
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int u0 = (wave * NT + n) * 16 + q * 4;
+        wofs[n] = (u0 / KS) * CH + (u0 % KS);
         h[n] = *(const f32x4*)&a.hinit[u0];
         c[n] = f32x4{0, 0, 0, 0}; pi[n] = c[n]; pf[n] = c[n]; po[n] = c[n];
         if (CELL == CELL_LSTM) {
@@ -142,19 +167,23 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
             *(f32x4*)&a.cs[(size_t)row * Hp + u0] = c[n];
         }
         *(f32x4*)&a.hs[(size_t)row * Hp + u0] = h[n];
-        *(f32x4*)&smem[j * LDH + u0] = h[n];
+        *(f32x4*)&smem[j * ROW + wofs[n]] = h[n];
     }
+
+    f32x4 x[NT][G];
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                x[n][g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4];
+    };
+    if (tmax > 0) load_x(0);
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
         if (t < tmax) {                                           // workgroup-uniform
-            f32x4 x[NT][G];
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-                    x[n][g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4];
-            const float* hb = smem + (t & 1) * 16 * LDH + j * LDH + q * KS;
+            const float* hb = smem + (t & 1) * 16 * ROW + j * ROW + q * CH;
             f32x4 acc[NT][G];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -196,7 +225,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
 #pragma unroll
                     for (int g = 0; g < G; ++g) { xs[g] = x[n][g][e]; as[g] = acc[n][g][e]; }
                     float hh = h[n][e], cc = c[n][e];
-                    cell_forward<CELL>(xs, as, m, hh, cc, pi[n][e], pf[n][e], po[n][e], s);
+                    cell_forward<CELL, true>(xs, as, m, hh, cc, pi[n][e], pf[n][e], po[n][e], s);
                     h[n][e] = hh; c[n][e] = cc;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
@@ -216,9 +245,10 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
             if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c[n];
         }
         if (t + 1 < tmax) {
+            load_x(t + 1);
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                *(f32x4*)&smem[((t + 1) & 1) * 16 * LDH + j * LDH + (wave * NT + n) * 16 + q * 4] = h[n];
+                *(f32x4*)&smem[((t + 1) & 1) * 16 * ROW + j * ROW + wofs[n]] = h[n];
             __syncthreads();
         }
     }
@@ -226,17 +256,23 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
 
 // ---------------------------------------------------------------------------------------
 // MFMA persistent backward (BPTT).  D[unit k][row] = sum_j W_hid[k][j] * dhi[row][j]:
-// A = W_hid rows of the wave's unit tile (JS_RES > 0: register resident, JS = G*Hp/4 j-steps),
+// A = W_hid rows of the wave's unit tile (KS_RES > 0: register resident, JS = G*Hp/4 j-steps),
 // B = this step's dhi tile in LDS.  dxt/dhi rows are streamed out for the scatter-add and the
 // split-K weight-gradient GEMM (dW_hid = hs_prev^T . dhi), which run after the chain.
+// The saved activations of step t-1 are prefetched before the barrier of step t so their HBM
+// latency hides under the MFMA phase; c_t / h_t of the step above are carried in registers.
 // ---------------------------------------------------------------------------------------
+template <int CELL, int NT>
+struct SavedAct { f32x4 sv[NT][4]; f32x4 hprev[NT]; f32x4 cprev[NT]; };
+
 template <int CELL, int NT, int KS_RES>
 __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(RecArgs a, int dbuf) {
     constexpr int G = Gates<CELL>::G;
     constexpr int JS_RES = G * KS_RES;
     const int Hp = KS_RES > 0 ? 4 * KS_RES : a.Hp;
-    const int GHp = G * Hp, JS = GHp / 4, LDB = GHp + 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [dbuf ? 2 : 1][16][LDB]
+    const int GHp = G * Hp, JS = GHp / 4;
+    const int CH = lds_chunk(JS), ROW = 4 * CH + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [dbuf ? 2 : 1][16][ROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * 16 + j;
@@ -263,6 +299,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
 
     f32x4 dh[NT], dc[NT], pi[NT], pf[NT], po[NT];
     f32x4 sdb[NT][G], sdp[NT][3];
+    int wofs[NT][G];       // LDS row offset of this lane's 4 units of gate g
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int u0 = (wave * NT + n) * 16 + q * 4;
@@ -274,9 +311,29 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
             po[n] = *(const f32x4*)&a.peep[2 * Hp + u0];
         }
 #pragma unroll
-        for (int g = 0; g < G; ++g) sdb[n][g] = z;
+        for (int g = 0; g < G; ++g) {
+            sdb[n][g] = z;
+            const int col = g * Hp + u0;
+            wofs[n][g] = (col / JS) * CH + (col % JS);
+        }
         sdp[n][0] = z; sdp[n][1] = z; sdp[n][2] = z;
     }
+
+    SavedAct<CELL, NT> cur, nxt;
+    f32x4 cnew[NT], hnew[NT];
+    auto load_saved = [&](int t, SavedAct<CELL, NT>& d) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const size_t o = ((size_t)t * Bp + row) * Hp + (wave * NT + n) * 16 + q * 4;
+            d.hprev[n] = *(const f32x4*)&a.hs[o];
+            if (CELL != CELL_VANILLA) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d.sv[n][k] = *(const f32x4*)&a.g[k][o];
+            }
+            if (CELL == CELL_LSTM) d.cprev[n] = *(const f32x4*)&a.cs[o];
+        }
+    };
+    bool have = false;
 
     for (int t = T - 1; t >= 0; --t) {
         if (a.dh_ext) {
@@ -296,31 +353,31 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
                 }
             continue;
         }
+        if (!have) {                                              // first active step: nothing prefetched yet
+            load_saved(t, cur);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const size_t o1 = ((size_t)(t + 1) * Bp + row) * Hp + (wave * NT + n) * 16 + q * 4;
+                cnew[n] = CELL == CELL_LSTM ? *(const f32x4*)&a.cs[o1] : f32x4{0, 0, 0, 0};
+                hnew[n] = CELL == CELL_VANILLA ? *(const f32x4*)&a.hs[o1] : f32x4{0, 0, 0, 0};
+            }
+            have = true;
+        }
         const bool m = t < mylen;
-        float* lds = smem + (dbuf ? (t & 1) : 0) * 16 * LDB;
+        float* lds = smem + (dbuf ? (t & 1) : 0) * 16 * ROW;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int u0 = (wave * NT + n) * 16 + q * 4;
-            const size_t o = ((size_t)t * Bp + row) * Hp + u0;
-            const size_t o1 = ((size_t)(t + 1) * Bp + row) * Hp + u0;
-            f32x4 sv[4], hprev, cprev, cnew, hnew;
-            const f32x4 z = f32x4{0, 0, 0, 0};
-            sv[0] = sv[1] = sv[2] = sv[3] = z; cprev = z; cnew = z; hnew = z;
-            hprev = *(const f32x4*)&a.hs[o];
-            if (CELL != CELL_VANILLA) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sv[k] = *(const f32x4*)&a.g[k][o];
-            }
-            if (CELL == CELL_LSTM) { cprev = *(const f32x4*)&a.cs[o]; cnew = *(const f32x4*)&a.cs[o1]; }
-            if (CELL == CELL_VANILLA) hnew = *(const f32x4*)&a.hs[o1];
             f32x4 vxi[G], vhi[G];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float s[4] = {sv[0][e], sv[1][e], sv[2][e], sv[3][e]};
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                if (CELL != CELL_VANILLA) { s[0] = cur.sv[n][0][e]; s[1] = cur.sv[n][1][e]; s[2] = cur.sv[n][2][e]; s[3] = cur.sv[n][3][e]; }
                 float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
                 float dhh = dh[n][e], dcc = dc[n][e];
-                cell_backward<CELL>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[n][e], pf[n][e],
-                                    po[n][e], dxi, dhi, dp);
+                const float cpv = CELL == CELL_LSTM ? cur.cprev[n][e] : 0.f;
+                cell_backward<CELL, true>(m, clip, dhh, dcc, s, cur.hprev[n][e], cpv, cnew[n][e], hnew[n][e], pi[n][e],
+                                          pf[n][e], po[n][e], dxi, dhi, dp);
                 dh[n][e] = dhh; dc[n][e] = dcc;
 #pragma unroll
                 for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[n][g][e] += dxi[g]; }
@@ -331,11 +388,12 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
                 const size_t og = ((size_t)t * Bp + row) * GHp + g * Hp + u0;
                 *(f32x4*)&a.dxt[og] = vxi[g];
                 if (CELL == CELL_GRU) *(f32x4*)&a.dhi[og] = vhi[g];
-                *(f32x4*)&lds[j * LDB + g * Hp + u0] = vhi[g];
+                *(f32x4*)&lds[j * ROW + wofs[n][g]] = vhi[g];
             }
         }
+        if (t > 0) load_saved(t - 1, nxt);                        // prefetch: in flight across the MFMA phase
         __syncthreads();
-        const float* db = lds + j * LDB + q * JS;
+        const float* db = lds + j * ROW + q * CH;
         f32x4 acc[NT][2];
 #pragma unroll
         for (int n = 0; n < NT; ++n) { acc[n][0] = f32x4{0, 0, 0, 0}; acc[n][1] = f32x4{0, 0, 0, 0}; }
@@ -362,7 +420,12 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
             }
         }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) dh[n] += acc[n][0] + acc[n][1];
+        for (int n = 0; n < NT; ++n) {
+            dh[n] += acc[n][0] + acc[n][1];
+            if (CELL == CELL_LSTM) cnew[n] = cur.cprev[n];          // c_{t-1} is c_t of the step below
+            if (CELL == CELL_VANILLA) hnew[n] = cur.hprev[n];
+        }
+        cur = nxt;
         if (!dbuf) __syncthreads();
     }
 
@@ -515,7 +578,7 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         return hipGetLastError();
     }
     const int nblk = a.Bp / 16;
-    const size_t lds = 2 * 16 * (size_t)(Hp + 4) * sizeof(float);
+    const size_t lds = 2 * 16 * (size_t)(4 * ((Hp / 4 + 63) / 64 * 64) + 4) * sizeof(float);
 #define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
         KERNEL<<<GRID, BLOCK, LDS, s>>>(__VA_ARGS__); } while (0)
@@ -565,7 +628,7 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         (void)hipFree(st);
         return e;
     }
-    const size_t one = 16 * (size_t)(GHp + 4) * sizeof(float);
+    const size_t one = 16 * (size_t)(4 * ((GHp / 4 + 63) / 64 * 64) + 4) * sizeof(float);
     const int dbuf = (2 * one <= 150 * 1024) ? 1 : 0;
     const size_t lds = dbuf ? 2 * one : one;
 #define BWD_RES(KS) LAUNCH_DYN((rec_bwd_mfma<CELL, 1, KS>), nblk, (Hp / 16) * 64, lds, a, dbuf)

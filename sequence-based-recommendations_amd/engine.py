@@ -25,6 +25,7 @@ LOSSES = {"CCE": 0, "Blackout": 1, "BPR": 2, "TOP1": 3}          # --loss, comma
 UPDATERS = {"adagrad": 0, "adadelta": 1, "rmsprop": 2, "nesterov": 3, "adam": 4}   # --u_m
 FLAG_SIMPLE_REC = 1
 FLAG_SIMPLE_GEMM = 2
+FLAG_ATOMIC_SCATTER = 4
 
 
 class SbrConfig(ctypes.Structure):

@@ -33,7 +33,9 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=0.3, popscale=1.0):
+def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0):
+    if scale is None:      # a tanh-only cell with wide layers is chaotic at large weights: keep it well conditioned
+        scale = 0.3 if (cell != "Vanilla" or max(layers) <= 64) else 0.05
     rng = np.random.default_rng(seed)
     params = O.init_params(cell, layers, N, rng, n_in0=N + n_opt)
     for p in params:                      # move every parameter (biases, inits, peepholes) off zero

@@ -66,6 +66,16 @@ def test_gradient_clip_active(cell):                       # tiny popularity -> 
     check(PU.compare_step(cell, [8], "CCE", N=19, B=4, T=5, popscale=1e-4))
 
 
+def test_atomic_scatter_fallback_agrees():               # SBR_FLAG_ATOMIC_SCATTER vs the sorted segment reduce
+    check(PU.compare_step("GRU", [16], "CCE", N=33, B=17, T=11, seed=5, flags=4))
+
+
+def test_scatter_with_heavy_duplicates():
+    # few items, long rows: segments of the sorted scatter span many 32-entry chunks (atomic seams)
+    check(PU.compare_step("GRU", [16], "CCE", N=12, B=40, T=30, seed=9))
+    check(PU.compare_step("LSTM", [20], "BPR", N=12, B=24, T=20, S=4, seed=9))
+
+
 def test_ragged_and_edge_lengths():
     # rows of length 1 and T, a row whose items are all id 0 (== the pad id), B not a multiple of 16
     check(PU.compare_step("GRU", [16], "CCE", N=33, B=17, T=11, seed=5))
@@ -84,6 +94,7 @@ def test_full_size_properties():
     eng = RNNEngine(cell="GRU", layers=[H], n_items=N, max_length=T, batch_size=B, loss="CCE", updater="adam")
     try:
         params, cfg, batch = PU.build_case("GRU", [H], "CCE", N, B, T, seed=1, scale=0.0)
+        batch["pop"][:] = 1.0
         eng.set_all_param_values(params)
         eng.set_batch(batch["X"], batch["mask"], batch["target"], None, batch["pop"])
         c1 = eng.forward_backward()
