@@ -103,6 +103,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         lay.a_dWc = take((size_t)lay.C * lay.HLp); lay.a_dbc = take(lay.C);
     }
     lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
+    lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
     lay.a_X = take((size_t)Bp * T * lay.F);
@@ -329,6 +330,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.hs = h->A(ly.a_hs); a.cs = h->A(ly.a_cs);
     for (int k = 0; k < 4; ++k) a.g[k] = h->A(ly.a_g[k]);
     a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
+    a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;
     return a;
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
@@ -434,6 +436,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         RecArgs a = rec_args(h, l);
         a.dh_last = l == y.L - 1 ? h->A(y.a_dhlast) : nullptr;
         a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
+        if (a.prof) a.prof += (size_t)(y.Bp / 16) * 16 * 8;
         SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
         if (l == 0) mark(h, 4);
         SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, y.Bp / 16, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
@@ -555,6 +558,7 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     if (nm == "h_last") { *dev_ptr = h_last(h); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
     if (nm == "logits") { *dev_ptr = h->A(y.a_logits); *n_floats = (size_t)y.Bp * y.N; return SBR_OK; }
     if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
+    if (nm == "prof") { *dev_ptr = h->A(y.a_prof); *n_floats = (size_t)2 * (y.Bp / 16) * 16 * 8 * 2; return SBR_OK; }
     if (nm == "rowcost") { *dev_ptr = h->A(y.a_rowcost); *n_floats = y.Bp; return SBR_OK; }
     if (nm == "act" && y.S > 0) { *dev_ptr = h->A(y.a_act); *n_floats = (size_t)y.Bp * y.C; return SBR_OK; }
     for (int l = 0; l < y.L; ++l) {

@@ -64,6 +64,7 @@ struct Layout {
     size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
     size_t a_ws; size_t ws_floats;        // split-K workspace
     size_t a_csum;                        // [16][max(N,C)] column-sum partials
+    size_t a_prof;                        // [2][nblk][16][4] uint64 in-kernel cycle counters (fwd, bwd)
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
 };
@@ -132,6 +133,7 @@ struct RecArgs {
     const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
     float* dxt; float* dhi; // dhi == dxt for LSTM/Vanilla
     float* part;            // [nblk][G*Hp + 5*Hp]
+    unsigned long long* prof; // SBR_FLAG_PROFILE_REC: [nblk][waves][4] cycle counters, else NULL
 };
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple);

@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
         }
     }
 
+    asm volatile("s_nop 15");   // MFMA D -> VALU read hazard across the loop exit (see sbr_rec.hip)
     float* out = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
     const long ld = g.ws ? g.N : g.ldc;
 #pragma unroll

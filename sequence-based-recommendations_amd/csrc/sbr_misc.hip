@@ -77,6 +77,55 @@ hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, 
 // rows are read once, coalesced, 16 B/lane; a row of dWin that lies entirely inside one chunk is
 // written with plain stores, only segments that straddle a chunk boundary use atomics.
 // ---------------------------------------------------------------------------------------
+// Zipf ids: thousands of entries share the hottest id, so per-entry global atomics on cnt[]/cur[]
+// serialise in one L2 channel (69 us each, and they slow every kernel running beside them).  For
+// catalogues whose counters fit LDS (n_ids <= SCAT_LDS_IDS) each workgroup histograms its slice in
+// LDS and issues ONE global atomic per distinct id it saw.
+#define SCAT_LDS_IDS 12288
+#define SCAT_BLOCK 1024
+__global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
+                                                                    int T, int Bp, int F, int n_ids, int per_block,
+                                                                    int* __restrict__ cnt) {
+    extern __shared__ int hist[];
+    for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const int total = T * Bp * F;
+    const int lo = blockIdx.x * per_block, hi = min(total, lo + per_block);
+    for (int i = lo + threadIdx.x; i < hi; i += SCAT_BLOCK) {
+        const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
+        if (t < len[b]) atomicAdd(&hist[X[((size_t)b * T + t) * F + f]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) { const int c = hist[i]; if (c) atomicAdd(&cnt[i], c); }
+}
+
+__global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
+                                                                   int T, int Bp, int F, int n_ids, int per_block,
+                                                                   int* __restrict__ cur, int* __restrict__ sid,
+                                                                   int* __restrict__ spos) {
+    extern __shared__ int hist[];          // [n_ids] counts, then cursors
+    for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const int total = T * Bp * F;
+    const int lo = blockIdx.x * per_block, hi = min(total, lo + per_block);
+    for (int i = lo + threadIdx.x; i < hi; i += SCAT_BLOCK) {
+        const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
+        if (t < len[b]) atomicAdd(&hist[X[((size_t)b * T + t) * F + f]], 1);
+    }
+    __syncthreads();
+    // reserve a contiguous slot range per id with one global atomic; hist[id] becomes the block's cursor
+    for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) { const int c = hist[i]; if (c) hist[i] = atomicAdd(&cur[i], c); }
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += SCAT_BLOCK) {
+        const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
+        if (t < len[b]) {
+            const int id = X[((size_t)b * T + t) * F + f];
+            const int slot = atomicAdd(&hist[id], 1);
+            sid[slot] = id; spos[slot] = pos;
+        }
+    }
+}
+
 __global__ void scat_count_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
                                   int* __restrict__ cnt) {
     const int total = T * Bp * F;
@@ -132,10 +181,19 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), s);
     if (e != hipSuccess) return e;
     const int total = T * Bp * F;
-    const int grid = min(1024, (total + 255) / 256);
-    scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
-    scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
-    scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos);
+    if (n_ids <= SCAT_LDS_IDS) {
+        const int per_block = 4096;
+        const int grid = (total + per_block - 1) / per_block;
+        const size_t lds = (size_t)n_ids * sizeof(int);
+        scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt);
+        scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos);
+    } else {
+        const int grid = min(1024, (total + 255) / 256);
+        scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
+        scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+        scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos);
+    }
     return hipGetLastError();
 }
 

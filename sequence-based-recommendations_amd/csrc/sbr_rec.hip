@@ -115,6 +115,15 @@ __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, flo
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_chunk(int kper) { return (kper + 63) / 64 * 64; }
 
+// Saved gate activations g[k] (forward -> BPTT only) live in a tile-blocked layout
+//   [t][row tile of 16][unit tile of 16][row 16][unit 16]
+// so that the 16x16 tile one wave owns is ONE contiguous KiB: a wave-wide 16-B store/load touches
+// 8 full 128-B lines instead of 16 half lines of 16 different rows (the row-major form made the
+// CU's memory pipeline, not the MFMA pipe, the per-step bottleneck).
+__device__ __forceinline__ size_t gate_index(int t, int row, int u, int Bp, int Hp) {
+    return (((size_t)t * (Bp >> 4) + (row >> 4)) * (Hp >> 4) + (u >> 4)) * 256 + (row & 15) * 16 + (u & 15);
+}
+
 // ---------------------------------------------------------------------------------------
 // MFMA persistent forward.  KS_RES > 0: Hp = 4*KS_RES compile-time, W_hid fragments in VGPRs.
 // KS_RES == 0: runtime Hp, fragments streamed from L2 every step.  NT unit tiles per wave.
@@ -150,6 +159,10 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
 #pragma unroll
                 for (int kk = 0; kk < KS_RES; ++kk)
                     W[n][g][kk] = a.Whid[(size_t)(q * KS + kk) * GHp + g * Hp + (wave * NT + n) * 16 + j];
+        // vmcnt(0) through the builtin (the waitcnt pass sees it): without it hipcc, unable to tell the
+        // one-off W loads from the per-step stores on the in-order vmcnt counter, makes every loop
+        // iteration wait for the PREVIOUS step's stores right after its first MFMAs (~1.5k cycles/step)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
 
     f32x4 h[NT], c[NT], pi[NT], pf[NT], po[NT];
@@ -170,19 +183,25 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
         *(f32x4*)&smem[j * ROW + wofs[n]] = h[n];
     }
 
-    f32x4 x[NT][G];
-    auto load_x = [&](int t) {
+    // xt is fetched one whole step ahead (issued at the top of step t for step t+1, BEFORE step t's
+    // stores): on the in-order vmcnt counter the loads then never queue behind fresh stores
+    f32x4 x[NT][G], xn[NT][G];
+    auto load_x = [&](int t, f32x4 (&d)[NT][G]) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                x[n][g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4];
+                d[n][g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4];
     };
-    if (tmax > 0) load_x(0);
+    if (tmax > 0) load_x(0, x);
     __syncthreads();
+    unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0, p_mfma = 0, p_epi = 0;
+    if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
 
     for (int t = 0; t < T; ++t) {
+        if (a.prof) p_ta = clock64();
         if (t < tmax) {                                           // workgroup-uniform
+            if (t + 1 < tmax) load_x(t + 1, xn);
             const float* hb = smem + (t & 1) * 16 * ROW + j * ROW + q * CH;
             f32x4 acc[NT][G];
 #pragma unroll
@@ -214,6 +233,10 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
                                                                                  acc[n][g], 0, 0, 0);
                 }
             }
+            // MFMA D -> VALU read is a software-managed hazard (8-pass XDL: 12 wait states).  hipcc pads it
+            // inside a basic block, but a branch between the last MFMA and the first read (streamed-W
+            // loop back-edge, or any `if`) got only `s_nop 0`: pad explicitly, 16 cycles per step.
+            asm volatile("s_nop 15");
             const bool m = t < mylen;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -231,7 +254,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
                     for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
                 }
                 if (CELL != CELL_VANILLA) {
-                    const size_t o = ((size_t)t * Bp + row) * Hp + u0;
+                    const size_t o = gate_index(t, row, u0, Bp, Hp);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][o] = sv[k];
                 }
@@ -245,12 +268,22 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
             if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c[n];
         }
         if (t + 1 < tmax) {
-            load_x(t + 1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < G; ++g) x[n][g] = xn[n][g];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 *(f32x4*)&smem[((t + 1) & 1) * 16 * ROW + j * ROW + wofs[n]] = h[n];
+            if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
             __syncthreads();
+            if (a.prof) p_bar += clock64() - p_ta;
         }
+    }
+    if (a.prof && lane == 0) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
+        o[4] = p_mfma; o[5] = p_epi;
     }
 }
 
@@ -295,6 +328,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) Wb[n][4 * j4 + e] = w[e];
             }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // see rec_fwd_mfma
     }
 
     f32x4 dh[NT], dc[NT], pi[NT], pf[NT], po[NT];
@@ -327,15 +361,19 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
             const size_t o = ((size_t)t * Bp + row) * Hp + (wave * NT + n) * 16 + q * 4;
             d.hprev[n] = *(const f32x4*)&a.hs[o];
             if (CELL != CELL_VANILLA) {
+                const size_t og = gate_index(t, row, (wave * NT + n) * 16 + q * 4, Bp, Hp);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d.sv[n][k] = *(const f32x4*)&a.g[k][o];
+                for (int k = 0; k < 4; ++k) d.sv[n][k] = *(const f32x4*)&a.g[k][og];
             }
             if (CELL == CELL_LSTM) d.cprev[n] = *(const f32x4*)&a.cs[o];
         }
     };
     bool have = false;
+    unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
+    if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
 
     for (int t = T - 1; t >= 0; --t) {
+        if (a.prof) p_ta = clock64();
         if (a.dh_ext) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -392,7 +430,9 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
             }
         }
         if (t > 0) load_saved(t - 1, nxt);                        // prefetch: in flight across the MFMA phase
+        if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
         __syncthreads();
+        if (a.prof) { const unsigned long long tc = clock64(); p_bar += tc - p_ta; p_ta = tc; }
         const float* db = lds + j * ROW + q * CH;
         f32x4 acc[NT][2];
 #pragma unroll
@@ -419,6 +459,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
                 }
             }
         }
+        asm volatile("s_nop 15");                                  // MFMA D -> VALU read hazard, see rec_fwd_mfma
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             dh[n] += acc[n][0] + acc[n][1];
@@ -427,6 +468,11 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
         }
         cur = nxt;
         if (!dbuf) __syncthreads();
+        if (a.prof) p_work += clock64() - p_ta;
+    }
+    if (a.prof && lane == 0) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
     }
 
     // per-workgroup partial sums -> part[block][ G*Hp | dpi | dpf | dpo | dcinit | dhinit ]
@@ -489,7 +535,7 @@ __global__ void rec_fwd_step_simple(RecArgs a, int t) {
     if (CELL == CELL_LSTM) { pi = a.peep[k]; pf = a.peep[Hp + k]; po = a.peep[2 * Hp + k]; }
     cell_forward<CELL>(x, acc, t < a.len[row], h, c, pi, pf, po, s);
     if (CELL != CELL_VANILLA)
-        for (int q = 0; q < 4; ++q) a.g[q][o0 + k] = s[q];
+        for (int q = 0; q < 4; ++q) a.g[q][gate_index(t, row, k, Bp, Hp)] = s[q];
     a.hs[o1 + k] = h;
     if (CELL == CELL_LSTM) a.cs[o1 + k] = c;
 }
@@ -508,7 +554,7 @@ __global__ void rec_bwd_elem_simple(RecArgs a, int t, float* dhstate, float* dcs
     if (a.dh_ext) dh += a.dh_ext[o0];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (CELL != CELL_VANILLA)
-        for (int q = 0; q < 4; ++q) s[q] = a.g[q][o0];
+        for (int q = 0; q < 4; ++q) s[q] = a.g[q][gate_index(t, row, k, Bp, Hp)];
     float cprev = 0.f, cnew = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
     if (CELL == CELL_LSTM) { cprev = a.cs[o0]; cnew = a.cs[o1]; pi = a.peep[k]; pf = a.peep[Hp + k]; po = a.peep[2 * Hp + k]; }
     float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};

@@ -1,0 +1,30 @@
+"""In-kernel cycle counters of the recurrent kernels (SBR_FLAG_PROFILE_REC): effective shader clock
+(s_memtime vs the 100 MHz s_memrealtime) and the split work / barrier-wait per wave."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from oracle import rnn_oracle as O
+from sbr_amd.engine import RNNEngine
+cell, layers, n_items, loss, ns = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
+B, T = 256, 200
+eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=B, loss=loss, n_samples=ns, flags=8)
+eng.set_all_param_values(O.init_params(cell, layers, n_items, np.random.default_rng(42), dtype=np.float32))
+hb = bench.synth_batches(1, B, T, n_items, ns, "full", 1235)[0]
+eng.set_batch(hb["X"], None, hb["target"], hb["samples"] if loss != "CCE" else None, hb["pop"], lengths=hb["lengths"])
+for _ in range(3):
+    eng.train_step(sync=True)
+raw = eng.debug_buffer("prof").view(np.uint64).reshape(2, B // 16, 16, 8)
+for k, name in enumerate(("rec_fwd", "rec_bwd")):
+    p = raw[k].astype(np.float64)
+    nw = int((p[0, :, 0] > 0).sum())
+    tot, real, work, bar = (p[:, :nw, i] for i in range(4))
+    mhz = tot / real * 100.0
+    print("%s: waves/block %d | kernel %.1f us (realtime) | shader clock %.0f MHz (min %.0f max %.0f)" % (
+        name, nw, real.mean() / 100.0, mhz.mean(), mhz.min(), mhz.max()))
+    if k == 0:
+        print("   fwd split by wave of block 0: mfma-issue %s  epilogue-math %s  (work - those = store/prefetch/LDS-write issue)" % (
+            np.round(p[0, :nw, 4] / T).astype(int).tolist(), np.round(p[0, :nw, 5] / T).astype(int).tolist()))
+    print("   per step: total %.0f cyc = work %.0f + barrier-wait %.0f   (by wave of block 0: work %s  bar %s)" % (
+        tot.mean() / T, work.mean() / T, bar.mean() / T, np.round(work[0] / T).astype(int).tolist(), np.round(bar[0] / T).astype(int).tolist()))
+eng.close()
