@@ -68,6 +68,7 @@ typedef struct sbr_config {
 
 #define SBR_FLAG_SIMPLE_REC  1   /* triage: per-step VALU recurrent kernels instead of the MFMA persistent ones */
 #define SBR_FLAG_SIMPLE_GEMM 2   /* triage: naive GEMM instead of the MFMA tiled one */
+#define SBR_FLAG_F32_MFMA 16      /* recurrent GEMM on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x6 split */
 #define SBR_FLAG_PROFILE_REC 8    /* recurrent kernels record s_memtime / s_memrealtime phase counters ("prof" debug buffer) */
 #define SBR_FLAG_ATOMIC_SCATTER 4 /* triage: per-element float atomics instead of the sorted segment reduce */
 

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <stdlib.h>
 
 static thread_local std::string g_err;
 void sbr_set_error(const char* fmt, ...) {
@@ -90,7 +91,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_dxt = take(tb * G * y.Hp);
         y.a_dhi = cfg.cell == SBR_CELL_GRU ? take(tb * G * y.Hp) : y.a_dxt;
         y.a_dhext = l < lay.L - 1 ? take(tb * y.Hp) : 0;
-        y.a_part = take((size_t)(Bp / 16) * (G * y.Hp + 5 * y.Hp));
+        y.a_part = take((size_t)Bp * (G * y.Hp + 5 * y.Hp));
         maxrec = std::max(maxrec, (size_t)y.Hp * G * y.Hp);
         if (l > 0) maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp);
     }
@@ -205,6 +206,13 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->arena = (float*)p; h->own_arena = true;
     }
     sbr_param_descs(h->lay, h->descs);
+    h->rpt = 16;
+    {   // rows per workgroup of the bf16x6 recurrent kernels: spread the batch over up to ~64 CUs
+        const char* e = getenv("SBR_RPT");
+        int r = e ? atoi(e) : 0;
+        if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) { r = 16; while (r > 1 && h->lay.Bp / r < 64) r >>= 1; }
+        h->rpt = r;
+    }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
@@ -330,6 +338,9 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.hs = h->A(ly.a_hs); a.cs = h->A(ly.a_cs);
     for (int k = 0; k < 4; ++k) a.g[k] = h->A(ly.a_g[k]);
     a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
+    a.xt_blocked = 0;
+    a.rpt = h->rpt;
+    a.f32_mfma = (y.cfg.flags & SBR_FLAG_F32_MFMA) ? 1 : 0;
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;
     return a;
 }
@@ -439,7 +450,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         if (a.prof) a.prof += (size_t)(y.Bp / 16) * 16 * 8;
         SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
         if (l == 0) mark(h, 4);
-        SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, y.Bp / 16, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+        SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, sbr_rec_bwd_blocks(a, simple_rec(h)), y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
                                               h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
         // dW_hid [Hp][G*Hp] = sum over (t,row) of hs[t]^T . dhi[t]   (hs slot t = h_{t-1})
         SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
@@ -451,7 +462,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             } else {
                 SBR_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
                 SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
-                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp));
+                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp, y.Bp));
             }
             mark(h, 6);
         } else {

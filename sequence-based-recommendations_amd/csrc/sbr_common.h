@@ -43,7 +43,7 @@ struct LayerLayout {
     size_t a_dxt;    // [T][Bp][G*Hp]    grad wrt xt (= grad wrt gates for LSTM/Vanilla)
     size_t a_dhi;    // [T][Bp][G*Hp]    GRU only: grad wrt hid_input
     size_t a_dhext;  // [T][Bp][Hp]      grad arriving from the layer above (layers below the top)
-    size_t a_part;   // [nblk][G*Hp + 5*Hp] per-workgroup partial sums: bias, peepholes, inits
+    size_t a_part;   // [Bp][G*Hp + 5*Hp] per-workgroup partial sums (up to one workgroup per row): bias, peepholes, inits
 };
 
 struct Layout {
@@ -82,6 +82,7 @@ struct sbr_handle {
     hipStream_t side;            // batch-only preprocessing (scatter sort) overlapped with the chain
     hipEvent_t ev_fork, ev_join;
     std::vector<ParamDesc> descs;
+    int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int n_rows;          // rows of the current batch (<= local_batch)
     int64_t step_count;  // adam t
     bool have_batch, fwd_done;
@@ -116,7 +117,15 @@ hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, con
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
                                int* offs, int* cur, int* sid, int* spos);
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
-                                 const int* offs, int n_ids, int max_entries, int GHp);
+                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp);
+
+// Tile-blocked activation layout [t][row tile of 16][column tile of 16][row 16][col 16] (floats):
+// the 16x16 tile one wave of the recurrent kernels owns is one contiguous KiB (8 full 128-B lines per
+// wave-wide 16-B access instead of 16 half lines of 16 different rows).  Used for xt (layer 0), the
+// saved gate activations, dxt and dhi; hs/cs stay row-major for the GEMM consumers.
+__host__ __device__ __forceinline__ size_t sbr_blocked_index(int t, int row, int col, int Bp, int ncols) {
+    return (((size_t)t * (Bp >> 4) + (row >> 4)) * (ncols >> 4) + (col >> 4)) * 256 + (row & 15) * 16 + (col & 15);
+}
 
 struct RecArgs {
     int cell, T, Bp, H, Hp, G;
@@ -133,10 +142,15 @@ struct RecArgs {
     const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
     float* dxt; float* dhi; // dhi == dxt for LSTM/Vanilla
     float* part;            // [nblk][G*Hp + 5*Hp]
+    int rpt;                // live batch rows per workgroup of the bf16x6 kernels (16, 8, 4, 2, 1); part[] has Bp/rpt blocks
+    int xt_blocked;         // xt is tile-blocked (layer 0: written by the gather) or row-major (GEMM output)
+    int f32_mfma;           // SBR_FLAG_F32_MFMA: exact-f32 v_mfma_f32_16x16x4_f32 kernels instead of bf16x6
     unsigned long long* prof; // SBR_FLAG_PROFILE_REC: [nblk][waves][4] cycle counters, else NULL
 };
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple);
+// number of part[] blocks the backward launch for these args writes
+int sbr_rec_bwd_blocks(const RecArgs& a, bool simple);
 // sums the per-workgroup partials into bias / peephole / init gradients
 hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk, int G, int Hp, int cell,
                                       float* db, float* dpeep, float* dcinit, float* dhinit);
@@ -144,9 +158,11 @@ hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk
 // Generic f32 GEMM on v_mfma_f32_16x16x4_f32:  C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n])
 // A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], C row-major with leading dim ldc.
 // ws: split-K workspace of ws_floats floats (may be NULL -> no split).
+// a_blk_Bp / b_blk_Bp > 0: that operand is a tile-blocked activation [pos = t*Bp + row][col] (strides ignored;
+// A: m = pos, k = col over K columns;  B: k = pos, n = col over N columns).
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                        float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
-                       bool simple);
+                       bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0);
 
 // full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N) in, dlogits out in place
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,

@@ -24,6 +24,7 @@ struct GemmArgs {
     float* C; long ldc;
     int M, N, K;
     const float* bias;
+    int a_blk_Bp, b_blk_Bp;   // > 0: operand is a tile-blocked activation [pos = t*Bp + row][col]
     int kchunk;      // K range per grid.z slice (multiple of BK)
     float* ws;       // split-K slabs [z][M][N] (NULL when gridDim.z == 1)
 };
@@ -40,21 +41,29 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
 
     // thread -> element mapping for the global loads: 4 elements per thread per operand,
     // contiguous along whichever dimension has unit stride
-    const bool a_kfast = g.sak == 1;
+    const bool a_kfast = g.sak == 1 || g.a_blk_Bp > 0;
     const int a_m = a_kfast ? (tid >> 2) : ((tid & 15) << 2);
     const int a_k = a_kfast ? ((tid & 3) << 2) : (tid >> 4);
-    const bool b_nfast = g.sbn == 1;
+    const bool b_nfast = g.sbn == 1 || g.b_blk_Bp > 0;
     const int b_n = b_nfast ? ((tid & 15) << 2) : (tid >> 2);
     const int b_k = b_nfast ? (tid >> 4) : ((tid & 3) << 2);
 
     float ra[4], rb[4];
+    auto a_addr = [&](int m, int k) -> size_t {   // blocked A: rows = positions, K columns
+        if (g.a_blk_Bp > 0) { const int t = m / g.a_blk_Bp; return sbr_blocked_index(t, m - t * g.a_blk_Bp, k, g.a_blk_Bp, g.K); }
+        return (size_t)((long)m * g.sam + (long)k * g.sak);
+    };
+    auto b_addr = [&](int k, int n) -> size_t {   // blocked B: k = positions, N columns
+        if (g.b_blk_Bp > 0) { const int t = k / g.b_blk_Bp; return sbr_blocked_index(t, k - t * g.b_blk_Bp, n, g.b_blk_Bp, g.N); }
+        return (size_t)((long)k * g.sbk + (long)n * g.sbn);
+    };
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = m0 + a_m + (a_kfast ? 0 : e), k = k0 + a_k + (a_kfast ? e : 0);
-            ra[e] = (m < g.M && k < kend) ? g.A[(long)m * g.sam + (long)k * g.sak] : 0.0f;
+            ra[e] = (m < g.M && k < kend) ? g.A[a_addr(m, k)] : 0.0f;
             const int n = n0 + b_n + (b_nfast ? e : 0), kb = k0 + b_k + (b_nfast ? 0 : e);
-            rb[e] = (n < g.N && kb < kend) ? g.B[(long)kb * g.sbk + (long)n * g.sbn] : 0.0f;
+            rb[e] = (n < g.N && kb < kend) ? g.B[b_addr(kb, n)] : 0.0f;
         }
     };
     auto store_tile = [&]() {
@@ -127,14 +136,20 @@ __global__ void gemm_naive(GemmArgs g) {
     if (i >= (size_t)g.M * g.N) return;
     const int m = i / g.N, n = i % g.N;
     float s = 0.0f;
-    for (int k = 0; k < g.K; ++k) s = fmaf(g.A[(long)m * g.sam + (long)k * g.sak], g.B[(long)k * g.sbk + (long)n * g.sbn], s);
+    for (int k = 0; k < g.K; ++k) {
+        size_t ia = (size_t)((long)m * g.sam + (long)k * g.sak), ib = (size_t)((long)k * g.sbk + (long)n * g.sbn);
+        if (g.a_blk_Bp > 0) { const int t = m / g.a_blk_Bp; ia = sbr_blocked_index(t, m - t * g.a_blk_Bp, k, g.a_blk_Bp, g.K); }
+        if (g.b_blk_Bp > 0) { const int t = k / g.b_blk_Bp; ib = sbr_blocked_index(t, k - t * g.b_blk_Bp, n, g.b_blk_Bp, g.N); }
+        s = fmaf(g.A[ia], g.B[ib], s);
+    }
     g.C[(long)m * g.ldc + n] = s + (g.bias ? g.bias[n] : 0.0f);
 }
 
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
-                       long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple) {
+                       long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple,
+                       int a_blk_Bp, int b_blk_Bp) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, K, nullptr};
+    GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, a_blk_Bp, b_blk_Bp, K, nullptr};
     if (simple) {
         const size_t n = (size_t)M * N;
         gemm_naive<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g);

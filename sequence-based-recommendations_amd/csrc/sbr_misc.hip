@@ -201,7 +201,7 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
 template <int NV>
 __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
-                                                          int n_ids, float* __restrict__ dWin, int R4) {
+                                                          int n_ids, float* __restrict__ dWin, int R4, int Bp) {
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int total = offs[n_ids];
@@ -255,12 +255,12 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
 }
 
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
-                                 const int* offs, int n_ids, int max_entries, int GHp) {
+                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp) {
     const int R4 = GHp / 4;
     const int chunks = (max_entries + SCAT_CHUNK - 1) / SCAT_CHUNK;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
-#define SR(NV) scat_reduce_kernel<NV><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4)
+#define SR(NV) scat_reduce_kernel<NV><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp)
     if (nv <= 1) SR(1); else if (nv <= 2) SR(2); else if (nv <= 4) SR(4); else if (nv <= 8) SR(8); else if (nv <= 16) SR(16);
     else return hipErrorInvalidValue;
 #undef SR

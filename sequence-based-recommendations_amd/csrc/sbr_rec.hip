@@ -121,7 +121,11 @@ __device__ __forceinline__ int lds_chunk(int kper) { return (kper + 63) / 64 * 6
 // 8 full 128-B lines instead of 16 half lines of 16 different rows (the row-major form made the
 // CU's memory pipeline, not the MFMA pipe, the per-step bottleneck).
 __device__ __forceinline__ size_t gate_index(int t, int row, int u, int Bp, int Hp) {
-    return (((size_t)t * (Bp >> 4) + (row >> 4)) * (Hp >> 4) + (u >> 4)) * 256 + (row & 15) * 16 + (u & 15);
+    return sbr_blocked_index(t, row, u, Bp, Hp);
+}
+// xt: blocked when the gather wrote it (layer 0), row-major when a GEMM did (layers >= 1)
+__device__ __forceinline__ size_t xt_index(int blocked, int t, int row, int col, int Bp, int ncols) {
+    return blocked ? sbr_blocked_index(t, row, col, Bp, ncols) : ((size_t)t * Bp + row) * ncols + col;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
             if (a.prof) p_bar += clock64() - p_ta;
         }
     }
-    if (a.prof && lane == 0) {
+    if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
         o[4] = p_mfma; o[5] = p_epi;
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
         if (!dbuf) __syncthreads();
         if (a.prof) p_work += clock64() - p_ta;
     }
-    if (a.prof && lane == 0) {
+    if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
     }
@@ -499,6 +503,366 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
 #pragma unroll
             for (int k = 0; k < 5; ++k) *(f32x4*)&part[GHp + k * Hp + u0] = v[G + k];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// "bf16x6" recurrent kernels: the same persistent structure, but the per-step GEMM runs on
+// v_mfma_f32_16x16x32_bf16 with every f32 operand split exactly into three bf16 planes
+// (v = b1 + b2 + b3, residual < 2^-26 |v|) and the six products of order >= 2^-18 kept:
+//     a.w ~= a1w1 + a1w2 + a2w1 + a1w3 + a2w2 + a3w1      (dropped terms < 2^-26 |a||w|)
+// bf16 x bf16 products are exact in f32 and the MFMA accumulates in f32, so the result is
+// f32-rounding class (tools/probes/mfma_bf16_probe.hip measures 2.7e-7 vs 6.2e-7 for an fmaf chain
+// on K=32) -- at 6 x 16 = 96 MFMA cycles per 16x16x32 block instead of 8 x 32 = 256 on the f32
+// MFMA (v_mfma_f32_16x16x4_f32), i.e. 2.67x less time on the matrix pipe, which is what bounds
+// the 2*T-step dependent chain.  Planes 1,2 of W_hid stay in VGPRs, plane 3 in LDS; h_t (resp.
+// dhi_t) is split by the producing wave and published to LDS as three bf16 planes.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float v, __bf16& b1, __bf16& b2, __bf16& b3) {
+    b1 = (__bf16)v; float r = v - (float)b1; b2 = (__bf16)r; r -= (float)b2; b3 = (__bf16)r;
+}
+__device__ __forceinline__ void split3x4(const f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); p1[e] = a; p2[e] = b; p3[e] = c; }
+}
+#define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+
+template <int CELL, int HP>
+__global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
+    constexpr int G = Gates<CELL>::G, KB = HP / 32, NW = HP / 16, GHP = G * HP;
+    constexpr int HROW = HP * 2 + 32;                    // bytes per row of one h plane (conflict-free b128 reads)
+    constexpr int W3_BYTES = G * KB * NW * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [G][KB][NW][64 lanes][16 B]
+    char* hbuf = smem_c + W3_BYTES;                      // [2][3 planes][16 rows][HROW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    // a workgroup owns a.rpt (<= 16) batch rows: with fewer rows per CU the per-CU store rate (~13 B/clk,
+    // the real bound of this chain once the matrix pipe is on bf16) is spread over more CUs; MFMA columns
+    // j >= rpt compute on a duplicate row and are never stored
+    const int rpt = a.rpt;
+    const bool live = j < rpt;
+    const int row = blockIdx.x * rpt + (live ? j : j % rpt);
+    const int T = a.T, Bp = a.Bp;
+    const int u0 = wave * 16 + q * 4;
+
+    const int mylen = live ? a.len[row] : 0;
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    // A operand planes: lane (unit j of the tile, k-group q) holds W_hid[kb*32 + 8q + e][g*HP + tile*16 + j]
+    bf16x8 W1[G][KB], W2[G][KB];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            bf16x8 w3v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 b1, b2, b3;
+                split3(a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + wave * 16 + j], b1, b2, b3);
+                W1[g][kb][e] = b1; W2[g][kb][e] = b2; w3v[e] = b3;
+            }
+            *(bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16) = w3v;
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // see rec_fwd_mfma: clear the VMEM scoreboard
+
+    f32x4 h, c, pi, pf, po;
+    {
+        const f32x4 z = f32x4{0, 0, 0, 0};
+        h = *(const f32x4*)&a.hinit[u0];
+        c = z; pi = z; pf = z; po = z;
+        if (CELL == CELL_LSTM) {
+            c = *(const f32x4*)&a.cinit[u0];
+            pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0];
+            if (live) *(f32x4*)&a.cs[(size_t)row * HP + u0] = c;
+        }
+        if (live) *(f32x4*)&a.hs[(size_t)row * HP + u0] = h;
+    }
+    auto publish_h = [&](int buf) {                      // three bf16 planes of this lane's 4 units
+        bf16x4 p1, p2, p3;
+        split3x4(h, p1, p2, p3);
+        char* base = hbuf + (size_t)buf * 3 * 16 * HROW + j * HROW + u0 * 2;
+        *(bf16x4*)(base) = p1; *(bf16x4*)(base + 16 * HROW) = p2; *(bf16x4*)(base + 32 * HROW) = p3;
+    };
+    publish_h(0);
+
+    f32x4 x[G], xn[G];
+    auto load_x = [&](int t, f32x4 (&d)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) d[g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHP + g * HP + u0];
+    };
+    if (tmax > 0) load_x(0, x);
+    __syncthreads();
+    unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
+    if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+
+    for (int t = 0; t < T; ++t) {
+        if (a.prof) p_ta = clock64();
+        if (t < tmax) {                                           // workgroup-uniform
+            if (t + 1 < tmax) load_x(t + 1, xn);
+            const char* hb = hbuf + (size_t)(t & 1) * 3 * 16 * HROW + j * HROW + q * 16;
+            f32x4 acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = f32x4{0, 0, 0, 0};
+            // operand reads of k-block kb+1 are issued BEFORE the MFMAs of k-block kb (register double
+            // buffer + sched_barrier): left alone, hipcc waits lgkmcnt(0) in front of every MFMA group and
+            // exposes the LDS latency KB times per step
+            bf16x8 hp[2][3], wp[2][G];
+            auto load_ops = [&](int kb, int s) {
+                hp[s][0] = *(const bf16x8*)(hb + kb * 64);
+                hp[s][1] = *(const bf16x8*)(hb + kb * 64 + 16 * HROW);
+                hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 32 * HROW);
+#pragma unroll
+                for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16);
+            };
+            load_ops(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int s = kb & 1;
+                if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // smallest terms first; gates interleaved so consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_nop 15");                             // MFMA D -> VALU read hazard (see rec_fwd_mfma)
+            const bool m = t < mylen;
+            f32x4 sv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xs[G], as[G], s[4];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { xs[g] = x[g][e]; as[g] = acc[g][e]; }
+                float hh = h[e], cc = c[e];
+                cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
+                h[e] = hh; c[e] = cc;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
+            }
+            if (CELL != CELL_VANILLA && live) {
+                const size_t o = gate_index(t, row, u0, Bp, HP);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][o] = sv[k];
+            }
+        }
+        if (live) {
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u0;
+            *(f32x4*)&a.hs[o] = h;
+            if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c;
+        }
+        if (t + 1 < tmax) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = xn[g];
+            publish_h((t + 1) & 1);
+            if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
+            __syncthreads();
+            if (a.prof) p_bar += clock64() - p_ta;
+        }
+    }
+    if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
+    }
+}
+
+template <int CELL, int HP>
+__global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
+    constexpr int G = Gates<CELL>::G, NW = HP / 16, GHP = G * HP, KB = GHP / 32;
+    constexpr int DROW = GHP * 2 + 32;                   // bytes per row of one dhi plane
+    constexpr int W3_BYTES = KB * NW * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [KB][NW][64][16 B]
+    char* dbufp = smem_c + W3_BYTES;                     // [dbuf ? 2 : 1][3][16][DROW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    // a workgroup owns a.rpt (<= 16) batch rows: with fewer rows per CU the per-CU store rate (~13 B/clk,
+    // the real bound of this chain once the matrix pipe is on bf16) is spread over more CUs; MFMA columns
+    // j >= rpt compute on a duplicate row and are never stored
+    const int rpt = a.rpt;
+    const bool live = j < rpt;
+    const int row = blockIdx.x * rpt + (live ? j : j % rpt);
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+    const int u0 = wave * 16 + q * 4;
+
+    const int mylen = live ? a.len[row] : 0;
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    // A operand planes: lane (unit j of the tile, k-group q) holds W_hid[tile*16 + j][kb*32 + 8q + e]
+    bf16x8 W1[KB], W2[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const float* src = a.Whid + (size_t)(wave * 16 + j) * GHP + kb * 32 + 8 * q;
+        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        bf16x8 w3v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 b1, b2, b3;
+            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
+            W1[kb][e] = b1; W2[kb][e] = b2; w3v[e] = b3;
+        }
+        *(bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16) = w3v;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    const f32x4 z4 = f32x4{0, 0, 0, 0};
+    f32x4 dh = (a.dh_last && live) ? *(const f32x4*)&a.dh_last[(size_t)row * HP + u0] : z4;
+    f32x4 dc = z4, pi = z4, pf = z4, po = z4;
+    if (CELL == CELL_LSTM) { pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0]; }
+    f32x4 sdb[G], sdp[3];
+#pragma unroll
+    for (int g = 0; g < G; ++g) sdb[g] = z4;
+    sdp[0] = z4; sdp[1] = z4; sdp[2] = z4;
+
+    SavedAct<CELL, 1> cur;
+    f32x4 cnew = z4, hnew = z4;
+    auto load_saved = [&](int t, SavedAct<CELL, 1>& d) {
+        const size_t o = ((size_t)t * Bp + row) * HP + u0;
+        d.hprev[0] = *(const f32x4*)&a.hs[o];
+        if (CELL != CELL_VANILLA) {
+            const size_t og = gate_index(t, row, u0, Bp, HP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d.sv[0][k] = *(const f32x4*)&a.g[k][og];
+        }
+        if (CELL == CELL_LSTM) d.cprev[0] = *(const f32x4*)&a.cs[o];
+    };
+    bool have = false;
+    unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
+    if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+    __syncthreads();                                              // W plane 3 visible
+
+    for (int t = T - 1; t >= 0; --t) {
+        if (a.prof) p_ta = clock64();
+        if (a.dh_ext && live) dh += *(const f32x4*)&a.dh_ext[((size_t)t * Bp + row) * HP + u0];
+        if (t >= tmax) {                                          // whole tile masked: zero rows
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const size_t o = ((size_t)t * Bp + row) * GHP + g * HP + u0;
+                if (live) {
+                    *(f32x4*)&a.dxt[o] = z4;
+                    if (CELL == CELL_GRU) *(f32x4*)&a.dhi[o] = z4;
+                }
+            }
+            continue;
+        }
+        if (!have) {
+            load_saved(t, cur);
+            const size_t o1 = ((size_t)(t + 1) * Bp + row) * HP + u0;
+            if (CELL == CELL_LSTM) cnew = *(const f32x4*)&a.cs[o1];
+            if (CELL == CELL_VANILLA) hnew = *(const f32x4*)&a.hs[o1];
+            have = true;
+        }
+        const bool m = t < mylen;
+        char* lds = dbufp + (size_t)(dbuf ? (t & 1) : 0) * 3 * 16 * DROW;
+        {
+            f32x4 vxi[G], vhi[G];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                if (CELL != CELL_VANILLA) { s[0] = cur.sv[0][0][e]; s[1] = cur.sv[0][1][e]; s[2] = cur.sv[0][2][e]; s[3] = cur.sv[0][3][e]; }
+                float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+                float dhh = dh[e], dcc = dc[e];
+                const float cpv = CELL == CELL_LSTM ? cur.cprev[0][e] : 0.f;
+                cell_backward<CELL, true>(m, clip, dhh, dcc, s, cur.hprev[0][e], cpv, cnew[e], hnew[e], pi[e], pf[e], po[e],
+                                          dxi, dhi, dp);
+                dh[e] = dhh; dc[e] = dcc;
+#pragma unroll
+                for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[g][e] += dxi[g]; }
+                sdp[0][e] += dp[0]; sdp[1][e] += dp[1]; sdp[2][e] += dp[2];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const size_t og = ((size_t)t * Bp + row) * GHP + g * HP + u0;
+                if (live) {
+                    *(f32x4*)&a.dxt[og] = vxi[g];
+                    if (CELL == CELL_GRU) *(f32x4*)&a.dhi[og] = vhi[g];
+                }
+                bf16x4 p1, p2, p3;
+                split3x4(vhi[g], p1, p2, p3);
+                char* base = lds + j * DROW + (g * HP + u0) * 2;
+                *(bf16x4*)(base) = p1; *(bf16x4*)(base + 16 * DROW) = p2; *(bf16x4*)(base + 32 * DROW) = p3;
+            }
+        }
+        // c_{t-1} / h_{t-1} double as c_t / h_t of the step below; then refill `cur` in place for step
+        // t-1: the loads are in flight across the barrier and the whole MFMA phase
+        if (CELL == CELL_LSTM) cnew = cur.cprev[0];
+        if (CELL == CELL_VANILLA) hnew = cur.hprev[0];
+        if (t > 0) load_saved(t - 1, cur);
+        if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
+        __syncthreads();
+        if (a.prof) { const unsigned long long tc = clock64(); p_bar += tc - p_ta; p_ta = tc; }
+        const char* db = lds + j * DROW + q * 16;
+        f32x4 acc[3] = {z4, z4, z4};
+        bf16x8 dp[2][3], wp[2];
+        auto load_ops = [&](int kb, int s) {                     // see rec_fwd_x6: software-pipelined operand reads
+            dp[s][0] = *(const bf16x8*)(db + kb * 64);
+            dp[s][1] = *(const bf16x8*)(db + kb * 64 + 16 * DROW);
+            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 32 * DROW);
+            wp[s] = *(const bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // three independent accumulators break the MFMA dependency chain
+            acc[0] = MFMA_BF16(wp[s], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][2], acc[1]);
+            acc[2] = MFMA_BF16(W2[kb], dp[s][1], acc[2]);
+            acc[0] = MFMA_BF16(W2[kb], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][1], acc[1]);
+            acc[2] = MFMA_BF16(W1[kb], dp[s][0], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
+        dh += acc[0] + acc[1] + acc[2];
+        if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
+        if (!dbuf) __syncthreads();
+        if (a.prof) p_bar += clock64() - p_ta;
+    }
+    if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
+    }
+
+    float* part = a.part + (size_t)blockIdx.x * (GHP + 5 * HP);
+    f32x4 v[G + 5];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = sdb[g];
+    v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2]; v[G + 3] = dc; v[G + 4] = dh;
+#pragma unroll
+    for (int k = 0; k < G + 5; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sum = v[k][e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+            v[k][e] = sum;
+        }
+    if (j == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) *(f32x4*)&part[g * HP + u0] = v[g];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) *(f32x4*)&part[GHP + k * HP + u0] = v[G + k];
     }
 }
 
@@ -624,10 +988,20 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         return hipGetLastError();
     }
     const int nblk = a.Bp / 16;
-    const size_t lds = 2 * 16 * (size_t)(4 * ((Hp / 4 + 63) / 64 * 64) + 4) * sizeof(float);
 #define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
         KERNEL<<<GRID, BLOCK, LDS, s>>>(__VA_ARGS__); } while (0)
+    if (!a.f32_mfma && (Hp == 32 || Hp == 64 || Hp == 128)) {
+        const size_t l6 = (size_t)Gates<CELL>::G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 16 * (size_t)(Hp * 2 + 32);
+        if (l6 <= 160 * 1024) {
+            const int nb6 = a.Bp / a.rpt;
+            if (Hp == 32) LAUNCH_DYN((rec_fwd_x6<CELL, 32>), nb6, Hp * 4, l6, a);
+            else if (Hp == 64) LAUNCH_DYN((rec_fwd_x6<CELL, 64>), nb6, Hp * 4, l6, a);
+            else LAUNCH_DYN((rec_fwd_x6<CELL, 128>), nb6, Hp * 4, l6, a);
+            return hipGetLastError();
+        }
+    }
+    const size_t lds = 2 * 16 * (size_t)(4 * ((Hp / 4 + 63) / 64 * 64) + 4) * sizeof(float);
 #define FWD_RES(KS) LAUNCH_DYN((rec_fwd_mfma<CELL, 1, KS>), nblk, (Hp / 16) * 64, lds, a)
     if (Hp == 16) FWD_RES(4);
     else if (Hp == 32) FWD_RES(8);
@@ -674,6 +1048,18 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         (void)hipFree(st);
         return e;
     }
+    if (!a.f32_mfma && (Hp == 32 || Hp == 64 || Hp == 128)) {
+        const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * 16 * (size_t)(GHp * 2 + 32);
+        const int db6 = (w3b + 2 * one6 <= 160 * 1024) ? 1 : 0;
+        const size_t l6 = w3b + (db6 ? 2 : 1) * one6;
+        if (l6 <= 160 * 1024) {
+            const int nb6 = a.Bp / a.rpt;
+            if (Hp == 32) LAUNCH_DYN((rec_bwd_x6<CELL, 32>), nb6, Hp * 4, l6, a, db6);
+            else if (Hp == 64) LAUNCH_DYN((rec_bwd_x6<CELL, 64>), nb6, Hp * 4, l6, a, db6);
+            else LAUNCH_DYN((rec_bwd_x6<CELL, 128>), nb6, Hp * 4, l6, a, db6);
+            return hipGetLastError();
+        }
+    }
     const size_t one = 16 * (size_t)(4 * ((GHp / 4 + 63) / 64 * 64) + 4) * sizeof(float);
     const int dbuf = (2 * one <= 150 * 1024) ? 1 : 0;
     const size_t lds = dbuf ? 2 * one : one;
@@ -691,6 +1077,17 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
     }
 #undef BWD_RES
     return hipGetLastError();
+}
+
+static bool uses_x6_bwd(const RecArgs& a) {
+    const int Hp = a.Hp, GHp = a.G * Hp;
+    if (a.f32_mfma || !(Hp == 32 || Hp == 64 || Hp == 128)) return false;
+    const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * 16 * (size_t)(GHp * 2 + 32);
+    return w3b + one6 <= 160 * 1024;
+}
+int sbr_rec_bwd_blocks(const RecArgs& a, bool simple) {
+    if (simple) return a.Bp / 16;                 // simple kernels accumulate into block 0, others zeroed
+    return uses_x6_bwd(a) ? a.Bp / a.rpt : a.Bp / 16;
 }
 
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple) {

@@ -26,6 +26,8 @@ UPDATERS = {"adagrad": 0, "adadelta": 1, "rmsprop": 2, "nesterov": 3, "adam": 4}
 FLAG_SIMPLE_REC = 1
 FLAG_SIMPLE_GEMM = 2
 FLAG_ATOMIC_SCATTER = 4
+FLAG_PROFILE_REC = 8
+FLAG_F32_MFMA = 16
 
 
 class SbrConfig(ctypes.Structure):

@@ -26,6 +26,12 @@ def test_one_layer_cce(cell, H):
     check(PU.compare_step(cell, [H], "CCE", N=61, B=37, T=9))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+@pytest.mark.parametrize("H", [20, 50, 128])
+def test_exact_f32_mfma_kernels(cell, H):                  # SBR_FLAG_F32_MFMA: v_mfma_f32_16x16x4_f32 path
+    check(PU.compare_step(cell, [H], "CCE", N=61, B=37, T=9, flags=16))
+
+
 @pytest.mark.parametrize("cell", ["GRU", "LSTM"])
 def test_streamed_whid_kernels(cell):                      # Hp = 192: W_hid fragments streamed from L2
     check(PU.compare_step(cell, [160], "CCE", N=61, B=21, T=8), tol_h=2e-4)

@@ -22,9 +22,10 @@ for k, name in enumerate(("rec_fwd", "rec_bwd")):
     mhz = tot / real * 100.0
     print("%s: waves/block %d | kernel %.1f us (realtime) | shader clock %.0f MHz (min %.0f max %.0f)" % (
         name, nw, real.mean() / 100.0, mhz.mean(), mhz.min(), mhz.max()))
-    if k == 0:
-        print("   fwd split by wave of block 0: mfma-issue %s  epilogue-math %s  (work - those = store/prefetch/LDS-write issue)" % (
-            np.round(p[0, :nw, 4] / T).astype(int).tolist(), np.round(p[0, :nw, 5] / T).astype(int).tolist()))
+    if k == 1:
+        print("   bwd split by wave of block 0: gate-math %s  store/LDS-write/prefetch issue %s  LDS-read+MFMA %s" % (
+            np.round(p[0, :nw, 4] / T).astype(int).tolist(), np.round(p[0, :nw, 5] / T).astype(int).tolist(),
+            np.round(p[0, :nw, 6] / T).astype(int).tolist()))
     print("   per step: total %.0f cyc = work %.0f + barrier-wait %.0f   (by wave of block 0: work %s  bar %s)" % (
         tot.mean() / T, work.mean() / T, bar.mean() / T, np.round(work[0] / T).astype(int).tolist(), np.round(bar[0] / T).astype(int).tolist()))
 eng.close()
