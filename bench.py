@@ -191,8 +191,21 @@ def main():
             del v["alg"]
         dom = max(("gather", "rec_fwd", "rec_bwd", "scatter"), key=lambda k: phases[k])
         d = kernels[dom]
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, gfx950 FETCH_SIZE x2 correction applied; profiles/round1_pmc.json), same config only
+        traffic = None
+        try:
+            if args.config == "c2" and args.lengths == "full" and B == 256 and T == 200:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))["kernels"]
+                key = {"rec_fwd": "rec_fwd_x6", "rec_bwd": "rec_bwd_x6", "gather": "gather_xt_kernel",
+                       "scatter": "scat_reduce_kernel"}[dom]
+                traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if key in k)
+        except Exception:
+            traffic = None
         result["roofline"] = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                              "unit": d["unit"], "frac": d["frac"], "traffic": None, "launch_us": d["us"]}
+                              "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launch_us": d["us"],
+                              "note": "algorithmic f32 FLOPs 2*L*H*G*H of the BPTT chain vs the f32 MFMA peak; the chain is "
+                                      "2*T dependent steps on <=64 CUs (DESIGN.md section 3)"}
         result["phases_us"] = {k: round(v, 2) for k, v in phases.items()}
         result["kernels"] = kernels
 
