@@ -688,7 +688,8 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
     constexpr int W3_BYTES = KB * NW * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* w3 = smem_c;                                   // [KB][NW][64][16 B]
-    char* dbufp = smem_c + W3_BYTES;                     // [dbuf ? 2 : 1][3][16][DROW]
+    char* dbufp = smem_c + W3_BYTES;                     // [dbuf ? 2 : 1][3][rpt][DROW]: only live rows are stored;
+                                                         // phantom MFMA columns read (broadcast) row j % rpt
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     // a workgroup owns a.rpt (<= 16) batch rows: with fewer rows per CU the per-CU store rate (~13 B/clk,
@@ -771,7 +772,8 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
             have = true;
         }
         const bool m = t < mylen;
-        char* lds = dbufp + (size_t)(dbuf ? (t & 1) : 0) * 3 * 16 * DROW;
+        const int prow = rpt * DROW;                              // bytes per plane
+        char* lds = dbufp + (size_t)(dbuf ? (t & 1) : 0) * 3 * prow;
         {
             f32x4 vxi[G], vhi[G];
 #pragma unroll
@@ -795,10 +797,12 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
                     *(f32x4*)&a.dxt[og] = vxi[g];
                     if (CELL == CELL_GRU) *(f32x4*)&a.dhi[og] = vhi[g];
                 }
-                bf16x4 p1, p2, p3;
-                split3x4(vhi[g], p1, p2, p3);
-                char* base = lds + j * DROW + (g * HP + u0) * 2;
-                *(bf16x4*)(base) = p1; *(bf16x4*)(base + 16 * DROW) = p2; *(bf16x4*)(base + 32 * DROW) = p3;
+                if (live) {
+                    bf16x4 p1, p2, p3;
+                    split3x4(vhi[g], p1, p2, p3);
+                    char* base = lds + j * DROW + (g * HP + u0) * 2;
+                    *(bf16x4*)(base) = p1; *(bf16x4*)(base + prow) = p2; *(bf16x4*)(base + 2 * prow) = p3;
+                }
             }
         }
         // c_{t-1} / h_{t-1} double as c_t / h_t of the step below; then refill `cur` in place for step
@@ -809,13 +813,13 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
         if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
         __syncthreads();
         if (a.prof) { const unsigned long long tc = clock64(); p_bar += tc - p_ta; p_ta = tc; }
-        const char* db = lds + j * DROW + q * 16;
+        const char* db = lds + (j % rpt) * DROW + q * 16;
         f32x4 acc[3] = {z4, z4, z4};
         bf16x8 dp[2][3], wp[2];
         auto load_ops = [&](int kb, int s) {                     // see rec_fwd_x6: software-pipelined operand reads
             dp[s][0] = *(const bf16x8*)(db + kb * 64);
-            dp[s][1] = *(const bf16x8*)(db + kb * 64 + 16 * DROW);
-            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 32 * DROW);
+            dp[s][1] = *(const bf16x8*)(db + kb * 64 + prow);
+            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * prow);
             wp[s] = *(const bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16);
         };
         load_ops(0, 0);
@@ -834,7 +838,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
-        dh += acc[0] + acc[1] + acc[2];
+        if (live) dh += acc[0] + acc[1] + acc[2];                 // phantom columns read a live row: keep their dh at 0
         if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
         if (!dbuf) __syncthreads();
         if (a.prof) p_bar += clock64() - p_ta;
@@ -1049,7 +1053,7 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         return e;
     }
     if (!a.f32_mfma && (Hp == 32 || Hp == 64 || Hp == 128)) {
-        const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * 16 * (size_t)(GHp * 2 + 32);
+        const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * (size_t)a.rpt * (GHp * 2 + 32);
         const int db6 = (w3b + 2 * one6 <= 160 * 1024) ? 1 : 0;
         const size_t l6 = w3b + (db6 ? 2 : 1) * one6;
         if (l6 <= 160 * 1024) {
@@ -1082,7 +1086,7 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
 static bool uses_x6_bwd(const RecArgs& a) {
     const int Hp = a.Hp, GHp = a.G * Hp;
     if (a.f32_mfma || !(Hp == 32 || Hp == 64 || Hp == 128)) return false;
-    const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * 16 * (size_t)(GHp * 2 + 32);
+    const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * (size_t)a.rpt * (GHp * 2 + 32);
     return w3b + one6 <= 160 * 1024;
 }
 int sbr_rec_bwd_blocks(const RecArgs& a, bool simple) {
