@@ -308,17 +308,27 @@ extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* len
     }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     hipStream_t s = h->stream;
-    if (n_rows < y.Bp) {   // padded rows: index 0, length 0, popularity 1
-        SBR_HIP(hipMemsetAsync(h->A(y.a_X), 0, (size_t)y.Bp * y.T * y.F * sizeof(int), s));
-        SBR_HIP(hipMemsetAsync(h->A(y.a_len), 0, (size_t)y.Bp * sizeof(int), s));
-        SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
+    h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);
+    h->bsmp = (const int*)h->A(y.a_smp); h->bpop = h->A(y.a_pop);
+    if (on_device && n_rows == y.Bp && pop) {
+        // device-resident inputs that cover every (padded) row: use them in place, no copies.  The caller
+        // keeps them alive and unchanged until the step has run (stream order), as with any device input.
+        h->bX = X; h->blen = lengths; h->bpop = pop;
+        if (target) h->btgt = target;
+        if (samples && y.S > 0) h->bsmp = samples;
+    } else {
+        if (n_rows < y.Bp) {   // padded rows: index 0, length 0, popularity 1
+            SBR_HIP(hipMemsetAsync(h->A(y.a_X), 0, (size_t)y.Bp * y.T * y.F * sizeof(int), s));
+            SBR_HIP(hipMemsetAsync(h->A(y.a_len), 0, (size_t)y.Bp * sizeof(int), s));
+            SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
+        }
+        SBR_HIP(hipMemcpyAsync(h->A(y.a_X), X, (size_t)n_rows * y.T * y.F * sizeof(int), kind, s));
+        SBR_HIP(hipMemcpyAsync(h->A(y.a_len), lengths, (size_t)n_rows * sizeof(int), kind, s));
+        if (target) SBR_HIP(hipMemcpyAsync(h->A(y.a_tgt), target, (size_t)n_tgt * sizeof(int), kind, s));
+        if (samples && y.S > 0) SBR_HIP(hipMemcpyAsync(h->A(y.a_smp), samples, (size_t)y.S * sizeof(int), kind, s));
+        if (pop) SBR_HIP(hipMemcpyAsync(h->A(y.a_pop), pop, (size_t)n_rows * sizeof(float), kind, s));
+        else SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
     }
-    SBR_HIP(hipMemcpyAsync(h->A(y.a_X), X, (size_t)n_rows * y.T * y.F * sizeof(int), kind, s));
-    SBR_HIP(hipMemcpyAsync(h->A(y.a_len), lengths, (size_t)n_rows * sizeof(int), kind, s));
-    if (target) SBR_HIP(hipMemcpyAsync(h->A(y.a_tgt), target, (size_t)n_tgt * sizeof(int), kind, s));
-    if (samples && y.S > 0) SBR_HIP(hipMemcpyAsync(h->A(y.a_smp), samples, (size_t)y.S * sizeof(int), kind, s));
-    if (pop) SBR_HIP(hipMemcpyAsync(h->A(y.a_pop), pop, (size_t)n_rows * sizeof(float), kind, s));
-    else SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
     if (!on_device) SBR_HIP(hipStreamSynchronize(s));   // caller's host arrays may be freed on return
     h->n_rows = n_rows; h->have_batch = true; h->fwd_done = false;
     return SBR_OK;
@@ -332,7 +342,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     RecArgs a; memset(&a, 0, sizeof(a));
     a.cell = y.cfg.cell; a.T = y.T; a.Bp = y.Bp; a.H = ly.H; a.Hp = ly.Hp; a.G = y.G;
     a.clip = y.cfg.grad_clip;
-    a.len = (const int*)h->A(y.a_len);
+    a.len = h->blen;
     a.xt = h->A(ly.a_xt); a.Whid = h->P(ly.p_Whid); a.peep = h->P(ly.p_peep);
     a.cinit = h->P(ly.p_cinit); a.hinit = h->P(ly.p_hinit);
     a.hs = h->A(ly.a_hs); a.cs = h->A(ly.a_cs);
@@ -364,7 +374,7 @@ extern "C" int sbr_forward(sbr_handle* h) {
         const LayerLayout& ly = y.layer[l];
         const int GHp = y.G * ly.Hp;
         if (l == 0) {
-            SBR_LAUNCH(launch_gather_xt(s, h->P(ly.p_Win), h->P(ly.p_b), (const int*)h->A(y.a_X), h->A(ly.a_xt), y.T, y.Bp,
+            SBR_LAUNCH(launch_gather_xt(s, h->P(ly.p_Win), h->P(ly.p_b), h->bX, h->A(ly.a_xt), y.T, y.Bp,
                                         y.F, GHp, h->n_rows));
             mark(h, 1);
         } else {   // dense layers: xt = hid_out(l-1) . W_in + b  (Lasagne precompute_input [3P], recurrent_layers.py:94-104)
@@ -392,13 +402,13 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     const bool sg = simple_gemm(h);
     float* hl = h_last(h);
     float* ws = h->A(y.a_ws);
-    const int* tgt = (const int*)h->A(y.a_tgt);
+    const int* tgt = h->btgt;
     SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));
     if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
         // batch-only work for the embedding scatter-add: side stream, joins before the reduce kernel
         SBR_HIP(hipEventRecord(h->ev_fork, s));
         SBR_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        SBR_LAUNCH(launch_scatter_sort(h->side, (const int*)h->A(y.a_X), (const int*)h->A(y.a_len), y.T, y.Bp, y.F,
+        SBR_LAUNCH(launch_scatter_sort(h->side, h->bX, h->blen, y.T, y.Bp, y.F,
                                        y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
                                        (int*)h->A(y.a_sid), (int*)h->A(y.a_spos)));
         SBR_HIP(hipEventRecord(h->ev_join, h->side));
@@ -407,7 +417,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         float* lg = h->A(y.a_logits);
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, N, R, N, Hp, nullptr, nullptr, 0, sg));
-        SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->A(y.a_pop), h->A(y.a_rowcost), R, N, y.Bg));
+        SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, y.Bg));
         SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
@@ -419,10 +429,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         const int C = y.C;
         int* cells = (int*)h->A(y.a_cells);
         float *Wc = h->A(y.a_Wc), *bc = h->A(y.a_bc), *act = h->A(y.a_act), *dWc = h->A(y.a_dWc), *dbc = h->A(y.a_dbc);
-        SBR_LAUNCH(launch_build_cells(s, tgt, (const int*)h->A(y.a_smp), y.Bg, y.S, cells));
+        SBR_LAUNCH(launch_build_cells(s, tgt, h->bsmp, y.Bg, y.S, cells));
         SBR_LAUNCH(launch_gather_rows(s, h->P(y.p_WoutT), h->P(y.p_bout), cells, C, Hp, Wc, bc));
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, Wc, 1, Hp, act, C, R, C, Hp, nullptr, nullptr, 0, sg));
-        SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->A(y.a_pop), h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
+        SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->bpop, h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
                                        y.cfg.loss, y.Bg));
         SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
         SBR_LAUNCH(launch_colsum_bias(s, act, R, C, C, dbc, nullptr, 0.0f, nullptr, h->A(y.a_csum)));
@@ -458,7 +468,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         if (l == 0) {
             mark(h, 5);
             if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
-                SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_X), a.len, y.T, y.Bp, y.F, GHp));
+                SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, h->bX, a.len, y.T, y.Bp, y.F, GHp));
             } else {
                 SBR_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
                 SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
@@ -550,7 +560,7 @@ extern "C" int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_hos
     if (rc != SBR_OK) return rc;
     float* lg = h->A(y.a_logits);
     if (exclude_seen)
-        SBR_LAUNCH(launch_exclude_seen(h->stream, lg, (const int*)h->A(y.a_X), (const int*)h->A(y.a_len), h->n_rows, y.T, y.F, y.N));
+        SBR_LAUNCH(launch_exclude_seen(h->stream, lg, h->bX, h->blen, h->n_rows, y.T, y.F, y.N));
     int* ids = (int*)h->A(y.a_topk);
     SBR_LAUNCH(launch_topk(h->stream, lg, h->n_rows, y.N, k, ids));
     SBR_HIP(hipMemcpyAsync(ids_host, ids, (size_t)h->n_rows * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -83,6 +83,8 @@ struct sbr_handle {
     hipEvent_t ev_fork, ev_join;
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
+    // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
+    const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
     int64_t step_count;  // adam t
     bool have_batch, fwd_done;

@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
                 for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16);
             };
             load_ops(0, 0);
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int s = kb & 1;
@@ -642,6 +643,9 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_nop 15");                             // MFMA D -> VALU read hazard (see rec_fwd_mfma)
+            // the gate-math / publish phase is VALU+LDS work that shares the SIMD's issue port with the partner
+            // wave's MFMA stream: give it priority, or it is starved for the whole length of that stream
+            __builtin_amdgcn_s_setprio(3);
             const bool m = t < mylen;
             f32x4 sv[4];
 #pragma unroll
@@ -823,6 +827,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
             wp[s] = *(const bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16);
         };
         load_ops(0, 0);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int s = kb & 1;
@@ -838,6 +843,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
+        __builtin_amdgcn_s_setprio(3);                            // gate-math phase ahead: see rec_fwd_x6
         if (live) dh += acc[0] + acc[1] + acc[2];                 // phantom columns read a live row: keep their dh at 0
         if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
         if (!dbuf) __syncthreads();
@@ -957,13 +963,25 @@ __global__ void rec_bwd_matvec_simple(RecArgs a, int t, float* dhstate, float* d
     }
 }
 
-__global__ void rec_reduce_partials(const float* part, int nblk, int G, int Hp, float* db, float* dpeep,
-                                    float* dcinit, float* dhinit) {
+// 64 outputs per workgroup x 4 slices of the block range; fixed summation order (deterministic)
+__global__ void __launch_bounds__(256) rec_reduce_partials(const float* __restrict__ part, int nblk, int G, int Hp,
+                                                           float* db, float* dpeep, float* dcinit, float* dhinit) {
+    __shared__ float red[4][64];
     const int GHp = G * Hp, n = GHp + 5 * Hp;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + e];   // fixed order: deterministic
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int b = grp;
+        for (; b + 12 < nblk; b += 16) {                       // 4 independent loads in flight
+            s0 += part[(size_t)b * n + e]; s1 += part[(size_t)(b + 4) * n + e];
+            s2 += part[(size_t)(b + 8) * n + e]; s3 += part[(size_t)(b + 12) * n + e];
+        }
+        for (; b < nblk; b += 4) s0 += part[(size_t)b * n + e];
+    }
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp != 0 || e >= n) return;
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (e < GHp) { db[e] = s; return; }
     const int k = (e - GHp) / Hp, u = (e - GHp) % Hp;
     if (k < 3) { if (dpeep) dpeep[k * Hp + u] = s; }
@@ -975,7 +993,7 @@ hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk
                                       float* dpeep, float* dcinit, float* dhinit) {
     const int n = G * Hp + 5 * Hp;
     const bool lstm = cell == SBR_CELL_LSTM;
-    rec_reduce_partials<<<(n + 255) / 256, 256, 0, s>>>(part, nblk, G, Hp, db, lstm ? dpeep : nullptr,
+    rec_reduce_partials<<<(n + 63) / 64, 256, 0, s>>>(part, nblk, G, Hp, db, lstm ? dpeep : nullptr,
                                                         lstm ? dcinit : nullptr, dhinit);
     return hipGetLastError();
 }
