@@ -91,7 +91,8 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_dxt = take(tb * G * y.Hp);
         y.a_dhi = cfg.cell == SBR_CELL_GRU ? take(tb * G * y.Hp) : y.a_dxt;
         y.a_dhext = l < lay.L - 1 ? take(tb * y.Hp) : 0;
-        y.a_part = take((size_t)Bp * (G * y.Hp + 5 * y.Hp));
+        y.a_state = take((size_t)2 * Bp * y.Hp);
+        y.a_part = take((size_t)SBR_BWD_CHUNKS * Bp * (G * y.Hp + 5 * y.Hp));
         maxrec = std::max(maxrec, (size_t)y.Hp * G * y.Hp);
         if (l > 0) maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp);
     }
@@ -107,6 +108,8 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
+    lay.ws2_floats = lay.ws_floats;
+    lay.a_ws2 = take(lay.ws2_floats);
     lay.a_X = take((size_t)Bp * T * lay.F);
     lay.a_len = take(Bp);
     lay.a_tgt = take(std::max(lay.Bg, Bp));
@@ -213,12 +216,25 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) { r = 16; while (r > 1 && h->lay.Bp / r < 64) r >>= 1; }
         h->rpt = r;
     }
+    {
+        const char* e = getenv("SBR_BWD_CHUNKS");
+        const int c = e ? atoi(e) : 2;
+        h->bwd_chunks = c < 1 ? 1 : (c > SBR_BWD_CHUNKS ? SBR_BWD_CHUNKS : c);
+    }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
-    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr;
+    for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
+    h->in_train_step = false; h->side_pending = false;
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_sort, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_lg, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chunk[3], hipEventDisableTiming) != hipSuccess) {
         sbr_set_error("side stream creation failed"); sbr_destroy(h); return SBR_EHIP;
     }
     // parameters, gradients, optimizer state and batch buffers start as zeros
@@ -237,6 +253,9 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_sort) (void)hipEventDestroy(h->ev_sort);
+    if (h->ev_lg) (void)hipEventDestroy(h->ev_lg);
+    for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -350,6 +369,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
     a.xt_blocked = 0;
     a.rpt = h->rpt;
+    a.t_lo = 0; a.t_hi = y.T; a.chunk = 0; a.state = h->A(ly.a_state);
     a.f32_mfma = (y.cfg.flags & SBR_FLAG_F32_MFMA) ? 1 : 0;
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;
     return a;
@@ -394,37 +414,54 @@ static float* h_last(sbr_handle* h) {   // hid_out[-1] (sparse_lstm.py:485-486) 
     return h->A(ly.a_hs) + (size_t)y.T * y.Bp * ly.Hp;
 }
 
+// The side stream carries everything that only feeds the optimizer (output-layer weight/bias gradients, the cost
+// scalar, the counting sort for the embedding scatter, the weight-gradient GEMM of finished BPTT chunks) so that
+// the main stream holds nothing but the dependent chain  logits -> softmax -> dh -> BPTT chunks -> scatter.
+static int side_join(sbr_handle* h) {
+    if (h->side_pending) {
+        SBR_HIP(hipEventRecord(h->ev_join, h->side));
+        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        h->side_pending = false;
+    }
+    return SBR_OK;
+}
+
 extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     if (!h->fwd_done) { sbr_set_error("sbr_loss_backward_output: call sbr_forward first"); return SBR_ESTATE; }
-    const Layout& y = h->lay; hipStream_t s = h->stream;
+    const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const int R = h->n_rows, Hp = y.HLp, N = y.N;
     const bool sg = simple_gemm(h);
     float* hl = h_last(h);
     float* ws = h->A(y.a_ws);
+    float* ws2 = h->A(y.a_ws2);
     const int* tgt = h->btgt;
     SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));
+    SBR_HIP(hipEventRecord(h->ev_fork, s));
+    SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
+    h->side_pending = true;
     if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
-        // batch-only work for the embedding scatter-add: side stream, joins before the reduce kernel
-        SBR_HIP(hipEventRecord(h->ev_fork, s));
-        SBR_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        SBR_LAUNCH(launch_scatter_sort(h->side, h->bX, h->blen, y.T, y.Bp, y.F,
+        // batch-only work for the embedding scatter-add; the scatter kernel waits for ev_sort
+        SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                        y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
                                        (int*)h->A(y.a_sid), (int*)h->A(y.a_spos)));
-        SBR_HIP(hipEventRecord(h->ev_join, h->side));
+        SBR_HIP(hipEventRecord(h->ev_sort, sd));
     }
     if (y.cfg.loss == SBR_LOSS_CCE) {
         float* lg = h->A(y.a_logits);
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, N, R, N, Hp, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, y.Bg));
-        SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
+        SBR_HIP(hipEventRecord(h->ev_lg, s));
+        // critical path: dh = dlogits . W_out^T feeds the BPTT chain
+        SBR_LAUNCH(launch_gemm(s, lg, N, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
+        // beside it: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h
+        SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg, 0));
+        SBR_LAUNCH(launch_sum_cost(sd, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
-        SBR_LAUNCH(launch_colsum_bias(s, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
-        // dW_out^T [N][Hp] = dlogits^T . h ;  dh = dlogits . W_out^T
-        SBR_LAUNCH(launch_gemm(s, lg, 1, N, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws, y.ws_floats, sg));
-        SBR_LAUNCH(launch_gemm(s, lg, N, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
+        SBR_LAUNCH(launch_colsum_bias(sd, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
+        SBR_LAUNCH(launch_gemm(sd, lg, 1, N, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws2, y.ws2_floats, sg));
     } else {
         const int C = y.C;
         int* cells = (int*)h->A(y.a_cells);
@@ -441,15 +478,18 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
     }
     mark(h, 3);
+    // called on its own (data-parallel: the caller all-reduces the output-layer gradients next): join now
+    if (!h->in_train_step) return side_join(h);
     return SBR_OK;
 }
 
 extern "C" int sbr_backward_recurrent(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     if (!h->fwd_done) { sbr_set_error("sbr_backward_recurrent: call sbr_forward first"); return SBR_ESTATE; }
-    const Layout& y = h->lay; hipStream_t s = h->stream;
+    const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const bool sg = simple_gemm(h);
     float* ws = h->A(y.a_ws);
+    float* ws2 = h->A(y.a_ws2);
     const int TB = y.T * y.Bp;
     for (int l = y.L - 1; l >= 0; --l) {
         const LayerLayout& ly = y.layer[l];
@@ -458,19 +498,44 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         a.dh_last = l == y.L - 1 ? h->A(y.a_dhlast) : nullptr;
         a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
         if (a.prof) a.prof += (size_t)(y.Bp / 16) * 16 * 8;
-        SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
-        if (l == 0) mark(h, 4);
-        SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, sbr_rec_bwd_blocks(a, simple_rec(h)), y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
-                                              h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
-        // dW_hid [Hp][G*Hp] = sum over (t,row) of hs[t]^T . dhi[t]   (hs slot t = h_{t-1})
-        SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
-                               y.ws_floats, sg));
+        const int nblk = sbr_rec_bwd_blocks(a, simple_rec(h));
+        // BPTT in time chunks when the bf16x6 kernel runs: dW_hid of a finished chunk is computed on the side
+        // stream (190 idle CUs) while the chain continues
+        const size_t slab = (size_t)ly.Hp * GHp;
+        int nc = (sbr_rec_bwd_chunkable(a, simple_rec(h)) && y.T >= 64 && !sg) ? h->bwd_chunks : 1;
+        int nsl = (int)std::min<size_t>(64 / nc, y.ws2_floats / (slab * nc));   // ~64 K-slices in total keep 768 workgroups busy
+        if (nsl < 1) nc = 1;
+        const bool side_wgrad = sbr_rec_bwd_chunkable(a, simple_rec(h)) && !sg && nsl >= 1;
+        if (nc > 1 || side_wgrad) {
+            for (int c = 0; c < nc; ++c) {
+                a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
+                SBR_LAUNCH(launch_rec_backward(s, a, false));
+                SBR_HIP(hipEventRecord(h->ev_chunk[c], s));
+                SBR_HIP(hipStreamWaitEvent(sd, h->ev_chunk[c], 0));
+                // dW_hid [Hp][G*Hp] += hs[t]^T . dhi[t] over the chunk's positions (hs slot t = h_{t-1})
+                SBR_LAUNCH(launch_gemm_slabs(sd, h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp, 1, ly.Hp,
+                                             a.dhi + (size_t)a.t_lo * y.Bp * GHp, GHp, 1, ly.Hp, GHp, (a.t_hi - a.t_lo) * y.Bp,
+                                             ws2 + (size_t)c * nsl * slab, nsl));
+            }
+            SBR_LAUNCH(launch_splitk_reduce(sd, ws2, nc * nsl, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
+            h->side_pending = true;
+            if (l == 0) mark(h, 4);
+            SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nc * nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+                                                  h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
+        } else {
+            SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
+            if (l == 0) mark(h, 4);
+            SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+                                                  h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
+            SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
+                                   y.ws_floats, sg));
+        }
         if (l == 0) {
             mark(h, 5);
             if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
                 SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, h->bX, a.len, y.T, y.Bp, y.F, GHp));
             } else {
-                SBR_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+                SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));
                 SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                  (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp, y.Bp));
             }
@@ -484,12 +549,14 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                    nullptr, 0, sg));
         }
     }
+    if (!h->in_train_step) return side_join(h);
     return SBR_OK;
 }
 
 extern "C" int sbr_apply_update(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     const Layout& y = h->lay;
+    { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
     h->step_count += 1;
     float* s1 = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
     SBR_LAUNCH(launch_update(h->stream, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, y.n_params, y.cfg.learning_rate,
@@ -510,6 +577,8 @@ extern "C" int sbr_train_step(sbr_handle* h, float* cost_host) {
     CHECK_ARG(h, "null handle");
     int rc;
     if (h->timing) h->ring_cur = h->ring_used % sbr_handle::kRing;
+    h->in_train_step = true;
+    struct Guard { sbr_handle* h; ~Guard() { h->in_train_step = false; } } guard{h};
     mark(h, 0);
     if ((rc = sbr_zero_grads(h)) != SBR_OK) return rc;
     if ((rc = sbr_forward(h)) != SBR_OK) return rc;

@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../include/sbr_rnn.h"
 
+#define SBR_BWD_CHUNKS 4       // BPTT launches per layer when T >= 64 (bf16x6 kernels)
 #define SBR_ALIGN_FLOATS 64   // every carved buffer starts on a 256-byte boundary
 
 static inline size_t sbr_align(size_t n_floats) { return (n_floats + SBR_ALIGN_FLOATS - 1) / SBR_ALIGN_FLOATS * SBR_ALIGN_FLOATS; }
@@ -43,7 +44,8 @@ struct LayerLayout {
     size_t a_dxt;    // [T][Bp][G*Hp]    grad wrt xt (= grad wrt gates for LSTM/Vanilla)
     size_t a_dhi;    // [T][Bp][G*Hp]    GRU only: grad wrt hid_input
     size_t a_dhext;  // [T][Bp][Hp]      grad arriving from the layer above (layers below the top)
-    size_t a_part;   // [Bp][G*Hp + 5*Hp] per-workgroup partial sums (up to one workgroup per row): bias, peepholes, inits
+    size_t a_state;  // [2][Bp][Hp] dh, dc carried between BPTT chunk launches
+    size_t a_part;   // [SBR_BWD_CHUNKS][Bp][G*Hp + 5*Hp] per-workgroup partial sums (up to one workgroup per row): bias, peepholes, inits
 };
 
 struct Layout {
@@ -62,7 +64,8 @@ struct Layout {
     size_t a_dhlast;                      // [Bp][HLp]
     size_t a_rowcost;                     // [Bp]
     size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
-    size_t a_ws; size_t ws_floats;        // split-K workspace
+    size_t a_ws; size_t ws_floats;        // split-K workspace (main stream)
+    size_t a_ws2; size_t ws2_floats;      // split-K workspace of the side stream (output-layer + weight gradients)
     size_t a_csum;                        // [16][max(N,C)] column-sum partials
     size_t a_prof;                        // [2][nblk][16][4] uint64 in-kernel cycle counters (fwd, bwd)
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
@@ -81,8 +84,12 @@ struct sbr_handle {
     hipStream_t stream;
     hipStream_t side;            // batch-only preprocessing (scatter sort) overlapped with the chain
     hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_sort, ev_lg, ev_chunk[SBR_BWD_CHUNKS];
+    bool in_train_step;  // phases called from sbr_train_step: the side stream joins only before the update
+    bool side_pending;   // side-stream work issued and not yet joined by the main stream
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
+    int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -143,7 +150,11 @@ struct RecArgs {
     const float* dh_last;   // [Bp][Hp] grad wrt the final hidden state (top layer) or NULL
     const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
     float* dxt; float* dhi; // dhi == dxt for LSTM/Vanilla
-    float* part;            // [nblk][G*Hp + 5*Hp]
+    // BPTT in time chunks (so the weight-gradient GEMM of finished chunks runs beside the chain): this launch
+    // covers t in [t_lo, t_hi); dh/dc cross launches through `state` [2][Bp][Hp]; part block = chunk*nblocks + block
+    int t_lo, t_hi, chunk;
+    float* state;
+    float* part;            // [chunks][nblk][G*Hp + 5*Hp]
     int rpt;                // live batch rows per workgroup of the bf16x6 kernels (16, 8, 4, 2, 1); part[] has Bp/rpt blocks
     int xt_blocked;         // xt is tile-blocked (layer 0: written by the gather) or row-major (GEMM output)
     int f32_mfma;           // SBR_FLAG_F32_MFMA: exact-f32 v_mfma_f32_16x16x4_f32 kernels instead of bf16x6
@@ -153,6 +164,8 @@ hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple);
 // number of part[] blocks the backward launch for these args writes
 int sbr_rec_bwd_blocks(const RecArgs& a, bool simple);
+// true when the backward launch honours RecArgs.t_lo/t_hi/chunk (bf16x6 kernels)
+bool sbr_rec_bwd_chunkable(const RecArgs& a, bool simple);
 // sums the per-workgroup partials into bias / peephole / init gradients
 hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk, int G, int Hp, int cell,
                                       float* db, float* dpeep, float* dcinit, float* dhinit);
@@ -165,6 +178,11 @@ hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                        float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
                        bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0);
+
+hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
+                             int N, int K, float* ws, int nsplit);
+hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
+                                const float* bias);
 
 // full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N) in, dlogits out in place
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,

@@ -145,6 +145,23 @@ __global__ void gemm_naive(GemmArgs g) {
     g.C[(long)m * g.ldc + n] = s + (g.bias ? g.bias[n] : 0.0f);
 }
 
+// split-K partial products only: writes exactly `nsplit` slabs [z][M][N] at ws (no reduction)
+hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
+                             int N, int K, float* ws, int nsplit) {
+    if (M <= 0 || N <= 0 || nsplit < 1) return hipSuccess;
+    GemmArgs g{A, sam, sak, B, sbk, sbn, ws, N, M, N, K, nullptr, 0, 0, K, ws};
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    g.kchunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;   // slices past K write zero slabs
+    gemm_f32_mfma<<<dim3(tn, tm, nsplit), 256, 0, s>>>(g);
+    return hipGetLastError();
+}
+hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
+                                const float* bias) {
+    const size_t n = (size_t)M * N;
+    gemm_splitk_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(ws, nslabs, M, N, C, ldc, bias);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                        long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple,
                        int a_blk_Bp, int b_blk_Bp) {

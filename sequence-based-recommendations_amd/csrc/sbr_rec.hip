@@ -729,8 +729,15 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
     const f32x4 z4 = f32x4{0, 0, 0, 0};
-    f32x4 dh = (a.dh_last && live) ? *(const f32x4*)&a.dh_last[(size_t)row * HP + u0] : z4;
-    f32x4 dc = z4, pi = z4, pf = z4, po = z4;
+    const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
+    f32x4 dh = z4, dc = z4, pi = z4, pf = z4, po = z4;
+    if (live) {
+        if (first) { if (a.dh_last) dh = *(const f32x4*)&a.dh_last[(size_t)row * HP + u0]; }
+        else {
+            dh = *(const f32x4*)&a.state[(size_t)row * HP + u0];
+            if (CELL == CELL_LSTM) dc = *(const f32x4*)&a.state[((size_t)Bp + row) * HP + u0];
+        }
+    }
     if (CELL == CELL_LSTM) { pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0]; }
     f32x4 sdb[G], sdp[3];
 #pragma unroll
@@ -754,7 +761,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
     if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
     __syncthreads();                                              // W plane 3 visible
 
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = a.t_hi - 1; t >= a.t_lo; --t) {
         if (a.prof) p_ta = clock64();
         if (a.dh_ext && live) dh += *(const f32x4*)&a.dh_ext[((size_t)t * Bp + row) * HP + u0];
         if (t >= tmax) {                                          // whole tile masked: zero rows
@@ -813,7 +820,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
         // t-1: the loads are in flight across the barrier and the whole MFMA phase
         if (CELL == CELL_LSTM) cnew = cur.cprev[0];
         if (CELL == CELL_VANILLA) hnew = cur.hprev[0];
-        if (t > 0) load_saved(t - 1, cur);
+        if (t > a.t_lo) load_saved(t - 1, cur);
         if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
         __syncthreads();
         if (a.prof) { const unsigned long long tc = clock64(); p_bar += tc - p_ta; p_ta = tc; }
@@ -854,11 +861,16 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
         o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
     }
 
-    float* part = a.part + (size_t)blockIdx.x * (GHP + 5 * HP);
+    if (!last && live) {                                          // hand dh / dc to the next chunk launch
+        *(f32x4*)&a.state[(size_t)row * HP + u0] = dh;
+        if (CELL == CELL_LSTM) *(f32x4*)&a.state[((size_t)Bp + row) * HP + u0] = dc;
+    }
+    float* part = a.part + ((size_t)a.chunk * gridDim.x + blockIdx.x) * (GHP + 5 * HP);
     f32x4 v[G + 5];
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] = sdb[g];
-    v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2]; v[G + 3] = dc; v[G + 4] = dh;
+    v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2];
+    v[G + 3] = last ? dc : z4; v[G + 4] = last ? dh : z4;       // init-state gradients come from the last chunk only
 #pragma unroll
     for (int k = 0; k < G + 5; ++k)
 #pragma unroll
@@ -1111,6 +1123,8 @@ int sbr_rec_bwd_blocks(const RecArgs& a, bool simple) {
     if (simple) return a.Bp / 16;                 // simple kernels accumulate into block 0, others zeroed
     return uses_x6_bwd(a) ? a.Bp / a.rpt : a.Bp / 16;
 }
+
+bool sbr_rec_bwd_chunkable(const RecArgs& a, bool simple) { return !simple && uses_x6_bwd(a); }
 
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple) {
     switch (a.cell) {

@@ -82,6 +82,15 @@ def test_scatter_with_heavy_duplicates():
     check(PU.compare_step("LSTM", [20], "BPR", N=12, B=24, T=20, S=4, seed=9))
 
 
+@pytest.mark.parametrize("chunks", ["1", "2", "4"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_long_sequences_chunked_bptt(cell, chunks, monkeypatch):
+    # T >= 64 switches the bf16x6 BPTT to time chunks (state carried between launches, weight-gradient GEMM of
+    # finished chunks on the side stream); ragged lengths put chunk borders inside and outside the valid range
+    monkeypatch.setenv("SBR_BWD_CHUNKS", chunks)
+    check(PU.compare_step(cell, [20], "CCE", N=41, B=9, T=70, seed=3), tol_h=2e-4)
+
+
 def test_ragged_and_edge_lengths():
     # rows of length 1 and T, a row whose items are all id 0 (== the pad id), B not a multiple of 16
     check(PU.compare_step("GRU", [16], "CCE", N=33, B=17, T=11, seed=5))
