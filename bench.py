@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="sequences per GPU per step")
     ap.add_argument("--max_length", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="(debug) take the data-parallel phase path even with one rank")
     ap.add_argument("--cpu-steps", type=int, default=3, help="max timed CPU-baseline steps")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the port scales to ~16 threads on the GPU box")
@@ -96,8 +97,9 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cell, layers, n_items, loss, n_samples = CONFIGS[args.config]
@@ -127,7 +129,7 @@ def main():
         if world > 1 and loss != "CCE":      # sampled heads need every rank's targets (rnn_sampling.py:137)
             tgt = dp.gather_targets(tgt)
         eng.set_batch_device(d["X"], d["lengths"], tgt, d["samples"] if loss != "CCE" else None, d["pop"], B)
-        if world == 1:
+        if world == 1 and not args.force_dp:
             eng.train_step(sync=False)       # one C call: zero grads, fwd, loss, BPTT, scatter, Adam
         else:
             dp.train_step()                  # same phases with the RCCL all-reduces in between
@@ -156,7 +158,7 @@ def main():
     if not np.isfinite(cost):
         raise ValueError("Cost is NaN")            # rnn_base.py:291-292
 
-    phases = eng.phase_times() if world == 1 else None
+    phases = eng.phase_times() if (world == 1 and not args.force_dp) else None
     ms_per_step = dt / args.steps * 1e3
     value = Bg * args.steps / dt
 
@@ -231,11 +233,18 @@ def main():
                                   "kind": "port", "sample": "%d train step(s) of the same %s workload (B=%d, T=%d): torch-CPU "
                                   "float32 port of the reference path (Theano/Lasagne not installable), %.2f s/step, "
                                   "%d threads of %d host cores" % (n, args.config, B, T, cdt, nthr, ncores)}
-    if rank == 0:
-        print(json.dumps(result))
     eng.close()
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush that first so the JSON line is the LAST line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ class DataParallel(object):
     def train_step(self):
         """One step on the batch already set on the engine; returns nothing (cost: read_cost())."""
         e = self.engine
-        if self.world == 1:
+        if self.world == 1 and not self.dist.is_initialized():
             e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()
             return
         e.zero_grads()
