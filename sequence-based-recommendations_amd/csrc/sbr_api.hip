@@ -89,7 +89,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_cs = cfg.cell == SBR_CELL_LSTM ? take(tb1 * y.Hp) : 0;
         for (int k = 0; k < 4; ++k) y.a_g[k] = cfg.cell == SBR_CELL_VANILLA ? 0 : take(tb * y.Hp);
         y.a_dxt = take(tb * G * y.Hp);
-        y.a_dhi = cfg.cell == SBR_CELL_GRU ? take(tb * G * y.Hp) : y.a_dxt;
+        y.a_dhi = cfg.cell == SBR_CELL_GRU ? take(tb * y.Hp) : y.a_dxt;
         y.a_dhext = l < lay.L - 1 ? take(tb * y.Hp) : 0;
         y.a_state = take((size_t)2 * Bp * y.Hp);
         y.a_part = take((size_t)SBR_BWD_CHUNKS * Bp * (G * y.Hp + 5 * y.Hp));
@@ -108,7 +108,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
-    lay.ws2_floats = lay.ws_floats;
+    lay.ws2_floats = 4 * lay.ws_floats;          // up to 256 weight-gradient slabs
     lay.a_ws2 = take(lay.ws2_floats);
     lay.a_X = take((size_t)Bp * T * lay.F);
     lay.a_len = take(Bp);
@@ -218,8 +218,10 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     }
     {
         const char* e = getenv("SBR_BWD_CHUNKS");
-        const int c = e ? atoi(e) : 2;
+        const int c = e ? atoi(e) : 1;   // chunking measured neutral-to-slower at C2 (relaunch ~20 us); kept + tested
         h->bwd_chunks = c < 1 ? 1 : (c > SBR_BWD_CHUNKS ? SBR_BWD_CHUNKS : c);
+        const char* w = getenv("SBR_WGRAD_SLICES");
+        h->wgrad_slices = w ? std::max(4, atoi(w)) : 256;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -503,7 +505,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // stream (190 idle CUs) while the chain continues
         const size_t slab = (size_t)ly.Hp * GHp;
         int nc = (sbr_rec_bwd_chunkable(a, simple_rec(h)) && y.T >= 64 && !sg) ? h->bwd_chunks : 1;
-        int nsl = (int)std::min<size_t>(64 / nc, y.ws2_floats / (slab * nc));   // ~64 K-slices in total keep 768 workgroups busy
+        int nsl = (int)std::min<size_t>(h->wgrad_slices / nc, y.ws2_floats / (slab * nc));   // K-slices (= workgroups of the wgrad kernel)
         if (nsl < 1) nc = 1;
         const bool side_wgrad = sbr_rec_bwd_chunkable(a, simple_rec(h)) && !sg && nsl >= 1;
         if (nc > 1 || side_wgrad) {
@@ -513,9 +515,21 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 SBR_HIP(hipEventRecord(h->ev_chunk[c], s));
                 SBR_HIP(hipStreamWaitEvent(sd, h->ev_chunk[c], 0));
                 // dW_hid [Hp][G*Hp] += hs[t]^T . dhi[t] over the chunk's positions (hs slot t = h_{t-1})
-                SBR_LAUNCH(launch_gemm_slabs(sd, h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp, 1, ly.Hp,
-                                             a.dhi + (size_t)a.t_lo * y.Bp * GHp, GHp, 1, ly.Hp, GHp, (a.t_hi - a.t_lo) * y.Bp,
-                                             ws2 + (size_t)c * nsl * slab, nsl));
+                const float* hsc = h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp;
+                const int Kc = (a.t_hi - a.t_lo) * y.Bp;
+                float* slabs = ws2 + (size_t)c * nsl * slab;
+                const bool gru = y.cfg.cell == SBR_CELL_GRU;
+                const float* dxc = a.dxt + (size_t)a.t_lo * y.Bp * GHp;
+                const float* dhcc = gru ? a.dhi + (size_t)a.t_lo * y.Bp * ly.Hp : nullptr;
+                hipError_t we = hipSuccess;
+                if (launch_wgrad_slabs(sd, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
+                    SBR_LAUNCH(we);
+                } else if (gru) {   // hid_input grad = [dxt_r | dxt_u | dhi_c]
+                    SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, 2 * ly.Hp, Kc, slabs, nsl, GHp, slab));
+                    SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dhcc, ly.Hp, 1, ly.Hp, ly.Hp, Kc, slabs + 2 * ly.Hp, nsl, GHp, slab));
+                } else {
+                    SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab));
+                }
             }
             SBR_LAUNCH(launch_splitk_reduce(sd, ws2, nc * nsl, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
             h->side_pending = true;
@@ -527,8 +541,15 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             if (l == 0) mark(h, 4);
             SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
                                                   h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
-            SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
-                                   y.ws_floats, sg));
+            if (y.cfg.cell == SBR_CELL_GRU) {
+                SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, 2 * ly.Hp, TB, nullptr,
+                                       ws, y.ws_floats, sg));
+                SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, ly.Hp, 1, h->Gd(ly.p_Whid) + 2 * ly.Hp, GHp, ly.Hp, ly.Hp, TB,
+                                       nullptr, ws, y.ws_floats, sg));
+            } else {
+                SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
+                                       y.ws_floats, sg));
+            }
         }
         if (l == 0) {
             mark(h, 5);
@@ -657,7 +678,7 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
         if (nm == "xt" + sfx) { *dev_ptr = h->A(ly.a_xt); *n_floats = tb * y.G * ly.Hp; return SBR_OK; }
         if (nm == "hs" + sfx) { *dev_ptr = h->A(ly.a_hs); *n_floats = (tb + y.Bp) * ly.Hp; return SBR_OK; }
         if (nm == "dxt" + sfx) { *dev_ptr = h->A(ly.a_dxt); *n_floats = tb * y.G * ly.Hp; return SBR_OK; }
-        if (nm == "dhi" + sfx) { *dev_ptr = h->A(ly.a_dhi); *n_floats = tb * y.G * ly.Hp; return SBR_OK; }
+        if (nm == "dhi" + sfx) { *dev_ptr = h->A(ly.a_dhi); *n_floats = tb * (y.cfg.cell == SBR_CELL_GRU ? 1 : y.G) * ly.Hp; return SBR_OK; }
     }
     sbr_set_error("unknown debug buffer '%s'", name);
     return SBR_EINVAL;

@@ -42,7 +42,7 @@ struct LayerLayout {
     size_t a_cs;     // [T+1][Bp][Hp]    LSTM cell states
     size_t a_g[4];   // [T][Bp][Hp]      LSTM i,f,g,o / GRU r,u,c~,hid_c
     size_t a_dxt;    // [T][Bp][G*Hp]    grad wrt xt (= grad wrt gates for LSTM/Vanilla)
-    size_t a_dhi;    // [T][Bp][G*Hp]    GRU only: grad wrt hid_input
+    size_t a_dhi;    // [T][Bp][Hp]      GRU only: candidate-gate slice of grad wrt hid_input (r,u slices equal dxt)
     size_t a_dhext;  // [T][Bp][Hp]      grad arriving from the layer above (layers below the top)
     size_t a_state;  // [2][Bp][Hp] dh, dc carried between BPTT chunk launches
     size_t a_part;   // [SBR_BWD_CHUNKS][Bp][G*Hp + 5*Hp] per-workgroup partial sums (up to one workgroup per row): bias, peepholes, inits
@@ -90,6 +90,7 @@ struct sbr_handle {
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)
+    int wgrad_slices;    // K-slices of the weight-gradient kernel (total over the chunks)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -149,7 +150,7 @@ struct RecArgs {
     // backward only
     const float* dh_last;   // [Bp][Hp] grad wrt the final hidden state (top layer) or NULL
     const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
-    float* dxt; float* dhi; // dhi == dxt for LSTM/Vanilla
+    float* dxt; float* dhi; // dhi: GRU only, compact [T][Bp][Hp] = candidate-gate slice of grad wrt hid_input (r,u slices == dxt)
     // BPTT in time chunks (so the weight-gradient GEMM of finished chunks runs beside the chain): this launch
     // covers t in [t_lo, t_hi); dh/dc cross launches through `state` [2][Bp][Hp]; part block = chunk*nblocks + block
     int t_lo, t_hi, chunk;
@@ -179,10 +180,15 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
                        float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
                        bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0);
 
+// slabs are [z][slab_stride] with row stride ws_ld: a GEMM may fill only a column range of wider slabs
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
-                             int N, int K, float* ws, int nsplit);
+                             int N, int K, float* ws, int nsplit, long ws_ld, size_t slab_stride);
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias);
+
+// dedicated dW_hid kernel: nslices slabs [Hp][GHp]; dhc != NULL: GRU compact candidate-gate array for cols >= 2*Hp
+bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const float* dhc, float* slabs, int Hp, int GHp,
+                        int npos, int nslices, hipError_t* err);
 
 // full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N) in, dlogits out in place
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,

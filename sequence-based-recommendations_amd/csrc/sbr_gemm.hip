@@ -26,7 +26,8 @@ struct GemmArgs {
     const float* bias;
     int a_blk_Bp, b_blk_Bp;   // > 0: operand is a tile-blocked activation [pos = t*Bp + row][col]
     int kchunk;      // K range per grid.z slice (multiple of BK)
-    float* ws;       // split-K slabs [z][M][N] (NULL when gridDim.z == 1)
+    float* ws;       // split-K slabs (NULL when gridDim.z == 1): slab z at ws + z*ws_stride, row stride ws_ld
+    long ws_ld; size_t ws_stride;
 };
 
 __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
@@ -104,8 +105,8 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
     }
 
     asm volatile("s_nop 15");   // MFMA D -> VALU read hazard across the loop exit (see sbr_rec.hip)
-    float* out = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
-    const long ld = g.ws ? g.N : g.ldc;
+    float* out = g.ws ? g.ws + (size_t)blockIdx.z * g.ws_stride : g.C;
+    const long ld = g.ws ? g.ws_ld : g.ldc;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -121,12 +122,28 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
         }
 }
 
-__global__ void gemm_splitk_reduce(const float* ws, int nsplit, int M, int N, float* C, long ldc, const float* bias) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    float s = 0.0f;
-    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * M * N + i];
-    const int m = i / N, n = i % N;
+// C = sum of the split-K slabs (+ bias): 64 outputs x 4 slab groups per workgroup, 4 loads in flight per
+// thread, fixed summation order (deterministic).  Slabs are read once, coalesced.
+__global__ void __launch_bounds__(256) gemm_splitk_reduce(const float* __restrict__ ws, int nsplit, int M, int N,
+                                                          float* __restrict__ C, long ldc, const float* __restrict__ bias) {
+    __shared__ float red[4][64];
+    const size_t MN = (size_t)M * N;
+    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < MN) {
+        int z = grp;
+        for (; z + 12 < nsplit; z += 16) {
+            s0 += ws[(size_t)z * MN + i]; s1 += ws[(size_t)(z + 4) * MN + i];
+            s2 += ws[(size_t)(z + 8) * MN + i]; s3 += ws[(size_t)(z + 12) * MN + i];
+        }
+        for (; z < nsplit; z += 4) s0 += ws[(size_t)z * MN + i];
+    }
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp != 0 || i >= MN) return;
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int m = (int)(i / N), n = (int)(i % N);
     C[(long)m * ldc + n] = s + (bias ? bias[n] : 0.0f);
 }
 
@@ -147,9 +164,9 @@ __global__ void gemm_naive(GemmArgs g) {
 
 // split-K partial products only: writes exactly `nsplit` slabs [z][M][N] at ws (no reduction)
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
-                             int N, int K, float* ws, int nsplit) {
+                             int N, int K, float* ws, int nsplit, long ws_ld, size_t slab_stride) {
     if (M <= 0 || N <= 0 || nsplit < 1) return hipSuccess;
-    GemmArgs g{A, sam, sak, B, sbk, sbn, ws, N, M, N, K, nullptr, 0, 0, K, ws};
+    GemmArgs g{A, sam, sak, B, sbk, sbn, ws, N, M, N, K, nullptr, 0, 0, K, ws, ws_ld, slab_stride};
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     g.kchunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;   // slices past K write zero slabs
     gemm_f32_mfma<<<dim3(tn, tm, nsplit), 256, 0, s>>>(g);
@@ -158,7 +175,7 @@ hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, 
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias) {
     const size_t n = (size_t)M * N;
-    gemm_splitk_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(ws, nslabs, M, N, C, ldc, bias);
+    gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, nslabs, M, N, C, ldc, bias);
     return hipGetLastError();
 }
 
@@ -166,7 +183,7 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
                        long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple,
                        int a_blk_Bp, int b_blk_Bp) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, a_blk_Bp, b_blk_Bp, K, nullptr};
+    GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, a_blk_Bp, b_blk_Bp, K, nullptr, (long)N, (size_t)M * N};
     if (simple) {
         const size_t n = (size_t)M * N;
         gemm_naive<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g);
@@ -188,7 +205,94 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
     gemm_f32_mfma<<<dim3(tn, tm, nsplit), 256, 0, s>>>(g);
     if (nsplit > 1) {
         const size_t n = (size_t)M * N;
-        gemm_splitk_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(ws, nsplit, M, N, C, ldc, bias);
+        gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, nsplit, M, N, C, ldc, bias);
     }
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Dedicated weight-gradient kernel: slab[z][Hp][GHp] = sum over the positions of K-slice z of
+//     hs[pos][:]^T (x) dz[pos][:]      (dW_hid = hs_prev^T . d hid_input, K = T*B positions)
+// Both operands are position-major rows, which is exactly the f32 MFMA fragment shape
+// (A[i][k] = hs[pos+k][unit i], B[k][j] = dz[pos+k][col j]): fragments are loaded straight from
+// global/L2 as 64-byte segments, no LDS, no transposes.  One workgroup = 8 waves as 2 (units) x 4
+// (columns); every workgroup produces a full Hp x GHp slab for its slice of positions, so each
+// activation row is read exactly once chip-wide.  GRU: columns >= 2*Hp come from the compact
+// candidate-gate array (sbr_rec.hip), the others from dxt.
+// ---------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ void __launch_bounds__(512) wgrad_kernel(const float* __restrict__ hs, const float* __restrict__ dxt,
+                                                    const float* __restrict__ dhc, float* __restrict__ slabs, int Hp, int GHp,
+                                                    int split_col, int npos, int pps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int m0 = wm * MT * 16, n0 = wn * NT * 16;
+    const int pbeg = blockIdx.x * pps, pend = min(npos, pbeg + pps);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+    // per-column-tile source (uniform per tile): dxt row stride GHp, or the compact array with stride Hp
+    const float* bsrc[NT]; int bld[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int n = n0 + b * 16;
+        if (dhc && n >= split_col) { bsrc[b] = dhc + (n - split_col) + j; bld[b] = Hp; }
+        else { bsrc[b] = dxt + n + j; bld[b] = GHp; }
+    }
+    const float* asrc = hs + m0 + j;
+    // fragments of k-step p+4 are fetched before the MFMAs of k-step p (register double buffer): with one
+    // workgroup per CU nothing else hides the L2/HBM latency of these loads
+    float af[2][MT], bf[2][NT];
+    auto fetch = [&](int p, int s) {
+        const int pos = p + q;
+        const bool ok = pos < pend;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) af[s][a] = ok ? asrc[(size_t)pos * Hp + a * 16] : 0.0f;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bf[s][b] = ok ? bsrc[b][(size_t)pos * bld[b]] : 0.0f;
+    };
+    auto mma = [&](int s) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][a], bf[s][b], acc[a][b], 0, 0, 0);
+    };
+    fetch(pbeg, 0);
+    for (int p = pbeg; p < pend; p += 8) {
+        fetch(p + 4, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(p + 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15");
+    float* out = slabs + (size_t)blockIdx.x * Hp * GHp;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(m0 + a * 16 + q * 4 + r) * GHp + n0 + b * 16 + j] = acc[a][b][r];
+}
+
+// returns false when the shape has no instantiation (caller falls back to the generic GEMM)
+bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const float* dhc, float* slabs, int Hp, int GHp,
+                        int npos, int nslices, hipError_t* err) {
+    const int mt = Hp / 32, nt = GHp / 64;
+    if (Hp % 32 || GHp % 64) return false;
+    const int pps = ((npos + nslices - 1) / nslices + 3) / 4 * 4;
+    const int split = dhc ? 2 * Hp : GHp;
+#define WG(MT, NT) wgrad_kernel<MT, NT><<<nslices, 512, 0, s>>>(hs, dxt, dhc, slabs, Hp, GHp, split, npos, pps)
+    if (mt == 4 && nt == 6) WG(4, 6); else if (mt == 4 && nt == 8) WG(4, 8); else if (mt == 4 && nt == 2) WG(4, 2);
+    else if (mt == 2 && nt == 3) WG(2, 3); else if (mt == 2 && nt == 4) WG(2, 4); else if (mt == 2 && nt == 1) WG(2, 1);
+    else if (mt == 1 && nt == 2) WG(1, 2); else return false;
+#undef WG
+    *err = hipGetLastError();
+    return true;
 }

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
                 for (int g = 0; g < G; ++g) {
                     const size_t o = ((size_t)t * Bp + row) * GHp + g * Hp + (wave * NT + n) * 16 + q * 4;
                     *(f32x4*)&a.dxt[o] = z;
-                    if (CELL == CELL_GRU) *(f32x4*)&a.dhi[o] = z;
+                    if (CELL == CELL_GRU && g == 2) *(f32x4*)&a.dhi[((size_t)t * Bp + row) * Hp + (wave * NT + n) * 16 + q * 4] = z;
                 }
             continue;
         }
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
             for (int g = 0; g < G; ++g) {
                 const size_t og = ((size_t)t * Bp + row) * GHp + g * Hp + u0;
                 *(f32x4*)&a.dxt[og] = vxi[g];
-                if (CELL == CELL_GRU) *(f32x4*)&a.dhi[og] = vhi[g];
+                if (CELL == CELL_GRU && g == 2) *(f32x4*)&a.dhi[((size_t)t * Bp + row) * Hp + u0] = vhi[g];
                 *(f32x4*)&lds[j * ROW + wofs[n][g]] = vhi[g];
             }
         }
@@ -603,6 +603,7 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
 
     for (int t = 0; t < T; ++t) {
         if (a.prof) p_ta = clock64();
+        f32x4 sv[4];
         if (t < tmax) {                                           // workgroup-uniform
             if (t + 1 < tmax) load_x(t + 1, xn);
             const char* hb = hbuf + (size_t)(t & 1) * 3 * 16 * HROW + j * HROW + q * 16;
@@ -647,7 +648,6 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
             // wave's MFMA stream: give it priority, or it is starved for the whole length of that stream
             __builtin_amdgcn_s_setprio(3);
             const bool m = t < mylen;
-            f32x4 sv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float xs[G], as[G], s[4];
@@ -659,16 +659,6 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
             }
-            if (CELL != CELL_VANILLA && live) {
-                const size_t o = gate_index(t, row, u0, Bp, HP);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][o] = sv[k];
-            }
-        }
-        if (live) {
-            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u0;
-            *(f32x4*)&a.hs[o] = h;
-            if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c;
         }
         if (t + 1 < tmax) {
 #pragma unroll
@@ -677,6 +667,18 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
             if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
             __syncthreads();
             if (a.prof) p_bar += clock64() - p_ta;
+        }
+        // this step's stores are issued AFTER the barrier: they leave the critical path (h_t is already
+        // published) and drain under the next step's MFMA phase
+        if (live) {
+            if (CELL != CELL_VANILLA && t < tmax) {
+                const size_t o = gate_index(t, row, u0, Bp, HP);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][o] = sv[k];
+            }
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u0;
+            *(f32x4*)&a.hs[o] = h;
+            if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c;
         }
     }
     if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
@@ -770,7 +772,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
                 const size_t o = ((size_t)t * Bp + row) * GHP + g * HP + u0;
                 if (live) {
                     *(f32x4*)&a.dxt[o] = z4;
-                    if (CELL == CELL_GRU) *(f32x4*)&a.dhi[o] = z4;
+                    if (CELL == CELL_GRU && g == 2) *(f32x4*)&a.dhi[((size_t)t * Bp + row) * HP + u0] = z4;
                 }
             }
             continue;
@@ -806,7 +808,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
                 const size_t og = ((size_t)t * Bp + row) * GHP + g * HP + u0;
                 if (live) {
                     *(f32x4*)&a.dxt[og] = vxi[g];
-                    if (CELL == CELL_GRU) *(f32x4*)&a.dhi[og] = vhi[g];
+                    if (CELL == CELL_GRU && g == 2) *(f32x4*)&a.dhi[((size_t)t * Bp + row) * HP + u0] = vhi[g];
                 }
                 if (live) {
                     bf16x4 p1, p2, p3;
@@ -948,7 +950,7 @@ __global__ void rec_bwd_elem_simple(RecArgs a, int t, float* dhstate, float* dcs
     for (int g = 0; g < G; ++g) {
         const size_t og = ((size_t)t * Bp + row) * GHp + g * Hp + k;
         a.dxt[og] = dxi[g];
-        if (CELL == CELL_GRU) a.dhi[og] = dhi[g];
+        if (CELL == CELL_GRU && g == 2) a.dhi[((size_t)t * Bp + row) * Hp + k] = dhi[g];
         atomicAdd(&a.part[g * Hp + k], dxi[g]);
     }
     if (CELL == CELL_LSTM) {
@@ -964,9 +966,14 @@ __global__ void rec_bwd_matvec_simple(RecArgs a, int t, float* dhstate, float* d
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Bp * Hp) return;
     const int row = idx / Hp, k = idx % Hp;
-    const float* d = a.dhi + ((size_t)t * Bp + row) * GHp;
+    // grad wrt hid_input: LSTM/Vanilla = dxt; GRU = [dxt_r, dxt_u, dhi_c] (only the candidate slice differs)
+    const float* d = a.dxt + ((size_t)t * Bp + row) * GHp;
+    const float* dc2 = a.dhi + ((size_t)t * Bp + row) * Hp;
     float v = 0.f;
-    for (int jj = 0; jj < GHp; ++jj) v = fmaf(d[jj], a.Whid[(size_t)k * GHp + jj], v);
+    for (int jj = 0; jj < GHp; ++jj) {
+        const float dv = (CELL == CELL_GRU && jj >= 2 * Hp) ? dc2[jj - 2 * Hp] : d[jj];
+        v = fmaf(dv, a.Whid[(size_t)k * GHp + jj], v);
+    }
     const float dh = dhstate[idx] + v;
     dhstate[idx] = dh;
     if (t == 0) {   // init-state gradients: column sums over rows
