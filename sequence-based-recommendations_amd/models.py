@@ -160,7 +160,10 @@ class RNNBase(object):
             sequences = []
             batch_size = 1 if test else self.batch_size
             while j < batch_size:
-                sequence, user_id = next(sequence_generator)
+                try:
+                    sequence, user_id = next(sequence_generator)
+                except StopIteration:       # the source ran dry (validation/test: epochs=1): end this generator too,
+                    return                  # as the reference's python-2 generator does implicitly
                 if not test:
                     k = int(min(batch_size - j, len(sequence) - 2, max_reuse_sequence))
                     seq_lengths = sorted(random.sample(range(2, len(sequence)), k))

@@ -163,6 +163,15 @@ def test_gen_mini_batch_policy():
     assert bi[0].shape == (1, 5, 1) and goal == [i % 50 for i in range(6, 12)]
 
 
+def test_gen_mini_batch_ends_with_a_finite_source():
+    # validation/test sets are streamed with epochs=1 (rnn_base.py:367): the batch generator must end with them
+    from sbr_amd.models import RNNOneHot
+    m = _model(RNNOneHot, max_length=5, batch_size=7)
+    src = iter([([[i % 50, 3.0] for i in range(8)], str(u)) for u in range(3)])
+    got = list(m._gen_mini_batch(src, test=True))
+    assert len(got) == 3 and all(goal == [4, 5, 6, 7] for _, goal in got)
+
+
 def test_save_load_roundtrip_layout(tmp_path):
     # checkpoints are plain pickled lists of arrays in Lasagne order, protocol 2 (rnn_base.py:470-479)
     import pickle
