@@ -106,6 +106,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     }
     lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
     lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
+    lay.a_fault = take(64);
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
     lay.ws2_floats = 4 * lay.ws_floats;          // up to 256 weight-gradient slabs
@@ -222,6 +223,10 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->bwd_chunks = c < 1 ? 1 : (c > SBR_BWD_CHUNKS ? SBR_BWD_CHUNKS : c);
         const char* w = getenv("SBR_WGRAD_SLICES");
         h->wgrad_slices = w ? std::max(4, atoi(w)) : 256;
+        const char* cl = getenv("SBR_CLUSTER");
+        h->cluster = cl ? atoi(cl) != 0 : 1;
+        const char* ln = getenv("SBR_CL_LINEAR");
+        h->cl_linear = ln ? atoi(ln) != 0 : 0;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -374,6 +379,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.t_lo = 0; a.t_hi = y.T; a.chunk = 0; a.state = h->A(ly.a_state);
     a.f32_mfma = (y.cfg.flags & SBR_FLAG_F32_MFMA) ? 1 : 0;
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;
+    a.cluster = h->cluster; a.cl_linear = h->cl_linear; a.fault = (int*)h->A(y.a_fault);
     return a;
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
@@ -590,7 +596,13 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
 extern "C" int sbr_read_cost(sbr_handle* h, float* cost_host) {
     CHECK_ARG(h && cost_host, "null argument");
     SBR_HIP(hipMemcpyAsync(cost_host, h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    int fault = 0;
+    if (h->cluster) SBR_HIP(hipMemcpyAsync(&fault, h->A(h->lay.a_fault), sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SBR_HIP(hipStreamSynchronize(h->stream));
+    if (fault) {
+        sbr_set_error("a cluster exchange wait of the wide-layer recurrent kernels timed out (results invalid); rerun with SBR_CLUSTER=0");
+        return SBR_EHIP;
+    }
     return SBR_OK;
 }
 

@@ -68,6 +68,7 @@ struct Layout {
     size_t a_ws2; size_t ws2_floats;      // split-K workspace of the side stream (output-layer + weight gradients)
     size_t a_csum;                        // [16][max(N,C)] column-sum partials
     size_t a_prof;                        // [2][nblk][16][4] uint64 in-kernel cycle counters (fwd, bwd)
+    size_t a_fault;                       // int: a cluster exchange wait timed out
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
 };
@@ -91,6 +92,7 @@ struct sbr_handle {
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)
     int wgrad_slices;    // K-slices of the weight-gradient kernel (total over the chunks)
+    int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -160,7 +162,15 @@ struct RecArgs {
     int xt_blocked;         // xt is tile-blocked (layer 0: written by the gather) or row-major (GEMM output)
     int f32_mfma;           // SBR_FLAG_F32_MFMA: exact-f32 v_mfma_f32_16x16x4_f32 kernels instead of bf16x6
     unsigned long long* prof; // SBR_FLAG_PROFILE_REC: [nblk][waves][4] cycle counters, else NULL
+    // cluster kernels (sbr_rec_cl.hip): several workgroups per row tile for layers too wide for one CU
+    int cluster;            // allowed (SBR_CLUSTER != 0)
+    int cl_linear;          // (experiment, SBR_CL_LINEAR=1) cluster members on consecutive workgroup ids = different XCDs
+    int* fault;             // set to 1 when a cluster exchange wait gave up (bounded spin)
 };
+#define SBR_CL_ROWS 8       // batch rows per cluster tile
+bool sbr_rec_cluster_ok(const RecArgs& a);
+hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
+hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple);
 // number of part[] blocks the backward launch for these args writes

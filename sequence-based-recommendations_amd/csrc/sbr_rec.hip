@@ -19,93 +19,7 @@
 //     (sparse_lstm.py:422-423); steps beyond the tile's longest row skip the MFMA work.
 #include "sbr_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define CELL_LSTM 0
-#define CELL_GRU 1
-#define CELL_VANILLA 2
-
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-// v_exp_f32 / v_rcp_f32 forms used by the MFMA kernels (1 ulp-class hardware transcendentals; the
-// libm forms above cost ~25 VALU instructions each and sat on the per-step critical path)
-__device__ __forceinline__ float sigm_fast(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float tanh_fast(float x) {   // 2*sigmoid(2x) - 1, abs error ~1 ulp(1.0)
-    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
-}
-template <bool FAST> __device__ __forceinline__ float sg(float x) { return FAST ? sigm_fast(x) : sigm(x); }
-template <bool FAST> __device__ __forceinline__ float th(float x) { return FAST ? tanh_fast(x) : tanhf(x); }
-__device__ __forceinline__ float clipf(float x, float c) { return c > 0.0f ? fminf(fmaxf(x, -c), c) : x; }
-template <int CELL> struct Gates { static constexpr int G = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1); };
-
-// ---------------------------------------------------------------------------------------
-// Scalar cell math shared by the MFMA kernels and the triage ("simple") kernels
-// ---------------------------------------------------------------------------------------
-// Forward: a[g] = (h_prev . W_hid)[g], x[g] = xt[g].  Updates h/c in place (masked rows copy),
-// writes the values saved for BPTT into sv[0..3].
-template <int CELL, bool FAST = false>
-__device__ __forceinline__ void cell_forward(const float* x, const float* a, bool m, float& h, float& c,
-                                             float pi, float pf, float po, float* sv) {
-    if (CELL == CELL_LSTM) {
-        float i = sg<FAST>(x[0] + a[0] + c * pi);             // sparse_lstm.py:397-402
-        float f = sg<FAST>(x[1] + a[1] + c * pf);
-        float g = th<FAST>(x[2] + a[2]);
-        float cn = f * c + i * g;                             // :407
-        float o = sg<FAST>(x[3] + a[3] + cn * po);            // :409-411
-        float hn = o * th<FAST>(cn);                          // :414
-        sv[0] = i; sv[1] = f; sv[2] = g; sv[3] = o;
-        c = m ? cn : c; h = m ? hn : h;                       // :422-423
-    } else if (CELL == CELL_GRU) {
-        float r = sg<FAST>(a[0] + x[0]);                      // :780-783
-        float u = sg<FAST>(a[1] + x[1]);
-        float cc = th<FAST>(x[2] + r * a[2]);                 // :786-792
-        float hn = (1.0f - u) * h + u * cc;                   // :795
-        sv[0] = r; sv[1] = u; sv[2] = cc; sv[3] = a[2];
-        h = m ? hn : h;                                       // :803
-    } else {
-        float hn = th<FAST>(x[0] + a[0]);                     // :1133-1143
-        h = m ? hn : h;                                       // :1150
-    }
-}
-
-// Backward of one step for one (row, unit).  In: dh, dc = grads wrt h_t, c_t; saved values.
-// Out: dxi[g], dhi[g] (grad wrt xt and wrt hid_input, both clipped), dh/dc updated to the part
-// that flows to step t-1 WITHOUT the dhi.W^T term (added by the caller); peephole partials.
-template <int CELL, bool FAST = false>
-__device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, float& dc, const float* sv, float hprev,
-                                              float cprev, float cnew, float hnew, float pi, float pf, float po,
-                                              float* dxi, float* dhi, float* dpeep) {
-    float dhn = m ? dh : 0.0f, dhp = m ? 0.0f : dh;
-    if (CELL == CELL_LSTM) {
-        float i = sv[0], f = sv[1], g = sv[2], o = sv[3];
-        float dcn = m ? dc : 0.0f, dcp = m ? 0.0f : dc;
-        float tc = th<FAST>(cnew);
-        float dzo = dhn * tc * o * (1.0f - o);
-        dcn += dhn * o * (1.0f - tc * tc) + dzo * po;
-        float dzi = dcn * g * i * (1.0f - i);
-        float dzf = dcn * cprev * f * (1.0f - f);
-        float dac = dcn * i * (1.0f - g * g);
-        dpeep[0] = dzi * cprev; dpeep[1] = dzf * cprev; dpeep[2] = dzo * cnew;
-        dxi[0] = dhi[0] = clipf(dzi, clip); dxi[1] = dhi[1] = clipf(dzf, clip);
-        dxi[2] = dhi[2] = clipf(dac, clip); dxi[3] = dhi[3] = clipf(dzo, clip);
-        dc = dcp + dcn * f + dzi * pi + dzf * pf;
-        dh = dhp;
-    } else if (CELL == CELL_GRU) {
-        float r = sv[0], u = sv[1], cc = sv[2], hic = sv[3];
-        float du = dhn * (cc - hprev);
-        float dq = clipf(dhn * u * (1.0f - cc * cc), clip);
-        float dzr = dq * hic * r * (1.0f - r);
-        float dzu = du * u * (1.0f - u);
-        dxi[0] = clipf(dzr, clip); dxi[1] = clipf(dzu, clip); dxi[2] = clipf(dq, clip);
-        dhi[0] = dxi[0]; dhi[1] = dxi[1]; dhi[2] = clipf(dq * r, clip);
-        dh = dhp + dhn * (1.0f - u);
-    } else {
-        float dq = clipf(dhn * (1.0f - hnew * hnew), clip);
-        dxi[0] = dhi[0] = clipf(dq, clip);
-        dh = dhp;
-    }
-}
+#include "sbr_cell.h"
 
 // ---------------------------------------------------------------------------------------
 // LDS tile layout shared by both MFMA kernels: 16 rows (batch rows of the tile) x K values, K split
@@ -518,18 +432,6 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
 // the 2*T-step dependent chain.  Planes 1,2 of W_hid stay in VGPRs, plane 3 in LDS; h_t (resp.
 // dhi_t) is split by the producing wave and published to LDS as three bf16 planes.
 // ---------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(float v, __bf16& b1, __bf16& b2, __bf16& b3) {
-    b1 = (__bf16)v; float r = v - (float)b1; b2 = (__bf16)r; r -= (float)b2; b3 = (__bf16)r;
-}
-__device__ __forceinline__ void split3x4(const f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); p1[e] = a; p2[e] = b; p3[e] = c; }
-}
-#define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
-
 template <int CELL, int HP>
 __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
     constexpr int G = Gates<CELL>::G, KB = HP / 32, NW = HP / 16, GHP = G * HP;
@@ -1028,6 +930,7 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         for (int t = 0; t < a.T; ++t) rec_fwd_step_simple<CELL><<<grid, blk, 0, s>>>(a, t);
         return hipGetLastError();
     }
+    if (sbr_rec_cluster_ok(a)) return launch_rec_forward_cl(s, a);
     const int nblk = a.Bp / 16;
 #define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
@@ -1089,6 +992,7 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         (void)hipFree(st);
         return e;
     }
+    if (sbr_rec_cluster_ok(a)) return launch_rec_backward_cl(s, a);
     if (!a.f32_mfma && (Hp == 32 || Hp == 64 || Hp == 128)) {
         const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * (size_t)a.rpt * (GHp * 2 + 32);
         const int db6 = (w3b + 2 * one6 <= 160 * 1024) ? 1 : 0;
@@ -1128,6 +1032,7 @@ static bool uses_x6_bwd(const RecArgs& a) {
 }
 int sbr_rec_bwd_blocks(const RecArgs& a, bool simple) {
     if (simple) return a.Bp / 16;                 // simple kernels accumulate into block 0, others zeroed
+    if (sbr_rec_cluster_ok(a)) return a.Bp / SBR_CL_ROWS;
     return uses_x6_bwd(a) ? a.Bp / a.rpt : a.Bp / 16;
 }
 

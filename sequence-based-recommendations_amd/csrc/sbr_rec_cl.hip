@@ -1,0 +1,474 @@
+// Cluster recurrent kernels for wide layers (Hp >= 256) on gfx950: W_hid no longer fits one CU
+// (LSTM-256: 1.5 MB of bf16 planes against 512 KB of VGPRs + 160 KB of LDS), so a CLUSTER of C = Hp/32
+// workgroups owns one tile of R batch rows for all T steps, each workgroup keeping the W_hid slice of its
+// 32 hidden units resident (planes 1,2 in VGPRs, plane 3 in LDS) exactly as the single-CU bf16x6 kernels do.
+//
+// What crosses workgroups per step is what the kernels write to HBM anyway:
+//   forward : h_t            -> the hs array      (every member needs all Hp values of h_{t-1})
+//   backward: dhi_t (= dxt_t, GRU: + the compact candidate slice) -> the dxt / dhc arrays
+// so the exchange costs no extra traffic.  It is synchronised by the data itself: the launcher fills the
+// array with a NaN sentinel (0xFFFFFFFF), producers publish with agent-scope write-through stores
+// (global_store ... sc1), consumers poll the exact 8-byte pieces they need with agent-scope loads until no
+// sentinel is left.  No flags, no fences, no grid barrier: one L2 round trip per step.
+//
+// Placement: workgroup ids are dispatched round-robin over the 8 XCDs, so the members of a cluster are the
+// ids {8*(grp*C + m) + x, m = 0..C-1}: same XCD, same L2, and a group of 8 clusters is contiguous in
+// dispatch order (no deadlock when the grid exceeds the resident capacity).  Correctness does not depend
+// on that placement (agent-scope accesses are coherent across XCDs), only the latency does.
+//
+// Inside a workgroup: 4 waves = 2 unit tiles x 2 K-halves; the K-half partial accumulators of the upper wave
+// are added through LDS by the lower wave, which also runs the gate math for its 16 units.
+// Cell math: sbr_cell.h (sparse_lstm.py:377-425, :764-805, :1120-1152); BPTT pinned by oracle/rnn_oracle.py.
+#include "sbr_cell.h"
+
+#define CL_SENT 0xFFFFFFFFu
+#define CL_SPIN_LIMIT 400000
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 cl_load(const float* p) {
+    return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cl_store4(float* p, const f32x4 v) {   // 16 B as two single-copy-atomic 8-B stores
+    union { float f[2]; u64 u; } a, b;
+    a.f[0] = v[0]; a.f[1] = v[1]; b.f[0] = v[2]; b.f[1] = v[3];
+    __hip_atomic_store((u64*)p, a.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((u64*)(p + 2), b.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool cl_has_sentinel(u64 v) {
+    return (unsigned)v == CL_SENT || (unsigned)(v >> 32) == CL_SENT;
+}
+
+// cluster / member of this workgroup; false = padding workgroup (no tile)
+__device__ __forceinline__ bool cl_ids(const RecArgs& a, int C, int ntiles, int& tile, int& m) {
+    const int bid = blockIdx.x;
+    if (a.cl_linear) { tile = bid / C; m = bid % C; }             // (experiment) members on consecutive ids = different XCDs
+    else { const int x = bid & 7, y = bid >> 3; m = y % C; tile = (y / C) * 8 + x; }
+    return tile < ntiles;
+}
+
+// Polls NP 8-byte pieces per thread; piece p covers floats [2*c2, 2*c2+1] of tile row r, where
+// p = tid + i*256, r = p / (W/2), c2 = p % (W/2).  src(r, col) returns the address.
+template <int NP, typename SRC>
+__device__ __forceinline__ void cl_fetch(u64 (&v)[NP], SRC src, int W, bool& dead, int* fault) {
+    const int tid = threadIdx.x;
+    int tries = 0;
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = tid + i * 256, r = p / (W >> 1), c2 = p % (W >> 1);
+            v[i] = cl_load(src(r, 2 * c2));
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) ok = ok && !cl_has_sentinel(v[i]);
+        if (ok || dead) break;
+        if (++tries > CL_SPIN_LIMIT) { dead = true; atomicOr(fault, 1); break; }   // bounded: never hang the GPU
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// splits the fetched pieces into three bf16 planes [plane][R][ROWB bytes]
+template <int NP>
+__device__ __forceinline__ void cl_publish(const u64 (&v)[NP], char* planes, int W, int ROWB, int PLANEB) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = tid + i * 256, r = p / (W >> 1), c2 = p % (W >> 1);
+        union { u64 u; float f[2]; } x; x.u = v[i];
+        __bf16 a1, a2, a3, b1, b2, b3;
+        split3(x.f[0], a1, a2, a3); split3(x.f[1], b1, b2, b3);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        char* base = planes + r * ROWB + c2 * 4;
+        *(bf16x2*)(base) = bf16x2{a1, b1};
+        *(bf16x2*)(base + PLANEB) = bf16x2{a2, b2};
+        *(bf16x2*)(base + 2 * PLANEB) = bf16x2{a3, b3};
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <int CELL, int HP, int R>
+__global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
+    constexpr int G = Gates<CELL>::G, C = HP / 32, KH = HP / 2, KBW = KH / 32, GHP = G * HP;
+    constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW;
+    constexpr int W3_BYTES = G * KBW * 4 * 1024;
+    constexpr int NP = R * HP / 2 / 256;
+    static_assert(R * HP / 2 % 256 == 0, "piece count");
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [G][KBW][4 waves][64 lanes][16 B]
+    char* hpl = smem_c + W3_BYTES;                       // [3 planes][R rows][HROW]
+    char* red = hpl + 3 * PLANEB;                        // [2 unit tiles][G][64 lanes][16 B]
+    int tile, mem;
+    if (!cl_ids(a, C, a.Bp / R, tile, mem)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = wave & 1, kh = wave >> 1;
+    const int j = lane & 15, q = lane >> 4;
+    const bool live = j < R;
+    const int rl = live ? j : j % R;                     // tile-local row; phantom MFMA columns duplicate a live row
+    const int row = tile * R + rl;
+    const int T = a.T, Bp = a.Bp;
+    const int ub = mem * 32 + ut * 16;                   // first unit of this wave's tile
+    const int u0 = ub + q * 4;                           // this lane's 4 units in the accumulator layout
+    const int k0 = kh * KH;
+    const bool fin = kh == 0;                            // this wave finishes (reduces, gate math, stores)
+
+    const int mylen = live ? a.len[row] : 0;
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    // A operand planes: lane (unit j of the tile, k-group q) holds W_hid[k0 + kb*32 + 8q + e][g*HP + ub + j]
+    bf16x8 W1[G][KBW], W2[G][KBW];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+            bf16x8 w3v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 b1, b2, b3;
+                split3(a.Whid[(size_t)(k0 + kb * 32 + 8 * q + e) * GHP + g * HP + ub + j], b1, b2, b3);
+                W1[g][kb][e] = b1; W2[g][kb][e] = b2; w3v[e] = b3;
+            }
+            *(bf16x8*)(w3 + ((g * KBW + kb) * 4 + wave) * 1024 + lane * 16) = w3v;
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    const f32x4 z = f32x4{0, 0, 0, 0};
+    f32x4 h = z, c = z, pi = z, pf = z, po = z;
+    if (fin) {
+        h = *(const f32x4*)&a.hinit[u0];
+        if (CELL == CELL_LSTM) {
+            c = *(const f32x4*)&a.cinit[u0];
+            pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0];
+            if (live) *(f32x4*)&a.cs[(size_t)row * HP + u0] = c;
+        }
+        if (live) cl_store4(&a.hs[(size_t)row * HP + u0], h);
+    }
+    f32x4 x[G], xn[G];
+    auto load_x = [&](int t, f32x4 (&d)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) d[g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHP + g * HP + u0];
+    };
+    if (fin && tmax > 0) load_x(0, x);
+    bool dead = false;
+    __syncthreads();                                     // W plane 3 visible
+
+    for (int t = 0; t < T; ++t) {
+        f32x4 sv[4];
+        if (t < tmax) {                                  // uniform over the whole cluster (same rows)
+            if (fin && t + 1 < tmax) load_x(t + 1, xn);
+            {   // h_{t-1} of all Hp units: slot t of hs, written by the C members of the cluster
+                u64 v[NP];
+                const float* base = a.hs + ((size_t)t * Bp + (size_t)tile * R) * HP;
+                cl_fetch<NP>(v, [&](int r, int col) { return base + (size_t)r * HP + col; }, HP, dead, a.fault);
+                cl_publish<NP>(v, hpl, HP, HROW, PLANEB);
+            }
+            __syncthreads();
+            const char* hb = hpl + rl * HROW + k0 * 2 + q * 16;
+            f32x4 acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = z;
+            bf16x8 hp[2][3], wp[2][G];
+            auto load_ops = [&](int kb, int s) {
+                hp[s][0] = *(const bf16x8*)(hb + kb * 64);
+                hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
+                hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+#pragma unroll
+                for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KBW + kb) * 4 + wave) * 1024 + lane * 16);
+            };
+            load_ops(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) {
+                const int s = kb & 1;
+                if (kb + 1 < KBW) load_ops(kb + 1, s ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_nop 15");                    // MFMA D -> VALU read hazard across the branch below
+            if (!fin) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) *(f32x4*)(red + ((ut * G + g) * 64 + lane) * 16) = acc[g];
+            }
+            __syncthreads();                             // partials visible; every wave is done reading hpl
+            if (fin) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] += *(const f32x4*)(red + ((ut * G + g) * 64 + lane) * 16);
+                const bool m = t < mylen;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xs[G], as[G], s[4];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) { xs[g] = x[g][e]; as[g] = acc[g][e]; }
+                    float hh = h[e], cc = c[e];
+                    cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
+                    h[e] = hh; c[e] = cc;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
+                }
+            }
+        }
+        if (fin && live) {
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u0;
+            cl_store4(&a.hs[o], h);                      // first: the other members are waiting for it
+            if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c;
+            if (CELL != CELL_VANILLA && t < tmax) {
+                const size_t og = sbr_blocked_index(t, row, u0, Bp, HP);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][og] = sv[k];
+            }
+        }
+        if (fin && t + 1 < tmax) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = xn[g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward (BPTT).  D[unit k][row] = sum_col W_hid[k][col] * dhi[row][col] over ALL G*Hp columns: each member
+// computes the rows of W_hid it owns (its 32 units) and needs the whole dhi_t row tile from the cluster.
+// ---------------------------------------------------------------------------------------
+template <int CELL, int HP, int R>
+__global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
+    constexpr int G = Gates<CELL>::G, C = HP / 32, GHP = G * HP, KH = GHP / 2, KBW = KH / 32;
+    constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW;
+    constexpr int W3_BYTES = KBW * 4 * 1024;
+    constexpr int NP = R * GHP / 2 / 256;
+    static_assert(R * GHP / 2 % 256 == 0, "piece count");
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [KBW][4 waves][64][16 B]
+    char* dpl = smem_c + W3_BYTES;                       // [3][R][DROW]
+    char* red = dpl + 3 * PLANEB;                        // [2 unit tiles][64 lanes][16 B]
+    int tile, mem;
+    if (!cl_ids(a, C, a.Bp / R, tile, mem)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = wave & 1, kh = wave >> 1;
+    const int j = lane & 15, q = lane >> 4;
+    const bool live = j < R;
+    const int rl = live ? j : j % R;
+    const int row = tile * R + rl;
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+    const int ub = mem * 32 + ut * 16;
+    const int u0 = ub + q * 4;
+    const int k0 = kh * KH;
+    const bool fin = kh == 0;
+
+    const int mylen = live ? a.len[row] : 0;
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    // A operand planes: lane (unit j of the tile, k-group q) holds W_hid[ub + j][k0 + kb*32 + 8q + e]
+    bf16x8 W1[KBW], W2[KBW];
+#pragma unroll
+    for (int kb = 0; kb < KBW; ++kb) {
+        const float* src = a.Whid + (size_t)(ub + j) * GHP + k0 + kb * 32 + 8 * q;
+        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        bf16x8 w3v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 b1, b2, b3;
+            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
+            W1[kb][e] = b1; W2[kb][e] = b2; w3v[e] = b3;
+        }
+        *(bf16x8*)(w3 + (kb * 4 + wave) * 1024 + lane * 16) = w3v;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    const f32x4 z4 = f32x4{0, 0, 0, 0};
+    f32x4 dh = z4, dc = z4, pi = z4, pf = z4, po = z4;
+    if (fin && live && a.dh_last) dh = *(const f32x4*)&a.dh_last[(size_t)row * HP + u0];
+    if (CELL == CELL_LSTM) { pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0]; }
+    f32x4 sdb[G], sdp[3];
+#pragma unroll
+    for (int g = 0; g < G; ++g) sdb[g] = z4;
+    sdp[0] = z4; sdp[1] = z4; sdp[2] = z4;
+
+    f32x4 sv[4], hprev = z4, cprev = z4, cnew = z4, hnew = z4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sv[k] = z4;
+    auto load_saved = [&](int t) {
+        const size_t o = ((size_t)t * Bp + row) * HP + u0;
+        hprev = *(const f32x4*)&a.hs[o];
+        if (CELL != CELL_VANILLA) {
+            const size_t og = sbr_blocked_index(t, row, u0, Bp, HP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = *(const f32x4*)&a.g[k][og];
+        }
+        if (CELL == CELL_LSTM) cprev = *(const f32x4*)&a.cs[o];
+    };
+    bool have = false, dead = false;
+    __syncthreads();                                     // W plane 3 visible
+
+    for (int t = T - 1; t >= 0; --t) {
+        if (fin && live && a.dh_ext) dh += *(const f32x4*)&a.dh_ext[((size_t)t * Bp + row) * HP + u0];
+        if (t >= tmax) {                                 // whole tile masked: zero rows, nobody waits for them
+            if (fin && live) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) *(f32x4*)&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u0] = z4;
+                if (CELL == CELL_GRU) *(f32x4*)&a.dhi[((size_t)t * Bp + row) * HP + u0] = z4;
+            }
+            continue;
+        }
+        if (fin) {
+            if (!have) {
+                load_saved(t);
+                const size_t o1 = ((size_t)(t + 1) * Bp + row) * HP + u0;
+                if (CELL == CELL_LSTM) cnew = *(const f32x4*)&a.cs[o1];
+                if (CELL == CELL_VANILLA) hnew = *(const f32x4*)&a.hs[o1];
+                have = true;
+            }
+            const bool m = t < mylen;
+            f32x4 vxi[G], vhi[G];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s[4] = {sv[0][e], sv[1][e], sv[2][e], sv[3][e]};
+                float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+                float dhh = dh[e], dcc = dc[e];
+                cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[e], pf[e], po[e], dxi, dhi, dp);
+                dh[e] = dhh; dc[e] = dcc;
+#pragma unroll
+                for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[g][e] += dxi[g]; }
+                sdp[0][e] += dp[0]; sdp[1][e] += dp[1]; sdp[2][e] += dp[2];
+            }
+            if (live) {
+                // dhi == dxi except the GRU candidate gate: dxt doubles as the exchange array
+#pragma unroll
+                for (int g = 0; g < G; ++g) cl_store4(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u0], vxi[g]);
+                if (CELL == CELL_GRU) cl_store4(&a.dhi[((size_t)t * Bp + row) * HP + u0], vhi[2]);
+            }
+            if (CELL == CELL_LSTM) cnew = cprev;
+            if (CELL == CELL_VANILLA) hnew = hprev;
+            if (t > 0) load_saved(t - 1);                // in flight across the exchange and the MFMA phase
+        }
+        {
+            u64 v[NP];
+            const float* bx = a.dxt + ((size_t)t * Bp + (size_t)tile * R) * GHP;
+            const float* bc = a.dhi + ((size_t)t * Bp + (size_t)tile * R) * HP;
+            cl_fetch<NP>(v, [&](int r, int col) {
+                return (CELL == CELL_GRU && col >= 2 * HP) ? bc + (size_t)r * HP + (col - 2 * HP) : bx + (size_t)r * GHP + col;
+            }, GHP, dead, a.fault);
+            cl_publish<NP>(v, dpl, GHP, DROW, PLANEB);
+        }
+        __syncthreads();
+        const char* db = dpl + rl * DROW + k0 * 2 + q * 16;
+        f32x4 acc[3] = {z4, z4, z4};
+        bf16x8 dp[2][3], wp[2];
+        auto load_ops = [&](int kb, int s) {
+            dp[s][0] = *(const bf16x8*)(db + kb * 64);
+            dp[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
+            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+            wp[s] = *(const bf16x8*)(w3 + (kb * 4 + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KBW) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = MFMA_BF16(wp[s], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][2], acc[1]);
+            acc[2] = MFMA_BF16(W2[kb], dp[s][1], acc[2]);
+            acc[0] = MFMA_BF16(W2[kb], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][1], acc[1]);
+            acc[2] = MFMA_BF16(W1[kb], dp[s][0], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15");
+        const f32x4 sum = acc[0] + acc[1] + acc[2];
+        if (!fin) *(f32x4*)(red + (ut * 64 + lane) * 16) = sum;
+        __syncthreads();                                 // partials visible; every wave is done reading dpl
+        if (fin && live) dh += sum + *(const f32x4*)(red + (ut * 64 + lane) * 16);
+    }
+
+    if (fin) {
+        float* part = a.part + (size_t)tile * (GHP + 5 * HP);
+        f32x4 v[G + 5];
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[g] = sdb[g];
+        v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2];
+        v[G + 3] = dc; v[G + 4] = dh;
+#pragma unroll
+        for (int k = 0; k < G + 5; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sum = v[k][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+                v[k][e] = sum;
+            }
+        if (j == 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) *(f32x4*)&part[g * HP + u0] = v[g];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) *(f32x4*)&part[GHP + k * HP + u0] = v[G + k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+bool sbr_rec_cluster_ok(const RecArgs& a) {
+    return a.cluster && !a.f32_mfma && a.Hp == 256 && a.Bp % SBR_CL_ROWS == 0;
+}
+
+static inline int cl_grid(const RecArgs& a, int C) {
+    const int ntiles = a.Bp / SBR_CL_ROWS;
+    return a.cl_linear ? ntiles * C : (ntiles + 7) / 8 * 8 * C;
+}
+
+#define CL_LAUNCH(KERNEL, C, LDS) do { \
+        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        KERNEL<<<cl_grid(a, C), 256, LDS, s>>>(a); } while (0)
+
+template <int CELL, int HP>
+static hipError_t fwd_cl(hipStream_t s, const RecArgs& a) {
+    constexpr int G = Gates<CELL>::G, R = SBR_CL_ROWS;
+    const size_t lds = (size_t)G * (HP / 64) * 4 * 1024 + 3 * (size_t)R * (HP * 2 + 32) + 2 * G * 1024;
+    hipError_t e = hipMemsetAsync(a.hs, 0xFF, (size_t)(a.T + 1) * a.Bp * HP * sizeof(float), s);   // sentinel: see the header
+    if (e != hipSuccess) return e;
+    CL_LAUNCH((rec_fwd_cl<CELL, HP, R>), HP / 32, lds);
+    return hipGetLastError();
+}
+template <int CELL, int HP>
+static hipError_t bwd_cl(hipStream_t s, const RecArgs& a) {
+    constexpr int G = Gates<CELL>::G, R = SBR_CL_ROWS, GHP = G * HP;
+    const size_t lds = (size_t)(GHP / 64) * 4 * 1024 + 3 * (size_t)R * (GHP * 2 + 32) + 2 * 1024;
+    hipError_t e = hipMemsetAsync(a.dxt, 0xFF, (size_t)a.T * a.Bp * GHP * sizeof(float), s);
+    if (e == hipSuccess && CELL == CELL_GRU) e = hipMemsetAsync(a.dhi, 0xFF, (size_t)a.T * a.Bp * HP * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    CL_LAUNCH((rec_bwd_cl<CELL, HP, R>), HP / 32, lds);
+    return hipGetLastError();
+}
+
+hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a) {
+    switch (a.cell) {
+        case SBR_CELL_LSTM: return fwd_cl<CELL_LSTM, 256>(s, a);
+        case SBR_CELL_GRU: return fwd_cl<CELL_GRU, 256>(s, a);
+        default: return fwd_cl<CELL_VANILLA, 256>(s, a);
+    }
+}
+hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a) {
+    switch (a.cell) {
+        case SBR_CELL_LSTM: return bwd_cl<CELL_LSTM, 256>(s, a);
+        case SBR_CELL_GRU: return bwd_cl<CELL_GRU, 256>(s, a);
+        default: return bwd_cl<CELL_VANILLA, 256>(s, a);
+    }
+}

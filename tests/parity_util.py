@@ -63,10 +63,10 @@ def oracle_batch(batch):
 
 
 def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
-                 reg=0.0, steps=2, popscale=1.0):
+                 reg=0.0, steps=2, popscale=1.0, scale=None):
     """Returns dict of relative errors (engine float32 vs oracle float64)."""
     params, cfg, batch = build_case(cell, layers, loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, full=full,
-                                    popscale=popscale)
+                                    popscale=popscale, scale=scale)
     cfg["regularization"] = reg
     eng = engine_for(cfg, N, B, T, S=S, F=F, n_opt=n_opt, updater=updater, flags=flags, reg=reg)
     out = {}

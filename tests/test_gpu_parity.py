@@ -37,6 +37,31 @@ def test_streamed_whid_kernels(cell):                      # Hp = 192: W_hid fra
     check(PU.compare_step(cell, [160], "CCE", N=61, B=21, T=8), tol_h=2e-4)
 
 
+@pytest.mark.parametrize("linear", ["0", "1"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_cluster_kernels_wide_layers(cell, linear, monkeypatch):
+    # Hp = 256 (configs C3/C4): 8 workgroups per 8-row tile exchange h_t / dhi_t through hs / dxt with
+    # sentinel polling.  linear=1 deliberately puts the members of a cluster on different XCDs (different L2s):
+    # the agent-scope exchange must stay coherent there too.
+    monkeypatch.setenv("SBR_CL_LINEAR", linear)
+    check(PU.compare_step(cell, [256], "CCE", N=61, B=37, T=9), tol_h=2e-4)
+
+
+def test_cluster_kernels_padded_width_and_long_ragged_rows():
+    # H = 200 pads to 256; T = 40 with ragged lengths (rows of a tile finish at different steps, tiles of
+    # padding rows finish at once); 2-layer stack: the lower layer receives dh_ext every step.
+    # scale 0.05: with N(0, 0.3) recurrent weights a 256-wide layer has spectral radius ~5 and 40 steps amplify
+    # float32 rounding beyond any fixed tolerance (in every kernel variant alike)
+    check(PU.compare_step("LSTM", [200], "CCE", N=41, B=19, T=40, seed=3, scale=0.05), tol_h=2e-4)
+    check(PU.compare_step("GRU", [256, 256], "CCE", N=41, B=9, T=12, seed=4, scale=0.05), tol_h=2e-4)
+
+
+def test_cluster_and_streamed_kernels_agree(monkeypatch):
+    # same wide layer through the single-workgroup streamed f32 kernels (SBR_CLUSTER=0)
+    monkeypatch.setenv("SBR_CLUSTER", "0")
+    check(PU.compare_step("LSTM", [256], "CCE", N=61, B=37, T=9), tol_h=2e-4)
+
+
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_triage_kernels_agree(cell):                       # SBR_FLAG_SIMPLE_REC | SBR_FLAG_SIMPLE_GEMM
     check(PU.compare_step(cell, [12], "CCE", N=23, B=5, T=7, flags=3))
