@@ -107,6 +107,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
     lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
     lay.a_fault = take(64);
+    lay.a_clx = take((size_t)Bp * 2 + 64);
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
     lay.ws2_floats = 4 * lay.ws_floats;          // up to 256 weight-gradient slabs
@@ -227,6 +228,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->cluster = cl ? atoi(cl) != 0 : 1;
         const char* ln = getenv("SBR_CL_LINEAR");
         h->cl_linear = ln ? atoi(ln) != 0 : 0;
+        h->cl_epoch = 0;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -380,6 +382,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.f32_mfma = (y.cfg.flags & SBR_FLAG_F32_MFMA) ? 1 : 0;
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;
     a.cluster = h->cluster; a.cl_linear = h->cl_linear; a.fault = (int*)h->A(y.a_fault);
+    a.clx = (int*)h->A(y.a_clx); a.epoch = (++h->cl_epoch) & 0x07FFFFFF;
     return a;
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }

@@ -69,6 +69,7 @@ struct Layout {
     size_t a_csum;                        // [16][max(N,C)] column-sum partials
     size_t a_prof;                        // [2][nblk][16][4] uint64 in-kernel cycle counters (fwd, bwd)
     size_t a_fault;                       // int: a cluster exchange wait timed out
+    size_t a_clx;                         // cluster handshake slots (ints)
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
 };
@@ -93,6 +94,7 @@ struct sbr_handle {
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)
     int wgrad_slices;    // K-slices of the weight-gradient kernel (total over the chunks)
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
+    int cl_epoch;
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -166,6 +168,8 @@ struct RecArgs {
     int cluster;            // allowed (SBR_CLUSTER != 0)
     int cl_linear;          // (experiment, SBR_CL_LINEAR=1) cluster members on consecutive workgroup ids = different XCDs
     int* fault;             // set to 1 when a cluster exchange wait gave up (bounded spin)
+    int* clx;               // [tiles][C] start-of-launch handshake: (epoch << 4) | XCC id of every member
+    int epoch;              // unique per launch (clx is never cleared)
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
 bool sbr_rec_cluster_ok(const RecArgs& a);

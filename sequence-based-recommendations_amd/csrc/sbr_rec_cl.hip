@@ -29,7 +29,11 @@ typedef unsigned long long u64;
 __device__ __forceinline__ u64 cl_load(const float* p) {
     return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void cl_store4(float* p, const f32x4 v) {   // 16 B as two single-copy-atomic 8-B stores
+// fast = every member of the cluster runs on the same XCC: one L2 is the coherence point, an ordinary store
+// (L1 is write-through) is visible to the members' L1-bypassing loads as soon as it reaches that L2.
+// Otherwise the store must write through to memory (sc1): measured ~3000-6000 cycles more per step.
+__device__ __forceinline__ void cl_store4(float* p, const f32x4 v, bool fast) {
+    if (fast) { *(f32x4*)p = v; return; }
     union { float f[2]; u64 u; } a, b;
     a.f[0] = v[0]; a.f[1] = v[1]; b.f[0] = v[2]; b.f[1] = v[3];
     __hip_atomic_store((u64*)p, a.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -45,6 +49,33 @@ __device__ __forceinline__ bool cl_ids(const RecArgs& a, int C, int ntiles, int&
     if (a.cl_linear) { tile = bid / C; m = bid % C; }             // (experiment) members on consecutive ids = different XCDs
     else { const int x = bid & 7, y = bid >> 3; m = y % C; tile = (y / C) * 8 + x; }
     return tile < ntiles;
+}
+
+// Start-of-launch handshake: every member publishes the XCC it runs on (HW_REG_XCC_ID) and reads the others'.
+// Returns true when the whole cluster shares one XCC (the placement in the header makes that the normal case;
+// nothing breaks when it does not hold -- the kernels then publish with write-through stores).
+__device__ __forceinline__ bool cl_same_xcc(const RecArgs& a, int C, int tile, int mem, int* lds_flag, bool& dead) {
+    const int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));           // hwreg(HW_REG_XCC_ID, 0, 4)
+    int* slots = a.clx + (size_t)tile * C;
+    if (threadIdx.x == 0) {
+        *lds_flag = 1;
+        __hip_atomic_store(&slots[mem], (a.epoch << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        int v = 0, tries = 0;
+        while (true) {
+            v = __hip_atomic_load(&slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 4) == a.epoch) break;
+            if (++tries > CL_SPIN_LIMIT) { dead = true; atomicOr(a.fault, 1); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if ((v & 15) != xcc || (v >> 4) != a.epoch) *lds_flag = 0;
+    }
+    __syncthreads();
+    const bool same = *lds_flag != 0;
+    __syncthreads();
+    return same;
 }
 
 // Polls NP 8-byte pieces per thread; piece p covers floats [2*c2, 2*c2+1] of tile row r, where
@@ -113,6 +144,8 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
     const int u0 = ub + q * 4;                           // this lane's 4 units in the accumulator layout
     const int k0 = kh * KH;
     const bool fin = kh == 0;                            // this wave finishes (reduces, gate math, stores)
+    bool dead = false;
+    const bool fast = cl_same_xcc(a, C, tile, mem, (int*)red, dead);
 
     const int mylen = live ? a.len[row] : 0;
     int tmax = mylen;
@@ -145,7 +178,7 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
             pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0];
             if (live) *(f32x4*)&a.cs[(size_t)row * HP + u0] = c;
         }
-        if (live) cl_store4(&a.hs[(size_t)row * HP + u0], h);
+        if (live) cl_store4(&a.hs[(size_t)row * HP + u0], h, fast);
     }
     f32x4 x[G], xn[G];
     auto load_x = [&](int t, f32x4 (&d)[G]) {
@@ -153,20 +186,28 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
         for (int g = 0; g < G; ++g) d[g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHP + g * HP + u0];
     };
     if (fin && tmax > 0) load_x(0, x);
-    bool dead = false;
     __syncthreads();                                     // W plane 3 visible
+    // SBR_FLAG_PROFILE_REC: cycles per phase (exchange wait | publish + barrier | LDS reads + MFMA | reduce
+    // barrier | gate math + stores), tools/rec_prof.py
+    u64 pc[5] = {0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0;
+    const bool prof = a.prof != nullptr;
+    if (prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+#define CL_TICK(i) do { if (prof) { const u64 n_ = clock64(); pc[i] += n_ - p_t; p_t = n_; } } while (0)
 
     for (int t = 0; t < T; ++t) {
         f32x4 sv[4];
         if (t < tmax) {                                  // uniform over the whole cluster (same rows)
+            if (prof && t == 0) p_t = clock64();
             if (fin && t + 1 < tmax) load_x(t + 1, xn);
             {   // h_{t-1} of all Hp units: slot t of hs, written by the C members of the cluster
                 u64 v[NP];
                 const float* base = a.hs + ((size_t)t * Bp + (size_t)tile * R) * HP;
                 cl_fetch<NP>(v, [&](int r, int col) { return base + (size_t)r * HP + col; }, HP, dead, a.fault);
+                CL_TICK(0);
                 cl_publish<NP>(v, hpl, HP, HROW, PLANEB);
             }
             __syncthreads();
+            CL_TICK(1);
             const char* hb = hpl + rl * HROW + k0 * 2 + q * 16;
             f32x4 acc[G];
 #pragma unroll
@@ -204,7 +245,9 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) *(f32x4*)(red + ((ut * G + g) * 64 + lane) * 16) = acc[g];
             }
+            CL_TICK(2);
             __syncthreads();                             // partials visible; every wave is done reading hpl
+            CL_TICK(3);
             if (fin) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] += *(const f32x4*)(red + ((ut * G + g) * 64 + lane) * 16);
@@ -224,7 +267,7 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
         }
         if (fin && live) {
             const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u0;
-            cl_store4(&a.hs[o], h);                      // first: the other members are waiting for it
+            cl_store4(&a.hs[o], h, fast);                // first: the other members are waiting for it
             if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c;
             if (CELL != CELL_VANILLA && t < tmax) {
                 const size_t og = sbr_blocked_index(t, row, u0, Bp, HP);
@@ -236,6 +279,13 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = xn[g];
         }
+        if (t < tmax) CL_TICK(4);
+    }
+    if (prof && lane == 0 && tile < 8) {
+        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = (u64)tmax;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[3 + i] = pc[i];
     }
 }
 
@@ -268,6 +318,8 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
     const int u0 = ub + q * 4;
     const int k0 = kh * KH;
     const bool fin = kh == 0;
+    bool dead = false;
+    const bool fast = cl_same_xcc(a, C, tile, mem, (int*)red, dead);
 
     const int mylen = live ? a.len[row] : 0;
     int tmax = mylen;
@@ -313,9 +365,14 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
         }
         if (CELL == CELL_LSTM) cprev = *(const f32x4*)&a.cs[o];
     };
-    bool have = false, dead = false;
+    bool have = false;
     __syncthreads();                                     // W plane 3 visible
+    // cycles per phase: gate math + publish stores | exchange wait | split + barrier | LDS reads + MFMA | reduce barrier
+    u64 pc[5] = {0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0;
+    const bool prof = a.prof != nullptr;
+    if (prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
 
+    if (prof) p_t = clock64();
     for (int t = T - 1; t >= 0; --t) {
         if (fin && live && a.dh_ext) dh += *(const f32x4*)&a.dh_ext[((size_t)t * Bp + row) * HP + u0];
         if (t >= tmax) {                                 // whole tile masked: zero rows, nobody waits for them
@@ -350,13 +407,14 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
             if (live) {
                 // dhi == dxi except the GRU candidate gate: dxt doubles as the exchange array
 #pragma unroll
-                for (int g = 0; g < G; ++g) cl_store4(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u0], vxi[g]);
-                if (CELL == CELL_GRU) cl_store4(&a.dhi[((size_t)t * Bp + row) * HP + u0], vhi[2]);
+                for (int g = 0; g < G; ++g) cl_store4(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u0], vxi[g], fast);
+                if (CELL == CELL_GRU) cl_store4(&a.dhi[((size_t)t * Bp + row) * HP + u0], vhi[2], fast);
             }
             if (CELL == CELL_LSTM) cnew = cprev;
             if (CELL == CELL_VANILLA) hnew = hprev;
             if (t > 0) load_saved(t - 1);                // in flight across the exchange and the MFMA phase
         }
+        CL_TICK(0);
         {
             u64 v[NP];
             const float* bx = a.dxt + ((size_t)t * Bp + (size_t)tile * R) * GHP;
@@ -364,9 +422,11 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
             cl_fetch<NP>(v, [&](int r, int col) {
                 return (CELL == CELL_GRU && col >= 2 * HP) ? bc + (size_t)r * HP + (col - 2 * HP) : bx + (size_t)r * GHP + col;
             }, GHP, dead, a.fault);
+            CL_TICK(1);
             cl_publish<NP>(v, dpl, GHP, DROW, PLANEB);
         }
         __syncthreads();
+        CL_TICK(2);
         const char* db = dpl + rl * DROW + k0 * 2 + q * 16;
         f32x4 acc[3] = {z4, z4, z4};
         bf16x8 dp[2][3], wp[2];
@@ -393,8 +453,16 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
         asm volatile("s_nop 15");
         const f32x4 sum = acc[0] + acc[1] + acc[2];
         if (!fin) *(f32x4*)(red + (ut * 64 + lane) * 16) = sum;
+        CL_TICK(3);
         __syncthreads();                                 // partials visible; every wave is done reading dpl
         if (fin && live) dh += sum + *(const f32x4*)(red + (ut * 64 + lane) * 16);
+        CL_TICK(4);
+    }
+    if (prof && lane == 0 && tile < 8) {
+        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = (u64)tmax;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[3 + i] = pc[i];
     }
 
     if (fin) {

@@ -1,0 +1,28 @@
+"""In-kernel cycle counters of the CLUSTER recurrent kernels (SBR_FLAG_PROFILE_REC, sbr_rec_cl.hip):
+per-step cycles by phase for the first 8 row tiles.   python tools/cl_prof.py [c4]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from oracle import rnn_oracle as O
+from sbr_amd.engine import RNNEngine
+cell, layers, n_items, loss, ns = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c4"]
+B, T = 256, 200
+C = 8
+eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=B, loss=loss, n_samples=ns, flags=8)
+eng.set_all_param_values(O.init_params(cell, layers, n_items, np.random.default_rng(42), dtype=np.float32))
+hb = bench.synth_batches(1, B, T, n_items, ns, "full", 1235)[0]
+eng.set_batch(hb["X"], None, hb["target"], hb["samples"] if loss != "CCE" else None, hb["pop"], lengths=hb["lengths"])
+for _ in range(3):
+    eng.train_step(sync=True)
+raw = eng.debug_buffer("prof").view(np.uint64).reshape(2, -1)
+names = (("rec_fwd_cl", ("exchange wait", "publish+barrier", "LDS+MFMA", "reduce barrier", "gate math+stores")),
+         ("rec_bwd_cl", ("gate math+stores", "exchange wait", "split+barrier", "LDS+MFMA", "reduce barrier")))
+for k, (name, ph) in enumerate(names):
+    p = raw[k][:8 * C * 4 * 8].reshape(8, C, 4, 8).astype(np.float64)      # [tile][member][wave][8]
+    tot, real = p[..., 0], p[..., 1]
+    print("%s: kernel %.1f us (realtime), shader clock %.0f MHz, %.0f cycles/step" % (
+        name, real.mean() / 100.0, (tot / real * 100.0).mean(), tot.mean() / T))
+    for w, wn in enumerate(("wave0 (tile0,fin)", "wave1 (tile1,fin)", "wave2 (tile0,K-hi)", "wave3 (tile1,K-hi)")):
+        print("   %-20s " % wn + "  ".join("%s %5.0f" % (ph[i], p[:, :, w, 3 + i].mean() / T) for i in range(5)))
+eng.close()
