@@ -78,55 +78,88 @@ __device__ __forceinline__ bool cl_same_xcc(const RecArgs& a, int C, int tile, i
     return same;
 }
 
-// Polls NP 8-byte pieces per thread; piece p covers floats [2*c2, 2*c2+1] of tile row r, where
-// p = tid + i*256, r = p / (W/2), c2 = p % (W/2).  src(r, col) returns the address.
+// Polls NP 16-byte pieces per thread; piece p covers floats [4*c4, 4*c4+3] of tile row r, where
+// p = tid + i*256, r = p / (W/4), c4 = p % (W/4).  src(r, col) returns the address.
+// fast (whole cluster on one XCC): 16-byte sc1 loads (bypass the CU's L1, served by the shared L2).  hipcc lowers
+// agent-scope atomic loads to sc1 only up to 8 bytes (0.54-0.70x the 16-byte rate), hence the inline asm: these
+// loads are invisible to the compiler's waitcnt insertion, so the wait is explicit and the values are re-defined
+// after it to pin their uses behind it.  (Tried and rejected: sc0 loads hit the stale L1 line; an L1 invalidate
+// per poll, buffer_inv sc1, costs ~15000 cycles.)
 template <int NP, typename SRC>
-__device__ __forceinline__ void cl_fetch(u64 (&v)[NP], SRC src, int W, bool& dead, int* fault) {
+__device__ __forceinline__ int cl_fetch(f32x4 (&v)[NP], SRC src, int W, bool fast, bool& dead, int* fault) {
     const int tid = threadIdx.x;
     int tries = 0;
     while (true) {
+        if (fast) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int p = tid + i * 256, r = p / (W >> 1), c2 = p % (W >> 1);
-            v[i] = cl_load(src(r, 2 * c2));
+            for (int i = 0; i < NP; ++i) {
+                const int p = tid + i * 256, r = p / (W >> 2), c4 = p % (W >> 2);
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(src(r, 4 * c4)) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(v[i]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int p = tid + i * 256, r = p / (W >> 2), c4 = p % (W >> 2);
+                const float* q = src(r, 4 * c4);
+                union { u64 u[2]; f32x4 f; } x;
+                x.u[0] = cl_load(q); x.u[1] = cl_load(q + 2);
+                v[i] = x.f;
+            }
         }
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) ok = ok && !cl_has_sentinel(v[i]);
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ok = ok && __float_as_uint(v[i][e]) != CL_SENT;
         if (ok || dead) break;
         if (++tries > CL_SPIN_LIMIT) { dead = true; atomicOr(fault, 1); break; }   // bounded: never hang the GPU
         __builtin_amdgcn_s_sleep(1);
     }
+    return tries;
 }
 
 // splits the fetched pieces into three bf16 planes [plane][R][ROWB bytes]
 template <int NP>
-__device__ __forceinline__ void cl_publish(const u64 (&v)[NP], char* planes, int W, int ROWB, int PLANEB) {
+__device__ __forceinline__ void cl_publish(const f32x4 (&v)[NP], char* planes, int W, int ROWB, int PLANEB) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int p = tid + i * 256, r = p / (W >> 1), c2 = p % (W >> 1);
-        union { u64 u; float f[2]; } x; x.u = v[i];
-        __bf16 a1, a2, a3, b1, b2, b3;
-        split3(x.f[0], a1, a2, a3); split3(x.f[1], b1, b2, b3);
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        char* base = planes + r * ROWB + c2 * 4;
-        *(bf16x2*)(base) = bf16x2{a1, b1};
-        *(bf16x2*)(base + PLANEB) = bf16x2{a2, b2};
-        *(bf16x2*)(base + 2 * PLANEB) = bf16x2{a3, b3};
+        const int p = tid + i * 256, r = p / (W >> 2), c4 = p % (W >> 2);
+        bf16x4 p1, p2, p3;
+        split3x4(v[i], p1, p2, p3);
+        char* base = planes + r * ROWB + c4 * 8;
+        *(bf16x4*)(base) = p1;
+        *(bf16x4*)(base + PLANEB) = p2;
+        *(bf16x4*)(base + 2 * PLANEB) = p3;
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 8 bytes to an exchange array (see cl_store4 for `fast`)
+__device__ __forceinline__ void cl_store2(float* p, const f32x2 v, bool fast) {
+    if (fast) { *(f32x2*)p = v; return; }
+    union { float f[2]; u64 u; } a; a.f[0] = v[0]; a.f[1] = v[1];
+    __hip_atomic_store((u64*)p, a.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// With R = 8 live rows the MFMA columns 8..15 hold a duplicate of rows 0..7 (the B operand repeats them), so the
+// accumulators of lane (j, q) and lane (j + 8, q) are identical: the lower lane finishes units 0,1 of its four,
+// the upper lane units 2,3 -- every lane does useful gate math and the per-step VALU chain is halved.
 template <int CELL, int HP, int R>
 __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
+    static_assert(R == 8, "the element split over duplicate MFMA columns assumes 8 live rows");
     constexpr int G = Gates<CELL>::G, C = HP / 32, KH = HP / 2, KBW = KH / 32, GHP = G * HP;
     constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW;
     constexpr int W3_BYTES = G * KBW * 4 * 1024;
-    constexpr int NP = R * HP / 2 / 256;
-    static_assert(R * HP / 2 % 256 == 0, "piece count");
+    constexpr int NP = R * HP / 4 / 256;
+    static_assert(R * HP / 4 % 256 == 0, "piece count");
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* w3 = smem_c;                                   // [G][KBW][4 waves][64 lanes][16 B]
     char* hpl = smem_c + W3_BYTES;                       // [3 planes][R rows][HROW]
@@ -136,21 +169,20 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ut = wave & 1, kh = wave >> 1;
     const int j = lane & 15, q = lane >> 4;
-    const bool live = j < R;
-    const int rl = live ? j : j % R;                     // tile-local row; phantom MFMA columns duplicate a live row
+    const int rl = j & 7, eh = j >> 3;                   // tile-local row; which half of the lane's 4 units it finishes
     const int row = tile * R + rl;
     const int T = a.T, Bp = a.Bp;
     const int ub = mem * 32 + ut * 16;                   // first unit of this wave's tile
-    const int u0 = ub + q * 4;                           // this lane's 4 units in the accumulator layout
+    const int u2 = ub + q * 4 + eh * 2;                  // the 2 units this lane finishes
     const int k0 = kh * KH;
     const bool fin = kh == 0;                            // this wave finishes (reduces, gate math, stores)
     bool dead = false;
     const bool fast = cl_same_xcc(a, C, tile, mem, (int*)red, dead);
 
-    const int mylen = live ? a.len[row] : 0;
+    const int mylen = a.len[row];
     int tmax = mylen;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+    for (int o = 1; o < 8; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
 
     // A operand planes: lane (unit j of the tile, k-group q) holds W_hid[k0 + kb*32 + 8q + e][g*HP + ub + j]
     bf16x8 W1[G][KBW], W2[G][KBW];
@@ -169,123 +201,147 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
         }
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
+    const f32x2 z2 = f32x2{0, 0};
     const f32x4 z = f32x4{0, 0, 0, 0};
-    f32x4 h = z, c = z, pi = z, pf = z, po = z;
+    f32x2 h = z2, c = z2, pi = z2, pf = z2, po = z2;
     if (fin) {
-        h = *(const f32x4*)&a.hinit[u0];
+        h = *(const f32x2*)&a.hinit[u2];
         if (CELL == CELL_LSTM) {
-            c = *(const f32x4*)&a.cinit[u0];
-            pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0];
-            if (live) *(f32x4*)&a.cs[(size_t)row * HP + u0] = c;
+            c = *(const f32x2*)&a.cinit[u2];
+            pi = *(const f32x2*)&a.peep[u2]; pf = *(const f32x2*)&a.peep[HP + u2]; po = *(const f32x2*)&a.peep[2 * HP + u2];
+            *(f32x2*)&a.cs[(size_t)row * HP + u2] = c;
         }
-        if (live) cl_store4(&a.hs[(size_t)row * HP + u0], h, fast);
+        cl_store2(&a.hs[(size_t)row * HP + u2], h, fast);
     }
-    f32x4 x[G], xn[G];
-    auto load_x = [&](int t, f32x4 (&d)[G]) {
+    f32x2 x[G], xn[G];
+    auto load_x = [&](int t, f32x2 (&d)[G]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) d[g] = *(const f32x4*)&a.xt[((size_t)t * Bp + row) * GHP + g * HP + u0];
+        for (int g = 0; g < G; ++g) d[g] = *(const f32x2*)&a.xt[((size_t)t * Bp + row) * GHP + g * HP + u2];
     };
     if (fin && tmax > 0) load_x(0, x);
     __syncthreads();                                     // W plane 3 visible
     // SBR_FLAG_PROFILE_REC: cycles per phase (exchange wait | publish + barrier | LDS reads + MFMA | reduce
-    // barrier | gate math + stores), tools/rec_prof.py
-    u64 pc[5] = {0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0;
+    // barrier | gate math + stores), tools/cl_prof.py
+    u64 pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0, p_tries = 0;
     const bool prof = a.prof != nullptr;
     if (prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
 #define CL_TICK(i) do { if (prof) { const u64 n_ = clock64(); pc[i] += n_ - p_t; p_t = n_; } } while (0)
 
-    for (int t = 0; t < T; ++t) {
-        f32x4 sv[4];
-        if (t < tmax) {                                  // uniform over the whole cluster (same rows)
-            if (prof && t == 0) p_t = clock64();
-            if (fin && t + 1 < tmax) load_x(t + 1, xn);
-            {   // h_{t-1} of all Hp units: slot t of hs, written by the C members of the cluster
-                u64 v[NP];
-                const float* base = a.hs + ((size_t)t * Bp + (size_t)tile * R) * HP;
-                cl_fetch<NP>(v, [&](int r, int col) { return base + (size_t)r * HP + col; }, HP, dead, a.fault);
-                CL_TICK(0);
-                cl_publish<NP>(v, hpl, HP, HROW, PLANEB);
-            }
+    // the per-step GEMM of this wave: acc[g] = sum over its K half of W_hid^T . h_{t-1}  (B operand from the LDS planes)
+    auto mfma_phase = [&](f32x4 (&acc)[G]) {
+        const char* hb = hpl + rl * HROW + k0 * 2 + q * 16;
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = z;
+        bf16x8 hp[2][3], wp[2][G];
+        auto load_ops = [&](int kb, int s) {
+            hp[s][0] = *(const bf16x8*)(hb + kb * 64);
+            hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
+            hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+#pragma unroll
+            for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KBW + kb) * 4 + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KBW) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15");                        // MFMA D -> VALU read hazard (the reader may sit behind a branch)
+    };
+    // h_{t-1} of all Hp units (slot t of hs, written by the C members of the cluster) -> bf16 planes in LDS
+    auto exchange = [&](int t) {
+        f32x4 v[NP];
+        const float* base = a.hs + ((size_t)t * Bp + (size_t)tile * R) * HP;
+        p_tries += cl_fetch<NP>(v, [&](int r, int col) { return base + (size_t)r * HP + col; }, HP, fast, dead, a.fault);
+        CL_TICK(0);
+        cl_publish<NP>(v, hpl, HP, HROW, PLANEB);
+    };
+    if (prof) p_t = clock64();
+
+    // Two roles, two loops with the same barrier sequence (2 per live step).  Separate loops keep the finishing
+    // waves' prefetched xt registers free of phi copies (a copy at a block end makes hipcc wait for the loads).
+    if (fin) {
+        for (int t = 0; t < tmax; ++t) {                 // tmax is uniform over the whole cluster (same rows)
+            load_x(t + 1 < tmax ? t + 1 : t, xn);        // unconditional (clamped): see rec_bwd_cl
+            exchange(t);
             __syncthreads();
             CL_TICK(1);
-            const char* hb = hpl + rl * HROW + k0 * 2 + q * 16;
             f32x4 acc[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = z;
-            bf16x8 hp[2][3], wp[2][G];
-            auto load_ops = [&](int kb, int s) {
-                hp[s][0] = *(const bf16x8*)(hb + kb * 64);
-                hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
-                hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
-#pragma unroll
-                for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KBW + kb) * 4 + wave) * 1024 + lane * 16);
-            };
-            load_ops(0, 0);
-#pragma unroll
-            for (int kb = 0; kb < KBW; ++kb) {
-                const int s = kb & 1;
-                if (kb + 1 < KBW) load_ops(kb + 1, s ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_nop 15");                    // MFMA D -> VALU read hazard across the branch below
-            if (!fin) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) *(f32x4*)(red + ((ut * G + g) * 64 + lane) * 16) = acc[g];
-            }
+            mfma_phase(acc);
             CL_TICK(2);
             __syncthreads();                             // partials visible; every wave is done reading hpl
             CL_TICK(3);
-            if (fin) {
+            f32x2 as2[G], sv[4];
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] += *(const f32x4*)(red + ((ut * G + g) * 64 + lane) * 16);
-                const bool m = t < mylen;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float xs[G], as[G], s[4];
-#pragma unroll
-                    for (int g = 0; g < G; ++g) { xs[g] = x[g][e]; as[g] = acc[g][e]; }
-                    float hh = h[e], cc = c[e];
-                    cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
-                    h[e] = hh; c[e] = cc;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
-                }
+            for (int g = 0; g < G; ++g) {
+                const f32x2 part = *(const f32x2*)(red + ((ut * G + g) * 64 + lane) * 16 + eh * 8);
+                as2[g] = (eh ? f32x2{acc[g][2], acc[g][3]} : f32x2{acc[g][0], acc[g][1]}) + part;
             }
-        }
-        if (fin && live) {
-            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u0;
-            cl_store4(&a.hs[o], h, fast);                // first: the other members are waiting for it
-            if (CELL == CELL_LSTM) *(f32x4*)&a.cs[o] = c;
-            if (CELL != CELL_VANILLA && t < tmax) {
-                const size_t og = sbr_blocked_index(t, row, u0, Bp, HP);
+            const bool m = t < mylen;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) *(f32x4*)&a.g[k][og] = sv[k];
+            for (int e = 0; e < 2; ++e) {
+                float xs[G], as[G], s[4];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { xs[g] = x[g][e]; as[g] = as2[g][e]; }
+                float hh = h[e], cc = c[e];
+                cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
+                h[e] = hh; c[e] = cc;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
             }
-        }
-        if (fin && t + 1 < tmax) {
+            // x <- xn BEFORE this step's stores are issued: vmcnt retires in order, so a copy placed after them
+            // would also wait for their acknowledgements (~1000 cycles measured)
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = xn[g];
-        }
-        if (t < tmax) CL_TICK(4);
-    }
-    if (prof && lane == 0 && tile < 8) {
-        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 8;
-        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = (u64)tmax;
+            __builtin_amdgcn_sched_barrier(0);
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u2;
+            cl_store2(&a.hs[o], h, fast);                // first: the other members are waiting for it
+            if (CELL == CELL_LSTM) *(f32x2*)&a.cs[o] = c;
+            if (CELL != CELL_VANILLA) {
+                const size_t og = sbr_blocked_index(t, row, u2, Bp, HP);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) o[3 + i] = pc[i];
+                for (int k = 0; k < 4; ++k) *(f32x2*)&a.g[k][og] = sv[k];
+            }
+            CL_TICK(4);
+        }
+        for (int t = tmax; t < T; ++t) {                 // past the tile's longest row: the state is carried
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u2;
+            *(f32x2*)&a.hs[o] = h;
+            if (CELL == CELL_LSTM) *(f32x2*)&a.cs[o] = c;
+        }
+    } else {
+        for (int t = 0; t < tmax; ++t) {
+            exchange(t);
+            __syncthreads();
+            CL_TICK(1);
+            f32x4 acc[G];
+            mfma_phase(acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) *(f32x4*)(red + ((ut * G + g) * 64 + lane) * 16) = acc[g];
+            CL_TICK(2);
+            __syncthreads();
+            CL_TICK(3);
+        }
+    }
+    if (prof && lane == 0 && tile < 4) {
+        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 16;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_tries;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[3 + i] = pc[i];
     }
 }
 
@@ -295,11 +351,12 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
 // ---------------------------------------------------------------------------------------
 template <int CELL, int HP, int R>
 __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
+    static_assert(R == 8, "the element split over duplicate MFMA columns assumes 8 live rows");
     constexpr int G = Gates<CELL>::G, C = HP / 32, GHP = G * HP, KH = GHP / 2, KBW = KH / 32;
     constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW;
     constexpr int W3_BYTES = KBW * 4 * 1024;
-    constexpr int NP = R * GHP / 2 / 256;
-    static_assert(R * GHP / 2 % 256 == 0, "piece count");
+    constexpr int NP = R * GHP / 4 / 256;
+    static_assert(R * GHP / 4 % 256 == 0, "piece count");
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* w3 = smem_c;                                   // [KBW][4 waves][64][16 B]
     char* dpl = smem_c + W3_BYTES;                       // [3][R][DROW]
@@ -309,22 +366,21 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ut = wave & 1, kh = wave >> 1;
     const int j = lane & 15, q = lane >> 4;
-    const bool live = j < R;
-    const int rl = live ? j : j % R;
+    const int rl = j & 7, eh = j >> 3;
     const int row = tile * R + rl;
     const int T = a.T, Bp = a.Bp;
     const float clip = a.clip;
     const int ub = mem * 32 + ut * 16;
-    const int u0 = ub + q * 4;
+    const int u2 = ub + q * 4 + eh * 2;
     const int k0 = kh * KH;
     const bool fin = kh == 0;
     bool dead = false;
     const bool fast = cl_same_xcc(a, C, tile, mem, (int*)red, dead);
 
-    const int mylen = live ? a.len[row] : 0;
+    const int mylen = a.len[row];
     int tmax = mylen;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+    for (int o = 1; o < 8; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
 
     // A operand planes: lane (unit j of the tile, k-group q) holds W_hid[ub + j][k0 + kb*32 + 8q + e]
     bf16x8 W1[KBW], W2[KBW];
@@ -343,90 +399,36 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
+    const f32x2 z2 = f32x2{0, 0};
     const f32x4 z4 = f32x4{0, 0, 0, 0};
-    f32x4 dh = z4, dc = z4, pi = z4, pf = z4, po = z4;
-    if (fin && live && a.dh_last) dh = *(const f32x4*)&a.dh_last[(size_t)row * HP + u0];
-    if (CELL == CELL_LSTM) { pi = *(const f32x4*)&a.peep[u0]; pf = *(const f32x4*)&a.peep[HP + u0]; po = *(const f32x4*)&a.peep[2 * HP + u0]; }
-    f32x4 sdb[G], sdp[3];
+    f32x2 dh = z2, dc = z2, pi = z2, pf = z2, po = z2;
+    if (fin && a.dh_last) dh = *(const f32x2*)&a.dh_last[(size_t)row * HP + u2];
+    if (CELL == CELL_LSTM) { pi = *(const f32x2*)&a.peep[u2]; pf = *(const f32x2*)&a.peep[HP + u2]; po = *(const f32x2*)&a.peep[2 * HP + u2]; }
+    f32x2 sdb[G], sdp[3];
 #pragma unroll
-    for (int g = 0; g < G; ++g) sdb[g] = z4;
-    sdp[0] = z4; sdp[1] = z4; sdp[2] = z4;
+    for (int g = 0; g < G; ++g) sdb[g] = z2;
+    sdp[0] = z2; sdp[1] = z2; sdp[2] = z2;
 
-    f32x4 sv[4], hprev = z4, cprev = z4, cnew = z4, hnew = z4;
+    f32x2 sv[4], hprev = z2, cprev = z2, cnew = z2, hnew = z2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sv[k] = z4;
+    for (int k = 0; k < 4; ++k) sv[k] = z2;
     auto load_saved = [&](int t) {
-        const size_t o = ((size_t)t * Bp + row) * HP + u0;
-        hprev = *(const f32x4*)&a.hs[o];
+        const size_t o = ((size_t)t * Bp + row) * HP + u2;
+        hprev = *(const f32x2*)&a.hs[o];
         if (CELL != CELL_VANILLA) {
-            const size_t og = sbr_blocked_index(t, row, u0, Bp, HP);
+            const size_t og = sbr_blocked_index(t, row, u2, Bp, HP);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sv[k] = *(const f32x4*)&a.g[k][og];
+            for (int k = 0; k < 4; ++k) sv[k] = *(const f32x2*)&a.g[k][og];
         }
-        if (CELL == CELL_LSTM) cprev = *(const f32x4*)&a.cs[o];
+        if (CELL == CELL_LSTM) cprev = *(const f32x2*)&a.cs[o];
     };
-    bool have = false;
     __syncthreads();                                     // W plane 3 visible
     // cycles per phase: gate math + publish stores | exchange wait | split + barrier | LDS reads + MFMA | reduce barrier
-    u64 pc[5] = {0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0;
+    u64 pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0, p_tries = 0;
     const bool prof = a.prof != nullptr;
     if (prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
 
-    if (prof) p_t = clock64();
-    for (int t = T - 1; t >= 0; --t) {
-        if (fin && live && a.dh_ext) dh += *(const f32x4*)&a.dh_ext[((size_t)t * Bp + row) * HP + u0];
-        if (t >= tmax) {                                 // whole tile masked: zero rows, nobody waits for them
-            if (fin && live) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) *(f32x4*)&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u0] = z4;
-                if (CELL == CELL_GRU) *(f32x4*)&a.dhi[((size_t)t * Bp + row) * HP + u0] = z4;
-            }
-            continue;
-        }
-        if (fin) {
-            if (!have) {
-                load_saved(t);
-                const size_t o1 = ((size_t)(t + 1) * Bp + row) * HP + u0;
-                if (CELL == CELL_LSTM) cnew = *(const f32x4*)&a.cs[o1];
-                if (CELL == CELL_VANILLA) hnew = *(const f32x4*)&a.hs[o1];
-                have = true;
-            }
-            const bool m = t < mylen;
-            f32x4 vxi[G], vhi[G];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s[4] = {sv[0][e], sv[1][e], sv[2][e], sv[3][e]};
-                float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
-                float dhh = dh[e], dcc = dc[e];
-                cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[e], pf[e], po[e], dxi, dhi, dp);
-                dh[e] = dhh; dc[e] = dcc;
-#pragma unroll
-                for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[g][e] += dxi[g]; }
-                sdp[0][e] += dp[0]; sdp[1][e] += dp[1]; sdp[2][e] += dp[2];
-            }
-            if (live) {
-                // dhi == dxi except the GRU candidate gate: dxt doubles as the exchange array
-#pragma unroll
-                for (int g = 0; g < G; ++g) cl_store4(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u0], vxi[g], fast);
-                if (CELL == CELL_GRU) cl_store4(&a.dhi[((size_t)t * Bp + row) * HP + u0], vhi[2], fast);
-            }
-            if (CELL == CELL_LSTM) cnew = cprev;
-            if (CELL == CELL_VANILLA) hnew = hprev;
-            if (t > 0) load_saved(t - 1);                // in flight across the exchange and the MFMA phase
-        }
-        CL_TICK(0);
-        {
-            u64 v[NP];
-            const float* bx = a.dxt + ((size_t)t * Bp + (size_t)tile * R) * GHP;
-            const float* bc = a.dhi + ((size_t)t * Bp + (size_t)tile * R) * HP;
-            cl_fetch<NP>(v, [&](int r, int col) {
-                return (CELL == CELL_GRU && col >= 2 * HP) ? bc + (size_t)r * HP + (col - 2 * HP) : bx + (size_t)r * GHP + col;
-            }, GHP, dead, a.fault);
-            CL_TICK(1);
-            cl_publish<NP>(v, dpl, GHP, DROW, PLANEB);
-        }
-        __syncthreads();
-        CL_TICK(2);
+    auto mfma_phase = [&]() -> f32x4 {                   // this wave's K half of dhi_t . W_hid^T for its 16 units
         const char* db = dpl + rl * DROW + k0 * 2 + q * 16;
         f32x4 acc[3] = {z4, z4, z4};
         bf16x8 dp[2][3], wp[2];
@@ -451,23 +453,96 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_nop 15");
-        const f32x4 sum = acc[0] + acc[1] + acc[2];
-        if (!fin) *(f32x4*)(red + (ut * 64 + lane) * 16) = sum;
-        CL_TICK(3);
-        __syncthreads();                                 // partials visible; every wave is done reading dpl
-        if (fin && live) dh += sum + *(const f32x4*)(red + (ut * 64 + lane) * 16);
-        CL_TICK(4);
-    }
-    if (prof && lane == 0 && tile < 8) {
-        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 8;
-        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = (u64)tmax;
+        return acc[0] + acc[1] + acc[2];
+    };
+    auto exchange = [&](int t) {                         // dhi_t of all G*Hp columns -> bf16 planes in LDS
+        f32x4 v[NP];
+        const float* bx = a.dxt + ((size_t)t * Bp + (size_t)tile * R) * GHP;
+        const float* bc = a.dhi + ((size_t)t * Bp + (size_t)tile * R) * HP;
+        p_tries += cl_fetch<NP>(v, [&](int r, int col) {
+            return (CELL == CELL_GRU && col >= 2 * HP) ? bc + (size_t)r * HP + (col - 2 * HP) : bx + (size_t)r * GHP + col;
+        }, GHP, fast, dead, a.fault);
+        CL_TICK(1);
+        cl_publish<NP>(v, dpl, GHP, DROW, PLANEB);
+    };
+    if (prof) p_t = clock64();
+
+    // Two roles, two loops with the same barrier sequence (see rec_fwd_cl)
+    if (fin) {
+        for (int t = T - 1; t >= tmax; --t) {            // whole tile masked: zero rows, nobody waits for them
+            if (a.dh_ext) dh += *(const f32x2*)&a.dh_ext[((size_t)t * Bp + row) * HP + u2];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) o[3 + i] = pc[i];
+            for (int g = 0; g < G; ++g) *(f32x2*)&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u2] = z2;
+            if (CELL == CELL_GRU) *(f32x2*)&a.dhi[((size_t)t * Bp + row) * HP + u2] = z2;
+        }
+        if (tmax > 0) {
+            load_saved(tmax - 1);
+            const size_t o1 = ((size_t)tmax * Bp + row) * HP + u2;
+            if (CELL == CELL_LSTM) cnew = *(const f32x2*)&a.cs[o1];
+            if (CELL == CELL_VANILLA) hnew = *(const f32x2*)&a.hs[o1];
+        }
+        for (int t = tmax - 1; t >= 0; --t) {
+            if (a.dh_ext) dh += *(const f32x2*)&a.dh_ext[((size_t)t * Bp + row) * HP + u2];
+            const bool m = t < mylen;
+            f32x2 vxi[G], vhi[G];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float s[4] = {sv[0][e], sv[1][e], sv[2][e], sv[3][e]};
+                float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+                float dhh = dh[e], dcc = dc[e];
+                cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[e], pf[e], po[e], dxi, dhi, dp);
+                dh[e] = dhh; dc[e] = dcc;
+#pragma unroll
+                for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[g][e] += dxi[g]; }
+                sdp[0][e] += dp[0]; sdp[1][e] += dp[1]; sdp[2][e] += dp[2];
+            }
+            if (CELL == CELL_LSTM) cnew = cprev;
+            if (CELL == CELL_VANILLA) hnew = hprev;
+            // Saved activations of step t-1, in flight across the exchange and the MFMA phase.  Three things keep
+            // them off the critical path (each measured): issued AFTER the gate math (sched_barrier: hipcc otherwise
+            // hoists them above the wait for this step's values, which then covers them too), BEFORE this step's
+            // stores (vmcnt retires in order: behind the stores they also wait for the store acknowledgements),
+            // and unconditionally (clamped index: a branch here makes the waitcnt pass fall back to vmcnt(0)).
+            __builtin_amdgcn_sched_barrier(0);
+            load_saved(t > 0 ? t - 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // dhi == dxi except the GRU candidate gate: dxt doubles as the exchange array
+#pragma unroll
+            for (int g = 0; g < G; ++g) cl_store2(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u2], vxi[g], fast);
+            if (CELL == CELL_GRU) cl_store2(&a.dhi[((size_t)t * Bp + row) * HP + u2], vhi[2], fast);
+            CL_TICK(0);
+            exchange(t);
+            __syncthreads();
+            CL_TICK(2);
+            const f32x4 sum = mfma_phase();
+            CL_TICK(3);
+            __syncthreads();                             // partials visible; every wave is done reading dpl
+            dh += (eh ? f32x2{sum[2], sum[3]} : f32x2{sum[0], sum[1]}) + *(const f32x2*)(red + (ut * 64 + lane) * 16 + eh * 8);
+            CL_TICK(4);
+        }
+    } else {
+        for (int t = tmax - 1; t >= 0; --t) {
+            CL_TICK(0);
+            exchange(t);
+            __syncthreads();
+            CL_TICK(2);
+            const f32x4 sum = mfma_phase();
+            *(f32x4*)(red + (ut * 64 + lane) * 16) = sum;
+            CL_TICK(3);
+            __syncthreads();
+            CL_TICK(4);
+        }
+    }
+    if (prof && lane == 0 && tile < 4) {
+        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 16;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_tries;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[3 + i] = pc[i];
     }
 
     if (fin) {
         float* part = a.part + (size_t)tile * (GHP + 5 * HP);
-        f32x4 v[G + 5];
+        f32x2 v[G + 5];
 #pragma unroll
         for (int g = 0; g < G; ++g) v[g] = sdb[g];
         v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2];
@@ -475,17 +550,17 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
 #pragma unroll
         for (int k = 0; k < G + 5; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {
                 float sum = v[k][e];
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+                for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);     // over the 8 rows; lanes j and j+8 hold different units
                 v[k][e] = sum;
             }
-        if (j == 0) {
+        if (rl == 0) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) *(f32x4*)&part[g * HP + u0] = v[g];
+            for (int g = 0; g < G; ++g) *(f32x2*)&part[g * HP + u2] = v[g];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) *(f32x4*)&part[GHP + k * HP + u0] = v[G + k];
+            for (int k = 0; k < 5; ++k) *(f32x2*)&part[GHP + k * HP + u2] = v[G + k];
         }
     }
 }

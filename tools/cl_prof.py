@@ -19,10 +19,11 @@ raw = eng.debug_buffer("prof").view(np.uint64).reshape(2, -1)
 names = (("rec_fwd_cl", ("exchange wait", "publish+barrier", "LDS+MFMA", "reduce barrier", "gate math+stores")),
          ("rec_bwd_cl", ("gate math+stores", "exchange wait", "split+barrier", "LDS+MFMA", "reduce barrier")))
 for k, (name, ph) in enumerate(names):
-    p = raw[k][:8 * C * 4 * 8].reshape(8, C, 4, 8).astype(np.float64)      # [tile][member][wave][8]
+    p = raw[k][:4 * C * 4 * 16].reshape(4, C, 4, 16).astype(np.float64)      # [tile][member][wave][8]
     tot, real = p[..., 0], p[..., 1]
     print("%s: kernel %.1f us (realtime), shader clock %.0f MHz, %.0f cycles/step" % (
         name, real.mean() / 100.0, (tot / real * 100.0).mean(), tot.mean() / T))
     for w, wn in enumerate(("wave0 (tile0,fin)", "wave1 (tile1,fin)", "wave2 (tile0,K-hi)", "wave3 (tile1,K-hi)")):
-        print("   %-20s " % wn + "  ".join("%s %5.0f" % (ph[i], p[:, :, w, 3 + i].mean() / T) for i in range(5)))
+        print("   %-20s polls/step %.2f  " % (wn, p[:, :, w, 2].mean() / T) + "  ".join("%s %5.0f" % (ph[i], p[:, :, w, 3 + i].mean() / T) for i in range(5))
+              + "  | fine " + " ".join("%.0f" % (p[:, :, w, 3 + i].mean() / T) for i in range(5, 10)))
 eng.close()
