@@ -215,7 +215,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     {   // rows per workgroup of the bf16x6 recurrent kernels: spread the batch over up to ~64 CUs
         const char* e = getenv("SBR_RPT");
         int r = e ? atoi(e) : 0;
-        if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) { r = 16; while (r > 1 && h->lay.Bp / r < 64) r >>= 1; }
+        if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) { r = 16; while (r > 4 && h->lay.Bp / r < 64) r >>= 1; }
         h->rpt = r;
     }
     {
@@ -229,6 +229,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         const char* ln = getenv("SBR_CL_LINEAR");
         h->cl_linear = ln ? atoi(ln) != 0 : 0;
         h->cl_epoch = 0;
+        const char* xs = getenv("SBR_X6_SPLIT");
+        h->x6_split = xs ? atoi(xs) != 0 : 1;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -377,7 +379,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     for (int k = 0; k < 4; ++k) a.g[k] = h->A(ly.a_g[k]);
     a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
     a.xt_blocked = 0;
-    a.rpt = h->rpt;
+    a.rpt = h->rpt; a.x6_split = h->x6_split;
     a.t_lo = 0; a.t_hi = y.T; a.chunk = 0; a.state = h->A(ly.a_state);
     a.f32_mfma = (y.cfg.flags & SBR_FLAG_F32_MFMA) ? 1 : 0;
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;

@@ -95,6 +95,7 @@ struct sbr_handle {
     int wgrad_slices;    // K-slices of the weight-gradient kernel (total over the chunks)
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
+    int x6_split;
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -162,6 +163,7 @@ struct RecArgs {
     float* part;            // [chunks][nblk][G*Hp + 5*Hp]
     int rpt;                // live batch rows per workgroup of the bf16x6 kernels (16, 8, 4, 2, 1); part[] has Bp/rpt blocks
     int xt_blocked;         // xt is tile-blocked (layer 0: written by the gather) or row-major (GEMM output)
+    int x6_split;           // 4-row tiles use the split-gate-math kernels (SBR_X6_SPLIT, default 1)
     int f32_mfma;           // SBR_FLAG_F32_MFMA: exact-f32 v_mfma_f32_16x16x4_f32 kernels instead of bf16x6
     unsigned long long* prof; // SBR_FLAG_PROFILE_REC: [nblk][waves][4] cycle counters, else NULL
     // cluster kernels (sbr_rec_cl.hip): several workgroups per row tile for layers too wide for one CU

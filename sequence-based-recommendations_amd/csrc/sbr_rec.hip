@@ -793,6 +793,314 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
 }
 
 // ---------------------------------------------------------------------------------------
+// bf16x6 kernels for 4-row tiles ("x6s": split gate math).  With rpt = 4 the MFMA columns 4..15 repeat rows
+// 0..3, so the four lanes (r, q), (r+4, q), (r+8, q), (r+12, q) hold identical accumulators.  Instead of
+// letting three of them idle, copy c = j >> 2 finishes unit c of the lane's four: every lane runs the cell
+// math for ONE (row, unit) pair -- the VALU part of the per-step critical path shrinks 4x, and all loads and
+// stores are 4 bytes per lane over 16 consecutive units of a row (full 64-byte segments).
+// Same data layout, same LDS operand planes (4 rows), same chunked-BPTT protocol as rec_fwd_x6 / rec_bwd_x6.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float pick4(const f32x4 v, int c) {
+    return c == 0 ? v[0] : (c == 1 ? v[1] : (c == 2 ? v[2] : v[3]));
+}
+
+template <int CELL, int HP>
+__global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
+    constexpr int G = Gates<CELL>::G, KB = HP / 32, NW = HP / 16, GHP = G * HP, R = 4;
+    constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW;
+    constexpr int W3_BYTES = G * KB * NW * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [G][KB][NW][64 lanes][16 B]
+    char* hbuf = smem_c + W3_BYTES;                      // [2][3 planes][R rows][HROW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int r = j & 3, c = j >> 2;                     // tile row; which of the lane's 4 accumulator units it finishes
+    const int row = blockIdx.x * R + r;
+    const int T = a.T, Bp = a.Bp;
+    const int u = wave * 16 + q * 4 + c;
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+    tmax = max(tmax, __shfl_xor(tmax, 1));
+    tmax = max(tmax, __shfl_xor(tmax, 2));
+
+    bf16x8 W1[G][KB], W2[G][KB];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            bf16x8 w3v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 b1, b2, b3;
+                split3(a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + wave * 16 + j], b1, b2, b3);
+                W1[g][kb][e] = b1; W2[g][kb][e] = b2; w3v[e] = b3;
+            }
+            *(bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16) = w3v;
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    float h = a.hinit[u], cst = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
+    if (CELL == CELL_LSTM) {
+        cst = a.cinit[u];
+        pi = a.peep[u]; pf = a.peep[HP + u]; po = a.peep[2 * HP + u];
+        a.cs[(size_t)row * HP + u] = cst;
+    }
+    a.hs[(size_t)row * HP + u] = h;
+    auto publish_h = [&](int buf) {
+        __bf16 p1, p2, p3;
+        split3(h, p1, p2, p3);
+        char* base = hbuf + (size_t)buf * 3 * PLANEB + r * HROW + u * 2;
+        *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
+    };
+    publish_h(0);
+
+    float x[G], xn[G];
+    auto load_x = [&](int t, float (&d)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) d[g] = a.xt[((size_t)t * Bp + row) * GHP + g * HP + u];
+    };
+    if (tmax > 0) load_x(0, x);
+    __syncthreads();
+    unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
+    if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+
+    for (int t = 0; t < T; ++t) {
+        if (a.prof) p_ta = clock64();
+        float sv[4];
+        if (t < tmax) {                                           // workgroup-uniform
+            if (t + 1 < tmax) load_x(t + 1, xn);
+            const char* hb = hbuf + (size_t)(t & 1) * 3 * PLANEB + r * HROW + q * 16;
+            f32x4 acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = f32x4{0, 0, 0, 0};
+            bf16x8 hp[2][3], wp[2][G];
+            auto load_ops = [&](int kb, int s) {
+                hp[s][0] = *(const bf16x8*)(hb + kb * 64);
+                hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
+                hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+#pragma unroll
+                for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16);
+            };
+            load_ops(0, 0);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int s = kb & 1;
+                if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_nop 15");                             // MFMA D -> VALU read hazard (see rec_fwd_mfma)
+            __builtin_amdgcn_s_setprio(3);
+            float as[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) as[g] = pick4(acc[g], c);
+            cell_forward<CELL, true>(x, as, t < mylen, h, cst, pi, pf, po, sv);
+        }
+        if (t + 1 < tmax) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = xn[g];
+            publish_h((t + 1) & 1);
+            if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
+            __syncthreads();
+            if (a.prof) p_bar += clock64() - p_ta;
+        }
+        // this step's stores are issued AFTER the barrier (see rec_fwd_x6)
+        if (CELL != CELL_VANILLA && t < tmax) {
+            const size_t o = gate_index(t, row, u, Bp, HP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.g[k][o] = sv[k];
+        }
+        const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
+        a.hs[o] = h;
+        if (CELL == CELL_LSTM) a.cs[o] = cst;
+    }
+    if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
+    }
+}
+
+template <int CELL, int HP>
+__global__ void __launch_bounds__(HP * 4) rec_bwd_x6s(RecArgs a, int dbuf) {
+    constexpr int G = Gates<CELL>::G, NW = HP / 16, GHP = G * HP, KB = GHP / 32, R = 4;
+    constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW;
+    constexpr int W3_BYTES = KB * NW * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [KB][NW][64][16 B]
+    char* dbufp = smem_c + W3_BYTES;                     // [dbuf ? 2 : 1][3][R][DROW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int r = j & 3, c = j >> 2;
+    const int row = blockIdx.x * R + r;
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+    const int u = wave * 16 + q * 4 + c;
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+    tmax = max(tmax, __shfl_xor(tmax, 1));
+    tmax = max(tmax, __shfl_xor(tmax, 2));
+
+    bf16x8 W1[KB], W2[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const float* src = a.Whid + (size_t)(wave * 16 + j) * GHP + kb * 32 + 8 * q;
+        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        bf16x8 w3v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 b1, b2, b3;
+            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
+            W1[kb][e] = b1; W2[kb][e] = b2; w3v[e] = b3;
+        }
+        *(bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16) = w3v;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    const f32x4 z4 = f32x4{0, 0, 0, 0};
+    const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
+    float dh = 0.f, dc = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
+    if (first) { if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u]; }
+    else {
+        dh = a.state[(size_t)row * HP + u];
+        if (CELL == CELL_LSTM) dc = a.state[((size_t)Bp + row) * HP + u];
+    }
+    if (CELL == CELL_LSTM) { pi = a.peep[u]; pf = a.peep[HP + u]; po = a.peep[2 * HP + u]; }
+    float sdb[G], sdp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) sdb[g] = 0.f;
+
+    float sv[4] = {0.f, 0.f, 0.f, 0.f}, hprev = 0.f, cprev = 0.f, cnew = 0.f, hnew = 0.f;
+    auto load_saved = [&](int t) {
+        const size_t o = ((size_t)t * Bp + row) * HP + u;
+        hprev = a.hs[o];
+        if (CELL != CELL_VANILLA) {
+            const size_t og = gate_index(t, row, u, Bp, HP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = a.g[k][og];
+        }
+        if (CELL == CELL_LSTM) cprev = a.cs[o];
+    };
+    bool have = false;
+    unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
+    if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+    __syncthreads();                                              // W plane 3 visible
+
+    for (int t = a.t_hi - 1; t >= a.t_lo; --t) {
+        if (a.prof) p_ta = clock64();
+        if (a.dh_ext) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
+        if (t >= tmax) {                                          // whole tile masked: zero rows
+#pragma unroll
+            for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = 0.f;
+            if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = 0.f;
+            continue;
+        }
+        if (!have) {
+            load_saved(t);
+            const size_t o1 = ((size_t)(t + 1) * Bp + row) * HP + u;
+            if (CELL == CELL_LSTM) cnew = a.cs[o1];
+            if (CELL == CELL_VANILLA) hnew = a.hs[o1];
+            have = true;
+        }
+        char* lds = dbufp + (size_t)(dbuf ? (t & 1) : 0) * 3 * PLANEB;
+        {
+            float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+            cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp);
+#pragma unroll
+            for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
+            sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = dxi[g];
+                if (CELL == CELL_GRU && g == 2) a.dhi[((size_t)t * Bp + row) * HP + u] = dhi[g];
+                __bf16 p1, p2, p3;
+                split3(dhi[g], p1, p2, p3);
+                char* base = lds + r * DROW + (g * HP + u) * 2;
+                *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
+            }
+        }
+        if (CELL == CELL_LSTM) cnew = cprev;
+        if (CELL == CELL_VANILLA) hnew = hprev;
+        if (t > a.t_lo) load_saved(t - 1);
+        if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
+        __syncthreads();
+        if (a.prof) { const unsigned long long tc = clock64(); p_bar += tc - p_ta; p_ta = tc; }
+        const char* db = lds + r * DROW + q * 16;
+        f32x4 acc[3] = {z4, z4, z4};
+        bf16x8 dp[2][3], wp[2];
+        auto load_ops = [&](int kb, int s) {
+            dp[s][0] = *(const bf16x8*)(db + kb * 64);
+            dp[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
+            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+            wp[s] = *(const bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = MFMA_BF16(wp[s], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][2], acc[1]);
+            acc[2] = MFMA_BF16(W2[kb], dp[s][1], acc[2]);
+            acc[0] = MFMA_BF16(W2[kb], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][1], acc[1]);
+            acc[2] = MFMA_BF16(W1[kb], dp[s][0], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
+        __builtin_amdgcn_s_setprio(3);
+        dh += pick4(acc[0] + acc[1] + acc[2], c);
+        if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
+        if (!dbuf) __syncthreads();
+        if (a.prof) p_bar += clock64() - p_ta;
+    }
+    if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_work; o[3] = p_bar;
+    }
+
+    if (!last) {                                                  // hand dh / dc to the next chunk launch
+        a.state[(size_t)row * HP + u] = dh;
+        if (CELL == CELL_LSTM) a.state[((size_t)Bp + row) * HP + u] = dc;
+    }
+    float* part = a.part + ((size_t)a.chunk * gridDim.x + blockIdx.x) * (GHP + 5 * HP);
+    float v[G + 5];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = sdb[g];
+    v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2];
+    v[G + 3] = last ? dc : 0.f; v[G + 4] = last ? dh : 0.f;      // init-state gradients come from the last chunk only
+#pragma unroll
+    for (int k = 0; k < G + 5; ++k) {
+        float sum = v[k];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);                                // over the 4 rows (lanes j, j+4, .. hold other units)
+        v[k] = sum;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) part[g * HP + u] = v[g];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) part[GHP + k * HP + u] = v[G + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Triage ("simple") kernels: one launch per time step, one thread per (row, unit), plain FMAs.
 // Same scalar cell math, none of the MFMA/LDS machinery (SBR_FLAG_SIMPLE_REC).
 // ---------------------------------------------------------------------------------------
@@ -939,6 +1247,13 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         const size_t l6 = (size_t)Gates<CELL>::G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 16 * (size_t)(Hp * 2 + 32);
         if (l6 <= 160 * 1024) {
             const int nb6 = a.Bp / a.rpt;
+            if (a.rpt == 4 && a.x6_split) {   // 4-row tiles: one (row, unit) pair per lane
+                const size_t l4 = (size_t)Gates<CELL>::G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 4 * (size_t)(Hp * 2 + 32);
+                if (Hp == 32) LAUNCH_DYN((rec_fwd_x6s<CELL, 32>), nb6, Hp * 4, l4, a);
+                else if (Hp == 64) LAUNCH_DYN((rec_fwd_x6s<CELL, 64>), nb6, Hp * 4, l4, a);
+                else LAUNCH_DYN((rec_fwd_x6s<CELL, 128>), nb6, Hp * 4, l4, a);
+                return hipGetLastError();
+            }
             if (Hp == 32) LAUNCH_DYN((rec_fwd_x6<CELL, 32>), nb6, Hp * 4, l6, a);
             else if (Hp == 64) LAUNCH_DYN((rec_fwd_x6<CELL, 64>), nb6, Hp * 4, l6, a);
             else LAUNCH_DYN((rec_fwd_x6<CELL, 128>), nb6, Hp * 4, l6, a);
@@ -999,6 +1314,12 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         const size_t l6 = w3b + (db6 ? 2 : 1) * one6;
         if (l6 <= 160 * 1024) {
             const int nb6 = a.Bp / a.rpt;
+            if (a.rpt == 4 && a.x6_split) {
+                if (Hp == 32) LAUNCH_DYN((rec_bwd_x6s<CELL, 32>), nb6, Hp * 4, l6, a, db6);
+                else if (Hp == 64) LAUNCH_DYN((rec_bwd_x6s<CELL, 64>), nb6, Hp * 4, l6, a, db6);
+                else LAUNCH_DYN((rec_bwd_x6s<CELL, 128>), nb6, Hp * 4, l6, a, db6);
+                return hipGetLastError();
+            }
             if (Hp == 32) LAUNCH_DYN((rec_bwd_x6<CELL, 32>), nb6, Hp * 4, l6, a, db6);
             else if (Hp == 64) LAUNCH_DYN((rec_bwd_x6<CELL, 64>), nb6, Hp * 4, l6, a, db6);
             else LAUNCH_DYN((rec_bwd_x6<CELL, 128>), nb6, Hp * 4, l6, a, db6);

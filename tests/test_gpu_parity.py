@@ -37,6 +37,21 @@ def test_streamed_whid_kernels(cell):                      # Hp = 192: W_hid fra
     check(PU.compare_step(cell, [160], "CCE", N=61, B=21, T=8), tol_h=2e-4)
 
 
+@pytest.mark.parametrize("rpt", ["1", "2", "8", "16"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_rows_per_workgroup_variants(cell, rpt, monkeypatch):
+    # default: 4-row tiles with the gate math split over the duplicate MFMA columns (rec_*_x6s, every other test);
+    # the general kernels (rec_*_x6) serve the other tile heights
+    monkeypatch.setenv("SBR_RPT", rpt)
+    check(PU.compare_step(cell, [50], "CCE", N=61, B=37, T=9))
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_general_kernel_on_four_row_tiles(cell, monkeypatch):
+    monkeypatch.setenv("SBR_X6_SPLIT", "0")
+    check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
+
+
 @pytest.mark.parametrize("linear", ["0", "1"])
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_cluster_kernels_wide_layers(cell, linear, monkeypatch):
