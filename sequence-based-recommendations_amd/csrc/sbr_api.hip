@@ -231,6 +231,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->cl_epoch = 0;
         const char* xs = getenv("SBR_X6_SPLIT");
         h->x6_split = xs ? atoi(xs) != 0 : 1;
+        const char* fg = getenv("SBR_FUSE_GATHER");
+        h->fuse_gather = fg ? atoi(fg) != 0 : 1;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -406,16 +408,21 @@ extern "C" int sbr_forward(sbr_handle* h) {
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
         const int GHp = y.G * ly.Hp;
+        RecArgs ra = rec_args(h, l);
         if (l == 0) {
-            SBR_LAUNCH(launch_gather_xt(s, h->P(ly.p_Win), h->P(ly.p_b), h->bX, h->A(ly.a_xt), y.T, y.Bp,
-                                        y.F, GHp, h->n_rows));
+            if (y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(ra, simple_rec(h))) {
+                ra.gX = h->bX; ra.gWin = h->P(ly.p_Win); ra.gbias = h->P(ly.p_b);   // gathered inside the forward kernel
+            } else {
+                SBR_LAUNCH(launch_gather_xt(s, h->P(ly.p_Win), h->P(ly.p_b), h->bX, h->A(ly.a_xt), y.T, y.Bp,
+                                            y.F, GHp, h->n_rows));
+            }
             mark(h, 1);
         } else {   // dense layers: xt = hid_out(l-1) . W_in + b  (Lasagne precompute_input [3P], recurrent_layers.py:94-104)
             const LayerLayout& lo = y.layer[l - 1];
             SBR_LAUNCH(launch_gemm(s, h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp, lo.Hp, 1, h->P(ly.p_Win), GHp, 1, h->A(ly.a_xt), GHp,
                                    y.T * y.Bp, GHp, lo.Hp, h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
         }
-        SBR_LAUNCH(launch_rec_forward(s, rec_args(h, l), simple_rec(h)));
+        SBR_LAUNCH(launch_rec_forward(s, ra, simple_rec(h)));
     }
     mark(h, 2);
     h->fwd_done = true;

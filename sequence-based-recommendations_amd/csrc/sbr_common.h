@@ -95,7 +95,7 @@ struct sbr_handle {
     int wgrad_slices;    // K-slices of the weight-gradient kernel (total over the chunks)
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
-    int x6_split;
+    int x6_split, fuse_gather;
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -164,6 +164,10 @@ struct RecArgs {
     int rpt;                // live batch rows per workgroup of the bf16x6 kernels (16, 8, 4, 2, 1); part[] has Bp/rpt blocks
     int xt_blocked;         // xt is tile-blocked (layer 0: written by the gather) or row-major (GEMM output)
     int x6_split;           // 4-row tiles use the split-gate-math kernels (SBR_X6_SPLIT, default 1)
+    // layer 0, one index per step: the embedding gather is fused into the forward kernel (xt is never written)
+    const int* gX;          // [Bp][T] item ids, or NULL: read xt
+    const float* gWin;      // [input_size][G*Hp]
+    const float* gbias;     // [G*Hp]
     int f32_mfma;           // SBR_FLAG_F32_MFMA: exact-f32 v_mfma_f32_16x16x4_f32 kernels instead of bf16x6
     unsigned long long* prof; // SBR_FLAG_PROFILE_REC: [nblk][waves][4] cycle counters, else NULL
     // cluster kernels (sbr_rec_cl.hip): several workgroups per row tile for layers too wide for one CU
@@ -178,6 +182,8 @@ bool sbr_rec_cluster_ok(const RecArgs& a);
 hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
+// true when the forward launch for these args can gather its input rows itself (RecArgs.gX/gWin/gbias)
+bool sbr_rec_fwd_can_fuse_gather(const RecArgs& a, bool simple);
 hipError_t launch_rec_backward(hipStream_t s, const RecArgs& a, bool simple);
 // number of part[] blocks the backward launch for these args writes
 int sbr_rec_bwd_blocks(const RecArgs& a, bool simple);

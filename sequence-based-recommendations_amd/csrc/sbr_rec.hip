@@ -855,12 +855,21 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
     };
     publish_h(0);
 
-    float x[G], xn[G];
-    auto load_x = [&](int t, float (&d)[G]) {
+    // Input of step t: a row of xt, or (layer 0, one index per step) gathered here: W_in[id[row][t]] + b
+    // (sparse_lstm.py:368 / :755 / :1111).  The id is fetched two steps ahead, the row one step ahead; the
+    // prefetches are unconditional with clamped indices (a branch around them costs a vmcnt(0), see sbr_rec_cl.hip).
+    const bool fuse = a.gX != nullptr;
+    float x[G], xn[G], bias[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) d[g] = a.xt[((size_t)t * Bp + row) * GHP + g * HP + u];
+    for (int g = 0; g < G; ++g) bias[g] = fuse ? a.gbias[g * HP + u] : 0.f;
+    auto load_id = [&](int t) -> int { return fuse ? a.gX[(size_t)row * T + (t < T ? t : T - 1)] : 0; };
+    auto load_x = [&](int t, int id, float (&d)[G]) {
+        const float* src = fuse ? a.gWin + (size_t)id * GHP + u : a.xt + ((size_t)(t < T ? t : T - 1) * Bp + row) * GHP + u;
+#pragma unroll
+        for (int g = 0; g < G; ++g) d[g] = src[g * HP];
     };
-    if (tmax > 0) load_x(0, x);
+    int id_next = load_id(1), id_nn = 0;
+    load_x(0, load_id(0), x);
     __syncthreads();
     unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
     if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
@@ -869,7 +878,8 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
         if (a.prof) p_ta = clock64();
         float sv[4];
         if (t < tmax) {                                           // workgroup-uniform
-            if (t + 1 < tmax) load_x(t + 1, xn);
+            load_x(t + 1, id_next, xn);
+            id_nn = load_id(t + 2);
             const char* hb = hbuf + (size_t)(t & 1) * 3 * PLANEB + r * HROW + q * 16;
             f32x4 acc[G];
 #pragma unroll
@@ -905,14 +915,15 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
             }
             asm volatile("s_nop 15");                             // MFMA D -> VALU read hazard (see rec_fwd_mfma)
             __builtin_amdgcn_s_setprio(3);
-            float as[G];
+            float as[G], xb[G];
 #pragma unroll
-            for (int g = 0; g < G; ++g) as[g] = pick4(acc[g], c);
-            cell_forward<CELL, true>(x, as, t < mylen, h, cst, pi, pf, po, sv);
+            for (int g = 0; g < G; ++g) { as[g] = pick4(acc[g], c); xb[g] = x[g] + bias[g]; }
+            cell_forward<CELL, true>(xb, as, t < mylen, h, cst, pi, pf, po, sv);
         }
         if (t + 1 < tmax) {
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = xn[g];
+            id_next = id_nn;
             publish_h((t + 1) & 1);
             if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
             __syncthreads();
@@ -1275,6 +1286,13 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
     }
 #undef FWD_RES
     return hipGetLastError();
+}
+
+bool sbr_rec_fwd_can_fuse_gather(const RecArgs& a, bool simple) {
+    const int Hp = a.Hp;
+    if (simple || a.f32_mfma || sbr_rec_cluster_ok(a) || !(Hp == 32 || Hp == 64 || Hp == 128)) return false;
+    const size_t l4 = (size_t)a.G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 4 * (size_t)(Hp * 2 + 32);
+    return a.rpt == 4 && a.x6_split && l4 <= 160 * 1024;
 }
 
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple) {

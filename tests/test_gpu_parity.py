@@ -46,6 +46,14 @@ def test_rows_per_workgroup_variants(cell, rpt, monkeypatch):
     check(PU.compare_step(cell, [50], "CCE", N=61, B=37, T=9))
 
 
+def test_unfused_gather_agrees(monkeypatch):
+    # default: layer 0 with one index per step gathers W_in rows inside the forward kernel; the separate gather
+    # kernel (also used for --rf / F > 1, the f32 and the cluster kernels) must give the same step
+    monkeypatch.setenv("SBR_FUSE_GATHER", "0")
+    check(PU.compare_step("GRU", [128], "CCE", N=61, B=37, T=9))
+    check(PU.compare_step("LSTM", [50], "CCE", N=61, B=37, T=9))
+
+
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_general_kernel_on_four_row_tiles(cell, monkeypatch):
     monkeypatch.setenv("SBR_X6_SPLIT", "0")
