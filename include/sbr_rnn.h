@@ -149,6 +149,43 @@ int sbr_synchronize(sbr_handle* h);
 int sbr_enable_timing(sbr_handle* h, int on);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native batch builder: replaces SequenceGenerator + _gen_mini_batch + _prepare_input
+ * (data_handling.py:126-174, rnn_base.py:373-420, rnn_one_hot.py:83-106, rnn_sampling.py:159-194) for
+ * the default training options (one item index per step, next-item target, no sequence noise).
+ * The training sequences live on the device in CSR form; a pass over the users is PLANNED on the host
+ * exactly as the reference fills its batches (users in file or shuffled order; user u contributes
+ * k = min(B - j, len(u) - 2) rows, a user that overflows the batch is truncated, rnn_base.py:400-415),
+ * and each batch is then BUILT by two kernels: k distinct sorted split points l in [2, len) per user
+ * (uniform without replacement = random.sample, :402), then per row the window items[max(0,l-T):l], its
+ * length, the target items[l], pop[target]**db and (sampled heads) S negatives, uniform or by inverse CDF
+ * of popularity**sampling_bias.  Same distribution as the reference, not the same random stream. */
+typedef struct sbr_dataset sbr_dataset;
+
+/* items: concatenated item ids of all training sequences; offsets: n_users+1 prefix offsets (host arrays). */
+int sbr_dataset_create(const int32_t* items, const int64_t* offsets, int64_t n_users, int32_t n_items, void* stream,
+                       sbr_dataset** out);
+int sbr_dataset_destroy(sbr_dataset* d);
+/* pop_db[n_items] = item_popularity ** diversity_bias (rnn_one_hot.py:103; NULL: all 1);
+ * sample_cdf[n_items] = cumsum(item_popularity ** sampling_bias) (rnn_sampling.py:159-163; NULL: uniform). */
+int sbr_dataset_set_tables(sbr_dataset* d, const float* pop_db, const double* sample_cdf);
+/* Plans one pass over the users in `order` (n_users ids, NULL = file order) for batches of batch_size rows.
+ * A trailing partial batch is carried into the next planned pass, as the reference's endless generator does.
+ * n_batches: complete batches now available (indices 0..n_batches-1 for sbr_build_batch). */
+int sbr_dataset_plan_pass(sbr_dataset* d, const int32_t* order, int32_t batch_size, int64_t* n_batches);
+/* The plan as host arrays, for tests and tooling: segment s = (user, k rows, first row, batch). */
+int sbr_dataset_plan_segments(sbr_dataset* d, int64_t* n_segments, const int32_t** seg_user, const int32_t** seg_k,
+                              const int32_t** seg_row0, const int32_t** seg_batch);
+/* Host-only planner behind sbr_dataset_plan_pass (no device needed; used by the CPU tests).  lengths[n_users];
+ * pend_*: the carried partial batch (in/out, capacity batch_size); seg_* capacity n_users + *n_pend. */
+int sbr_plan_pass_host(const int64_t* lengths, const int32_t* order, int64_t n_users, int32_t batch_size,
+                       int32_t* pend_user, int32_t* pend_k, int32_t* n_pend, int32_t* seg_user, int32_t* seg_k,
+                       int32_t* seg_row0, int32_t* seg_batch, int64_t* n_segments, int64_t* n_batches);
+/* Builds planned batch `batch` into the engine's own batch buffers (rows [row_offset, row_offset+local_batch)
+ * of the global batch for X / lengths / pop; targets: local rows for CCE, all rows for the sampled heads) and
+ * makes it the current batch, as sbr_set_batch does.  Entirely on the handle's stream; no host sync. */
+int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

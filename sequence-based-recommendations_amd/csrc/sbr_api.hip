@@ -18,9 +18,6 @@ void sbr_set_error(const char* fmt, ...) {
 extern "C" const char* sbr_last_error(void) { return g_err.c_str(); }
 extern "C" int sbr_abi_version(void) { return SBR_ABI_VERSION; }
 
-#define CHECK_ARG(cond, ...) do { if (!(cond)) { sbr_set_error(__VA_ARGS__); return SBR_EINVAL; } } while (0)
-#define SBR_LAUNCH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-    sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
 
 // ---------------------------------------------------------------------------------------
 // Layout
@@ -693,6 +690,11 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     if (nm == "h_last") { *dev_ptr = h_last(h); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
     if (nm == "logits") { *dev_ptr = h->A(y.a_logits); *n_floats = (size_t)y.Bp * y.N; return SBR_OK; }
     if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
+    if (nm == "batch_X") { *dev_ptr = (void*)h->bX; *n_floats = (size_t)y.Bp * y.T * y.F; return SBR_OK; }
+    if (nm == "batch_lengths") { *dev_ptr = (void*)h->blen; *n_floats = y.Bp; return SBR_OK; }
+    if (nm == "batch_target") { *dev_ptr = (void*)h->btgt; *n_floats = y.S > 0 ? y.Bg : y.Bp; return SBR_OK; }
+    if (nm == "batch_pop") { *dev_ptr = (void*)h->bpop; *n_floats = y.Bp; return SBR_OK; }
+    if (nm == "batch_samples") { *dev_ptr = (void*)h->bsmp; *n_floats = y.S; return SBR_OK; }
     if (nm == "prof") { *dev_ptr = h->A(y.a_prof); *n_floats = (size_t)2 * (y.Bp / 16) * 16 * 8 * 2; return SBR_OK; }
     if (nm == "rowcost") { *dev_ptr = h->A(y.a_rowcost); *n_floats = y.Bp; return SBR_OK; }
     if (nm == "act" && y.S > 0) { *dev_ptr = h->A(y.a_act); *n_floats = (size_t)y.Bp * y.C; return SBR_OK; }

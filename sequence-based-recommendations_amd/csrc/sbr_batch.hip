@@ -1,0 +1,322 @@
+// Native batch builder (see include/sbr_rnn.h): the reference's SequenceGenerator +
+// _gen_mini_batch + _prepare_input (data_handling.py:126-174, rnn_base.py:373-420, rnn_one_hot.py:83-106,
+// rnn_sampling.py:159-194) with the training set resident in HBM as CSR and every per-batch array produced by
+// two kernels on the engine's stream.  The host only walks the user list once per pass (integer bookkeeping).
+#include "sbr_common.h"
+#include <algorithm>
+
+struct sbr_dataset {
+    int64_t n_users, nnz; int n_items;
+    hipStream_t stream;
+    int* d_items; long long* d_off;
+    float* d_popdb; double* d_cdf;
+    std::vector<int64_t> len;                       // host copy of the sequence lengths
+    std::vector<int> pend_user, pend_k;             // trailing partial batch carried into the next pass
+    std::vector<int> seg_user, seg_k, seg_row0, seg_batch, batch_begin;   // host plan (batch_begin: n_batches+1)
+    int *d_seg_user, *d_seg_k, *d_seg_row0, *d_batch_begin; size_t cap_su, cap_sk, cap_sr, cap_bb;
+    int *d_split, *d_rowuser; size_t cap_rows;      // per-row scratch of the batch being built
+    int64_t n_batches; int batch_size;
+};
+
+
+// ---------------------------------------------------------------------------------------
+// host planner (rnn_base.py:394-415): users in order; k = min(B - j, len - 2); j += k; a full batch closes
+// ---------------------------------------------------------------------------------------
+extern "C" int sbr_plan_pass_host(const int64_t* lengths, const int32_t* order, int64_t n_users, int32_t B,
+                                  int32_t* pend_user, int32_t* pend_k, int32_t* n_pend, int32_t* seg_user, int32_t* seg_k,
+                                  int32_t* seg_row0, int32_t* seg_batch, int64_t* n_segments, int64_t* n_batches) {
+    CHECK_ARG(lengths && pend_user && pend_k && n_pend && seg_user && seg_k && seg_row0 && seg_batch && n_segments && n_batches,
+              "null argument");
+    CHECK_ARG(B >= 1 && n_users >= 0 && *n_pend >= 0 && *n_pend <= B, "bad batch size / pending count");
+    int64_t ns = 0, nb = 0; int j = 0;
+    for (int i = 0; i < *n_pend; ++i) {             // rows of the partial batch the previous pass left behind
+        seg_user[ns] = pend_user[i]; seg_k[ns] = pend_k[i]; seg_row0[ns] = j; seg_batch[ns] = (int)nb; ++ns;
+        j += pend_k[i];
+    }
+    CHECK_ARG(j < B || *n_pend == 0, "pending rows fill a whole batch");
+    for (int64_t i = 0; i < n_users; ++i) {
+        const int u = order ? order[i] : (int)i;
+        CHECK_ARG(u >= 0 && u < n_users, "user id %d out of range", u);
+        const int64_t L = lengths[u];
+        if (L < 2) continue;                        // SequenceGenerator min_length=2 (data_handling.py:143)
+        const int k = (int)std::min<int64_t>(B - j, L - 2);
+        if (k <= 0) continue;                       // len == 2: random.sample(range(2,2), 0) -> no rows, user consumed
+        seg_user[ns] = u; seg_k[ns] = k; seg_row0[ns] = j; seg_batch[ns] = (int)nb; ++ns;
+        j += k;
+        if (j == B) { ++nb; j = 0; }
+    }
+    // the segments of the unfinished batch nb sit at the tail: they become the next pass's pending prefix
+    int64_t first = ns;
+    while (first > 0 && seg_batch[first - 1] == nb) --first;
+    const int np = (int)(ns - first);
+    for (int i = 0; i < np; ++i) { pend_user[i] = seg_user[first + i]; pend_k[i] = seg_k[first + i]; }
+    ns = first;
+    *n_pend = np; *n_segments = ns; *n_batches = nb;
+    return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {      // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ unsigned key32(unsigned long long seed, unsigned a, unsigned b) {
+    return (unsigned)(mix64(seed ^ mix64(((unsigned long long)a << 32) | b)) >> 32);
+}
+
+// One workgroup per segment: k distinct split points out of the n = len - 2 candidates {2..len-1}, uniformly
+// (random.sample, rnn_base.py:402) and in ascending order (sorted(...)).  Every candidate gets a 32-bit key
+// hashed from (seed, user, index); the k smallest keys win: a 4-pass radix select in LDS finds the k-th key,
+// an ordered compaction writes the winners.  Key ties at the threshold are broken by index.
+__global__ void __launch_bounds__(256) bb_split_kernel(const long long* __restrict__ off, const int* __restrict__ seg_user,
+                                                       const int* __restrict__ seg_k, const int* __restrict__ seg_row0,
+                                                       int seg_begin, unsigned long long seed, int* __restrict__ split,
+                                                       int* __restrict__ rowuser) {
+    __shared__ int hist[256];
+    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int s_remaining, s_base, s_ties;
+    __shared__ int wsum[8];
+    const int s = seg_begin + blockIdx.x, tid = threadIdx.x;
+    const int user = seg_user[s], k = seg_k[s], row0 = seg_row0[s];
+    const int n = (int)(off[user + 1] - off[user]) - 2;
+    const unsigned long long sd = seed ^ mix64(0x5EEDull + (unsigned long long)user);
+    if (tid == 0) { s_prefix = 0; s_mask = 0; s_remaining = k; }
+    __syncthreads();
+    if (k < n) {
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            for (int i = tid; i < n; i += 256) {
+                const unsigned key = key32(sd, 1u, (unsigned)i);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining, b = 0;
+                while (b < 255 && hist[b] < rem) { rem -= hist[b]; ++b; }      // bin holding the k-th smallest key
+                s_remaining = rem; s_prefix = prefix | ((unsigned)b << (8 * pass)); s_mask = mask | (0xFFu << (8 * pass));
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned thr = s_prefix;                 // the k-th smallest key; s_remaining of the keys equal to it are taken
+    const int take_ties = s_remaining;
+    if (tid == 0) { s_base = 0; s_ties = 0; }
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        bool lt = false, eq = false;
+        if (i < n) {
+            if (k >= n) lt = true;
+            else { const unsigned key = key32(sd, 1u, (unsigned)i); lt = key < thr; eq = key == thr; }
+        }
+        // ordered rank of the equal keys first (needed to decide which of them are taken)
+        const int lane = tid & 63, wv = tid >> 6;
+        const unsigned long long beq = __ballot(eq);
+        int eq_before = __popcll(beq & ((1ull << lane) - 1));
+        if (lane == 0) wsum[wv] = __popcll(beq);
+        __syncthreads();
+        for (int w = 0; w < wv; ++w) eq_before += wsum[w];
+        const int eq_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const bool sel = lt || (eq && s_ties + eq_before < take_ties);
+        __syncthreads();
+        const unsigned long long bs = __ballot(sel);
+        int before = __popcll(bs & ((1ull << lane) - 1));
+        if (lane == 0) wsum[4 + wv] = __popcll(bs);
+        __syncthreads();
+        for (int w = 0; w < wv; ++w) before += wsum[4 + w];
+        const int total = wsum[4] + wsum[5] + wsum[6] + wsum[7];
+        if (sel) { const int pos = s_base + before; if (pos < k) { split[row0 + pos] = 2 + i; rowuser[row0 + pos] = user; } }
+        __syncthreads();
+        if (tid == 0) { s_base += total; s_ties += eq_total; }
+        __syncthreads();
+    }
+}
+
+// One wave per local row: X row, length, target, pop**db.  Blocks past the rows draw the S negatives.
+__global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ items, const long long* __restrict__ off,
+                                                     const int* __restrict__ split, const int* __restrict__ rowuser,
+                                                     const float* __restrict__ popdb, const double* __restrict__ cdf,
+                                                     int n_items, int T, int row_offset, int local_rows, int Bp, int tgt_rows,
+                                                     int tgt_offset, int S, unsigned long long seed, int* __restrict__ X,
+                                                     int* __restrict__ lengths, int* __restrict__ target, float* __restrict__ pop,
+                                                     int* __restrict__ samples) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b < Bp) {
+        if (b >= local_rows) {                                     // padded rows: index 0, length 0, popularity 1
+            for (int t = lane; t < T; t += 64) X[(size_t)b * T + t] = 0;
+            if (lane == 0) { lengths[b] = 0; pop[b] = 1.0f; }
+            return;
+        }
+        const int g = row_offset + b, l = split[g];
+        const long long o = off[rowuser[g]];
+        const int start = max(0, l - T), n_in = l - start;         // rnn_base.py:410: at most max_length items before l
+        for (int t = lane; t < T; t += 64) X[(size_t)b * T + t] = t < n_in ? items[o + start + t] : 0;
+        if (lane == 0) {
+            lengths[b] = n_in;
+            pop[b] = popdb ? popdb[items[o + l]] : 1.0f;           // rnn_one_hot.py:103
+        }
+        return;
+    }
+    const int e = (b - Bp) * 64 + lane;
+    if (e < tgt_rows) {                                            // targets: the first item after the split (:407, n_targets=1)
+        const int g = tgt_offset + e;
+        target[e] = items[off[rowuser[g]] + split[g]];
+    }
+    const int si = e - ((tgt_rows + 63) / 64) * 64;
+    if (si >= 0 && si < S) {
+        const unsigned long long r = mix64(seed ^ mix64(0xA5A5ull + (unsigned long long)si));
+        if (!cdf) samples[si] = (int)(r % (unsigned long long)n_items);          // np.random.choice(n_items, S) (rnn_sampling.py:191)
+        else {                                                     // bisect(cumsum, uniform(0, cumsum[-1])) (:159-163)
+            const double x = (double)(r >> 11) * (1.0 / 9007199254740992.0) * cdf[n_items - 1];
+            int lo = 0, hi = n_items;                              // first index with cdf[idx] > x
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > x) hi = mid; else lo = mid + 1; }
+            samples[si] = min(lo, n_items - 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------
+extern "C" int sbr_dataset_create(const int32_t* items, const int64_t* offsets, int64_t n_users, int32_t n_items, void* stream,
+                                  sbr_dataset** out) {
+    CHECK_ARG(items && offsets && out && n_users >= 1 && n_items >= 1, "bad dataset arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { sbr_set_error("no HIP device: the batch builder is device code"); return SBR_EHIP; }
+    const int64_t nnz = offsets[n_users];
+    CHECK_ARG(offsets[0] == 0 && nnz >= 0, "offsets must start at 0");
+    sbr_dataset* d = new sbr_dataset();
+    d->n_users = n_users; d->nnz = nnz; d->n_items = n_items; d->stream = (hipStream_t)stream;
+    d->d_items = nullptr; d->d_off = nullptr; d->d_popdb = nullptr; d->d_cdf = nullptr;
+    d->d_seg_user = d->d_seg_k = d->d_seg_row0 = d->d_batch_begin = nullptr; d->cap_su = d->cap_sk = d->cap_sr = d->cap_bb = 0;
+    d->d_split = d->d_rowuser = nullptr; d->cap_rows = 0; d->n_batches = 0; d->batch_size = 0;
+    d->len.resize(n_users);
+    for (int64_t u = 0; u < n_users; ++u) {
+        d->len[u] = offsets[u + 1] - offsets[u];
+        if (d->len[u] < 0) { delete d; sbr_set_error("offsets not monotone at user %lld", (long long)u); return SBR_EINVAL; }
+    }
+    for (int64_t i = 0; i < nnz; ++i)
+        if (items[i] < 0 || items[i] >= n_items) { delete d; sbr_set_error("item id %d out of range [0,%d)", items[i], n_items); return SBR_EINVAL; }
+    if (hipMalloc(&d->d_items, std::max<int64_t>(nnz, 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&d->d_off, (n_users + 1) * sizeof(long long)) != hipSuccess) {
+        sbr_dataset_destroy(d); sbr_set_error("hipMalloc failed for the dataset"); return SBR_ENOMEM;
+    }
+    SBR_HIP(hipMemcpyAsync(d->d_items, items, nnz * sizeof(int), hipMemcpyHostToDevice, d->stream));
+    SBR_HIP(hipMemcpyAsync(d->d_off, offsets, (n_users + 1) * sizeof(long long), hipMemcpyHostToDevice, d->stream));
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    *out = d;
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_destroy(sbr_dataset* d) {
+    if (!d) return SBR_OK;
+    (void)hipFree(d->d_items); (void)hipFree(d->d_off); (void)hipFree(d->d_popdb); (void)hipFree(d->d_cdf);
+    (void)hipFree(d->d_seg_user); (void)hipFree(d->d_seg_k); (void)hipFree(d->d_seg_row0); (void)hipFree(d->d_batch_begin);
+    (void)hipFree(d->d_split); (void)hipFree(d->d_rowuser);
+    delete d;
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_set_tables(sbr_dataset* d, const float* pop_db, const double* cdf) {
+    CHECK_ARG(d, "null dataset");
+    (void)hipFree(d->d_popdb); (void)hipFree(d->d_cdf); d->d_popdb = nullptr; d->d_cdf = nullptr;
+    if (pop_db) {
+        SBR_HIP(hipMalloc(&d->d_popdb, d->n_items * sizeof(float)));
+        SBR_HIP(hipMemcpyAsync(d->d_popdb, pop_db, d->n_items * sizeof(float), hipMemcpyHostToDevice, d->stream));
+    }
+    if (cdf) {
+        for (int i = 1; i < d->n_items; ++i) CHECK_ARG(cdf[i] >= cdf[i - 1], "sample_cdf must be non-decreasing");
+        CHECK_ARG(cdf[d->n_items - 1] > 0, "sample_cdf has no mass");
+        SBR_HIP(hipMalloc(&d->d_cdf, d->n_items * sizeof(double)));
+        SBR_HIP(hipMemcpyAsync(d->d_cdf, cdf, d->n_items * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    }
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    return SBR_OK;
+}
+
+static int upload(int** dev, size_t* cap, const std::vector<int>& v, hipStream_t s) {
+    if (v.size() > *cap) {
+        (void)hipFree(*dev); *dev = nullptr;
+        *cap = v.size() + v.size() / 2 + 64;
+        SBR_HIP(hipMalloc(dev, *cap * sizeof(int)));
+    }
+    if (!v.empty()) SBR_HIP(hipMemcpyAsync(*dev, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_plan_pass(sbr_dataset* d, const int32_t* order, int32_t B, int64_t* n_batches) {
+    CHECK_ARG(d && n_batches && B >= 1, "bad plan arguments");
+    if (d->batch_size != B) { d->pend_user.clear(); d->pend_k.clear(); d->batch_size = B; }
+    std::vector<int> pu(B), pk(B);
+    int np = (int)d->pend_user.size();
+    std::copy(d->pend_user.begin(), d->pend_user.end(), pu.begin());
+    std::copy(d->pend_k.begin(), d->pend_k.end(), pk.begin());
+    const size_t cap = (size_t)d->n_users + np + 1;
+    d->seg_user.resize(cap); d->seg_k.resize(cap); d->seg_row0.resize(cap); d->seg_batch.resize(cap);
+    int64_t ns = 0, nb = 0;
+    const int rc = sbr_plan_pass_host(d->len.data(), order, d->n_users, B, pu.data(), pk.data(), &np, d->seg_user.data(),
+                                      d->seg_k.data(), d->seg_row0.data(), d->seg_batch.data(), &ns, &nb);
+    if (rc != SBR_OK) return rc;
+    d->pend_user.assign(pu.begin(), pu.begin() + np); d->pend_k.assign(pk.begin(), pk.begin() + np);
+    d->seg_user.resize(ns); d->seg_k.resize(ns); d->seg_row0.resize(ns); d->seg_batch.resize(ns);
+    d->batch_begin.assign(nb + 1, 0);
+    for (int64_t s = 0; s < ns; ++s) d->batch_begin[d->seg_batch[s] + 1] = (int)s + 1;
+    for (int64_t b = 1; b <= nb; ++b) d->batch_begin[b] = std::max(d->batch_begin[b], d->batch_begin[b - 1]);
+    // the previous plan may still be read by batches in flight on the stream: order the uploads behind them
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    int r;
+    if ((r = upload(&d->d_seg_user, &d->cap_su, d->seg_user, d->stream)) != SBR_OK) return r;
+    if ((r = upload(&d->d_seg_k, &d->cap_sk, d->seg_k, d->stream)) != SBR_OK) return r;
+    if ((r = upload(&d->d_seg_row0, &d->cap_sr, d->seg_row0, d->stream)) != SBR_OK) return r;
+    if ((r = upload(&d->d_batch_begin, &d->cap_bb, d->batch_begin, d->stream)) != SBR_OK) return r;
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    d->n_batches = nb; *n_batches = nb;
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_plan_segments(sbr_dataset* d, int64_t* n_segments, const int32_t** seg_user, const int32_t** seg_k,
+                                         const int32_t** seg_row0, const int32_t** seg_batch) {
+    CHECK_ARG(d && n_segments, "null argument");
+    *n_segments = (int64_t)d->seg_user.size();
+    if (seg_user) *seg_user = d->seg_user.data();
+    if (seg_k) *seg_k = d->seg_k.data();
+    if (seg_row0) *seg_row0 = d->seg_row0.data();
+    if (seg_batch) *seg_batch = d->seg_batch.data();
+    return SBR_OK;
+}
+
+extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uint64_t seed) {
+    CHECK_ARG(h && d, "null handle / dataset");
+    const Layout& y = h->lay;
+    CHECK_ARG(y.F == 1, "the native batch builder covers one index per step (no --rf/--mf/--uf features)");
+    CHECK_ARG(d->n_items == y.N && y.cfg.input_size == y.N, "dataset has %d items, the model %d", d->n_items, y.N);
+    CHECK_ARG(d->batch_size == y.Bg, "the pass was planned for batches of %d rows, the model's global batch is %d", d->batch_size, y.Bg);
+    CHECK_ARG(batch >= 0 && batch < d->n_batches, "batch %lld outside the planned pass [0,%lld)", (long long)batch, (long long)d->n_batches);
+    CHECK_ARG(d->stream == h->stream, "dataset and engine must share one stream");
+    hipStream_t s = h->stream;
+    if ((size_t)y.Bg > d->cap_rows) {
+        (void)hipFree(d->d_split); (void)hipFree(d->d_rowuser); d->d_split = d->d_rowuser = nullptr;
+        SBR_HIP(hipMalloc(&d->d_split, (size_t)y.Bg * sizeof(int)));
+        SBR_HIP(hipMalloc(&d->d_rowuser, (size_t)y.Bg * sizeof(int)));
+        d->cap_rows = y.Bg;
+    }
+    const int sb = d->batch_begin[batch], se = d->batch_begin[batch + 1];
+    const unsigned long long sd = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(batch + 1));
+    bb_split_kernel<<<se - sb, 256, 0, s>>>(d->d_off, d->d_seg_user, d->d_seg_k, d->d_seg_row0, sb, sd, d->d_split, d->d_rowuser);
+    SBR_LAUNCH(hipGetLastError());
+    const bool sampled = y.S > 0;
+    const int tgt_rows = sampled ? y.Bg : y.B, tgt_offset = sampled ? 0 : y.cfg.row_offset;
+    const int extra = (tgt_rows + 63) / 64 + (y.S + 63) / 64;
+    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(d->d_items, d->d_off, d->d_split, d->d_rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
+                                                y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, (int*)h->A(y.a_X),
+                                                (int*)h->A(y.a_len), (int*)h->A(y.a_tgt), h->A(y.a_pop), (int*)h->A(y.a_smp));
+    SBR_LAUNCH(hipGetLastError());
+    h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);
+    h->bsmp = (const int*)h->A(y.a_smp); h->bpop = h->A(y.a_pop);
+    h->n_rows = y.B; h->have_batch = true; h->fwd_done = false;
+    return SBR_OK;
+}

@@ -118,6 +118,10 @@ void sbr_set_error(const char* fmt, ...);
 #define SBR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
 
+#define CHECK_ARG(cond, ...) do { if (!(cond)) { sbr_set_error(__VA_ARGS__); return SBR_EINVAL; } } while (0)
+#define SBR_LAUNCH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
+
 // ---------------------------------------------------------------------------------------
 // Kernel launchers (each returns hipGetLastError())
 // ---------------------------------------------------------------------------------------

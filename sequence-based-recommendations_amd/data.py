@@ -68,6 +68,73 @@ class SequenceGenerator(object):
                 yield sequence, self.users[li]
 
 
+class NativeBatchBuilder(object):
+    """Training batches built on the device (sbr_dataset_* / sbr_build_batch in include/sbr_rnn.h):
+    the stand-in for `_gen_mini_batch(sequence_noise(dataset.training_set()))` + `_prepare_input`
+    (rnn_base.py:373-420, rnn_one_hot.py:83-106, rnn_sampling.py:159-194) under the default training options.
+
+    The training file is parsed once (SequenceGenerator.load) and uploaded as CSR.  Per pass the users are walked in
+    file order, or reshuffled like data_handling.py:139-141 with --tshuffle; the walk prints the reference's
+    "Opening file (n)" line and keeps `training_set.epochs` (the fractional pass counter the training loop records,
+    rnn_base.py:312) up to date per batch.  `next()` makes the next batch the engine's current batch."""
+
+    def __init__(self, engine, training_set, n_items, batch_size, pop_db=None, sample_cdf=None, seed=None):
+        from .engine import DeviceDataset
+        if not hasattr(training_set, "users"):
+            training_set.load()
+        self.engine, self.ts, self.batch_size = engine, training_set, int(batch_size)
+        lengths = np.array([len(x) for x in training_set.items], dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        items = np.concatenate(training_set.items).astype(np.int32) if len(lengths) else np.zeros(0, np.int32)
+        self.ds = DeviceDataset(engine, items, offsets, n_items)
+        self.ds.set_tables(pop_db, sample_cdf)
+        self.n_users = len(lengths)
+        self.seed = int(seed if seed is not None else random.getrandbits(63))
+        self.passes, self.cursor, self.n_batches, self.built = 0, 0, 0, 0
+        self._frac = np.zeros(0)
+
+    def _plan(self):
+        self.passes += 1
+        print("Opening file ({})".format(self.passes))
+        order = None
+        if self.ts.shuffle:
+            random.shuffle(self.ts.order)
+            order = np.asarray(self.ts.order, dtype=np.int32)
+        self.n_batches = self.ds.plan_pass(order, self.batch_size)
+        seg = self.ds.segments()
+        # fraction of the pass consumed when batch b is complete: position of its last user in the walk
+        pos = np.empty(self.n_users, dtype=np.int64)
+        pos[np.arange(self.n_users) if order is None else order] = np.arange(self.n_users)
+        self._frac = np.zeros(self.n_batches)
+        if len(seg):
+            last_user = np.zeros(self.n_batches, dtype=np.int64)
+            last_user[seg[:, 3]] = seg[:, 0]               # later segments of a batch overwrite earlier ones
+            self._frac = pos[last_user] / float(max(1, self.n_users))
+        self.cursor = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        guard = 0
+        while self.cursor >= self.n_batches:
+            self._plan()
+            guard += 1
+            if guard > 4 + self.batch_size:      # no pass can complete a batch: nothing to train on
+                raise StopIteration
+        b = self.cursor
+        self.engine.build_batch(self.ds, b, self.seed + self.built)
+        self.cursor += 1
+        self.built += 1
+        self.ts.epochs = self.passes - 1 + float(self._frac[b])
+        return b
+
+    next = __next__
+
+    def close(self):
+        self.ds.close()
+
+
 class DataHandler(object):
     """Directory resolver + `stats` loader + item popularity cache (data_handling.py:12-102)."""
 

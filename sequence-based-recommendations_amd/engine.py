@@ -46,7 +46,9 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_param_shape", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
            "sbr_train_step", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
-           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times"]
+           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times",
+           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_plan_pass",
+           "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
 _lib = None
 
@@ -85,6 +87,15 @@ def load_library(path=None):
     lib.sbr_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_size_t]
     lib.sbr_enable_timing.argtypes = [vp, ctypes.c_int]
     lib.sbr_phase_times.argtypes = [vp, f32p]
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]
+    lib.sbr_dataset_destroy.argtypes = [vp]
+    lib.sbr_dataset_set_tables.argtypes = [vp, vp, vp]
+    lib.sbr_dataset_plan_pass.argtypes = [vp, vp, ctypes.c_int32, i64p]
+    lib.sbr_dataset_plan_segments.argtypes = [vp, i64p, ctypes.POINTER(i32p), ctypes.POINTER(i32p), ctypes.POINTER(i32p),
+                                              ctypes.POINTER(i32p)]
+    lib.sbr_plan_pass_host.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, i32p, vp, vp, vp, vp, i64p, i64p]
+    lib.sbr_build_batch.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_uint64]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -102,6 +113,79 @@ def mask_to_lengths(mask):
     if not np.array_equal(mask != 0, np.arange(mask.shape[1])[None, :] < lengths[:, None]):
         raise ValueError("mask must be a left-aligned prefix mask (rows of ones followed by zeros)")
     return lengths
+
+
+def plan_pass_host(lengths, order, batch_size, pending=None, lib=None):
+    """The batch plan of one pass over the users (sbr_plan_pass_host; no GPU needed): which user contributes how many
+    rows to which batch, exactly as the reference fills its batches (rnn_base.py:394-415).
+    Returns (segments, n_batches, pending): segments = int array (n, 4) of (user, k, first_row, batch) for the complete
+    batches; pending = [(user, k), ...] of the trailing partial batch, to be passed to the next pass."""
+    lib = lib or load_library()
+    lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    order_a = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
+    pending = list(pending or [])
+    pu, pk = np.zeros(batch_size, np.int32), np.zeros(batch_size, np.int32)
+    for i, (u, k) in enumerate(pending):
+        pu[i], pk[i] = u, k
+    npend = ctypes.c_int32(len(pending))
+    cap = n + len(pending) + 1
+    su, sk, sr, sb = (np.zeros(cap, np.int32) for _ in range(4))
+    ns, nb = ctypes.c_int64(), ctypes.c_int64()
+    rc = lib.sbr_plan_pass_host(lengths.ctypes.data, None if order_a is None else order_a.ctypes.data, n, batch_size,
+                                pu.ctypes.data, pk.ctypes.data, ctypes.byref(npend), su.ctypes.data, sk.ctypes.data,
+                                sr.ctypes.data, sb.ctypes.data, ctypes.byref(ns), ctypes.byref(nb))
+    if rc != 0:
+        raise ValueError(lib.sbr_last_error().decode("utf-8", "replace"))
+    seg = np.stack([su[:ns.value], sk[:ns.value], sr[:ns.value], sb[:ns.value]], axis=1)
+    return seg, nb.value, [(int(pu[i]), int(pk[i])) for i in range(npend.value)]
+
+
+class DeviceDataset(object):
+    """The training sequences in HBM (CSR) + the per-pass batch plan (sbr_dataset_* in include/sbr_rnn.h)."""
+
+    def __init__(self, engine, items, offsets, n_items):
+        self.engine, self.lib = engine, engine.lib
+        items = np.ascontiguousarray(items, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.n_users, self.n_batches = len(offsets) - 1, 0
+        d = ctypes.c_void_p()
+        with engine.torch.cuda.device(engine.device):
+            engine._check(self.lib.sbr_dataset_create(items.ctypes.data, offsets.ctypes.data, self.n_users, int(n_items),
+                                                      ctypes.c_void_p(engine.stream.cuda_stream), ctypes.byref(d)))
+        self.d = d
+
+    def set_tables(self, pop_db=None, sample_cdf=None):
+        a = None if pop_db is None else np.ascontiguousarray(pop_db, dtype=np.float32)
+        c = None if sample_cdf is None else np.ascontiguousarray(sample_cdf, dtype=np.float64)
+        self.engine._check(self.lib.sbr_dataset_set_tables(self.d, None if a is None else a.ctypes.data,
+                                                           None if c is None else c.ctypes.data))
+
+    def plan_pass(self, order, batch_size):
+        o = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
+        nb = ctypes.c_int64()
+        self.engine._check(self.lib.sbr_dataset_plan_pass(self.d, None if o is None else o.ctypes.data, int(batch_size),
+                                                          ctypes.byref(nb)))
+        self.n_batches = nb.value
+        return nb.value
+
+    def segments(self):
+        n = ctypes.c_int64()
+        ptrs = [ctypes.POINTER(ctypes.c_int32)() for _ in range(4)]
+        self.engine._check(self.lib.sbr_dataset_plan_segments(self.d, ctypes.byref(n), *[ctypes.byref(p) for p in ptrs]))
+        return np.stack([np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+                         for p in ptrs], axis=1)
+
+    def close(self):
+        if getattr(self, "d", None):
+            self.lib.sbr_dataset_destroy(self.d)
+            self.d = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class RNNEngine(object):
@@ -202,6 +286,24 @@ class RNNEngine(object):
         for i, a in enumerate(arrays):
             arr[i] = a.ctypes.data
         return arr
+
+    def build_batch(self, dataset, batch, seed):
+        """Native batch builder: planned batch `batch` of `dataset` becomes the current batch (no host arrays)."""
+        self._check(self.lib.sbr_build_batch(self.h, dataset.d, int(batch), ctypes.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    def current_batch(self):
+        """Host copies of the current batch held in the engine's own buffers (tests/tooling):
+        X (B,T), lengths (B,), target, pop (B,), samples (S,)."""
+        out = {}
+        for name, rows in (("X", self.local_batch * self.max_length * self.n_feat), ("lengths", self.local_batch),
+                           ("target", self.batch_size if self.n_samples else self.local_batch), ("pop", self.local_batch),
+                           ("samples", self.n_samples)):
+            if rows == 0:
+                continue
+            buf = self.debug_buffer("batch_" + name)[:rows]
+            out[name] = buf if name == "pop" else buf.view(np.int32)
+        out["X"] = out["X"].reshape(self.local_batch, self.max_length, self.n_feat)
+        return out
 
     def section(self, which):
         """torch view of a flat arena section: 'params', 'grads' (last element = cost), 'state'.

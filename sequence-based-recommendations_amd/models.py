@@ -230,7 +230,8 @@ class RNNBase(object):
         iterations, epochs_offset = 0, 0
         if load_last_model:
             epochs_offset = self.load_last(save_dir)
-        batch_generator = self._gen_mini_batch(self.sequence_noise(dataset.training_set()))
+        native = self._native_batch_builder(dataset)
+        batch_generator = native if native is not None else self._gen_mini_batch(self.sequence_noise(dataset.training_set()))
         start_time = time()
         next_save = int(progress)
         train_costs, current_train_cost, epochs = [], [], []
@@ -240,7 +241,7 @@ class RNNBase(object):
             while time() - start_time < max_time and iterations < max_iter:
                 try:
                     batch = next(batch_generator)
-                    cost = self.train_function(*batch)
+                    cost = self.engine.train_step() if native is not None else self.train_function(*batch)
                     if np.isnan(cost):
                         raise ValueError("Cost is NaN")
                 except StopIteration:
@@ -284,6 +285,22 @@ class RNNBase(object):
         best_run = int(np.argmax(np.array(metrics[validation_metrics[0]]) * self.metrics[validation_metrics[0]]["direction"]))
         # the reference raises KeyError here when the best run was not saved (--save None): return None instead
         return ({m: metrics[m][best_run] for m in self.metrics.keys()}, time() - start_time, filename.get(best_run))
+
+    def _native_batch_builder(self, dataset):
+        """Device-side batch builder when the options are the defaults it covers (one item index per step, next-item
+        target, no sequence noise); None -> the reference-style host generator.  SBR_NATIVE_BATCHES=0 disables it."""
+        if os.environ.get("SBR_NATIVE_BATCHES", "1") == "0":
+            return None
+        ts = self.target_selection
+        if self._input_size() != 1 or self.sequence_noise.name != "" or ts.n_targets != 1 or ts.shuffle or ts.bias >= 0.0:
+            return None
+        from .data import NativeBatchBuilder
+        pop = np.asarray(dataset.item_popularity, dtype=np.float64)
+        db = float(getattr(self, "diversity_bias", 0.0))
+        sb = float(getattr(self, "sampling_bias", 0.0))
+        cdf = np.cumsum(np.power(pop, sb)) if (sb > 0.0 and getattr(self, "effective_sampling", 0)) else None
+        return NativeBatchBuilder(self.engine, dataset.training_set, self.n_items, self.batch_size,
+                                  pop_db=np.power(pop, db).astype(np.float32), sample_cdf=cdf)
 
     def _compute_validation_metrics(self, metrics):
         from .data import Evaluator

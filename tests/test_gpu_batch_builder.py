@@ -1,0 +1,152 @@
+"""GPU tests of the native batch builder (sbr_dataset_* / sbr_build_batch): every built batch is
+checked against the reference's batch semantics (rnn_base.py:394-415, rnn_one_hot.py:83-106, rnn_sampling.py:159-194)
+on data whose item ids encode (user, position), and the split-point / negative-sample distributions against the laws
+the reference draws from (random.sample, np.random.choice, bisect over cumsum(pop**bias))."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def encoded_dataset(lengths):
+    """items[u][p] = 1 + u * 64 + p : a row's target reveals (user, split point)."""
+    items = [1 + u * 64 + np.arange(L) for u, L in enumerate(lengths)]
+    offsets = np.concatenate([[0], np.cumsum(lengths)])
+    return np.concatenate(items).astype(np.int32), offsets.astype(np.int64), 1 + 64 * len(lengths)
+
+
+def make(lengths, B, T, loss="CCE", S=0, local_batch=None, row_offset=0):
+    from sbr_amd.engine import RNNEngine, DeviceDataset
+    items, offsets, n_items = encoded_dataset(lengths)
+    eng = RNNEngine(cell="GRU", layers=[16], n_items=n_items, max_length=T, batch_size=B, loss=loss, n_samples=S,
+                    local_batch=local_batch, row_offset=row_offset)
+    return eng, DeviceDataset(eng, items, offsets, n_items), items, offsets
+
+
+def check_batch(cur, seg_rows, items, offsets, lengths, T, pop_db=None, row_offset=0):
+    """seg_rows: the plan's (user, k, row0) for this batch."""
+    X, lens, tgt, pop = cur["X"][:, :, 0], cur["lengths"], cur["target"], cur["pop"]
+    want_user = np.concatenate([[u] * k for u, k, _ in seg_rows])
+    B = len(lens)
+    for b in range(B):
+        g = row_offset + b
+        u, l = (tgt[b] - 1) // 64, (tgt[b] - 1) % 64
+        assert u == want_user[g]
+        assert 2 <= l < lengths[u]                                            # random.sample(range(2, len), k)
+        start = max(0, l - T)
+        seq = items[offsets[u]:offsets[u + 1]]
+        assert lens[b] == l - start
+        assert np.array_equal(X[b, :lens[b]], seq[start:l]) and not X[b, lens[b]:].any()
+        assert pop[b] == (1.0 if pop_db is None else pop_db[tgt[b]])
+    ls = (tgt - 1) % 64
+    for u, k, r0 in seg_rows:                                                 # sorted, distinct within a user
+        seg = ls[max(r0 - row_offset, 0):max(r0 + k - row_offset, 0)]
+        assert np.all(np.diff(seg) > 0)
+
+
+def test_built_batches_follow_the_reference_semantics():
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(1, 40, size=60)
+    lengths[5], lengths[17] = 2, 63
+    B, T = 32, 10
+    eng, ds, items, offsets = make(lengths, B, T)
+    pop_db = rng.uniform(0.5, 2.0, size=1 + 64 * len(lengths)).astype(np.float32)
+    ds.set_tables(pop_db, None)
+    order = rng.permutation(len(lengths)).astype(np.int32)
+    nb = ds.plan_pass(order, B)
+    seg = ds.segments()
+    assert nb >= 5
+    for b in range(nb):
+        eng.build_batch(ds, b, seed=1234 + b)
+        rows = [(int(u), int(k), int(r0)) for u, k, r0, bb in seg if bb == b]
+        check_batch(eng.current_batch(), rows, items, offsets, lengths, T, pop_db)
+    # the same (batch, seed) rebuilds the same batch; another seed another one
+    eng.build_batch(ds, 0, seed=7); a = eng.current_batch()["target"].copy()
+    eng.build_batch(ds, 0, seed=7); assert np.array_equal(a, eng.current_batch()["target"])
+    eng.build_batch(ds, 0, seed=8); assert not np.array_equal(a, eng.current_batch()["target"])
+    with pytest.raises(ValueError):
+        eng.build_batch(ds, nb, seed=0)                                       # outside the planned pass
+    ds.close(); eng.close()
+
+
+def test_split_points_are_uniform_without_replacement():
+    # one user of 34 items fills the batch alone: k = 8 of the 32 candidates {2..33}; every candidate must come up
+    # with probability k/n, pairs never repeat inside a batch (checked above), chi-square against the uniform law
+    lengths = [34]
+    B, T, n_draws = 8, 6, 1500
+    eng, ds, items, offsets = make(lengths, B, T)
+    ds.plan_pass(None, B)
+    counts = np.zeros(34)
+    for i in range(n_draws):
+        eng.build_batch(ds, 0, seed=99 + i)
+        counts[(eng.current_batch()["target"] - 1) % 64] += 1
+    assert counts[:2].sum() == 0 and counts.sum() == n_draws * B
+    exp = n_draws * B / 32.0
+    chi2 = ((counts[2:] - exp) ** 2 / exp).sum()
+    assert chi2 < 70.0, chi2                                                   # 31 dof: p(chi2 > 70) ~ 1e-4
+    ds.close(); eng.close()
+
+
+def test_negative_samples_follow_uniform_and_popularity_laws():
+    lengths = [20] * 8
+    B, T, S = 16, 6, 64
+    eng, ds, items, offsets = make(lengths, B, T, loss="BPR", S=S)
+    n_items = 1 + 64 * len(lengths)
+    ds.plan_pass(None, B)
+    got = []
+    for i in range(300):
+        eng.build_batch(ds, 0, seed=5 + i)
+        cur = eng.current_batch()
+        got.append(cur["samples"].copy())
+        assert len(cur["target"]) == B                                         # sampled heads: all global rows
+    got = np.concatenate(got)
+    assert got.min() >= 0 and got.max() < n_items
+    h = np.bincount(got, minlength=n_items)
+    exp = len(got) / n_items
+    assert ((h - exp) ** 2 / exp).sum() < n_items + 6 * np.sqrt(2 * n_items)   # uniform: np.random.choice(n_items, S)
+    # popularity ** sampling_bias by inverse CDF (rnn_sampling.py:159-163): mass only where popularity > 0
+    pop = np.zeros(n_items); pop[10:20] = np.arange(1, 11)
+    ds.set_tables(None, np.cumsum(pop ** 0.5))
+    got = []
+    for i in range(300):
+        eng.build_batch(ds, 0, seed=1000 + i)
+        got.append(eng.current_batch()["samples"].copy())
+    got = np.concatenate(got)
+    assert got.min() >= 10 and got.max() < 20
+    freq = np.bincount(got, minlength=n_items)[10:20] / len(got)
+    want = pop[10:20] ** 0.5 / (pop[10:20] ** 0.5).sum()
+    assert np.abs(freq - want).max() < 0.02
+    ds.close(); eng.close()
+
+
+def test_data_parallel_ranks_build_their_rows_of_the_same_global_batch():
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(3, 30, size=40)
+    B, T = 32, 8
+    full, dsf, items, offsets = make(lengths, B, T)
+    dsf.plan_pass(None, B)
+    full.build_batch(dsf, 1, seed=42)
+    whole = full.current_batch()
+    for r in range(2):
+        eng, ds, _, _ = make(lengths, B, T, local_batch=16, row_offset=16 * r)
+        ds.plan_pass(None, B)
+        eng.build_batch(ds, 1, seed=42)
+        part = eng.current_batch()
+        for k in ("X", "lengths", "target", "pop"):
+            assert np.array_equal(part[k], whole[k][16 * r:16 * (r + 1)]), k
+        ds.close(); eng.close()
+    dsf.close(); full.close()
+
+
+def test_training_from_native_batches_matches_host_batches_in_quality(tmp_path, monkeypatch):
+    # same synthetic rule-following dataset as test_gpu_train_cli: both builders must learn it
+    from test_gpu_train_cli import make_dataset
+    from sbr_amd import train as Tr
+    res = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("SBR_NATIVE_BATCHES", native)
+        root = make_dataset(str(tmp_path / ("ds" + native)), n_users=120)
+        metrics, _, _ = Tr.main(["-d", root, "-b", "16", "--max_length", "12", "--max_iter", "400", "--progress", "400",
+                                 "--save", "None", "--r_t", "GRU", "--r_l", "32", "--u_l", "0.01"])
+        res[native] = metrics["sps"]
+    assert res["1"] > 0.2 and res["0"] > 0.2, res

@@ -222,3 +222,59 @@ def test_data_handler_reads_the_preprocess_format(tmp_path):
     assert list(dh.item_popularity) == [1, 1, 2, 1]
     seqs = list(dh.training_set(epochs=1))
     assert seqs[0] == ([[1, 4.0], [2, 3.5], [3, 5.0]], "0") and seqs[1][1] == "1"
+
+
+def _host_segments(lengths, order, B, n_batches):
+    """(user, k) per batch as the reference-style generator produces them: item ids encode (user, position)."""
+    from sbr_amd.models import RNNOneHot
+    m = _model(RNNOneHot, max_length=6, batch_size=B)
+    m.n_items = 10 ** 7
+
+    def gen():
+        while True:
+            for u in order:
+                if lengths[u] >= 2:
+                    yield [[u * 1000 + p, 3.0] for p in range(lengths[u])], str(u)
+    m._prepare_input = lambda sequences: [(int(uid), tgt[0][0] % 1000) for uid, _, tgt in sequences]
+    g = m._gen_mini_batch(gen())
+    out = []
+    for b in range(n_batches):
+        rows = next(g)
+        assert len(rows) == B
+        segs = []
+        for u, l in rows:
+            if segs and segs[-1][0] == u:
+                assert l > segs[-1][2]                       # sorted distinct split points within a user
+                segs[-1] = (u, segs[-1][1] + 1, l)
+            else:
+                segs.append((u, 1, l))
+        out.append([(u, k) for u, k, _ in segs])
+    return out
+
+
+@pytest.mark.parametrize("B,seed", [(7, 0), (16, 1), (5, 2)])
+def test_native_batch_plan_equals_the_reference_fill_order(lib, B, seed):
+    # rnn_base.py:394-415: users in order, k = min(B - j, len - 2), overflowing users truncated, len-2 users consumed
+    # without rows; the partial batch at the end of a pass continues with the first users of the next pass
+    from sbr_amd.engine import plan_pass_host
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(1, 14, size=23)
+    lengths[3], lengths[11] = 2, 40                           # a 2-item user (no rows), one that fills several batches alone
+    order = list(rng.permutation(len(lengths)))
+    pending, got = [], []
+    for _ in range(3):                                        # three passes with carry-over
+        seg, nb, pending = plan_pass_host(lengths, order, B, pending, lib=lib)
+        for b in range(nb):
+            rows = seg[seg[:, 3] == b]
+            assert rows[:, 1].sum() == B and list(rows[:, 2]) == list(np.cumsum(np.r_[0, rows[:-1, 1]]))
+            got.append([(int(u), int(k)) for u, k in rows[:, :2]])
+    want = _host_segments(lengths, order, B, len(got))
+    assert got == want
+
+
+def test_native_batch_plan_rejects_bad_arguments(lib):
+    from sbr_amd.engine import plan_pass_host
+    with pytest.raises(ValueError):
+        plan_pass_host([5, 6], [0, 7], 4, lib=lib)            # user id out of range
+    seg, nb, pend = plan_pass_host([1, 2, 2], None, 4, lib=lib)    # nothing long enough: no rows at all
+    assert len(seg) == 0 and nb == 0 and pend == []
