@@ -286,6 +286,27 @@ class RNNBase(object):
         # the reference raises KeyError here when the best run was not saved (--save None): return None instead
         return ({m: metrics[m][best_run] for m in self.metrics.keys()}, time() - start_time, filename.get(best_run))
 
+    def batched_test_predictions(self, sequence_generator, k=10):
+        """Batched form of the reference's per-user validation loop (rnn_base.py:358-371): the same
+        test instances `_gen_mini_batch(..., test=True)` yields one by one (split in the middle, last max_length items
+        in, the rest as goal) are stacked batch_size at a time and ranked by one test_function call -- rows are
+        independent in every kernel, so the ordered top-k ids are identical to the one-row calls.
+        Yields (goals, ids) per chunk in the generator's order."""
+        Xs, masks, goals = [], [], []
+
+        def flush():
+            ids = self.engine.test_function((np.concatenate(Xs), np.concatenate(masks)), k=k,
+                                            exclude_seen=self.interactions_are_unique)
+            out = (list(goals), [ids[i] for i in range(len(goals))])
+            del Xs[:], masks[:], goals[:]
+            return out
+        for batch_input, goal in self._gen_mini_batch(sequence_generator, test=True):
+            Xs.append(batch_input[0]); masks.append(batch_input[1]); goals.append(goal)
+            if len(goals) == self.batch_size:
+                yield flush()
+        if goals:
+            yield flush()
+
     def _native_batch_builder(self, dataset):
         """Device-side batch builder when the options are the defaults it covers (one item index per step, next-item
         target, no sequence noise); None -> the reference-style host generator.  SBR_NATIVE_BATCHES=0 disables it."""
@@ -305,8 +326,9 @@ class RNNBase(object):
     def _compute_validation_metrics(self, metrics):
         from .data import Evaluator
         ev = Evaluator(self.dataset, k=10)
-        for batch_input, goal in self._gen_mini_batch(self.dataset.validation_set(epochs=1), test=True):
-            ev.add_instance(goal, self.test_function(batch_input))
+        for goals, ids in self.batched_test_predictions(self.dataset.validation_set(epochs=1), k=10):
+            for goal, row in zip(goals, ids):
+                ev.add_instance(goal, row)
         metrics["recall"].append(ev.average_recall())
         metrics["sps"].append(ev.sps())
         metrics["ndcg"].append(ev.average_ndcg())

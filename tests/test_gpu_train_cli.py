@@ -77,3 +77,29 @@ def test_training_learns_the_synthetic_rule(tmp_path):
     metrics, _, _ = T.main(["-d", root, "-b", "16", "--max_length", "12", "--max_iter", "400", "--progress", "400",
                             "--save", "None", "--r_t", "GRU", "--r_l", "32", "--u_l", "0.01"])
     assert metrics["sps"] > 0.2          # items follow "+2 or +3": far above the 10/30 chance level of sps@10... with k=10
+
+
+def test_batched_validation_ranks_exactly_like_one_row_calls(tmp_path):
+    # the validation pass stacks batch_size users per test_function call; ordered top-k ids and all
+    # six metrics must equal the reference-style one-user-at-a-time loop (rnn_base.py:358-371)
+    from sbr_amd import options as parse, train as T
+    from sbr_amd.data import DataHandler, Evaluator
+    root = make_dataset(str(tmp_path / "ds"), n_users=60)
+    argv = ["-d", root, "-b", "8", "--max_length", "10", "--r_t", "GRU", "--r_l", "16"]
+    args = parse.command_parser(parse.predictor_command_parser, parse.training_command_parser, T.early_stopping_command_parser, argv=argv)
+    predictor = parse.get_predictor(args)
+    dataset = DataHandler(dirname=root)
+    predictor.prepare_model(dataset)
+    predictor.train(dataset, max_iter=30, progress=10 ** 9, autosave="None")
+    one, ev1 = [], Evaluator(dataset, k=10)
+    for batch_input, goal in predictor._gen_mini_batch(dataset.validation_set(epochs=1), test=True):
+        ids = predictor.test_function(batch_input)
+        one.append(list(ids)); ev1.add_instance(goal, ids)
+    many, ev2 = [], Evaluator(dataset, k=10)
+    for goals, ids in predictor.batched_test_predictions(dataset.validation_set(epochs=1), k=10):
+        for goal, row in zip(goals, ids):
+            many.append(list(row)); ev2.add_instance(goal, row)
+    assert len(one) == 8 and one == many
+    for m in ("average_recall", "sps", "average_ndcg", "user_coverage", "item_coverage", "blockbuster_share"):
+        assert getattr(ev1, m)() == getattr(ev2, m)()
+    predictor.engine.close()
