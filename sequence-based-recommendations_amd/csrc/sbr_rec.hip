@@ -874,52 +874,65 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
     unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
     if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
 
-    for (int t = 0; t < T; ++t) {
-        if (a.prof) p_ta = clock64();
-        float sv[4];
-        if (t < tmax) {                                           // workgroup-uniform
-            load_x(t + 1, id_next, xn);
-            id_nn = load_id(t + 2);
-            const char* hb = hbuf + (size_t)(t & 1) * 3 * PLANEB + r * HROW + q * 16;
-            f32x4 acc[G];
+    // The values a step saves for BPTT (gate activations, h_t, c_t) are stored from INSIDE the next step's MFMA
+    // stream (after its first k-block): address math and store issue then hide under the matrix pipe instead of
+    // sitting between the barrier and the first MFMA (~650 cycles per step measured).  h / cst / sv still hold
+    // step t-1's values there: the gate math that overwrites them comes after the MFMA loop.
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store_step = [&](int t) {
+        if (CELL != CELL_VANILLA) {
+            const size_t o = gate_index(t, row, u, Bp, HP);
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = f32x4{0, 0, 0, 0};
-            bf16x8 hp[2][3], wp[2][G];
-            auto load_ops = [&](int kb, int s) {
-                hp[s][0] = *(const bf16x8*)(hb + kb * 64);
-                hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
-                hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
-#pragma unroll
-                for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16);
-            };
-            load_ops(0, 0);
-            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const int s = kb & 1;
-                if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_nop 15");                             // MFMA D -> VALU read hazard (see rec_fwd_mfma)
-            __builtin_amdgcn_s_setprio(3);
-            float as[G], xb[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { as[g] = pick4(acc[g], c); xb[g] = x[g] + bias[g]; }
-            cell_forward<CELL, true>(xb, as, t < mylen, h, cst, pi, pf, po, sv);
+            for (int k = 0; k < 4; ++k) a.g[k][o] = sv[k];
         }
+        const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
+        a.hs[o] = h;
+        if (CELL == CELL_LSTM) a.cs[o] = cst;
+    };
+    for (int t = 0; t < tmax; ++t) {                              // tmax is workgroup-uniform
+        if (a.prof) p_ta = clock64();
+        load_x(t + 1, id_next, xn);
+        id_nn = load_id(t + 2);
+        const char* hb = hbuf + (size_t)(t & 1) * 3 * PLANEB + r * HROW + q * 16;
+        f32x4 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = f32x4{0, 0, 0, 0};
+        bf16x8 hp[2][3], wp[2][G];
+        auto load_ops = [&](int kb, int s) {
+            hp[s][0] = *(const bf16x8*)(hb + kb * 64);
+            hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
+            hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+#pragma unroll
+            for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb == 0 && t > 0) { store_step(t - 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard (see rec_fwd_mfma)
+        __builtin_amdgcn_s_setprio(3);
+        float as[G], xb[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { as[g] = pick4(acc[g], c); xb[g] = x[g] + bias[g]; }
+        cell_forward<CELL, true>(xb, as, t < mylen, h, cst, pi, pf, po, sv);
         if (t + 1 < tmax) {
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = xn[g];
@@ -929,12 +942,9 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
             __syncthreads();
             if (a.prof) p_bar += clock64() - p_ta;
         }
-        // this step's stores are issued AFTER the barrier (see rec_fwd_x6)
-        if (CELL != CELL_VANILLA && t < tmax) {
-            const size_t o = gate_index(t, row, u, Bp, HP);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a.g[k][o] = sv[k];
-        }
+    }
+    if (tmax > 0) store_step(tmax - 1);
+    for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
         a.hs[o] = h;
         if (CELL == CELL_LSTM) a.cs[o] = cst;
@@ -1006,57 +1016,55 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6s(RecArgs a, int dbuf) {
         }
         if (CELL == CELL_LSTM) cprev = a.cs[o];
     };
-    bool have = false;
     unsigned long long p_c0 = 0, p_r0 = 0, p_work = 0, p_bar = 0, p_ta = 0;
     if (a.prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
     __syncthreads();                                              // W plane 3 visible
 
-    for (int t = a.t_hi - 1; t >= a.t_lo; --t) {
+    const int t_live = min(a.t_hi, tmax);                         // steps [t_live, t_hi) are masked for the whole tile
+    for (int t = a.t_hi - 1; t >= max(t_live, a.t_lo); --t) {     // zero rows; dh_ext still accumulates
+        if (a.dh_ext) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = 0.f;
+        if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = 0.f;
+    }
+    if (t_live > a.t_lo) {
+        load_saved(t_live - 1);
+        const size_t o1 = ((size_t)t_live * Bp + row) * HP + u;
+        if (CELL == CELL_LSTM) cnew = a.cs[o1];
+        if (CELL == CELL_VANILLA) hnew = a.hs[o1];
+    }
+    for (int t = t_live - 1; t >= a.t_lo; --t) {
         if (a.prof) p_ta = clock64();
         if (a.dh_ext) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
-        if (t >= tmax) {                                          // whole tile masked: zero rows
-#pragma unroll
-            for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = 0.f;
-            if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = 0.f;
-            continue;
-        }
-        if (!have) {
-            load_saved(t);
-            const size_t o1 = ((size_t)(t + 1) * Bp + row) * HP + u;
-            if (CELL == CELL_LSTM) cnew = a.cs[o1];
-            if (CELL == CELL_VANILLA) hnew = a.hs[o1];
-            have = true;
-        }
         char* lds = dbufp + (size_t)(dbuf ? (t & 1) : 0) * 3 * PLANEB;
-        {
-            float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
-            cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp);
+        float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp);
 #pragma unroll
-            for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
-            sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2];
+        for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
+        sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = dxi[g];
-                if (CELL == CELL_GRU && g == 2) a.dhi[((size_t)t * Bp + row) * HP + u] = dhi[g];
-                __bf16 p1, p2, p3;
-                split3(dhi[g], p1, p2, p3);
-                char* base = lds + r * DROW + (g * HP + u) * 2;
-                *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
-            }
+        for (int g = 0; g < G; ++g) {
+            __bf16 p1, p2, p3;
+            split3(dhi[g], p1, p2, p3);
+            char* base = lds + r * DROW + (g * HP + u) * 2;
+            *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
         }
         if (CELL == CELL_LSTM) cnew = cprev;
         if (CELL == CELL_VANILLA) hnew = hprev;
-        if (t > a.t_lo) load_saved(t - 1);
+        // saved activations of step t-1: unconditional (clamped) and fenced, see sbr_rec_cl.hip on in-order vmcnt
+        __builtin_amdgcn_sched_barrier(0);
+        load_saved(t > a.t_lo ? t - 1 : t);
+        __builtin_amdgcn_sched_barrier(0);
         if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
         __syncthreads();
         if (a.prof) { const unsigned long long tc = clock64(); p_bar += tc - p_ta; p_ta = tc; }
         const char* db = lds + r * DROW + q * 16;
         f32x4 acc[3] = {z4, z4, z4};
-        bf16x8 dp[2][3], wp[2];
+        bf16x8 dpl[2][3], wp[2];
         auto load_ops = [&](int kb, int s) {
-            dp[s][0] = *(const bf16x8*)(db + kb * 64);
-            dp[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
-            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+            dpl[s][0] = *(const bf16x8*)(db + kb * 64);
+            dpl[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
+            dpl[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
             wp[s] = *(const bf16x8*)(w3 + (kb * NW + wave) * 1024 + lane * 16);
         };
         load_ops(0, 0);
@@ -1066,13 +1074,21 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6s(RecArgs a, int dbuf) {
             const int s = kb & 1;
             if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = MFMA_BF16(wp[s], dp[s][0], acc[0]);
-            acc[1] = MFMA_BF16(W1[kb], dp[s][2], acc[1]);
-            acc[2] = MFMA_BF16(W2[kb], dp[s][1], acc[2]);
-            acc[0] = MFMA_BF16(W2[kb], dp[s][0], acc[0]);
-            acc[1] = MFMA_BF16(W1[kb], dp[s][1], acc[1]);
-            acc[2] = MFMA_BF16(W1[kb], dp[s][0], acc[2]);
+            acc[0] = MFMA_BF16(wp[s], dpl[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dpl[s][2], acc[1]);
+            acc[2] = MFMA_BF16(W2[kb], dpl[s][1], acc[2]);
+            acc[0] = MFMA_BF16(W2[kb], dpl[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dpl[s][1], acc[1]);
+            acc[2] = MFMA_BF16(W1[kb], dpl[s][0], acc[2]);
             __builtin_amdgcn_sched_barrier(0);
+            if (kb == 0) {
+                // this step's outputs leave from inside the MFMA stream (see rec_fwd_x6s): off the gate-math ->
+                // publish -> barrier critical section, hidden under the matrix pipe
+#pragma unroll
+                for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = dxi[g];
+                if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = dhi[2];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
