@@ -185,13 +185,15 @@ def main():
             "rec_bwd": {"bound": "mfma", "alg": rec_flops, "unit": "TFLOP/s"},
             "scatter": {"bound": "hbm", "alg": Ltot * (row_bytes * 2 + 4), "unit": "GB/s"},      # read dxt + add row
         }
+        if eng.query("fused_gather"):      # the rows are gathered inside rec_fwd: this phase is only the gradient memset
+            del kernels["gather"]
         for k, v in kernels.items():
             us = phases[k]
             peak = HBM_PEAK_GBS if v["bound"] == "hbm" else F32_MFMA_PEAK_TFLOPS
             ach = (v["alg"] / (us * 1e-6)) / (1e9 if v["bound"] == "hbm" else 1e12) if us > 0 else 0.0
             v.update(us=round(us, 2), achieved=round(ach, 3), peak=peak, frac=round(ach / peak, 5))
             del v["alg"]
-        dom = max(("gather", "rec_fwd", "rec_bwd", "scatter"), key=lambda k: phases[k])
+        dom = max(kernels, key=lambda k: phases[k])
         d = kernels[dom]
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, gfx950 FETCH_SIZE x2 correction applied; profiles/round1_pmc.json), same config only
@@ -199,7 +201,7 @@ def main():
         try:
             if args.config == "c2" and args.lengths == "full" and B == 256 and T == 200:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))["kernels"]
-                key = {"rec_fwd": "rec_fwd_x6", "rec_bwd": "rec_bwd_x6", "gather": "gather_xt_kernel",
+                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel",
                        "scatter": "scat_reduce_kernel"}[dom]
                 traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if key in k)
         except Exception:

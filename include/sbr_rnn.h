@@ -147,6 +147,10 @@ int sbr_synchronize(sbr_handle* h);
  * handle's stream): gather, rec_fwd, output, rec_bwd, wgrad, scatter, update, total. */
 #define SBR_N_PHASES 8
 int sbr_enable_timing(sbr_handle* h, int on);
+/* Which kernels this handle's shapes select (tooling: bench.py names the kernels it prices):
+ * "fused_gather" (layer-0 input rows gathered inside the forward kernel), "rows_per_workgroup",
+ * "cluster" (multi-workgroup recurrent kernels for the top layer), "arena_bytes". */
+int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 
 /* ------------------------------------------------------------------------------------------------

@@ -723,6 +723,19 @@ extern "C" int sbr_synchronize(sbr_handle* h) {
     return SBR_OK;
 }
 
+extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
+    CHECK_ARG(h && what && value, "null argument");
+    const Layout& y = h->lay; const std::string w(what);
+    if (w == "fused_gather") {
+        RecArgs a = rec_args(h, 0);
+        *value = (y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(a, simple_rec(h))) ? 1 : 0;
+    } else if (w == "rows_per_workgroup") *value = h->rpt;
+    else if (w == "cluster") { RecArgs a = rec_args(h, y.L - 1); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
+    else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
+    else { sbr_set_error("unknown query '%s'", what); return SBR_EINVAL; }
+    return SBR_OK;
+}
+
 extern "C" int sbr_enable_timing(sbr_handle* h, int on) {
     CHECK_ARG(h, "null handle");
     if (on)

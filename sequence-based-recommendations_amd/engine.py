@@ -46,7 +46,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_param_shape", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
            "sbr_train_step", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
-           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times",
+           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
@@ -88,6 +88,7 @@ def load_library(path=None):
     lib.sbr_enable_timing.argtypes = [vp, ctypes.c_int]
     lib.sbr_phase_times.argtypes = [vp, f32p]
     i64p = ctypes.POINTER(ctypes.c_int64)
+    lib.sbr_query.argtypes = [vp, ctypes.c_char_p, i64p]
     lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]
     lib.sbr_dataset_destroy.argtypes = [vp]
     lib.sbr_dataset_set_tables.argtypes = [vp, vp, vp]
@@ -448,6 +449,11 @@ class RNNEngine(object):
         out = np.empty(n.value, dtype=np.float32)
         self._check(self.lib.sbr_copy_to_host(self.h, ptr, ctypes.c_void_p(out.ctypes.data), n.value))
         return out
+
+    def query(self, what):
+        v = ctypes.c_int64()
+        self._check(self.lib.sbr_query(self.h, what.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def synchronize(self):
         self._check(self.lib.sbr_synchronize(self.h))
