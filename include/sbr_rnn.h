@@ -126,6 +126,14 @@ int sbr_loss_backward_output(sbr_handle* h);
 int sbr_backward_recurrent(sbr_handle* h);
 int sbr_apply_update(sbr_handle* h);
 int sbr_read_cost(sbr_handle* h, float* cost_host);
+/* The phases put everything that only feeds the optimizer (output-layer weight/bias gradients, the cost, the
+ * weight-gradient kernels) on an internal side stream.  Called one by one they join it at their end so that the
+ * caller may read the gradients on `stream`.  A data-parallel driver that orders its collectives itself turns the
+ * joins off: after sbr_loss_backward_output the output-layer slice is complete ON THE SIDE STREAM (sbr_query
+ * "side_stream" returns it) -- all-reduce it from there while `stream` runs the BPTT chain -- and calls
+ * sbr_join_side before touching the rest.  sbr_apply_update always joins. */
+int sbr_set_deferred_join(sbr_handle* h, int on);
+int sbr_join_side(sbr_handle* h);
 
 /* predict_function(X, mask) (rnn_base.py:188-194) on the current batch: scores (rows,N);
  * softmax probabilities for CCE (DenseLayer softmax, rnn_one_hot.py:65), raw activations
@@ -149,7 +157,7 @@ int sbr_synchronize(sbr_handle* h);
 int sbr_enable_timing(sbr_handle* h, int on);
 /* Which kernels this handle's shapes select (tooling: bench.py names the kernels it prices):
  * "fused_gather" (layer-0 input rows gathered inside the forward kernel), "rows_per_workgroup",
- * "cluster" (multi-workgroup recurrent kernels for the top layer), "arena_bytes". */
+ * "cluster" (multi-workgroup recurrent kernels for the top layer), "arena_bytes", "side_stream" (hipStream_t). */
 int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 

@@ -235,8 +235,14 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
-    h->in_train_step = false; h->side_pending = false;
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+    h->in_train_step = false; h->side_pending = false; h->deferred_join = false;
+    // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
+    // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
+    // every "overlapped" kernel serialised: +150 us per step in the data-parallel path).  Streams of another priority
+    // level get their own queues.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_sort, hipEventDisableTiming) != hipSuccess ||
@@ -495,7 +501,14 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
     }
     mark(h, 3);
-    // called on its own (data-parallel: the caller all-reduces the output-layer gradients next): join now
+    if (h->deferred_join && !h->in_train_step) {
+        // the caller orders its collective behind the SIDE stream: make that stream also cover what this phase wrote
+        // to the output-layer gradients on the main stream (sampled heads)
+        SBR_HIP(hipEventRecord(h->ev_lg, s));
+        SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg, 0));
+        return SBR_OK;
+    }
+    // called on its own (the caller reads the output-layer gradients next): join now
     if (!h->in_train_step) return side_join(h);
     return SBR_OK;
 }
@@ -585,8 +598,18 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                    nullptr, 0, sg));
         }
     }
-    if (!h->in_train_step) return side_join(h);
+    if (!h->in_train_step && !h->deferred_join) return side_join(h);
     return SBR_OK;
+}
+
+extern "C" int sbr_set_deferred_join(sbr_handle* h, int on) {
+    CHECK_ARG(h, "null handle");
+    h->deferred_join = on != 0;
+    return SBR_OK;
+}
+extern "C" int sbr_join_side(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    return side_join(h);
 }
 
 extern "C" int sbr_apply_update(sbr_handle* h) {
@@ -732,6 +755,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
     } else if (w == "rows_per_workgroup") *value = h->rpt;
     else if (w == "cluster") { RecArgs a = rec_args(h, y.L - 1); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
+    else if (w == "side_stream") *value = (int64_t)(intptr_t)h->side;
     else { sbr_set_error("unknown query '%s'", what); return SBR_EINVAL; }
     return SBR_OK;
 }

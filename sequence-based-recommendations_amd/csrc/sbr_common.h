@@ -89,6 +89,7 @@ struct sbr_handle {
     hipEvent_t ev_sort, ev_lg, ev_chunk[SBR_BWD_CHUNKS];
     bool in_train_step;  // phases called from sbr_train_step: the side stream joins only before the update
     bool side_pending;   // side-stream work issued and not yet joined by the main stream
+    bool deferred_join;  // phases called one by one do not join the side stream (sbr_set_deferred_join)
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)

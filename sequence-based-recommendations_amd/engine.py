@@ -12,6 +12,11 @@ import os
 
 import numpy as np
 
+# HIP multiplexes streams onto this many hardware queues (default 4); the engine's side stream, torch's streams and
+# RCCL's must not pile onto one queue.  Read when the HIP runtime initialises, i.e. it only helps when this module is
+# imported before the first device call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
@@ -47,6 +52,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_train_step", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
+           "sbr_set_deferred_join", "sbr_join_side",
            "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
@@ -89,6 +95,8 @@ def load_library(path=None):
     lib.sbr_phase_times.argtypes = [vp, f32p]
     i64p = ctypes.POINTER(ctypes.c_int64)
     lib.sbr_query.argtypes = [vp, ctypes.c_char_p, i64p]
+    lib.sbr_set_deferred_join.argtypes = [vp, ctypes.c_int]
+    lib.sbr_join_side.argtypes = [vp]
     lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]
     lib.sbr_dataset_destroy.argtypes = [vp]
     lib.sbr_dataset_set_tables.argtypes = [vp, vp, vp]
@@ -449,6 +457,16 @@ class RNNEngine(object):
         out = np.empty(n.value, dtype=np.float32)
         self._check(self.lib.sbr_copy_to_host(self.h, ptr, ctypes.c_void_p(out.ctypes.data), n.value))
         return out
+
+    def set_deferred_join(self, on=True):
+        self._check(self.lib.sbr_set_deferred_join(self.h, 1 if on else 0))
+
+    def join_side(self):
+        self._check(self.lib.sbr_join_side(self.h))
+
+    def side_stream(self):
+        """torch view of the engine's internal side stream (data-parallel: collectives ordered behind it)."""
+        return self.torch.cuda.ExternalStream(self.query("side_stream"), device=self.device)
 
     def query(self, what):
         v = ctypes.c_int64()

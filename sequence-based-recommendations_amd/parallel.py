@@ -7,7 +7,9 @@ CPU tests), and every rank applies the identical optimizer step to its replica.
 Overlap: the output-layer gradients (W_out, b_out + the cost scalar that rides at the end of the
 section) are final after `loss_backward_output`, so their all-reduce is launched asynchronously
 and runs on RCCL's stream while the BPTT chain of `backward_recurrent` executes; the recurrent
-part follows.  The sampled heads need the targets of ALL rows on every rank (Blackout's softmax
+part follows.  With the HIP engine the first collective is ordered behind the engine's SIDE stream
+(where those gradients are produced), so the main stream goes straight on to the BPTT chain instead
+of waiting for them (`sbr_set_deferred_join`, include/sbr_rnn.h).  The sampled heads need the targets of ALL rows on every rank (Blackout's softmax
 spans every target column, rnn_sampling.py:68-72,137): `gather_targets` all-gathers B int32.
 
 `engine` is anything with the RNNEngine phase methods -- the CPU tests pass an oracle-backed
@@ -23,6 +25,12 @@ class DataParallel(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.grads, self.split = engine.section("grads")
+        # stream-level overlap needs the engine's side stream and device tensors (RCCL); the gloo CPU tests use a
+        # stand-in engine without either
+        self.side = None
+        if hasattr(engine, "side_stream") and getattr(self.grads, "is_cuda", False):
+            self.side = engine.side_stream()
+            engine.set_deferred_join(True)
 
     @staticmethod
     def shard(batch_size, world, rank):
@@ -44,13 +52,20 @@ class DataParallel(object):
         """One step on the batch already set on the engine; returns nothing (cost: read_cost())."""
         e = self.engine
         if self.world == 1 and not self.dist.is_initialized():
-            e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()
+            e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()   # joins inside
             return
         e.zero_grads()
         e.forward()
         e.loss_backward_output()
-        w_out = self.dist.all_reduce(self.grads[self.split:], group=self.group, async_op=True)
-        e.backward_recurrent()
+        if self.side is not None:
+            import torch
+            with torch.cuda.stream(self.side):       # RCCL waits for the side stream only; the main stream runs the chain
+                w_out = self.dist.all_reduce(self.grads[self.split:], group=self.group, async_op=True)
+            e.backward_recurrent()
+            e.join_side()                            # weight-gradient kernels of the recurrent part
+        else:
+            w_out = self.dist.all_reduce(self.grads[self.split:], group=self.group, async_op=True)
+            e.backward_recurrent()
         w_rec = self.dist.all_reduce(self.grads[:self.split], group=self.group, async_op=True)
         w_out.wait()
         w_rec.wait()
