@@ -232,6 +232,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->fuse_gather = fg ? atoi(fg) != 0 : 1;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
+    h->grads_clean = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
@@ -400,7 +401,9 @@ static inline void mark(sbr_handle* h, int i) {
 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
+    if (h->grads_clean) return SBR_OK;            // the optimizer kernel zeroes every gradient it consumes
     SBR_HIP(hipMemsetAsync(h->Gd(0), 0, (h->lay.n_params + 1) * sizeof(float), h->stream));
+    h->grads_clean = true;
     return SBR_OK;
 }
 
@@ -455,11 +458,12 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const int R = h->n_rows, Hp = y.HLp, N = y.N;
     const bool sg = simple_gemm(h);
+    h->grads_clean = false;
     float* hl = h_last(h);
     float* ws = h->A(y.a_ws);
     float* ws2 = h->A(y.a_ws2);
     const int* tgt = h->btgt;
-    SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));
+    if (R < y.Bp) SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));   // padded rows carry no gradient
     SBR_HIP(hipEventRecord(h->ev_fork, s));
     SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     h->side_pending = true;
@@ -518,6 +522,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
     if (!h->fwd_done) { sbr_set_error("sbr_backward_recurrent: call sbr_forward first"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const bool sg = simple_gemm(h);
+    h->grads_clean = false;
     float* ws = h->A(y.a_ws);
     float* ws2 = h->A(y.a_ws2);
     const int TB = y.T * y.Bp;
@@ -621,6 +626,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     SBR_LAUNCH(launch_update(h->stream, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, y.n_params, y.cfg.learning_rate,
                              y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count));
     mark(h, 7);
+    h->grads_clean = true;
     h->fwd_done = false;
     return SBR_OK;
 }

@@ -102,6 +102,7 @@ struct sbr_handle {
     int n_rows;          // rows of the current batch (<= local_batch)
     int64_t step_count;  // adam t
     bool have_batch, fwd_done;
+    bool grads_clean;    // the gradient section is all zero (fresh arena, or the update kernel cleared it)
     bool timing;
     // ring of per-step event sets, read back after the timed region (no per-step sync)
     static const int kRing = 64;
@@ -234,7 +235,7 @@ hipError_t launch_sampled_loss(hipStream_t s, float* act, const float* bc, const
 hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float* dWc, const float* dbc,
                                 const int* cells, int C, int Hp);
 // optimizers (lasagne.updates.* [3P], update_manager.py:24-82)
-hipError_t launch_update(hipStream_t s, int updater, float* p, const float* g, float* s0, float* s1, size_t n,
+hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t);
 // top-k (rnn_base.py:196-211)
 hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F,

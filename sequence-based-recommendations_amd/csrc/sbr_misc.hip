@@ -527,10 +527,11 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
 // K13 optimizers: lasagne.updates.{adagrad,adadelta,rmsprop,nesterov_momentum,adam} [3P]
 // (update_manager.py:24-82), applied densely to the whole flat parameter section.
 // ---------------------------------------------------------------------------------------
-__global__ void update_kernel(int updater, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s0,
+__global__ void update_kernel(int updater, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
                               float* __restrict__ s1, size_t n, float lr, float rho, float b1, float b2, float a_t) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
+        g[i] = 0.0f;                                      // the gradient section is clean for the next step (no memset)
         float pi = p[i];
         if (updater == SBR_UPD_ADAGRAD) {                 // eps 1e-6
             const float acc = s0[i] + gi * gi;
@@ -556,7 +557,7 @@ __global__ void update_kernel(int updater, float* __restrict__ p, const float* _
     }
 }
 
-hipError_t launch_update(hipStream_t s, int updater, float* p, const float* g, float* s0, float* s1, size_t n, float lr,
+hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n, float lr,
                          float rho, float b1, float b2, long t) {
     float a_t = 0.0f;
     if (updater == SBR_UPD_ADAM)
