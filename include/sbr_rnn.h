@@ -145,6 +145,13 @@ int sbr_predict_scores(sbr_handle* h, int probs, float* out_host);
  * (interactions_are_unique, rnn_base.py:200-201).  Ties break to the lowest id. */
 int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_host);
 
+/* The dense GEMM of the hot path on caller-provided DEVICE buffers (parity tests of the kernels themselves):
+ * C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]); ws: split-K workspace (may be NULL).
+ * exact_f32 != 0: v_mfma_f32_16x16x4_f32 kernel; 0: bf16x6 kernel where the shape allows it. */
+int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* ws, size_t ws_floats,
+                   int32_t exact_f32);
+
 /* Named device buffers for parity tests: "h_last" (rows,Hp), "logits", "xt0", "hs0" ... */
 int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr, size_t* n_floats);
 /* Copy n_floats from a device pointer to host (tests without torch). */

@@ -409,6 +409,7 @@ extern "C" int sbr_zero_grads(sbr_handle* h) {
 
 extern "C" int sbr_forward(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
+    sbr_gemm_set_exact_f32((h->lay.cfg.flags & SBR_FLAG_F32_MFMA) != 0);
     if (!h->have_batch) { sbr_set_error("sbr_forward: no batch set"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream;
     for (int l = 0; l < y.L; ++l) {
@@ -454,6 +455,7 @@ static int side_join(sbr_handle* h) {
 
 extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
+    sbr_gemm_set_exact_f32((h->lay.cfg.flags & SBR_FLAG_F32_MFMA) != 0);
     if (!h->fwd_done) { sbr_set_error("sbr_loss_backward_output: call sbr_forward first"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const int R = h->n_rows, Hp = y.HLp, N = y.N;
@@ -519,6 +521,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
 
 extern "C" int sbr_backward_recurrent(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
+    sbr_gemm_set_exact_f32((h->lay.cfg.flags & SBR_FLAG_F32_MFMA) != 0);
     if (!h->fwd_done) { sbr_set_error("sbr_backward_recurrent: call sbr_forward first"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const bool sg = simple_gemm(h);
@@ -670,6 +673,9 @@ static int full_scores(sbr_handle* h, int do_softmax) {
     int rc;
     if (!h->fwd_done && (rc = sbr_forward(h)) != SBR_OK) return rc;
     float* lg = h->A(y.a_logits);
+    // scoring always runs the exact-f32 kernel: a row's scores (hence its ranked ids) must not depend on how many rows
+    // share the call (the bf16x6 kernel takes over at >= 96 rows and rounds differently)
+    sbr_gemm_set_exact_f32(true);
     SBR_LAUNCH(launch_gemm(h->stream, h_last(h), y.HLp, 1, h->P(y.p_WoutT), 1, y.HLp, lg, y.N, h->n_rows, y.N, y.HLp, nullptr,
                            nullptr, 0, simple_gemm(h)));
     SBR_LAUNCH(launch_softmax_rows(h->stream, lg, h->P(y.p_bout), h->n_rows, y.N, do_softmax));
@@ -749,6 +755,16 @@ extern "C" int sbr_copy_to_host(sbr_handle* h, const void* dev_ptr, float* host,
 extern "C" int sbr_synchronize(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     SBR_HIP(hipStreamSynchronize(h->stream));
+    return SBR_OK;
+}
+
+extern "C" int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                              float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* ws,
+                              size_t ws_floats, int32_t exact_f32) {
+    CHECK_ARG(A && B && C, "null operand");
+    sbr_gemm_set_exact_f32(exact_f32 != 0);
+    SBR_LAUNCH(launch_gemm((hipStream_t)stream, A, (long)sam, (long)sak, B, (long)sbk, (long)sbn, C, (long)ldc, M, N, K, bias, ws,
+                           ws_floats, false));
     return SBR_OK;
 }
 

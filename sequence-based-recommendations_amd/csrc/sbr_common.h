@@ -208,6 +208,11 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
                        float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
                        bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0);
 
+// bf16x6 GEMM (sbr_gemm_x6.hip): false = shape not supported, use the f32 kernel
+bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                    int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err);
+void sbr_gemm_set_exact_f32(bool on);
+
 // slabs are [z][slab_stride] with row stride ws_ld: a GEMM may fill only a column range of wider slabs
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
                              int N, int K, float* ws, int nsplit, long ws_ld, size_t slab_stride);

@@ -10,6 +10,7 @@
 // registers while the MFMAs of the current one run.  Split-K over grid.z writes partial slabs
 // that a second kernel sums in fixed order (deterministic).
 #include "sbr_common.h"
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -162,10 +163,20 @@ __global__ void gemm_naive(GemmArgs g) {
     g.C[(long)m * g.ldc + n] = s + (g.bias ? g.bias[n] : 0.0f);
 }
 
+// SBR_FLAG_F32_MFMA: keep every GEMM on the exact-f32 kernel (set per call by the API layer; a handle is not thread-safe)
+static bool g_gemm_exact_f32 = false;
+void sbr_gemm_set_exact_f32(bool on) { g_gemm_exact_f32 = on; }
+
 // split-K partial products only: writes exactly `nsplit` slabs [z][M][N] at ws (no reduction)
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
                              int N, int K, float* ws, int nsplit, long ws_ld, size_t slab_stride) {
     if (M <= 0 || N <= 0 || nsplit < 1) return hipSuccess;
+    if (!g_gemm_exact_f32) {
+        const int kc = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;   // slices past K write zero slabs
+        hipError_t e = hipSuccess;
+        // nsplit == 1 would take the "write C" form: identical here (slab 0, no bias)
+        if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, nsplit, kc, slab_stride, &e)) return e;
+    }
     GemmArgs g{A, sam, sak, B, sbk, sbn, ws, N, M, N, K, nullptr, 0, 0, K, ws, ws_ld, slab_stride};
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     g.kchunk = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;   // slices past K write zero slabs
@@ -188,6 +199,28 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
         const size_t n = (size_t)M * N;
         gemm_naive<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g);
         return hipGetLastError();
+    }
+    if (!g_gemm_exact_f32 && a_blk_Bp == 0 && b_blk_Bp == 0 && M >= 96 && N >= 96 && K >= 32) {
+        const int t = ((M + 127) / 128) * ((N + 127) / 128);
+        int ns = 1;
+        if (ws && K >= 512) {
+            ns = std::max(1, 512 / t);
+            ns = std::min(ns, K / 128);
+            ns = (int)std::min<size_t>((size_t)ns, ws_floats / ((size_t)M * N));
+            ns = std::max(ns, 1);
+        }
+        int kc = ((K + ns - 1) / ns + 31) / 32 * 32;
+        ns = std::max(1, (K + kc - 1) / kc);
+        hipError_t e = hipSuccess;
+        if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ns > 1 ? ws : C, ns > 1 ? (long)N : ldc, M, N, K, bias, ns, kc,
+                           (size_t)M * N, &e)) {
+            if (e == hipSuccess && ns > 1) {
+                const size_t n = (size_t)M * N;
+                gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, ns, M, N, C, ldc, bias);
+                e = hipGetLastError();
+            }
+            return e;
+        }
     }
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     int nsplit = 1;

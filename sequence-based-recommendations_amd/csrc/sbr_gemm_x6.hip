@@ -1,0 +1,168 @@
+// float32 GEMM on the bf16 matrix pipe ("bf16x6", see sbr_rec.hip): every f32 operand element is split exactly into
+// three bf16 planes when its tile is written to LDS, and the six products of order >= 2^-18 are issued on
+// v_mfma_f32_16x16x32_bf16 -- f32-rounding-class results at 6 x 16 cycles per 16x16x32 block instead of 8 x 32 on
+// v_mfma_f32_16x16x4_f32 (2.67x less matrix-pipe time; the split costs ~7 VALU per loaded element, amortised over a
+// 128-wide tile).  Serves the dense pieces of the hot path whose shapes fill a 128x128 tile: output projection
+// logits = h.W_out and its backward pair (rnn_one_hot.py:65, K7/K9), the weight gradients dW_hid / dW_in after the
+// BPTT chain, the layer >= 2 input projections.
+//
+//   C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n]),  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+//
+// Workgroup = 256 threads, 128x128 output tile, BK = 32 (one MFMA K).  Threads 0..127 load the A tile, 128..255 the
+// B tile: 4 rows x 8 k each, vectorised along whichever dimension has unit stride (16/8/4-byte loads by alignment),
+// next tile prefetched into registers while the MFMAs of the current one run.  LDS holds each operand as three bf16
+// planes [128 rows][32 k] with an 80-byte row stride (conflict-free ds_read_b128 / ds_write_b128).  Each wave owns a
+// 64x64 sub-tile = 4x4 MFMA tiles.  Split-K over grid.z writes partial slabs (summed by gemm_splitk_reduce).
+#include "sbr_cell.h"
+
+#define XM 128
+#define XN 128
+#define XK 32
+#define XROW 80                       // bytes per LDS row: 32 bf16 + 16 pad
+#define XPLANE (128 * XROW)
+
+struct GemmX6Args {
+    const float* A; long sam, sak;
+    const float* B; long sbk, sbn;
+    float* C; long ldc; size_t slab_stride;
+    int M, N, K, kchunk;
+    const float* bias;
+};
+
+// 4 rows x 8 k of one operand tile into v[row][k], from p = &operand(r0, k0).  RFAST: unit stride runs along the rows
+// (srow == 1), else along k (sk == 1).  VEC: floats per load instruction (4; the scalar form is kept for the ragged edge path only).  nr / nk: rows
+// and k's inside the matrix (4 / 8 for interior tiles: the branch-free path).
+template <int VEC, bool RFAST>
+__device__ __forceinline__ void x6_load(const float* __restrict__ p, long stride, int nr, int nk, float (&v)[4][8]) {
+    if (nr == 4 && nk == 8) {
+        if (!RFAST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* r = p + (long)i * stride;                      // stride = srow
+                if (VEC == 4) {
+                    const f32x4 t0 = *(const f32x4*)r, t1 = *(const f32x4*)(r + 4);
+                    v[i][0] = t0[0]; v[i][1] = t0[1]; v[i][2] = t0[2]; v[i][3] = t0[3];
+                    v[i][4] = t1[0]; v[i][5] = t1[1]; v[i][6] = t1[2]; v[i][7] = t1[3];
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) v[i][kk] = r[kk];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float* r = p + (long)kk * stride;                     // stride = sk
+                if (VEC == 4) { const f32x4 t = *(const f32x4*)r; v[0][kk] = t[0]; v[1][kk] = t[1]; v[2][kk] = t[2]; v[3][kk] = t[3]; }
+                else { v[0][kk] = r[0]; v[1][kk] = r[1]; v[2][kk] = r[2]; v[3][kk] = r[3]; }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            v[i][kk] = (i < nr && kk < nk) ? (RFAST ? p[(long)kk * stride + i] : p[(long)i * stride + kk]) : 0.0f;
+}
+
+template <int VA, bool RA, int VB, bool RB>
+__global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
+    __shared__ __attribute__((aligned(16))) char sA[3 * XPLANE];
+    __shared__ __attribute__((aligned(16))) char sB[3 * XPLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int j = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * XM, n0 = blockIdx.x * XN;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+
+    // loader role: A tile (waves 0,1) or B tile (waves 2,3); rows rg*4..+3, k-chunk kc*8..+7
+    const bool ldB = tid >= 128;
+    const int lt = tid & 127, rg = lt >> 2, kc = lt & 3;
+    const int r0 = (ldB ? n0 : m0) + rg * 4;
+    const int nr = max(0, min(4, (ldB ? g.N : g.M) - r0));
+    const long srow = ldB ? g.sbn : g.sam, sk = ldB ? g.sbk : g.sak;
+    const float* src = (ldB ? g.B : g.A) + (long)r0 * srow + (long)(kbeg + kc * 8) * sk;   // advanced by 32 k per step
+    const long kstep = 32 * sk;
+    char* sdst = (ldB ? sB : sA) + (rg * 4) * XROW + kc * 16;
+
+    float v[4][8];
+    auto load = [&](int k0) {
+        const int nk = max(0, min(8, kend - (k0 + kc * 8)));
+        if (ldB) x6_load<VB, RB>(src, RB ? sk : srow, nr, nk, v);
+        else x6_load<VA, RA>(src, RA ? sk : srow, nr, nk, v);
+        src += kstep;
+    };
+    const f32x4 z = f32x4{0, 0, 0, 0};
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = z;
+
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += XK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 p1, p2, p3;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) { __bf16 a, b, c; split3(v[i][kk], a, b, c); p1[kk] = a; p2[kk] = b; p3[kk] = c; }
+            *(bf16x8*)(sdst + i * XROW) = p1;
+            *(bf16x8*)(sdst + i * XROW + XPLANE) = p2;
+            *(bf16x8*)(sdst + i * XROW + 2 * XPLANE) = p3;
+        }
+        __syncthreads();
+        if (k0 + XK < kend) load(k0 + XK);                 // in flight while this tile's MFMAs run
+        bf16x8 a[3][4], b[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[p][t] = *(const bf16x8*)(sA + p * XPLANE + (wm * 64 + t * 16 + j) * XROW + q * 16);
+                b[p][t] = *(const bf16x8*)(sB + p * XPLANE + (wn * 64 + t * 16 + j) * XROW + q * 16);
+            }
+        // smallest terms first: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1; 16 independent accumulators per term
+#define X6_TERM(PA, PB) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
+            acc[mi][ni] = MFMA_BF16(a[PA][mi], b[PB][ni], acc[mi][ni]);
+        X6_TERM(0, 2) X6_TERM(2, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0)
+#undef X6_TERM
+        __syncthreads();
+    }
+
+    float* out = g.C + (size_t)blockIdx.z * g.slab_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + mi * 16 + 4 * q + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + j;
+                if (n < g.N) out[(long)m * g.ldc + n] = acc[mi][ni][r] + (g.bias ? g.bias[n] : 0.0f);
+            }
+        }
+}
+
+static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte loads along the unit-stride dimension
+    return ((uintptr_t)p & 15) == 0 && (other_stride & 3) == 0;
+}
+
+// true = launched (err holds the launch status).  false = the caller uses the f32 kernel: shape too small for a
+// 128x128 tile, no unit stride, or an operand whose rows are not 16-byte aligned (e.g. N = 3706 item columns: scalar
+// loads would make the split the bottleneck).  nsplit == 1: C (row stride ldc, + bias); nsplit > 1: slab z at
+// C + z*slab_stride, row stride ldc.
+bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                    int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err) {
+    if (M < 96 || N < 96 || K < 32) return false;
+    if (!(sam == 1 || sak == 1) || !(sbk == 1 || sbn == 1)) return false;
+    const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
+    if (!x6_aligned(A, ra ? sak : sam) || !x6_aligned(B, rb ? sbk : sbn)) return false;
+    GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias};
+    const dim3 grid((N + XN - 1) / XN, (M + XM - 1) / XM, nsplit);
+    if (ra && rb) gemm_x6_kernel<4, true, 4, true><<<grid, 256, 0, s>>>(g);
+    else if (ra) gemm_x6_kernel<4, true, 4, false><<<grid, 256, 0, s>>>(g);
+    else if (rb) gemm_x6_kernel<4, false, 4, true><<<grid, 256, 0, s>>>(g);
+    else gemm_x6_kernel<4, false, 4, false><<<grid, 256, 0, s>>>(g);
+    *err = hipGetLastError();
+    return true;
+}

@@ -52,7 +52,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_train_step", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
-           "sbr_set_deferred_join", "sbr_join_side",
+           "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm",
            "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
@@ -95,6 +95,8 @@ def load_library(path=None):
     lib.sbr_phase_times.argtypes = [vp, f32p]
     i64p = ctypes.POINTER(ctypes.c_int64)
     lib.sbr_query.argtypes = [vp, ctypes.c_char_p, i64p]
+    lib.sbr_debug_gemm.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64,
+                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, ctypes.c_size_t, ctypes.c_int32]
     lib.sbr_set_deferred_join.argtypes = [vp, ctypes.c_int]
     lib.sbr_join_side.argtypes = [vp]
     lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]

@@ -1,0 +1,69 @@
+"""The dense GEMM kernels of the hot path on their own (sbr_debug_gemm): exact-f32 MFMA kernel and the bf16x6 kernel
+against float64, on the operand layouts and edge shapes the engine uses (output projection NT/NN/TN forms with
+N = 3706 / 26744 item columns, weight gradients with K = T*B positions, unaligned leading dimensions, split-K)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run(M, N, K, a_t, b_t, exact, bias=False, ws_floats=0, seed=0, lda_pad=0, ldb_pad=0):
+    import torch
+    from sbr_amd.engine import load_library
+    lib = load_library()
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda")
+    # A(m,k): stored [M][K+pad] (k fast) or, transposed, [K][M+pad] (m fast); same for B(k,n)
+    if a_t:
+        Ah = rng.standard_normal((K, M + lda_pad)).astype(np.float32); A64 = Ah[:, :M].T.astype(np.float64)
+        sam, sak = 1, M + lda_pad
+    else:
+        Ah = rng.standard_normal((M, K + lda_pad)).astype(np.float32); A64 = Ah[:, :K].astype(np.float64)
+        sam, sak = K + lda_pad, 1
+    if b_t:
+        Bh = rng.standard_normal((N, K + ldb_pad)).astype(np.float32); B64 = Bh[:, :K].T.astype(np.float64)
+        sbk, sbn = 1, K + ldb_pad
+    else:
+        Bh = rng.standard_normal((K, N + ldb_pad)).astype(np.float32); B64 = Bh[:, :N].astype(np.float64)
+        sbk, sbn = N + ldb_pad, 1
+    A, B = torch.from_numpy(Ah).to(dev), torch.from_numpy(Bh).to(dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    bv = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev) if bias else None
+    ws = torch.empty(ws_floats, device=dev) if ws_floats else None
+    rc = lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn,
+                            C.data_ptr(), N, M, N, K, bv.data_ptr() if bias else None, ws.data_ptr() if ws_floats else None,
+                            ws_floats, 1 if exact else 0)
+    assert rc == 0, lib.sbr_last_error()
+    torch.cuda.synchronize()
+    ref = A64 @ B64 + (bv.cpu().numpy().astype(np.float64)[None, :] if bias else 0.0)
+    scale = np.sqrt(K)                                      # entries ~ N(0, K)
+    return float(np.abs(C.cpu().numpy() - ref).max() / scale)
+
+
+SHAPES = [
+    # (M, N, K, a_t, b_t, ws)   engine use
+    (256, 3706, 128, False, True, 0),            # logits = h . W_out^T            (NT, N not a multiple of 4 or 128)
+    (256, 128, 3706, False, False, 1 << 20),     # dh = dlogits . W_out            (NN, split-K, rows of 3706 floats: 8-byte aligned)
+    (3706, 128, 256, True, False, 1 << 22),      # dW_out^T = dlogits^T . h        (TN)
+    (128, 384, 51200, True, False, 1 << 22),     # dW_hid = hs^T . dhi             (TN, K = T*B positions)
+    (200, 130, 97, False, False, 0),             # ragged everything, odd leading dimensions (4-byte loads)
+    (131, 257, 64, True, True, 0),
+    (96, 96, 32, False, True, 0),                # smallest shape the bf16x6 kernel takes
+    (512, 1024, 256, False, False, 0),           # layer >= 2 input projection
+]
+
+
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_kernels_against_float64(shape, exact):
+    M, N, K, a_t, b_t, ws = shape
+    err = run(M, N, K, a_t, b_t, exact, bias=(ws == 0), ws_floats=ws)
+    assert err < 5e-6, (shape, exact, err)                  # f32-rounding class for both kernels
+
+
+def test_gemm_unaligned_leading_dimensions():
+    for pad in (1, 2, 3):
+        assert run(160, 200, 128, False, False, False, lda_pad=pad, ldb_pad=pad) < 3e-6
+        assert run(160, 200, 128, True, True, False, lda_pad=pad, ldb_pad=pad) < 3e-6
