@@ -226,6 +226,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         const char* ln = getenv("SBR_CL_LINEAR");
         h->cl_linear = ln ? atoi(ln) != 0 : 0;
         h->cl_epoch = 0;
+        const char* wx = getenv("SBR_WGRAD_X6");
+        h->wgrad_x6 = wx ? atoi(wx) != 0 : 0;
         const char* xs = getenv("SBR_X6_SPLIT");
         h->x6_split = xs ? atoi(xs) != 0 : 1;
         const char* fg = getenv("SBR_FUSE_GATHER");
@@ -543,7 +545,11 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         int nc = (sbr_rec_bwd_chunkable(a, simple_rec(h)) && y.T >= 64 && !sg) ? h->bwd_chunks : 1;
         int nsl = (int)std::min<size_t>(h->wgrad_slices / nc, y.ws2_floats / (slab * nc));   // K-slices (= workgroups of the wgrad kernel)
         if (nsl < 1) nc = 1;
-        const bool side_wgrad = sbr_rec_bwd_chunkable(a, simple_rec(h)) && !sg && nsl >= 1;
+        const bool side_wgrad = !simple_rec(h) && !sg && nsl >= 1;   // weight gradients on the side stream
+        // the bf16x6 GEMM covers the slab with 128x128 tiles: ~512 workgroups in all is enough (the dedicated f32
+        // kernel, one workgroup per slab, wants many thin slabs)
+        const bool wg_gemm = h->wgrad_x6 || !(ly.Hp == 32 || ly.Hp == 64 || ly.Hp == 128);
+        if (wg_gemm && nsl > 1) nsl = std::max(1, std::min(nsl, 512 / (((ly.Hp + 127) / 128) * ((GHp + 127) / 128)) / nc));
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
@@ -558,7 +564,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 const float* dxc = a.dxt + (size_t)a.t_lo * y.Bp * GHp;
                 const float* dhcc = gru ? a.dhi + (size_t)a.t_lo * y.Bp * ly.Hp : nullptr;
                 hipError_t we = hipSuccess;
-                if (launch_wgrad_slabs(sd, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
+                if (!wg_gemm && launch_wgrad_slabs(sd, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
                     SBR_LAUNCH(we);
                 } else if (gru) {   // hid_input grad = [dxt_r | dxt_u | dhi_c]
                     SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, 2 * ly.Hp, Kc, slabs, nsl, GHp, slab));

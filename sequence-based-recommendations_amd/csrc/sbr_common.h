@@ -97,6 +97,7 @@ struct sbr_handle {
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
     int x6_split, fuse_gather;
+    int wgrad_x6;        // weight gradients through the bf16x6 GEMM instead of the dedicated f32 kernel (SBR_WGRAD_X6)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
