@@ -322,9 +322,53 @@ __global__ void __launch_bounds__(256) softmax_cce_kernel(float* __restrict__ lo
     if (threadIdx.x == 0) rowcost[r] = (logf(se) + mx - xy) * scale;
 }
 
+// Same, with the row held in LDS (N * 4 bytes <= ~150 KB, i.e. catalogues up to ~38 k items): one read and one write
+// of the logits instead of three reads and two writes, 1024 threads per row, hardware exp2.  C4 (N = 26744): 133 -> ~30 us.
+__global__ void __launch_bounds__(1024) softmax_cce_lds_kernel(float* __restrict__ logits, const float* __restrict__ bout,
+                                                               const int* __restrict__ target, const float* __restrict__ pop,
+                                                               float* __restrict__ rowcost, int N, int Bglobal) {
+    extern __shared__ float row[];
+    __shared__ float red[16];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* x = logits + (size_t)r * N;
+    float mx = -INFINITY;
+    for (int n = tid; n < N; n += 1024) { const float v = x[n] + bout[n]; row[n] = v; mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+    __syncthreads();
+    float se = 0.0f;
+    for (int n = tid; n < N; n += 1024) { const float e = __builtin_amdgcn_exp2f((row[n] - mx) * 1.4426950408889634f); row[n] = e; se += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    if (lane == 0) red[wv] = se;
+    const int y = target[r];
+    const float scale = 1.0f / (pop[r] * (float)Bglobal);
+    __syncthreads();
+    se = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) se += red[w];                 // fixed order: deterministic
+    const float inv = 1.0f / se;
+    // cost = log(se) + mx - x_y with x_y recovered from e_y = exp(x_y - mx): keep it exact instead: re-read the logit
+    const float xy = x[y] + bout[y];
+    __syncthreads();                                           // everyone has read x[y] before the row is overwritten
+    for (int n = tid; n < N; n += 1024) x[n] = (row[n] * inv - (n == y ? 1.0f : 0.0f)) * scale;
+    if (tid == 0) rowcost[r] = (logf(se) + mx - xy) * scale;
+}
+
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
                               float* rowcost, int rows, int N, int Bglobal) {
     if (rows <= 0) return hipSuccess;
+    const size_t lds = (size_t)N * sizeof(float);
+    if (lds <= 150 * 1024) {
+        (void)hipFuncSetAttribute((const void*)softmax_cce_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        softmax_cce_lds_kernel<<<rows, 1024, lds, s>>>(logits, bout, target, pop, rowcost, N, Bglobal);
+        return hipGetLastError();
+    }
     softmax_cce_kernel<<<rows, 256, 0, s>>>(logits, bout, target, pop, rowcost, N, Bglobal);
     return hipGetLastError();
 }
