@@ -227,7 +227,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->cl_linear = ln ? atoi(ln) != 0 : 0;
         h->cl_epoch = 0;
         const char* wx = getenv("SBR_WGRAD_X6");
-        h->wgrad_x6 = wx ? atoi(wx) != 0 : 0;
+        h->wgrad_x6 = wx ? atoi(wx) != 0 : 1;
         const char* xs = getenv("SBR_X6_SPLIT");
         h->x6_split = xs ? atoi(xs) != 0 : 1;
         const char* fg = getenv("SBR_FUSE_GATHER");
@@ -548,8 +548,11 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         const bool side_wgrad = !simple_rec(h) && !sg && nsl >= 1;   // weight gradients on the side stream
         // the bf16x6 GEMM covers the slab with 128x128 tiles: ~512 workgroups in all is enough (the dedicated f32
         // kernel, one workgroup per slab, wants many thin slabs)
-        const bool wg_gemm = h->wgrad_x6 || !(ly.Hp == 32 || ly.Hp == 64 || ly.Hp == 128);
-        if (wg_gemm && nsl > 1) nsl = std::max(1, std::min(nsl, 512 / (((ly.Hp + 127) / 128) * ((GHp + 127) / 128)) / nc));
+        const bool wg_gemm = (h->wgrad_x6 && !(y.cfg.flags & SBR_FLAG_F32_MFMA) && ly.Hp >= 96) || !(ly.Hp == 32 || ly.Hp == 64 || ly.Hp == 128);
+        if (wg_gemm && nsl > 1) {
+            static const int wgs = getenv("SBR_WGRAD_X6_WGS") ? atoi(getenv("SBR_WGRAD_X6_WGS")) : 512;
+            nsl = std::max(1, std::min(nsl, wgs / (((ly.Hp + 127) / 128) * ((GHp + 127) / 128)) / nc));
+        }
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
@@ -566,6 +569,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 hipError_t we = hipSuccess;
                 if (!wg_gemm && launch_wgrad_slabs(sd, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
                     SBR_LAUNCH(we);
+                } else if (gru && launch_gemm_slabs_x6(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab, dhcc, ly.Hp,
+                                                       2 * ly.Hp, &we)) {
+                    SBR_LAUNCH(we);     // one bf16x6 GEMM: columns [0, 2Hp) from dxt, the candidate-gate columns from the compact array
                 } else if (gru) {   // hid_input grad = [dxt_r | dxt_u | dhi_c]
                     SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, 2 * ly.Hp, Kc, slabs, nsl, GHp, slab));
                     SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dhcc, ly.Hp, 1, ly.Hp, ly.Hp, Kc, slabs + 2 * ly.Hp, nsl, GHp, slab));

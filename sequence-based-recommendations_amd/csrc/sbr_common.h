@@ -97,7 +97,7 @@ struct sbr_handle {
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
     int x6_split, fuse_gather;
-    int wgrad_x6;        // weight gradients through the bf16x6 GEMM instead of the dedicated f32 kernel (SBR_WGRAD_X6)
+    int wgrad_x6;        // weight gradients through the bf16x6 GEMM instead of the dedicated f32 kernel (SBR_WGRAD_X6, default 1; the f32 kernel serves Hp < 96 and SBR_FLAG_F32_MFMA)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
     int n_rows;          // rows of the current batch (<= local_batch)
@@ -211,12 +211,17 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
 
 // bf16x6 GEMM (sbr_gemm_x6.hip): false = shape not supported, use the f32 kernel
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
-                    int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err);
+                    int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
+                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0);
 void sbr_gemm_set_exact_f32(bool on);
 
 // slabs are [z][slab_stride] with row stride ws_ld: a GEMM may fill only a column range of wider slabs
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
                              int N, int K, float* ws, int nsplit, long ws_ld, size_t slab_stride);
+// same through the bf16x6 kernel only, with the B columns >= n_split taken from B2 (row stride sbk2); false: not launched
+bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
+                          int K, float* ws, int nsplit, long ws_ld, size_t slab_stride, const float* B2, long sbk2, int n_split,
+                          hipError_t* err);
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias);
 

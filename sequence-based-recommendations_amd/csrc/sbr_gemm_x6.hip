@@ -27,6 +27,7 @@ struct GemmX6Args {
     float* C; long ldc; size_t slab_stride;
     int M, N, K, kchunk;
     const float* bias;
+    const float* B2; long sbk2; int n_split;   // columns n >= n_split of B come from B2[k*sbk2 + (n - n_split)] (GRU weight gradients)
 };
 
 // 4 rows x 8 k of one operand tile into v[row][k], from p = &operand(r0, k0).  RFAST: unit stride runs along the rows
@@ -80,8 +81,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     const int lt = tid & 127, rg = lt >> 2, kc = lt & 3;
     const int r0 = (ldB ? n0 : m0) + rg * 4;
     const int nr = max(0, min(4, (ldB ? g.N : g.M) - r0));
-    const long srow = ldB ? g.sbn : g.sam, sk = ldB ? g.sbk : g.sak;
+    long srow = ldB ? g.sbn : g.sam, sk = ldB ? g.sbk : g.sak;
     const float* src = (ldB ? g.B : g.A) + (long)r0 * srow + (long)(kbeg + kc * 8) * sk;   // advanced by 32 k per step
+    if (ldB && g.B2 && r0 >= g.n_split) { sk = g.sbk2; src = g.B2 + (long)(r0 - g.n_split) * srow + (long)(kbeg + kc * 8) * sk; }
     const long kstep = 32 * sk;
     char* sdst = (ldB ? sB : sA) + (rg * 4) * XROW + kc * 16;
 
@@ -152,12 +154,14 @@ static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte 
 // loads would make the split the bottleneck).  nsplit == 1: C (row stride ldc, + bias); nsplit > 1: slab z at
 // C + z*slab_stride, row stride ldc.
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
-                    int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err) {
+                    int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
+                    const float* B2, long sbk2, int n_split) {
     if (M < 96 || N < 96 || K < 32) return false;
+    if (B2 && (sbn != 1 || (n_split & 3) || !x6_aligned(B2, sbk2))) return false;
     if (!(sam == 1 || sak == 1) || !(sbk == 1 || sbn == 1)) return false;
     const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
     if (!x6_aligned(A, ra ? sak : sam) || !x6_aligned(B, rb ? sbk : sbn)) return false;
-    GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias};
+    GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split};
     const dim3 grid((N + XN - 1) / XN, (M + XM - 1) / XM, nsplit);
     if (ra && rb) gemm_x6_kernel<4, true, 4, true><<<grid, 256, 0, s>>>(g);
     else if (ra) gemm_x6_kernel<4, true, 4, false><<<grid, 256, 0, s>>>(g);

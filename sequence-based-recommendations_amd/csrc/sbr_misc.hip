@@ -197,7 +197,8 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
     return hipGetLastError();
 }
 
-#define SCAT_CHUNK 32
+#define SCAT_CHUNK 64
+#define SCAT_FLY 8     // rows in flight per wave
 template <int NV>
 __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
@@ -228,11 +229,11 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
             acc[v] = f32x4{0, 0, 0, 0};
         }
     };
-    for (int i = 0; i < cnt; i += 4) {
-        f32x4 val[4][NV];
-        int ids[4];
+    for (int i = 0; i < cnt; i += SCAT_FLY) {
+        f32x4 val[SCAT_FLY][NV];
+        int ids[SCAT_FLY];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                        // 4 rows in flight
+        for (int u = 0; u < SCAT_FLY; ++u) {                 // rows in flight
             const int ii = min(i + u, cnt - 1);
             ids[u] = __shfl(my_id, ii);
             const size_t pos = (size_t)__shfl(my_pos, ii);
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SCAT_FLY; ++u) {
             if (i + u < cnt) {                                 // wave-uniform
                 if (ids[u] != cur_id) { flush(cur_id); cur_id = ids[u]; }
 #pragma unroll
