@@ -804,54 +804,70 @@ __device__ __forceinline__ float pick4(const f32x4 v, int c) {
     return c == 0 ? v[0] : (c == 1 ? v[1] : (c == 2 ? v[2] : v[3]));
 }
 
-template <int CELL, int HP>
-__global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
-    constexpr int G = Gates<CELL>::G, KB = HP / 32, NW = HP / 16, GHP = G * HP, R = 4;
+template <int CELL, int HP, int NT = 1>
+__global__ void __launch_bounds__(HP * 4 / NT) rec_fwd_x6s(RecArgs a) {
+    // NT unit tiles per wave (only NT = 1 is launched).  Measured and rejected: NT = 2 at HP = 128 (4 waves, one per
+    // SIMD, to remove the ~900-cycle skew between the two waves that share a matrix pipe): 414 registers put the
+    // resident W planes in AGPRs, every MFMA operand then needs v_accvgpr_read copies, and a single wave issues one
+    // MFMA per ~28 cycles instead of 16: 5280 cycles per step against 3760 with two waves per SIMD.
+    constexpr int G = Gates<CELL>::G, KB = HP / 32, NW = HP / 16, NWV = NW / NT, GHP = G * HP, R = 4;
     constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW;
     constexpr int W3_BYTES = G * KB * NW * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    char* w3 = smem_c;                                   // [G][KB][NW][64 lanes][16 B]
+    char* w3 = smem_c;                                   // [G][KB][NW tiles][64 lanes][16 B]
     char* hbuf = smem_c + W3_BYTES;                      // [2][3 planes][R rows][HROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int r = j & 3, c = j >> 2;                     // tile row; which of the lane's 4 accumulator units it finishes
     const int row = blockIdx.x * R + r;
     const int T = a.T, Bp = a.Bp;
-    const int u = wave * 16 + q * 4 + c;
+    int u[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) u[n] = (wave + n * NWV) * 16 + q * 4 + c;
 
     const int mylen = a.len[row];
     int tmax = mylen;
     tmax = max(tmax, __shfl_xor(tmax, 1));
     tmax = max(tmax, __shfl_xor(tmax, 2));
 
-    bf16x8 W1[G][KB], W2[G][KB];
+    bf16x8 W1[NT][G][KB], W2[NT][G][KB];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            bf16x8 w3v;
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                __bf16 b1, b2, b3;
-                split3(a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + wave * 16 + j], b1, b2, b3);
-                W1[g][kb][e] = b1; W2[g][kb][e] = b2; w3v[e] = b3;
+            for (int kb = 0; kb < KB; ++kb) {
+                const int tile = wave + n * NWV;
+                bf16x8 w3v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    __bf16 b1, b2, b3;
+                    split3(a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + tile * 16 + j], b1, b2, b3);
+                    W1[n][g][kb][e] = b1; W2[n][g][kb][e] = b2; w3v[e] = b3;
+                }
+                *(bf16x8*)(w3 + ((g * KB + kb) * NW + tile) * 1024 + lane * 16) = w3v;
             }
-            *(bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16) = w3v;
-        }
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
-    float h = a.hinit[u], cst = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
-    if (CELL == CELL_LSTM) {
-        cst = a.cinit[u];
-        pi = a.peep[u]; pf = a.peep[HP + u]; po = a.peep[2 * HP + u];
-        a.cs[(size_t)row * HP + u] = cst;
+    float h[NT], cst[NT], pi[NT], pf[NT], po[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        h[n] = a.hinit[u[n]]; cst[n] = 0.f; pi[n] = 0.f; pf[n] = 0.f; po[n] = 0.f;
+        if (CELL == CELL_LSTM) {
+            cst[n] = a.cinit[u[n]];
+            pi[n] = a.peep[u[n]]; pf[n] = a.peep[HP + u[n]]; po[n] = a.peep[2 * HP + u[n]];
+            a.cs[(size_t)row * HP + u[n]] = cst[n];
+        }
+        a.hs[(size_t)row * HP + u[n]] = h[n];
     }
-    a.hs[(size_t)row * HP + u] = h;
     auto publish_h = [&](int buf) {
-        __bf16 p1, p2, p3;
-        split3(h, p1, p2, p3);
-        char* base = hbuf + (size_t)buf * 3 * PLANEB + r * HROW + u * 2;
-        *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            __bf16 p1, p2, p3;
+            split3(h[n], p1, p2, p3);
+            char* base = hbuf + (size_t)buf * 3 * PLANEB + r * HROW + u[n] * 2;
+            *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
+        }
     };
     publish_h(0);
 
@@ -859,14 +875,18 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
     // (sparse_lstm.py:368 / :755 / :1111).  The id is fetched two steps ahead, the row one step ahead; the
     // prefetches are unconditional with clamped indices (a branch around them costs a vmcnt(0), see sbr_rec_cl.hip).
     const bool fuse = a.gX != nullptr;
-    float x[G], xn[G], bias[G];
+    float x[NT][G], xn[NT][G], bias[NT][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) bias[g] = fuse ? a.gbias[g * HP + u] : 0.f;
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < G; ++g) bias[n][g] = fuse ? a.gbias[g * HP + u[n]] : 0.f;
     auto load_id = [&](int t) -> int { return fuse ? a.gX[(size_t)row * T + (t < T ? t : T - 1)] : 0; };
-    auto load_x = [&](int t, int id, float (&d)[G]) {
-        const float* src = fuse ? a.gWin + (size_t)id * GHP + u : a.xt + ((size_t)(t < T ? t : T - 1) * Bp + row) * GHP + u;
+    auto load_x = [&](int t, int id, float (&d)[NT][G]) {
+        const float* src = fuse ? a.gWin + (size_t)id * GHP : a.xt + ((size_t)(t < T ? t : T - 1) * Bp + row) * GHP;
 #pragma unroll
-        for (int g = 0; g < G; ++g) d[g] = src[g * HP];
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < G; ++g) d[n][g] = src[g * HP + u[n]];
     };
     int id_next = load_id(1), id_nn = 0;
     load_x(0, load_id(0), x);
@@ -878,64 +898,78 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
     // stream (after its first k-block): address math and store issue then hide under the matrix pipe instead of
     // sitting between the barrier and the first MFMA (~650 cycles per step measured).  h / cst / sv still hold
     // step t-1's values there: the gate math that overwrites them comes after the MFMA loop.
-    float sv[4] = {0.f, 0.f, 0.f, 0.f};
-    auto store_step = [&](int t) {
-        if (CELL != CELL_VANILLA) {
-            const size_t o = gate_index(t, row, u, Bp, HP);
+    float sv[NT][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a.g[k][o] = sv[k];
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv[n][k] = 0.f;
+    auto store_step = [&](int t) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (CELL != CELL_VANILLA) {
+                const size_t o = gate_index(t, row, u[n], Bp, HP);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a.g[k][o] = sv[n][k];
+            }
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u[n];
+            a.hs[o] = h[n];
+            if (CELL == CELL_LSTM) a.cs[o] = cst[n];
         }
-        const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
-        a.hs[o] = h;
-        if (CELL == CELL_LSTM) a.cs[o] = cst;
     };
     for (int t = 0; t < tmax; ++t) {                              // tmax is workgroup-uniform
         if (a.prof) p_ta = clock64();
         load_x(t + 1, id_next, xn);
         id_nn = load_id(t + 2);
         const char* hb = hbuf + (size_t)(t & 1) * 3 * PLANEB + r * HROW + q * 16;
-        f32x4 acc[G];
+        f32x4 acc[NT][G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = f32x4{0, 0, 0, 0};
-        bf16x8 hp[2][3], wp[2][G];
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[n][g] = f32x4{0, 0, 0, 0};
+        bf16x8 hp[2][3], wp[2][NT][G];
         auto load_ops = [&](int kb, int s) {
             hp[s][0] = *(const bf16x8*)(hb + kb * 64);
             hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
             hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
 #pragma unroll
-            for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave) * 1024 + lane * 16);
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    wp[s][n][g] = *(const bf16x8*)(w3 + ((g * KB + kb) * NW + wave + n * NWV) * 1024 + lane * 16);
         };
         load_ops(0, 0);
         __builtin_amdgcn_s_setprio(0);
+#define X6S_TERM(WOP, HOP) _Pragma("unroll") for (int n = 0; n < NT; ++n) _Pragma("unroll") for (int g = 0; g < G; ++g) \
+            acc[n][g] = MFMA_BF16(WOP, HOP, acc[n][g]);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int s = kb & 1;
             if (kb + 1 < KB) load_ops(kb + 1, s ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+            X6S_TERM(wp[s][n][g], hp[s][0])
+            X6S_TERM(W1[n][g][kb], hp[s][2])
+            X6S_TERM(W2[n][g][kb], hp[s][1])
+            X6S_TERM(W2[n][g][kb], hp[s][0])
+            X6S_TERM(W1[n][g][kb], hp[s][1])
+            X6S_TERM(W1[n][g][kb], hp[s][0])
             __builtin_amdgcn_sched_barrier(0);
             if (kb == 0 && t > 0) { store_step(t - 1); __builtin_amdgcn_sched_barrier(0); }
         }
+#undef X6S_TERM
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard (see rec_fwd_mfma)
         __builtin_amdgcn_s_setprio(3);
-        float as[G], xb[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) { as[g] = pick4(acc[g], c); xb[g] = x[g] + bias[g]; }
-        cell_forward<CELL, true>(xb, as, t < mylen, h, cst, pi, pf, po, sv);
+        for (int n = 0; n < NT; ++n) {
+            float as[G], xb[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { as[g] = pick4(acc[n][g], c); xb[g] = x[n][g] + bias[n][g]; }
+            cell_forward<CELL, true>(xb, as, t < mylen, h[n], cst[n], pi[n], pf[n], po[n], sv[n]);
+        }
         if (t + 1 < tmax) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) x[g] = xn[g];
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < G; ++g) x[n][g] = xn[n][g];
             id_next = id_nn;
             publish_h((t + 1) & 1);
             if (a.prof) { const unsigned long long tc = clock64(); p_work += tc - p_ta; p_ta = tc; }
@@ -945,9 +979,12 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6s(RecArgs a) {
     }
     if (tmax > 0) store_step(tmax - 1);
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
-        const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
-        a.hs[o] = h;
-        if (CELL == CELL_LSTM) a.cs[o] = cst;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u[n];
+            a.hs[o] = h[n];
+            if (CELL == CELL_LSTM) a.cs[o] = cst[n];
+        }
     }
     if (a.prof && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
