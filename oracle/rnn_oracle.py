@@ -65,15 +65,19 @@ def recurrent_param_shapes(cell, n_in, H):
     raise ValueError("Unknown layer type")  # recurrent_layers.py:90
 
 
-def model_param_shapes(cell, layers, n_items, n_in0=None):
+def model_param_shapes(cell, layers, n_items, n_in0=None, embedding=0, n_feat=1):
     """Whole-model list: layer 0 (index input, input_size = n_items + n_optional,
     rnn_one_hot.py:48-49), dense layers >= 1 (recurrent_layers.py:94-104), then the
     output DenseLayer/BlackoutLayer W (H_last, N), b (N,) (rnn_one_hot.py:65,
-    rnn_sampling.py:131)."""
+    rnn_sampling.py:131).  --r_emb E (recurrent_layers.py:46-50): an EmbeddingLayer W (input_size, E) comes first and
+    layer 0 becomes a dense Lasagne layer over the n_feat * E flattened embedding."""
     if n_in0 is None:
         n_in0 = n_items
     shapes = []
     n_in = n_in0
+    if embedding > 0:
+        shapes.append(("emb.W", (n_in0, embedding)))
+        n_in = n_feat * embedding
     for li, H in enumerate(layers):
         for name, shp in recurrent_param_shapes(cell, n_in, H):
             shapes.append(("l%d." % li + name, shp))
@@ -82,14 +86,16 @@ def model_param_shapes(cell, layers, n_items, n_in0=None):
     return shapes
 
 
-def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dtype=np.float64):
+def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dtype=np.float64, embedding=0, n_feat=1):
     """Lasagne default initialisers [3P]: Gate W_in/W_hid/W_cell Normal(std=0.1),
     b Constant(0), cell_init/hid_init Constant(0) (sparse_lstm.py:156-162); output W
     GlorotUniform(gain) = U(+-gain*sqrt(6/(fan_in+fan_out))), b 0 (rnn_sampling.py:131)."""
     out = []
-    for name, shp in model_param_shapes(cell, layers, n_items, n_in0):
+    for name, shp in model_param_shapes(cell, layers, n_items, n_in0, embedding, n_feat):
         base = name.split(".")[1]
-        if name == "out.W":
+        if name == "emb.W":
+            a = rng.normal(0.0, 0.01, size=shp)          # lasagne EmbeddingLayer default W=init.Normal() (std 0.01) [3P]
+        elif name == "out.W":
             lim = last_layer_init * np.sqrt(6.0 / (shp[0] + shp[1]))
             a = rng.uniform(-lim, lim, size=shp)
         elif base.startswith("W_"):
@@ -100,10 +106,11 @@ def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dty
     return out
 
 
-def split_params(params, cell, layers):
-    """Split the flat Lasagne-ordered list into per-layer dicts + output (W, b)."""
+def split_params(params, cell, layers, embedding=0):
+    """Split the flat Lasagne-ordered list into per-layer dicts + output (W, b); with --r_emb the embedding table is the
+    extra FIRST entry: use split_embedding() to peel it off."""
     per = []
-    pos = 0
+    pos = 1 if embedding else 0
     for H in layers:
         names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
         per.append(dict(zip(names, params[pos:pos + len(names)])))
@@ -310,15 +317,18 @@ def layer_grads_to_list(layer, cell, inp, index_input, bw):
 # --------------------------------------------------------------------------------------
 # Whole-network forward / backward
 # --------------------------------------------------------------------------------------
-def network_forward(params, cell, layers, X, mask):
+def network_forward(params, cell, layers, X, mask, embedding=0):
     """recurrent_layers.py:57-68: layer 0 index-input, later layers dense; only the
     last layer returns its final step (sparse_lstm.py:485-486: hid_out[-1], valid
-    because X is left-aligned and masked steps copy state).  Returns h_last (B,H), caches."""
-    per, W_out, b_out = split_params(params, cell, layers)
+    because X is left-aligned and masked steps copy state).  Returns h_last (B,H), caches.
+    embedding > 0 (--r_emb, recurrent_layers.py:46-50): X -> W_emb[X] (B,T,F,E) flattened to (B,T,F*E), every layer dense."""
+    per, W_out, b_out = split_params(params, cell, layers, embedding)
     caches = []
     inp = X
+    if embedding:
+        inp = params[0][X, :].reshape(X.shape[0], X.shape[1], -1)
     for li, layer in enumerate(per):
-        xt = input_projection(layer, cell, inp, index_input=(li == 0))
+        xt = input_projection(layer, cell, inp, index_input=(li == 0 and not embedding))
         hid, cache = recurrent_forward(layer, cell, xt, mask)
         cache["inp"] = inp
         caches.append(cache)
@@ -327,18 +337,23 @@ def network_forward(params, cell, layers, X, mask):
     return h_last, caches
 
 
-def network_backward(params, cell, layers, caches, dh_last):
-    per, _, _ = split_params(params, cell, layers)
+def network_backward(params, cell, layers, caches, dh_last, embedding=0, X=None):
+    per, _, _ = split_params(params, cell, layers, embedding)
     grads = [None] * len(per)
     T, B, _ = caches[-1]["xt"].shape
     dhid = np.zeros((T, B, layers[-1])); dhid[-1] = dh_last
+    d_inp = None
     for li in range(len(per) - 1, -1, -1):
         bw = recurrent_backward(per[li], cell, caches[li], dhid)
-        gl, d_inp = layer_grads_to_list(per[li], cell, caches[li]["inp"], li == 0, bw)
+        gl, d_inp = layer_grads_to_list(per[li], cell, caches[li]["inp"], li == 0 and not embedding, bw)
         grads[li] = gl
         if li > 0:
             dhid = np.transpose(d_inp, (1, 0, 2))
     flat = []
+    if embedding:      # EmbeddingLayer gradient = AdvancedIncSubtensor over the indices: duplicates accumulate [3P]
+        dE = np.zeros_like(params[0])
+        np.add.at(dE, X.reshape(-1), d_inp.reshape(-1, embedding))
+        flat.append(dE)
     for gl in grads:
         flat += gl
     return flat
@@ -444,16 +459,16 @@ def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, 
 def cost_and_grads(params, cfg, batch):
     """cost + gradient list (Lasagne parameter order) for one batch = the symbolic part
     of RNNBase._compile_train_function (rnn_base.py:175-186) before the updates."""
-    cell, layers = cfg["cell"], cfg["layers"]
-    per, W_out, b_out = split_params(params, cell, layers)
-    h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"])
+    cell, layers, emb = cfg["cell"], cfg["layers"], cfg.get("embedding", 0)
+    per, W_out, b_out = split_params(params, cell, layers, emb)
+    h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"], emb)
     if cfg["loss"] == "CCE":
         cost, act, (dh, dW, db) = cce_cost_and_grads(h, W_out, b_out, batch["target"], batch["pop"],
                                                      cfg.get("regularization", 0.0), batch.get("Bglobal"))
     else:
         cost, act, (dh, dW, db) = sampled_cost_and_grads(h, W_out, b_out, batch["target"], batch["samples"],
                                                          batch["pop"], cfg["loss"], batch.get("row_offset", 0))
-    grads = network_backward(params, cell, layers, caches, dh) + [dW, db]
+    grads = network_backward(params, cell, layers, caches, dh, emb, batch["X"]) + [dW, db]
     return cost, grads, {"h": h, "act": act}
 
 
@@ -511,9 +526,9 @@ def predict_scores(params, cfg, X, mask):
     """predict_function output (rnn_base.py:188-194): one-hot head = softmax
     probabilities (DenseLayer nonlinearity, rnn_one_hot.py:65); sampling head = raw
     full activations (BlackoutLayer deterministic branch, sparse_lstm.py:37-40)."""
-    cell, layers = cfg["cell"], cfg["layers"]
-    _, W_out, b_out = split_params(params, cell, layers)
-    h, _ = network_forward(params, cell, layers, X, mask)
+    cell, layers, emb = cfg["cell"], cfg["layers"], cfg.get("embedding", 0)
+    _, W_out, b_out = split_params(params, cell, layers, emb)
+    h, _ = network_forward(params, cell, layers, X, mask, emb)
     logits = h @ W_out + b_out
     return (softmax_rows(logits) if cfg["loss"] == "CCE" else logits), logits
 

@@ -87,8 +87,8 @@ def layer_forward(layer, cell, inp, mask, index_input):
     return torch.stack(outs, dim=0)
 
 
-def split_params(params, cell, layers, names_fn):
-    per, pos = [], 0
+def split_params(params, cell, layers, names_fn, embedding=0):
+    per, pos = [], (1 if embedding else 0)
     for H in layers:
         names = [n for n, _ in names_fn(cell, 1, H)]
         per.append(dict(zip(names, params[pos:pos + len(names)])))
@@ -98,11 +98,14 @@ def split_params(params, cell, layers, names_fn):
 
 def network_cost(params, cfg, batch, names_fn):
     """cost tensor of the whole network (rnn_one_hot.py:37-78 / rnn_sampling.py:93-137)."""
-    cell, layers = cfg["cell"], cfg["layers"]
-    per, W_out, b_out = split_params(params, cell, layers, names_fn)
+    cell, layers, emb = cfg["cell"], cfg["layers"], cfg.get("embedding", 0)
+    per, W_out, b_out = split_params(params, cell, layers, names_fn, emb)
     inp = batch["X"]
+    if emb:                                             # EmbeddingLayer + flatten(outdim=3) (recurrent_layers.py:46-50)
+        X = batch["X"].long()
+        inp = params[0][X].reshape(X.shape[0], X.shape[1], -1)
     for li, layer in enumerate(per):
-        hid = layer_forward(layer, cell, inp, batch["mask"], index_input=(li == 0))
+        hid = layer_forward(layer, cell, inp, batch["mask"], index_input=(li == 0 and not emb))
         inp = hid.transpose(0, 1)
     h = hid[-1]
     pop = batch["pop"]

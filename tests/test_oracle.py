@@ -92,6 +92,33 @@ def test_multi_index_input_rating_feature():
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU", "Vanilla"])
+@pytest.mark.parametrize("F,n_opt", [(1, 0), (2, 10)])
+def test_embedding_layer_option(cell, F, n_opt):
+    # --r_emb E (recurrent_layers.py:46-50): EmbeddingLayer + flatten, dense layer 0; NumPy BPTT vs torch autograd vs FD
+    rng = np.random.default_rng(5)
+    B, T, N, S, E = 3, 5, 7, 4, 3
+    layers = [4, 3]
+    params = O.init_params(cell, layers, N, rng, n_in0=N + n_opt, embedding=E, n_feat=F)
+    assert params[0].shape == (N + n_opt, E) and params[1].shape[0] == F * E
+    for p in params:
+        p += rng.normal(0, 0.3, size=p.shape)
+    batch = make_batch(rng, B, T, N, S, F=F, n_in0=N + n_opt)
+    cfg = dict(cell=cell, layers=layers, loss="CCE", regularization=0.0, embedding=E)
+    c1, g1, aux = O.cost_and_grads(params, cfg, batch)
+    c2, g2, h2, _ = R.cost_and_grads(params, cfg, batch, O.recurrent_param_shapes)
+    assert abs(c1 - c2) <= 1e-10 * abs(c2) and len(g1) == len(params)
+    for a, b in zip(g1, g2):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    eps = 1e-6
+    for idx in [(0, 1), (int(batch["X"][0, 0, 0]), 2)]:          # rows hit by the batch (and maybe one that is not)
+        old = params[0][idx]
+        params[0][idx] = old + eps; cp, _, _ = O.cost_and_grads(params, cfg, batch)
+        params[0][idx] = old - eps; cm, _, _ = O.cost_and_grads(params, cfg, batch)
+        params[0][idx] = old
+        assert abs((cp - cm) / (2 * eps) - g1[0][idx]) <= 1e-6 * max(1.0, abs(g1[0][idx]))
+
+
 def test_param_order_and_shapes_match_lasagne_layout():
     # LSTM-OHE 1 layer = 19 arrays, GRU-OHE = 12 arrays
     assert len(O.model_param_shapes("LSTM", [20], 3706)) == 19
