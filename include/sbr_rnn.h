@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 1
+#define SBR_ABI_VERSION 2
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -64,6 +64,8 @@ typedef struct sbr_config {
     float regularization;           /* -r: >0 L2, <0 L1, on b_out only (rnn_one_hot.py:73-77) */
     float grad_clip;                /* 100 (recurrent_layers.py:19); <=0 disables */
     int32_t flags;                  /* SBR_FLAG_* */
+    int32_t embedding_size;         /* --r_emb E (recurrent_layers.py:46-50): EmbeddingLayer (input_size, E) + flatten in front of
+                                     * DENSE recurrent layers (layer 0 input = n_feat * E); 0 = index-input layer 0 */
 } sbr_config;
 
 #define SBR_FLAG_SIMPLE_REC  1   /* triage: per-step VALU recurrent kernels instead of the MFMA persistent ones */

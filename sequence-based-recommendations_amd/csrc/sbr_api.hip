@@ -39,6 +39,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     if (cfg.row_offset < 0 || cfg.row_offset + cfg.local_batch > cfg.batch_size) LFAIL("row_offset/local_batch outside the global batch");
     if (cfg.loss != SBR_LOSS_CCE && cfg.n_samples < 1) LFAIL("sampled losses need n_samples >= 1");
     if (cfg.learning_rate <= 0.0f) LFAIL("learning_rate must be > 0");
+    if (cfg.embedding_size < 0 || cfg.embedding_size > 4096) LFAIL("embedding_size must be in [0,4096]");
 #undef LFAIL
     lay = Layout();
     lay.cfg = cfg;
@@ -49,13 +50,16 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.C = lay.Bg + lay.S;
     const int G = lay.G, T = lay.T, Bp = lay.Bp;
 
+    lay.E = cfg.embedding_size > 0 ? cfg.embedding_size : 0;
+    lay.Ep = (lay.E + 3) / 4 * 4;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += sbr_align(n); return o; };
+    lay.p_Emb = lay.E ? take((size_t)cfg.input_size * lay.Ep) : 0;
     for (int l = 0; l < lay.L; ++l) {
         LayerLayout& y = lay.layer[l];
         y.H = cfg.layers[l]; y.Hp = sbr_pad_hidden(y.H); y.G = G;
-        y.n_in = l == 0 ? cfg.input_size : cfg.layers[l - 1];
-        y.n_in_p = l == 0 ? cfg.input_size : lay.layer[l - 1].Hp;
+        y.n_in = l == 0 ? (lay.E ? lay.F * lay.E : cfg.input_size) : cfg.layers[l - 1];
+        y.n_in_p = l == 0 ? (lay.E ? lay.F * lay.Ep : cfg.input_size) : lay.layer[l - 1].Hp;
         y.p_Win = take((size_t)y.n_in_p * G * y.Hp);
         y.p_b = take((size_t)G * y.Hp);
         y.p_Whid = take((size_t)y.Hp * G * y.Hp);
@@ -91,8 +95,9 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_state = take((size_t)2 * Bp * y.Hp);
         y.a_part = take((size_t)SBR_BWD_CHUNKS * Bp * (G * y.Hp + 5 * y.Hp));
         maxrec = std::max(maxrec, (size_t)y.Hp * G * y.Hp);
-        if (l > 0) maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp);
+        if (l > 0 || lay.E) maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp);
     }
+    if (lay.E) { lay.a_emb = take((size_t)T * Bp * lay.F * lay.Ep); lay.a_demb = take((size_t)T * Bp * lay.F * lay.Ep); }
     lay.a_logits = take((size_t)Bp * lay.N);
     lay.a_dhlast = take((size_t)Bp * lay.HLp);
     lay.a_rowcost = take(Bp);
@@ -130,6 +135,7 @@ void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out) {
     static const char* gru_g[3] = {"updategate", "resetgate", "hidden_update"};       // sparse_lstm.py:660-668
     static const char* van_g[1] = {"hidden_update"};
     const char* const* gn = cell == SBR_CELL_LSTM ? lstm_g : (cell == SBR_CELL_GRU ? gru_g : van_g);
+    if (lay.E) out.push_back({"emb.W", 0, 8, 0, lay.cfg.input_size, lay.E, 2});   // lasagne EmbeddingLayer comes first
     for (int l = 0; l < lay.L; ++l) {
         const LayerLayout& y = lay.layer[l];
         char pre[16]; snprintf(pre, sizeof(pre), "l%d.", l);
@@ -162,7 +168,14 @@ static void convert_param(const Layout& lay, const ParamDesc& d, float* image, f
     auto mv = [&](size_t io, size_t ao) { if (to_image) image[io] = arr[ao]; else arr[ao] = image[io]; };
     const int gp = stacked_pos(lay.cfg.cell, d.gate);
     switch (d.kind) {
-        case 0: for (int64_t r = 0; r < d.d0; ++r) for (int64_t c = 0; c < d.d1; ++c) mv(y.p_Win + r * GHp + gp * y.Hp + c, r * d.d1 + c); break;
+        case 0:
+            for (int64_t r = 0; r < d.d0; ++r) {
+                // layer 0 behind an embedding: logical row f*E + e is stored at f*Ep + e
+                const int64_t rs = (lay.E && d.layer == 0) ? (r / lay.E) * lay.Ep + r % lay.E : r;
+                for (int64_t c = 0; c < d.d1; ++c) mv(y.p_Win + rs * GHp + gp * y.Hp + c, r * d.d1 + c);
+            }
+            break;
+        case 8: for (int64_t r = 0; r < d.d0; ++r) for (int64_t c = 0; c < d.d1; ++c) mv(lay.p_Emb + r * lay.Ep + c, r * d.d1 + c); break;
         case 1: for (int64_t r = 0; r < d.d0; ++r) for (int64_t c = 0; c < d.d1; ++c) mv(y.p_Whid + r * GHp + gp * y.Hp + c, r * d.d1 + c); break;
         case 2: for (int64_t c = 0; c < d.d0; ++c) mv(y.p_b + gp * y.Hp + c, c); break;
         case 3: for (int64_t c = 0; c < d.d0; ++c) mv(y.p_peep + d.gate * y.Hp + c, c); break;
@@ -418,7 +431,12 @@ extern "C" int sbr_forward(sbr_handle* h) {
         const LayerLayout& ly = y.layer[l];
         const int GHp = y.G * ly.Hp;
         RecArgs ra = rec_args(h, l);
-        if (l == 0) {
+        if (l == 0 && y.E) {   // --r_emb: embeddings of the F indices, flattened, then a dense input projection
+            SBR_LAUNCH(launch_gather_concat(s, h->P(y.p_Emb), h->bX, h->A(y.a_emb), y.T, y.Bp, y.F, y.Ep));
+            SBR_LAUNCH(launch_gemm(s, h->A(y.a_emb), ly.n_in_p, 1, h->P(ly.p_Win), GHp, 1, h->A(ly.a_xt), GHp, y.T * y.Bp, GHp,
+                                   ly.n_in_p, h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
+            mark(h, 1);
+        } else if (l == 0) {
             if (y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(ra, simple_rec(h))) {
                 ra.gX = h->bX; ra.gWin = h->P(ly.p_Win); ra.gbias = h->P(ly.p_b);   // gathered inside the forward kernel
             } else {
@@ -471,11 +489,11 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     SBR_HIP(hipEventRecord(h->ev_fork, s));
     SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     h->side_pending = true;
-    if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
+    if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E) {
         // batch-only work for the embedding scatter-add; the scatter kernel waits for ev_sort
         SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                        y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
-                                       (int*)h->A(y.a_sid), (int*)h->A(y.a_spos)));
+                                       (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
         SBR_HIP(hipEventRecord(h->ev_sort, sd));
     }
     if (y.cfg.loss == SBR_LOSS_CCE) {
@@ -599,7 +617,19 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                        y.ws_floats, sg));
             }
         }
-        if (l == 0) {
+        if (l == 0 && y.E) {
+            mark(h, 5);
+            // dense layer 0 behind the embedding: dW_in = emb^T . dxt, d_emb = dxt . W_in^T, then the scatter-add of the
+            // F*T*B embedding-gradient rows into dW_emb (EmbeddingLayer gradient: duplicates accumulate [3P])
+            SBR_LAUNCH(launch_gemm(s, h->A(y.a_emb), 1, ly.n_in_p, a.dxt, GHp, 1, h->Gd(ly.p_Win), GHp, ly.n_in_p, GHp, TB, nullptr, ws,
+                                   y.ws_floats, sg));
+            SBR_LAUNCH(launch_gemm(s, a.dxt, GHp, 1, h->P(ly.p_Win), 1, GHp, h->A(y.a_demb), ly.n_in_p, TB, ly.n_in_p, GHp, nullptr,
+                                   nullptr, 0, sg));
+            SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));
+            SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(y.p_Emb), h->A(y.a_demb), (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                             (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, y.Ep, y.Bp));
+            mark(h, 6);
+        } else         if (l == 0) {
             mark(h, 5);
             if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
                 SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, h->bX, a.len, y.T, y.Bp, y.F, GHp));
@@ -785,7 +815,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
     const Layout& y = h->lay; const std::string w(what);
     if (w == "fused_gather") {
         RecArgs a = rec_args(h, 0);
-        *value = (y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(a, simple_rec(h))) ? 1 : 0;
+        *value = (y.E == 0 && y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(a, simple_rec(h))) ? 1 : 0;
     } else if (w == "rows_per_workgroup") *value = h->rpt;
     else if (w == "cluster") { RecArgs a = rec_args(h, y.L - 1); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));

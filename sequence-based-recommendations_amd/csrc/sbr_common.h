@@ -52,6 +52,9 @@ struct Layout {
     sbr_config cfg;
     int L, G, T, B, Bp, N, F, Bg, S, C;   // C = Bg + S sampled columns
     int HLp;                              // padded width of the top layer
+    int E, Ep;                            // --r_emb: embedding width and its stored width (multiple of 4); 0 = none
+    size_t p_Emb;                         // [input_size][Ep]
+    size_t a_emb, a_demb;                 // [T][Bp][F*Ep] flattened embeddings = dense input of layer 0, and its gradient
     LayerLayout layer[SBR_MAX_LAYERS];
     size_t p_WoutT, p_bout;               // [N][HLp], [N]
     size_t n_params;                      // floats in the parameter section
@@ -136,8 +139,12 @@ hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, con
                                int T, int Bp, int F, int GHp);
 // counting sort of the valid (position, id) pairs by id (depends on the batch only), then one wave per
 // chunk of 32 sorted entries reduces the dxt rows of equal id in registers
+// concat != 0: entry (pos, f) addresses row pos*F + f of the gradient array (embedding layer: the F embeddings of a step are
+// concatenated, not summed)
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos);
+                               int* offs, int* cur, int* sid, int* spos, int concat = 0);
+// emb[t][b][f*Ep + e] = W_emb[X[b][t][f]][e]          (lasagne EmbeddingLayer + flatten(outdim=3), recurrent_layers.py:48)
+hipError_t launch_gather_concat(hipStream_t s, const float* Wemb, const int* X, float* out, int T, int Bp, int F, int Ep);
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp);
 

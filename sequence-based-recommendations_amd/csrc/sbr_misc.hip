@@ -57,6 +57,25 @@ __global__ void gather_xt_kernel(const f32x4* __restrict__ Win, const f32x4* __r
     }
 }
 
+__global__ void gather_concat_kernel(const f32x4* __restrict__ W, const int* __restrict__ X, f32x4* __restrict__ out, int T,
+                                     int Bp, int F, int E4) {
+    const size_t total = (size_t)T * Bp * F * E4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e4 = (int)(i % E4);
+        const size_t pf = i / E4;                      // (t*Bp + b)*F + f
+        const int f = (int)(pf % F);
+        const size_t pos = pf / F;
+        const int b = (int)(pos % Bp), t = (int)(pos / Bp);
+        out[i] = W[(size_t)X[((size_t)b * T + t) * F + f] * E4 + e4];
+    }
+}
+hipError_t launch_gather_concat(hipStream_t s, const float* Wemb, const int* X, float* out, int T, int Bp, int F, int Ep) {
+    const size_t total = (size_t)T * Bp * F * (Ep / 4);
+    const int grid = (int)min((size_t)256 * 16, (total + 255) / 256);
+    gather_concat_kernel<<<grid, 256, 0, s>>>((const f32x4*)Wemb, X, (f32x4*)out, T, Bp, F, Ep / 4);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, const int* X, float* xt, int T, int Bp,
                             int F, int GHp, int) {
     const int R4 = GHp / 4;
@@ -102,7 +121,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* _
 __global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
                                                                    int T, int Bp, int F, int n_ids, int per_block,
                                                                    int* __restrict__ cur, int* __restrict__ sid,
-                                                                   int* __restrict__ spos) {
+                                                                   int* __restrict__ spos, int concat) {
     extern __shared__ int hist[];          // [n_ids] counts, then cursors
     for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
     __syncthreads();
@@ -121,7 +140,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __
         if (t < len[b]) {
             const int id = X[((size_t)b * T + t) * F + f];
             const int slot = atomicAdd(&hist[id], 1);
-            sid[slot] = id; spos[slot] = pos;
+            sid[slot] = id; spos[slot] = concat ? i : pos;
         }
     }
 }
@@ -164,20 +183,20 @@ __global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__
 }
 
 __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
-                                 int* __restrict__ cur, int* __restrict__ sid, int* __restrict__ spos) {
+                                 int* __restrict__ cur, int* __restrict__ sid, int* __restrict__ spos, int concat) {
     const int total = T * Bp * F;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
         if (t < len[b]) {
             const int id = X[((size_t)b * T + t) * F + f];
             const int slot = atomicAdd(&cur[id], 1);
-            sid[slot] = id; spos[slot] = pos;
+            sid[slot] = id; spos[slot] = concat ? i : pos;
         }
     }
 }
 
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos) {
+                               int* offs, int* cur, int* sid, int* spos, int concat) {
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), s);
     if (e != hipSuccess) return e;
     const int total = T * Bp * F;
@@ -187,12 +206,12 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
         const size_t lds = (size_t)n_ids * sizeof(int);
         scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt);
         scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
-        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos);
+        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat);
     } else {
         const int grid = min(1024, (total + 255) / 256);
         scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
         scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
-        scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos);
+        scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos, concat);
     }
     return hipGetLastError();
 }

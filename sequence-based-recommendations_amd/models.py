@@ -47,8 +47,8 @@ class RNNBase(object):
         if self.use_movies_features or self.use_users_features:
             # the reference dereferences feature tables that are always None (rnn_base.py:27-29,572,607)
             raise NotImplementedError("movie/user features (--mf/--uf) are unusable in the reference and unsupported here")
-        if self.recurrent_layer.bidirectional or self.recurrent_layer.embedding_size > 0:
-            raise NotImplementedError("--r_bi / --r_emb are not part of the round-1 hot path")
+        if self.recurrent_layer.bidirectional:
+            raise NotImplementedError("--r_bi is not part of the round-1 hot path")
         self._input_type = "int32"
         self.name = "RNN base"
         self.metrics = {"recall": {"direction": 1}, "sps": {"direction": 1}, "user_coverage": {"direction": 1},
@@ -72,7 +72,8 @@ class RNNBase(object):
         self.n_items = dataset.n_items
         kw = dict(cell=self.recurrent_layer.layer_type, layers=self.recurrent_layer.layers, n_items=self.n_items,
                   max_length=self.max_length, batch_size=self.batch_size, grad_clip=float(self.recurrent_layer.grad_clip),
-                  input_size=self.n_items + self._n_optional_features(), n_feat=self._input_size())
+                  input_size=self.n_items + self._n_optional_features(), n_feat=self._input_size(),
+                  embedding_size=self.recurrent_layer.embedding_size)
         kw.update(self.updater.engine_kwargs())
         kw.update(self._engine_kwargs())
         self.engine = RNNEngine(**kw)
@@ -96,9 +97,13 @@ class RNNBase(object):
         cell = self.recurrent_layer.layer_type
         per_layer = {"LSTM": 17, "GRU": 10, "Vanilla": 4}[cell]
         n_gate = {"LSTM": 12, "GRU": 9, "Vanilla": 3}[cell]
-        for i in range(last):
+        first = 0
+        if self.recurrent_layer.embedding_size > 0:        # EmbeddingLayer W: init.Normal() = std 0.01 [3P]
+            values[0] = rng.normal(0.0, 0.01, size=self.engine.param_shapes[0]).astype(np.float32)
+            first = 1
+        for i in range(first, last):
             shp = self.engine.param_shapes[i]
-            k = i % per_layer
+            k = (i - first) % per_layer
             is_weight = (k < n_gate and k % 3 != 2) or (cell == "LSTM" and 12 <= k < 15)
             values[i] = (rng.normal(0.0, 0.1, size=shp) if is_weight else np.zeros(shp)).astype(np.float32)
         self.engine.set_all_param_values(values)

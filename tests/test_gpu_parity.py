@@ -101,6 +101,18 @@ def test_two_layer_stack(cell):                            # recurrent_layers.py
     check(PU.compare_step(cell, [20, 12], "CCE", N=30, B=6, T=6))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_embedding_layer_option(cell):
+    # --r_emb E (recurrent_layers.py:46-50): EmbeddingLayer + flatten in front of dense layers; E = 6 pads to 8 columns,
+    # F = 2 concatenates the two embeddings of a step; the table's gradient is a scatter-add with duplicates
+    check(PU.compare_step(cell, [20], "CCE", N=61, B=37, T=9, emb=6))
+    check(PU.compare_step(cell, [20, 12], "CCE", N=41, B=19, T=7, F=2, n_opt=10, emb=5))
+
+
+def test_embedding_layer_with_sampled_head_and_wide_layer():
+    check(PU.compare_step("GRU", [128], "BPR", N=61, B=37, T=9, S=8, emb=16))
+
+
 def test_rating_feature_two_indices_per_step():            # --rf: F=2, input_size = N + 10
     check(PU.compare_step("LSTM", [8], "CCE", N=19, B=4, T=5, F=2, n_opt=10))
 
