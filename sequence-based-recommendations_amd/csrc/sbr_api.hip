@@ -249,9 +249,9 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     h->grads_clean = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
-    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr;
+    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
-    h->in_train_step = false; h->side_pending = false; h->deferred_join = false;
+    h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
     // every "overlapped" kernel serialised: +150 us per step in the data-parallel path).  Streams of another priority
@@ -263,6 +263,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_sort, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_lg, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
@@ -287,6 +288,7 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_sort) (void)hipEventDestroy(h->ev_sort);
     if (h->ev_lg) (void)hipEventDestroy(h->ev_lg);
+    if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
@@ -489,6 +491,15 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     SBR_HIP(hipEventRecord(h->ev_fork, s));
     SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     h->side_pending = true;
+    h->fill_done = false;
+    if (!simple_rec(h)) {   // cluster BPTT kernels: the sentinel fill of their exchange arrays runs beside the output phase
+        bool any = false;
+        for (int l = 0; l < y.L; ++l) {
+            RecArgs a = rec_args(h, l);
+            if (sbr_rec_cluster_ok(a)) { SBR_LAUNCH(sbr_rec_bwd_cl_fill(sd, a)); any = true; }
+        }
+        if (any) { SBR_HIP(hipEventRecord(h->ev_fill, sd)); h->fill_done = true; }
+    }
     if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E) {
         // batch-only work for the embedding scatter-add; the scatter kernel waits for ev_sort
         SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
@@ -553,6 +564,10 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         const LayerLayout& ly = y.layer[l];
         const int GHp = y.G * ly.Hp;
         RecArgs a = rec_args(h, l);
+        if (h->fill_done && sbr_rec_cluster_ok(a)) {
+            a.sentinel_done = 1;
+            if (l == y.L - 1) SBR_HIP(hipStreamWaitEvent(s, h->ev_fill, 0));
+        }
         a.dh_last = l == y.L - 1 ? h->A(y.a_dhlast) : nullptr;
         a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
         if (a.prof) a.prof += (size_t)(y.Bp / 16) * 16 * 8;

@@ -89,10 +89,11 @@ struct sbr_handle {
     hipStream_t stream;
     hipStream_t side;            // batch-only preprocessing (scatter sort) overlapped with the chain
     hipEvent_t ev_fork, ev_join;
-    hipEvent_t ev_sort, ev_lg, ev_chunk[SBR_BWD_CHUNKS];
+    hipEvent_t ev_sort, ev_lg, ev_fill, ev_chunk[SBR_BWD_CHUNKS];
     bool in_train_step;  // phases called from sbr_train_step: the side stream joins only before the update
     bool side_pending;   // side-stream work issued and not yet joined by the main stream
     bool deferred_join;  // phases called one by one do not join the side stream (sbr_set_deferred_join)
+    bool fill_done;      // the cluster BPTT sentinel fill of this step was issued on the side stream (ev_fill)
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)
@@ -188,6 +189,7 @@ struct RecArgs {
     int cluster;            // allowed (SBR_CLUSTER != 0)
     int cl_linear;          // (experiment, SBR_CL_LINEAR=1) cluster members on consecutive workgroup ids = different XCDs
     int* fault;             // set to 1 when a cluster exchange wait gave up (bounded spin)
+    int sentinel_done;      // the backward exchange arrays were already filled with the sentinel (side stream)
     int* clx;               // [tiles][C] start-of-launch handshake: (epoch << 4) | XCC id of every member
     int epoch;              // unique per launch (clx is never cleared)
 };
@@ -195,6 +197,7 @@ struct RecArgs {
 bool sbr_rec_cluster_ok(const RecArgs& a);
 hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
+hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 // true when the forward launch for these args can gather its input rows itself (RecArgs.gX/gWin/gbias)
 bool sbr_rec_fwd_can_fuse_gather(const RecArgs& a, bool simple);

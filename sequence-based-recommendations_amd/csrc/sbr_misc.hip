@@ -100,7 +100,7 @@ hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, 
 // serialise in one L2 channel (69 us each, and they slow every kernel running beside them).  For
 // catalogues whose counters fit LDS (n_ids <= SCAT_LDS_IDS) each workgroup histograms its slice in
 // LDS and issues ONE global atomic per distinct id it saw.
-#define SCAT_LDS_IDS 12288
+#define SCAT_LDS_IDS 36864    // 144 KB of LDS counters: catalogues up to ~37 k ids (C4's 26 744) take the LDS path
 #define SCAT_BLOCK 1024
 __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
                                                                     int T, int Bp, int F, int n_ids, int per_block,
@@ -204,6 +204,8 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
         const int per_block = 4096;
         const int grid = (total + per_block - 1) / per_block;
         const size_t lds = (size_t)n_ids * sizeof(int);
+        (void)hipFuncSetAttribute((const void*)scat_count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scat_fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt);
         scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
         scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat);

@@ -1343,7 +1343,9 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
 
 bool sbr_rec_fwd_can_fuse_gather(const RecArgs& a, bool simple) {
     const int Hp = a.Hp;
-    if (simple || a.f32_mfma || sbr_rec_cluster_ok(a) || !(Hp == 32 || Hp == 64 || Hp == 128)) return false;
+    if (simple || a.f32_mfma) return false;
+    if (sbr_rec_cluster_ok(a)) return true;               // rec_fwd_cl gathers its own rows too
+    if (!(Hp == 32 || Hp == 64 || Hp == 128)) return false;
     const size_t l4 = (size_t)a.G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 4 * (size_t)(Hp * 2 + 32);
     return a.rpt == 4 && a.x6_split && l4 <= 160 * 1024;
 }

@@ -213,12 +213,20 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
         }
         cl_store2(&a.hs[(size_t)row * HP + u2], h, fast);
     }
-    f32x2 x[G], xn[G];
-    auto load_x = [&](int t, f32x2 (&d)[G]) {
+    // Input of step t: a row of xt, or (layer 0, one index per step) W_in[id[row][t]] + b gathered here, id two steps
+    // ahead, row one step ahead (see rec_fwd_x6s)
+    const bool fuse = a.gX != nullptr;
+    f32x2 x[G], xn[G], bias[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) d[g] = *(const f32x2*)&a.xt[((size_t)t * Bp + row) * GHP + g * HP + u2];
+    for (int g = 0; g < G; ++g) bias[g] = (fuse && fin) ? *(const f32x2*)&a.gbias[g * HP + u2] : z2;
+    auto load_id = [&](int t) -> int { return fuse ? a.gX[(size_t)row * T + (t < T ? t : T - 1)] : 0; };
+    auto load_x = [&](int t, int id, f32x2 (&d)[G]) {
+        const float* src = fuse ? a.gWin + (size_t)id * GHP + u2 : a.xt + ((size_t)(t < T ? t : T - 1) * Bp + row) * GHP + u2;
+#pragma unroll
+        for (int g = 0; g < G; ++g) d[g] = *(const f32x2*)&src[g * HP];
     };
-    if (fin && tmax > 0) load_x(0, x);
+    int id_next = 0, id_nn = 0;
+    if (fin) { id_next = load_id(1); load_x(0, load_id(0), x); }
     __syncthreads();                                     // W plane 3 visible
     // SBR_FLAG_PROFILE_REC: cycles per phase (exchange wait | publish + barrier | LDS reads + MFMA | reduce
     // barrier | gate math + stores), tools/cl_prof.py
@@ -276,7 +284,8 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
     // waves' prefetched xt registers free of phi copies (a copy at a block end makes hipcc wait for the loads).
     if (fin) {
         for (int t = 0; t < tmax; ++t) {                 // tmax is uniform over the whole cluster (same rows)
-            load_x(t + 1 < tmax ? t + 1 : t, xn);        // unconditional (clamped): see rec_bwd_cl
+            load_x(t + 1, id_next, xn);                  // unconditional (clamped): see rec_bwd_cl
+            id_nn = load_id(t + 2);
             exchange(t);
             __syncthreads();
             CL_TICK(1);
@@ -296,7 +305,7 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
             for (int e = 0; e < 2; ++e) {
                 float xs[G], as[G], s[4];
 #pragma unroll
-                for (int g = 0; g < G; ++g) { xs[g] = x[g][e]; as[g] = as2[g][e]; }
+                for (int g = 0; g < G; ++g) { xs[g] = x[g][e] + bias[g][e]; as[g] = as2[g][e]; }
                 float hh = h[e], cc = c[e];
                 cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
                 h[e] = hh; c[e] = cc;
@@ -307,6 +316,7 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
             // would also wait for their acknowledgements (~1000 cycles measured)
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = xn[g];
+            id_next = id_nn;
             __builtin_amdgcn_sched_barrier(0);
             const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u2;
             cl_store2(&a.hs[o], h, fast);                // first: the other members are waiting for it
@@ -594,11 +604,19 @@ template <int CELL, int HP>
 static hipError_t bwd_cl(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G, R = SBR_CL_ROWS, GHP = G * HP;
     const size_t lds = (size_t)(GHP / 64) * 4 * 1024 + 3 * (size_t)R * (GHP * 2 + 32) + 2 * 1024;
-    hipError_t e = hipMemsetAsync(a.dxt, 0xFF, (size_t)a.T * a.Bp * GHP * sizeof(float), s);
-    if (e == hipSuccess && CELL == CELL_GRU) e = hipMemsetAsync(a.dhi, 0xFF, (size_t)a.T * a.Bp * HP * sizeof(float), s);
-    if (e != hipSuccess) return e;
+    if (!a.sentinel_done) {                               // else: sbr_rec_bwd_cl_fill ran on the side stream during the output phase
+        const hipError_t e = sbr_rec_bwd_cl_fill(s, a);
+        if (e != hipSuccess) return e;
+    }
     CL_LAUNCH((rec_bwd_cl<CELL, HP, R>), HP / 32, lds);
     return hipGetLastError();
+}
+
+// the sentinel fill of the backward exchange arrays (dxt, GRU: + the compact candidate slice)
+hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a) {
+    hipError_t e = hipMemsetAsync(a.dxt, 0xFF, (size_t)a.T * a.Bp * a.G * a.Hp * sizeof(float), s);
+    if (e == hipSuccess && a.cell == SBR_CELL_GRU) e = hipMemsetAsync(a.dhi, 0xFF, (size_t)a.T * a.Bp * a.Hp * sizeof(float), s);
+    return e;
 }
 
 hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a) {
