@@ -249,9 +249,9 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     h->grads_clean = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
-    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr;
+    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
-    h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false;
+    h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
     // every "overlapped" kernel serialised: +150 us per step in the data-parallel path).  Streams of another priority
@@ -264,6 +264,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipEventCreateWithFlags(&h->ev_sort, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_lg, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_og, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
@@ -289,6 +290,7 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->ev_sort) (void)hipEventDestroy(h->ev_sort);
     if (h->ev_lg) (void)hipEventDestroy(h->ev_lg);
     if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
+    if (h->ev_og) (void)hipEventDestroy(h->ev_og);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
@@ -522,6 +524,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
         SBR_LAUNCH(launch_colsum_bias(sd, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
         SBR_LAUNCH(launch_gemm(sd, lg, 1, N, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws2, y.ws2_floats, sg));
+        SBR_HIP(hipEventRecord(h->ev_og, sd)); h->og_recorded = true;   // output-layer gradients + cost complete
     } else {
         const int C = y.C;
         int* cells = (int*)h->A(y.a_cells);
@@ -536,6 +539,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_gemm(s, act, 1, C, hl, Hp, 1, dWc, Hp, C, Hp, R, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
+        SBR_HIP(hipEventRecord(h->ev_og, s)); h->og_recorded = true;
     }
     mark(h, 3);
     if (h->deferred_join && !h->in_train_step) {
@@ -680,11 +684,28 @@ extern "C" int sbr_join_side(sbr_handle* h) {
 extern "C" int sbr_apply_update(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     const Layout& y = h->lay;
-    { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
     h->step_count += 1;
     float* s1 = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
-    SBR_LAUNCH(launch_update(h->stream, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, y.n_params, y.cfg.learning_rate,
-                             y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count));
+    auto upd = [&](size_t lo, size_t hi) -> hipError_t {
+        if (hi <= lo) return hipSuccess;
+        return launch_update(h->stream, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1 ? s1 + lo : nullptr, hi - lo,
+                             y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
+    };
+    if (h->side_pending && h->og_recorded) {
+        // The last thing the side stream produces is dW_hid (weight-gradient GEMM + slab reduction, 240 us at C4).  Every
+        // other parameter is updated while it finishes: the main stream waits only for the output-layer gradients
+        // (recorded long ago), updates all ranges except the W_hid blocks, joins, then updates those.
+        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
+        size_t pos = 0;
+        for (int l = 0; l < y.L; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
+        SBR_LAUNCH(upd(pos, y.n_params));
+        { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+        for (int l = 0; l < y.L; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
+    } else {
+        { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+        SBR_LAUNCH(upd(0, y.n_params));
+    }
+    h->og_recorded = false;
     mark(h, 7);
     h->grads_clean = true;
     h->fwd_done = false;

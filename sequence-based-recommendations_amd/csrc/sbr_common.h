@@ -89,10 +89,11 @@ struct sbr_handle {
     hipStream_t stream;
     hipStream_t side;            // batch-only preprocessing (scatter sort) overlapped with the chain
     hipEvent_t ev_fork, ev_join;
-    hipEvent_t ev_sort, ev_lg, ev_fill, ev_chunk[SBR_BWD_CHUNKS];
+    hipEvent_t ev_sort, ev_lg, ev_fill, ev_og, ev_chunk[SBR_BWD_CHUNKS];
     bool in_train_step;  // phases called from sbr_train_step: the side stream joins only before the update
     bool side_pending;   // side-stream work issued and not yet joined by the main stream
     bool deferred_join;  // phases called one by one do not join the side stream (sbr_set_deferred_join)
+    bool og_recorded;    // ev_og marks the output-layer gradients of this step complete
     bool fill_done;      // the cluster BPTT sentinel fill of this step was issued on the side stream (ev_fill)
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
