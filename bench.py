@@ -211,6 +211,32 @@ def main():
                               "note": "algorithmic f32 FLOPs 2*L*H*G*H of the BPTT chain vs the f32 MFMA peak; the chain is "
                                       "2*T dependent steps on <=64 CUs (DESIGN.md section 3)"}
         result["phases_us"] = {k: round(v, 2) for k, v in phases.items()}
+        # the dense output projection on its own (logits = h . W_out^T, rnn_one_hot.py:65): the same kernel the step
+        # runs, timed with HIP events on this shape (north_star: MFMA utilisation of the output projection)
+        try:
+            import ctypes
+            Hl = layers[-1]
+            A, Bm = torch.randn(B, Hl, device=dev), torch.randn(n_items, Hl, device=dev)
+            C = torch.empty(B, n_items, device=dev)
+
+            def proj():
+                rc = eng.lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), Hl, 1,
+                                            Bm.data_ptr(), 1, Hl, C.data_ptr(), n_items, B, n_items, Hl, None, None, 0, 0)
+                assert rc == 0
+            for _ in range(3):
+                proj()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                proj()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            tf = 2.0 * B * n_items * Hl / us / 1e6
+            kernels["output_projection"] = {"bound": "mfma", "unit": "TFLOP/s", "us": round(us, 2), "achieved": round(tf, 3),
+                                            "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 5),
+                                            "shape": "M=%d N=%d K=%d" % (B, n_items, Hl)}
+        except Exception as ex:      # never let the side measurement break the bench line
+            log("output projection timing skipped:", ex)
         result["kernels"] = kernels
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -12,13 +12,15 @@
 
 static inline size_t sbr_align(size_t n_floats) { return (n_floats + SBR_ALIGN_FLOATS - 1) / SBR_ALIGN_FLOATS * SBR_ALIGN_FLOATS; }
 static inline int sbr_gates(int cell) { return cell == SBR_CELL_LSTM ? 4 : (cell == SBR_CELL_GRU ? 3 : 1); }
-// Hidden size padded for the MFMA tiling: 16/32/64/128 (W_hid register-resident kernels are
-// instantiated for those), above that the next multiple of 64 (streamed-W kernels).
+// Hidden size padded for the MFMA tiling: 16/32/64/128 (W_hid register-resident single-workgroup kernels), 256 for
+// anything in (128, 256] (the cluster kernels of sbr_rec_cl.hip: a 150-wide layer padded to 256 runs ~6x faster there
+// than at 192 on the streamed f32 kernels), above that the next multiple of 64 (streamed-W kernels).
 static inline int sbr_pad_hidden(int H) {
     if (H <= 16) return 16;
     if (H <= 32) return 32;
     if (H <= 64) return 64;
     if (H <= 128) return 128;
+    if (H <= 256) return 256;
     return (H + 63) / 64 * 64;
 }
 

@@ -33,8 +33,12 @@ def test_exact_f32_mfma_kernels(cell, H):                  # SBR_FLAG_F32_MFMA: 
 
 
 @pytest.mark.parametrize("cell", ["GRU", "LSTM"])
-def test_streamed_whid_kernels(cell):                      # Hp = 192: W_hid fragments streamed from L2
-    check(PU.compare_step(cell, [160], "CCE", N=61, B=21, T=8), tol_h=2e-4)
+def test_streamed_whid_kernels(cell):                      # Hp = 320: W_hid fragments streamed from L2 (f32 MFMA kernels)
+    check(PU.compare_step(cell, [300], "CCE", N=61, B=21, T=8, scale=0.05), tol_h=2e-4)
+
+
+def test_width_between_128_and_256_takes_the_cluster_kernels():
+    check(PU.compare_step("GRU", [160], "CCE", N=61, B=21, T=8), tol_h=2e-4)
 
 
 @pytest.mark.parametrize("rpt", ["1", "2", "8", "16"])
