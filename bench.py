@@ -158,7 +158,10 @@ def main():
     if not np.isfinite(cost):
         raise ValueError("Cost is NaN")            # rnn_base.py:291-292
 
-    phases = eng.phase_times() if (world == 1 and not args.force_dp) else None
+    try:        # per-phase HIP-event times of this rank (data-parallel: the all-reduce waits sit inside "rec_bwd" / "update")
+        phases = eng.phase_times()
+    except Exception:
+        phases = None
     ms_per_step = dt / args.steps * 1e3
     value = Bg * args.steps / dt
 

@@ -420,6 +420,10 @@ static inline void mark(sbr_handle* h, int i) {
 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
+    if (!h->in_train_step && h->timing) {         // phase-by-phase step (data-parallel driver): this call opens the step
+        h->ring_cur = h->ring_used % sbr_handle::kRing;
+        mark(h, 0);
+    }
     if (h->grads_clean) return SBR_OK;            // the optimizer kernel zeroes every gradient it consumes
     SBR_HIP(hipMemsetAsync(h->Gd(0), 0, (h->lay.n_params + 1) * sizeof(float), h->stream));
     h->grads_clean = true;
@@ -707,6 +711,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     }
     h->og_recorded = false;
     mark(h, 7);
+    if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;
     h->fwd_done = false;
     return SBR_OK;
