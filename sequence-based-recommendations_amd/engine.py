@@ -65,6 +65,10 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    try:        # torch bundles its own libamdhip64: it must be the one already loaded when the extension binds to HIP,
+        import torch  # noqa: F401  otherwise two runtimes coexist and this library sees no device
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError("HIP extension %s is missing: build it with __graft_entry__.build() "
                            "(there is no CPU fallback)" % path)
