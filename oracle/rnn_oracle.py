@@ -65,7 +65,7 @@ def recurrent_param_shapes(cell, n_in, H):
     raise ValueError("Unknown layer type")  # recurrent_layers.py:90
 
 
-def model_param_shapes(cell, layers, n_items, n_in0=None, embedding=0, n_feat=1):
+def model_param_shapes(cell, layers, n_items, n_in0=None, embedding=0, n_feat=1, bidirectional=False):
     """Whole-model list: layer 0 (index input, input_size = n_items + n_optional,
     rnn_one_hot.py:48-49), dense layers >= 1 (recurrent_layers.py:94-104), then the
     output DenseLayer/BlackoutLayer W (H_last, N), b (N,) (rnn_one_hot.py:65,
@@ -78,20 +78,26 @@ def model_param_shapes(cell, layers, n_items, n_in0=None, embedding=0, n_feat=1)
     if embedding > 0:
         shapes.append(("emb.W", (n_in0, embedding)))
         n_in = n_feat * embedding
+    D = 2 if bidirectional else 1
     for li, H in enumerate(layers):
-        for name, shp in recurrent_param_shapes(cell, n_in, H):
-            shapes.append(("l%d." % li + name, shp))
-        n_in = H
-    shapes += [("out.W", (layers[-1], n_items)), ("out.b", (n_items,))]
+        # --r_bi (recurrent_layers.py:70-76): a forward and a backwards layer over the same input, ConcatLayer on the
+        # feature axis; parameters of the forward layer come first
+        for d in range(D):
+            tag = "l%d." % li if D == 1 else "l%d%s." % (li, "fb"[d])
+            for name, shp in recurrent_param_shapes(cell, n_in, H):
+                shapes.append((tag + name, shp))
+        n_in = D * H
+    shapes += [("out.W", (D * layers[-1], n_items)), ("out.b", (n_items,))]
     return shapes
 
 
-def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dtype=np.float64, embedding=0, n_feat=1):
+def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dtype=np.float64, embedding=0, n_feat=1,
+                bidirectional=False):
     """Lasagne default initialisers [3P]: Gate W_in/W_hid/W_cell Normal(std=0.1),
     b Constant(0), cell_init/hid_init Constant(0) (sparse_lstm.py:156-162); output W
     GlorotUniform(gain) = U(+-gain*sqrt(6/(fan_in+fan_out))), b 0 (rnn_sampling.py:131)."""
     out = []
-    for name, shp in model_param_shapes(cell, layers, n_items, n_in0, embedding, n_feat):
+    for name, shp in model_param_shapes(cell, layers, n_items, n_in0, embedding, n_feat, bidirectional):
         base = name.split(".")[1]
         if name == "emb.W":
             a = rng.normal(0.0, 0.01, size=shp)          # lasagne EmbeddingLayer default W=init.Normal() (std 0.01) [3P]
@@ -106,15 +112,16 @@ def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dty
     return out
 
 
-def split_params(params, cell, layers, embedding=0):
+def split_params(params, cell, layers, embedding=0, bidirectional=False):
     """Split the flat Lasagne-ordered list into per-layer dicts + output (W, b); with --r_emb the embedding table is the
-    extra FIRST entry: use split_embedding() to peel it off."""
+    extra FIRST entry (params[0]); with --r_bi every layer contributes two dicts (forward, backwards)."""
     per = []
     pos = 1 if embedding else 0
     for H in layers:
-        names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
-        per.append(dict(zip(names, params[pos:pos + len(names)])))
-        pos += len(names)
+        for _ in range(2 if bidirectional else 1):
+            names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
+            per.append(dict(zip(names, params[pos:pos + len(names)])))
+            pos += len(names)
     W_out, b_out = params[pos], params[pos + 1]
     assert pos + 2 == len(params)
     return per, W_out, b_out
@@ -317,38 +324,65 @@ def layer_grads_to_list(layer, cell, inp, index_input, bw):
 # --------------------------------------------------------------------------------------
 # Whole-network forward / backward
 # --------------------------------------------------------------------------------------
-def network_forward(params, cell, layers, X, mask, embedding=0):
+def network_forward(params, cell, layers, X, mask, embedding=0, bidirectional=False):
     """recurrent_layers.py:57-68: layer 0 index-input, later layers dense; only the
     last layer returns its final step (sparse_lstm.py:485-486: hid_out[-1], valid
     because X is left-aligned and masked steps copy state).  Returns h_last (B,H), caches.
-    embedding > 0 (--r_emb, recurrent_layers.py:46-50): X -> W_emb[X] (B,T,F,E) flattened to (B,T,F*E), every layer dense."""
-    per, W_out, b_out = split_params(params, cell, layers, embedding)
+    embedding > 0 (--r_emb, recurrent_layers.py:46-50): X -> W_emb[X] (B,T,F,E) flattened to (B,T,F*E), every layer dense.
+    bidirectional (--r_bi, :70-76): per layer a second scan with go_backwards=True over the same input (time axis flipped,
+    mask included: the padded steps come FIRST and copy hid_init); sequence outputs are flipped back (sparse_lstm.py:492-493)
+    and concatenated on the feature axis; with only_return_final both directions contribute their LAST scan output
+    (:485-486), i.e. the backwards one its state after consuming x_0."""
+    D = 2 if bidirectional else 1
+    per, W_out, b_out = split_params(params, cell, layers, embedding, bidirectional)
     caches = []
     inp = X
     if embedding:
         inp = params[0][X, :].reshape(X.shape[0], X.shape[1], -1)
-    for li, layer in enumerate(per):
-        xt = input_projection(layer, cell, inp, index_input=(li == 0 and not embedding))
-        hid, cache = recurrent_forward(layer, cell, xt, mask)
-        cache["inp"] = inp
-        caches.append(cache)
-        inp = np.transpose(hid, (1, 0, 2))            # (B,T,H) dimshuffle back: :489
-    h_last = caches[-1]["hs"][-1]
-    return h_last, caches
+    finals = []
+    for li in range(len(layers)):
+        index_input = (li == 0 and not embedding)
+        outs, finals = [], []
+        for d in range(D):
+            layer = per[li * D + d]
+            src, m = (inp, mask) if d == 0 else (inp[:, ::-1], mask[:, ::-1])
+            xt = input_projection(layer, cell, src, index_input=index_input)
+            hid, cache = recurrent_forward(layer, cell, xt, m)
+            cache["inp"] = src
+            caches.append(cache)
+            finals.append(cache["hs"][-1])
+            outs.append(hid if d == 0 else hid[::-1])
+        inp = np.transpose(np.concatenate(outs, axis=2), (1, 0, 2))     # (B,T,D*H) dimshuffle back: :489
+    return np.concatenate(finals, axis=1), caches
 
 
-def network_backward(params, cell, layers, caches, dh_last, embedding=0, X=None):
-    per, _, _ = split_params(params, cell, layers, embedding)
+def network_backward(params, cell, layers, caches, dh_last, embedding=0, X=None, bidirectional=False):
+    D = 2 if bidirectional else 1
+    per, _, _ = split_params(params, cell, layers, embedding, bidirectional)
     grads = [None] * len(per)
     T, B, _ = caches[-1]["xt"].shape
-    dhid = np.zeros((T, B, layers[-1])); dhid[-1] = dh_last
+    HL = layers[-1]
+    # gradient wrt every step of each direction's scan output, in that scan's own time order
+    dhid = []
+    for d in range(D):
+        g = np.zeros((T, B, HL)); g[-1] = dh_last[:, d * HL:(d + 1) * HL]
+        dhid.append(g)
     d_inp = None
-    for li in range(len(per) - 1, -1, -1):
-        bw = recurrent_backward(per[li], cell, caches[li], dhid)
-        gl, d_inp = layer_grads_to_list(per[li], cell, caches[li]["inp"], li == 0 and not embedding, bw)
-        grads[li] = gl
+    for li in range(len(layers) - 1, -1, -1):
+        index_input = (li == 0 and not embedding)
+        d_inp = None
+        for d in range(D):
+            k = li * D + d
+            bw = recurrent_backward(per[k], cell, caches[k], dhid[d])
+            gl, di = layer_grads_to_list(per[k], cell, caches[k]["inp"], index_input, bw)
+            grads[k] = gl
+            if di is not None:
+                di = di if d == 0 else di[:, ::-1]            # back to forward time
+                d_inp = di if d_inp is None else d_inp + di
         if li > 0:
-            dhid = np.transpose(d_inp, (1, 0, 2))
+            H = layers[li - 1]
+            dseq = np.transpose(d_inp, (1, 0, 2))             # (T,B,D*H) wrt the concatenated output of layer li-1
+            dhid = [dseq[:, :, :H]] + ([dseq[::-1, :, H:2 * H]] if D == 2 else [])
     flat = []
     if embedding:      # EmbeddingLayer gradient = AdvancedIncSubtensor over the indices: duplicates accumulate [3P]
         dE = np.zeros_like(params[0])
@@ -459,16 +493,16 @@ def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, 
 def cost_and_grads(params, cfg, batch):
     """cost + gradient list (Lasagne parameter order) for one batch = the symbolic part
     of RNNBase._compile_train_function (rnn_base.py:175-186) before the updates."""
-    cell, layers, emb = cfg["cell"], cfg["layers"], cfg.get("embedding", 0)
-    per, W_out, b_out = split_params(params, cell, layers, emb)
-    h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"], emb)
+    cell, layers, emb, bi = cfg["cell"], cfg["layers"], cfg.get("embedding", 0), cfg.get("bidirectional", False)
+    per, W_out, b_out = split_params(params, cell, layers, emb, bi)
+    h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"], emb, bi)
     if cfg["loss"] == "CCE":
         cost, act, (dh, dW, db) = cce_cost_and_grads(h, W_out, b_out, batch["target"], batch["pop"],
                                                      cfg.get("regularization", 0.0), batch.get("Bglobal"))
     else:
         cost, act, (dh, dW, db) = sampled_cost_and_grads(h, W_out, b_out, batch["target"], batch["samples"],
                                                          batch["pop"], cfg["loss"], batch.get("row_offset", 0))
-    grads = network_backward(params, cell, layers, caches, dh, emb, batch["X"]) + [dW, db]
+    grads = network_backward(params, cell, layers, caches, dh, emb, batch["X"], bi) + [dW, db]
     return cost, grads, {"h": h, "act": act}
 
 
@@ -526,9 +560,9 @@ def predict_scores(params, cfg, X, mask):
     """predict_function output (rnn_base.py:188-194): one-hot head = softmax
     probabilities (DenseLayer nonlinearity, rnn_one_hot.py:65); sampling head = raw
     full activations (BlackoutLayer deterministic branch, sparse_lstm.py:37-40)."""
-    cell, layers, emb = cfg["cell"], cfg["layers"], cfg.get("embedding", 0)
-    _, W_out, b_out = split_params(params, cell, layers, emb)
-    h, _ = network_forward(params, cell, layers, X, mask, emb)
+    cell, layers, emb, bi = cfg["cell"], cfg["layers"], cfg.get("embedding", 0), cfg.get("bidirectional", False)
+    _, W_out, b_out = split_params(params, cell, layers, emb, bi)
+    h, _ = network_forward(params, cell, layers, X, mask, emb, bi)
     logits = h @ W_out + b_out
     return (softmax_rows(logits) if cfg["loss"] == "CCE" else logits), logits
 

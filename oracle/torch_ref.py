@@ -87,27 +87,35 @@ def layer_forward(layer, cell, inp, mask, index_input):
     return torch.stack(outs, dim=0)
 
 
-def split_params(params, cell, layers, names_fn, embedding=0):
+def split_params(params, cell, layers, names_fn, embedding=0, bidirectional=False):
     per, pos = [], (1 if embedding else 0)
     for H in layers:
-        names = [n for n, _ in names_fn(cell, 1, H)]
-        per.append(dict(zip(names, params[pos:pos + len(names)])))
-        pos += len(names)
+        for _ in range(2 if bidirectional else 1):
+            names = [n for n, _ in names_fn(cell, 1, H)]
+            per.append(dict(zip(names, params[pos:pos + len(names)])))
+            pos += len(names)
     return per, params[pos], params[pos + 1]
 
 
 def network_cost(params, cfg, batch, names_fn):
     """cost tensor of the whole network (rnn_one_hot.py:37-78 / rnn_sampling.py:93-137)."""
-    cell, layers, emb = cfg["cell"], cfg["layers"], cfg.get("embedding", 0)
-    per, W_out, b_out = split_params(params, cell, layers, names_fn, emb)
+    cell, layers, emb, bi = cfg["cell"], cfg["layers"], cfg.get("embedding", 0), cfg.get("bidirectional", False)
+    per, W_out, b_out = split_params(params, cell, layers, names_fn, emb, bi)
     inp = batch["X"]
     if emb:                                             # EmbeddingLayer + flatten(outdim=3) (recurrent_layers.py:46-50)
         X = batch["X"].long()
         inp = params[0][X].reshape(X.shape[0], X.shape[1], -1)
-    for li, layer in enumerate(per):
-        hid = layer_forward(layer, cell, inp, batch["mask"], index_input=(li == 0 and not emb))
-        inp = hid.transpose(0, 1)
-    h = hid[-1]
+    D = 2 if bi else 1
+    mask = batch["mask"]
+    for li in range(len(layers)):
+        outs, finals = [], []
+        for d in range(D):          # --r_bi: second scan over the time-flipped input and mask, outputs flipped back
+            src, m = (inp, mask) if d == 0 else (torch.flip(inp, dims=[1]), torch.flip(mask, dims=[1]))
+            hid = layer_forward(per[li * D + d], cell, src, m, index_input=(li == 0 and not emb))
+            finals.append(hid[-1])
+            outs.append(hid if d == 0 else torch.flip(hid, dims=[0]))
+        inp = torch.cat(outs, dim=2).transpose(0, 1)
+    h = torch.cat(finals, dim=1)
     pop = batch["pop"]
     B = h.shape[0]
     if cfg["loss"] == "CCE":

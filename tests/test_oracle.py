@@ -119,6 +119,35 @@ def test_embedding_layer_option(cell, F, n_opt):
         assert abs((cp - cm) / (2 * eps) - g1[0][idx]) <= 1e-6 * max(1.0, abs(g1[0][idx]))
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU", "Vanilla"])
+@pytest.mark.parametrize("layers,emb", [([4], 0), ([4, 3], 0), ([3, 2], 3)])
+def test_bidirectional_option(cell, layers, emb):
+    # --r_bi (recurrent_layers.py:70-76): forward + backwards layer per level, concatenated; NumPy BPTT vs torch autograd vs FD
+    rng = np.random.default_rng(11)
+    B, T, N, S = 3, 5, 7, 4
+    params = O.init_params(cell, layers, N, rng, embedding=emb, bidirectional=True)
+    per = {"LSTM": 17, "GRU": 10, "Vanilla": 4}[cell]
+    assert len(params) == (1 if emb else 0) + 2 * per * len(layers) + 2 and params[-2].shape == (2 * layers[-1], N)
+    for p in params:
+        p += rng.normal(0, 0.3, size=p.shape)
+    batch = make_batch(rng, B, T, N, S)
+    cfg = dict(cell=cell, layers=layers, loss="CCE", regularization=0.0, embedding=emb, bidirectional=True)
+    c1, g1, aux = O.cost_and_grads(params, cfg, batch)
+    c2, g2, h2, _ = R.cost_and_grads(params, cfg, batch, O.recurrent_param_shapes)
+    assert abs(c1 - c2) <= 1e-10 * abs(c2) and np.allclose(aux["h"], h2, rtol=0, atol=1e-12)
+    for a, b in zip(g1, g2):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    eps = 1e-6
+    for pi in (0, len(params) // 2, len(params) - 3):
+        p = params[pi]
+        idx = tuple(rng.integers(0, s) for s in p.shape)
+        old = p[idx]
+        p[idx] = old + eps; cp, _, _ = O.cost_and_grads(params, cfg, batch)
+        p[idx] = old - eps; cm, _, _ = O.cost_and_grads(params, cfg, batch)
+        p[idx] = old
+        assert abs((cp - cm) / (2 * eps) - g1[pi][idx]) <= 1e-6 * max(1.0, abs(g1[pi][idx]))
+
+
 def test_param_order_and_shapes_match_lasagne_layout():
     # LSTM-OHE 1 layer = 19 arrays, GRU-OHE = 12 arrays
     assert len(O.model_param_shapes("LSTM", [20], 3706)) == 19
