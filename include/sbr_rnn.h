@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 2
+#define SBR_ABI_VERSION 3
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -66,6 +66,8 @@ typedef struct sbr_config {
     int32_t flags;                  /* SBR_FLAG_* */
     int32_t embedding_size;         /* --r_emb E (recurrent_layers.py:46-50): EmbeddingLayer (input_size, E) + flatten in front of
                                      * DENSE recurrent layers (layer 0 input = n_feat * E); 0 = index-input layer 0 */
+    int32_t bidirectional;          /* --r_bi (recurrent_layers.py:70-76): every level = a forward and a backwards layer over the same
+                                     * input, concatenated on the feature axis (next level / output layer see 2*H features) */
 } sbr_config;
 
 #define SBR_FLAG_SIMPLE_REC  1   /* triage: per-step VALU recurrent kernels instead of the MFMA persistent ones */

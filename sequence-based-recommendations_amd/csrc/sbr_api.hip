@@ -52,24 +52,28 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
 
     lay.E = cfg.embedding_size > 0 ? cfg.embedding_size : 0;
     lay.Ep = (lay.E + 3) / 4 * 4;
+    lay.D = cfg.bidirectional ? 2 : 1;
+    const int D = lay.D;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += sbr_align(n); return o; };
     lay.p_Emb = lay.E ? take((size_t)cfg.input_size * lay.Ep) : 0;
-    for (int l = 0; l < lay.L; ++l) {
-        LayerLayout& y = lay.layer[l];
-        y.H = cfg.layers[l]; y.Hp = sbr_pad_hidden(y.H); y.G = G;
-        y.n_in = l == 0 ? (lay.E ? lay.F * lay.E : cfg.input_size) : cfg.layers[l - 1];
-        y.n_in_p = l == 0 ? (lay.E ? lay.F * lay.Ep : cfg.input_size) : lay.layer[l - 1].Hp;
-        y.p_Win = take((size_t)y.n_in_p * G * y.Hp);
-        y.p_b = take((size_t)G * y.Hp);
-        y.p_Whid = take((size_t)y.Hp * G * y.Hp);
-        y.p_peep = take((size_t)3 * y.Hp);
-        y.p_cinit = take(y.Hp);
-        y.p_hinit = take(y.Hp);
-    }
-    lay.HLp = lay.layer[lay.L - 1].Hp;
+    for (int l = 0; l < lay.L; ++l)
+        for (int d = 0; d < D; ++d) {            // --r_bi: forward layer's parameters first (recurrent_layers.py:72-74)
+            LayerLayout& y = lay.layer[l * D + d];
+            y.H = cfg.layers[l]; y.Hp = sbr_pad_hidden(y.H); y.G = G;
+            y.n_in = l == 0 ? (lay.E ? lay.F * lay.E : cfg.input_size) : D * cfg.layers[l - 1];
+            y.n_in_p = l == 0 ? (lay.E ? lay.F * lay.Ep : cfg.input_size) : D * lay.layer[(l - 1) * D].Hp;
+            y.p_Win = take((size_t)y.n_in_p * G * y.Hp);
+            y.p_b = take((size_t)G * y.Hp);
+            y.p_Whid = take((size_t)y.Hp * G * y.Hp);
+            y.p_peep = take((size_t)3 * y.Hp);
+            y.p_cinit = take(y.Hp);
+            y.p_hinit = take(y.Hp);
+        }
+    lay.HLp = lay.layer[(lay.L - 1) * D].Hp;
+    lay.HLt = D * lay.HLp;
     lay.p_split = off;
-    lay.p_WoutT = take((size_t)lay.N * lay.HLp);
+    lay.p_WoutT = take((size_t)lay.N * lay.HLt);
     lay.p_bout = take(lay.N);
     lay.n_params = off;
     lay.n_state_arrays = (cfg.updater == SBR_UPD_ADAM || cfg.updater == SBR_UPD_ADADELTA) ? 2 : 1;
@@ -81,9 +85,10 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     // NB: state arrays are addressed as s_state + k*n_params; n_params is already 64-aligned.
 
     off = 0;
-    size_t maxrec = 0;
-    for (int l = 0; l < lay.L; ++l) {
-        LayerLayout& y = lay.layer[l];
+    size_t maxrec = 0, max_dense_in = 0;
+    for (int pl = 0; pl < lay.L * D; ++pl) {
+        LayerLayout& y = lay.layer[pl];
+        const int l = pl / D;
         const size_t tb = (size_t)T * Bp, tb1 = (size_t)(T + 1) * Bp;
         y.a_xt = take(tb * G * y.Hp);
         y.a_hs = take(tb1 * y.Hp);
@@ -95,16 +100,32 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_state = take((size_t)2 * Bp * y.Hp);
         y.a_part = take((size_t)SBR_BWD_CHUNKS * Bp * (G * y.Hp + 5 * y.Hp));
         maxrec = std::max(maxrec, (size_t)y.Hp * G * y.Hp);
-        if (l > 0 || lay.E) maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp);
+        if (l > 0 || lay.E) { maxrec = std::max(maxrec, (size_t)y.n_in_p * G * y.Hp); max_dense_in = std::max(max_dense_in, (size_t)y.n_in_p); }
     }
     if (lay.E) { lay.a_emb = take((size_t)T * Bp * lay.F * lay.Ep); lay.a_demb = take((size_t)T * Bp * lay.F * lay.Ep); }
+    if (D == 2) {
+        lay.a_Xr = take((size_t)Bp * T * lay.F);
+        if (lay.E) lay.a_embr = take((size_t)T * Bp * lay.F * lay.Ep);
+        for (int l = 0; l + 1 < lay.L; ++l) {
+            lay.a_cat[l] = take((size_t)T * Bp * 2 * lay.layer[l * 2].Hp);
+            lay.a_catr[l] = take((size_t)T * Bp * 2 * lay.layer[l * 2].Hp);
+        }
+        lay.a_hcat = take((size_t)Bp * lay.HLt);
+        lay.a_dhl[0] = take((size_t)Bp * lay.HLp); lay.a_dhl[1] = take((size_t)Bp * lay.HLp);
+        if (max_dense_in) { lay.a_dinp[0] = take((size_t)T * Bp * max_dense_in); lay.a_dinp[1] = take((size_t)T * Bp * max_dense_in); }
+        if (!lay.E) {
+            lay.a_s2cnt = take((size_t)cfg.input_size + 1); lay.a_s2off = take((size_t)cfg.input_size + 1);
+            lay.a_s2cur = take((size_t)cfg.input_size + 1);
+            lay.a_s2sid = take((size_t)T * Bp * lay.F); lay.a_s2pos = take((size_t)T * Bp * lay.F);
+        }
+    }
     lay.a_logits = take((size_t)Bp * lay.N);
-    lay.a_dhlast = take((size_t)Bp * lay.HLp);
+    lay.a_dhlast = take((size_t)Bp * lay.HLt);
     lay.a_rowcost = take(Bp);
     if (lay.S > 0) {
-        lay.a_Wc = take((size_t)lay.C * lay.HLp); lay.a_bc = take(lay.C);
+        lay.a_Wc = take((size_t)lay.C * lay.HLt); lay.a_bc = take(lay.C);
         lay.a_act = take((size_t)Bp * lay.C);
-        lay.a_dWc = take((size_t)lay.C * lay.HLp); lay.a_dbc = take(lay.C);
+        lay.a_dWc = take((size_t)lay.C * lay.HLt); lay.a_dbc = take(lay.C);
     }
     lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
     lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
@@ -136,9 +157,12 @@ void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out) {
     static const char* van_g[1] = {"hidden_update"};
     const char* const* gn = cell == SBR_CELL_LSTM ? lstm_g : (cell == SBR_CELL_GRU ? gru_g : van_g);
     if (lay.E) out.push_back({"emb.W", 0, 8, 0, lay.cfg.input_size, lay.E, 2});   // lasagne EmbeddingLayer comes first
-    for (int l = 0; l < lay.L; ++l) {
-        const LayerLayout& y = lay.layer[l];
-        char pre[16]; snprintf(pre, sizeof(pre), "l%d.", l);
+    for (int pl = 0; pl < lay.L * lay.D; ++pl) {
+        const LayerLayout& y = lay.layer[pl];
+        const int l = pl;      // ParamDesc.layer indexes lay.layer[] (level * D + direction)
+        char pre[16];
+        if (lay.D == 1) snprintf(pre, sizeof(pre), "l%d.", pl);
+        else snprintf(pre, sizeof(pre), "l%d%c.", pl / 2, "fb"[pl & 1]);
         for (int g = 0; g < lay.G; ++g) {
             out.push_back({std::string(pre) + "W_in_to_" + gn[g], l, 0, g, y.n_in, y.H, 2});
             out.push_back({std::string(pre) + "W_hid_to_" + gn[g], l, 1, g, y.H, y.H, 2});
@@ -152,8 +176,8 @@ void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out) {
         }
         out.push_back({std::string(pre) + "hid_init", l, 5, 0, 1, y.H, 2});
     }
-    out.push_back({"out.W", lay.L - 1, 6, 0, lay.layer[lay.L - 1].H, lay.N, 2});
-    out.push_back({"out.b", lay.L - 1, 7, 0, lay.N, 1, 1});
+    out.push_back({"out.W", (lay.L - 1) * lay.D, 6, 0, lay.D * lay.layer[(lay.L - 1) * lay.D].H, lay.N, 2});
+    out.push_back({"out.b", (lay.L - 1) * lay.D, 7, 0, lay.N, 1, 1});
 }
 
 // position of Lasagne gate g (creation order) inside the stacked matrices:
@@ -170,8 +194,12 @@ static void convert_param(const Layout& lay, const ParamDesc& d, float* image, f
     switch (d.kind) {
         case 0:
             for (int64_t r = 0; r < d.d0; ++r) {
-                // layer 0 behind an embedding: logical row f*E + e is stored at f*Ep + e
-                const int64_t rs = (lay.E && d.layer == 0) ? (r / lay.E) * lay.Ep + r % lay.E : r;
+                // stored row of logical input row r: behind an embedding f*E + e -> f*Ep + e; above another level its
+                // D concatenated outputs of H units each are stored Hp apart
+                int64_t rs = r;
+                const int level = d.layer / lay.D;
+                if (level == 0 && lay.E) rs = (r / lay.E) * lay.Ep + r % lay.E;
+                else if (level > 0) { const LayerLayout& lo = lay.layer[(level - 1) * lay.D]; rs = (r / lo.H) * lo.Hp + r % lo.H; }
                 for (int64_t c = 0; c < d.d1; ++c) mv(y.p_Win + rs * GHp + gp * y.Hp + c, r * d.d1 + c);
             }
             break;
@@ -181,7 +209,12 @@ static void convert_param(const Layout& lay, const ParamDesc& d, float* image, f
         case 3: for (int64_t c = 0; c < d.d0; ++c) mv(y.p_peep + d.gate * y.Hp + c, c); break;
         case 4: for (int64_t c = 0; c < d.d1; ++c) mv(y.p_cinit + c, c); break;
         case 5: for (int64_t c = 0; c < d.d1; ++c) mv(y.p_hinit + c, c); break;
-        case 6: for (int64_t k = 0; k < d.d0; ++k) for (int64_t n = 0; n < d.d1; ++n) mv(lay.p_WoutT + n * lay.HLp + k, k * d.d1 + n); break;
+        case 6:
+            for (int64_t k = 0; k < d.d0; ++k) {
+                const int64_t ks = (k / y.H) * lay.HLp + k % y.H;     // --r_bi: [forward H | backwards H] stored HLp apart
+                for (int64_t n = 0; n < d.d1; ++n) mv(lay.p_WoutT + n * lay.HLt + ks, k * d.d1 + n);
+            }
+            break;
         case 7: for (int64_t n = 0; n < d.d0; ++n) mv(lay.p_bout + n, n); break;
     }
 }
@@ -430,11 +463,131 @@ extern "C" int sbr_zero_grads(sbr_handle* h) {
     return SBR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// --r_bi (recurrent_layers.py:70-76).  Level l = forward layer lay.layer[2l] + backwards layer lay.layer[2l+1] over the
+// same input.  The backwards layer runs the ordinary kernels on per-row time-reversed copies of its input (see the
+// helper kernels in sbr_misc.hip), so every recurrent kernel of the unidirectional path is reused unchanged.
+// ---------------------------------------------------------------------------------------
+static int side_join(sbr_handle* h);
+
+static int forward_bi(sbr_handle* h) {
+    const Layout& y = h->lay; hipStream_t s = h->stream;
+    const int TB = y.T * y.Bp;
+    int* Xr = (int*)h->A(y.a_Xr);
+    if (!y.E) SBR_LAUNCH(launch_rev_rows_int(s, h->bX, h->blen, Xr, y.T, y.Bp, y.F));
+    else {
+        SBR_LAUNCH(launch_gather_concat(s, h->P(y.p_Emb), h->bX, h->A(y.a_emb), y.T, y.Bp, y.F, y.Ep));
+        SBR_LAUNCH(launch_rev_rows(s, h->A(y.a_emb), h->blen, h->A(y.a_embr), y.T, y.Bp, y.F * y.Ep));
+    }
+    for (int l = 0; l < y.L; ++l) {
+        for (int d = 0; d < 2; ++d) {
+            const int pl = 2 * l + d;
+            const LayerLayout& ly = y.layer[pl];
+            const int GHp = y.G * ly.Hp;
+            RecArgs ra = rec_args(h, pl);
+            if (l == 0 && !y.E) {
+                const int* idx = d ? Xr : h->bX;
+                if (y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(ra, simple_rec(h))) {
+                    ra.gX = idx; ra.gWin = h->P(ly.p_Win); ra.gbias = h->P(ly.p_b);
+                } else {
+                    SBR_LAUNCH(launch_gather_xt(s, h->P(ly.p_Win), h->P(ly.p_b), idx, h->A(ly.a_xt), y.T, y.Bp, y.F, GHp, h->n_rows));
+                }
+            } else {   // dense input: the (reversed) flattened embeddings or the (reversed) concatenated outputs of the level below
+                const float* inp = l == 0 ? h->A(d ? y.a_embr : y.a_emb) : h->A(d ? y.a_catr[l - 1] : y.a_cat[l - 1]);
+                SBR_LAUNCH(launch_gemm(s, inp, ly.n_in_p, 1, h->P(ly.p_Win), GHp, 1, h->A(ly.a_xt), GHp, TB, GHp, ly.n_in_p,
+                                       h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
+            }
+            if (l == 0 && d == 1) mark(h, 1);
+            SBR_LAUNCH(launch_rec_forward(s, ra, simple_rec(h)));
+        }
+        const LayerLayout& lf = y.layer[2 * l]; const LayerLayout& lb = y.layer[2 * l + 1];
+        if (l + 1 < y.L) {
+            SBR_LAUNCH(launch_cat_outputs(s, h->A(lf.a_hs), h->A(lb.a_hs), h->blen, h->A(y.a_cat[l]), y.T, y.Bp, lf.Hp));
+            SBR_LAUNCH(launch_rev_rows(s, h->A(y.a_cat[l]), h->blen, h->A(y.a_catr[l]), y.T, y.Bp, 2 * lf.Hp));
+        } else {   // only_return_final: both directions' last scan output (sparse_lstm.py:485-486)
+            SBR_LAUNCH(launch_hcat(s, h->A(lf.a_hs) + (size_t)TB * lf.Hp, h->A(lb.a_hs) + (size_t)TB * lb.Hp, h->A(y.a_hcat), y.Bp, lf.Hp));
+        }
+    }
+    mark(h, 2);
+    h->fwd_done = true;
+    return SBR_OK;
+}
+
+static int backward_bi(sbr_handle* h) {
+    const Layout& y = h->lay; hipStream_t s = h->stream;
+    const bool sg = simple_gemm(h);
+    float* ws = h->A(y.a_ws);
+    const int TB = y.T * y.Bp;
+    SBR_LAUNCH(launch_split_cols(s, h->A(y.a_dhlast), h->A(y.a_dhl[0]), h->A(y.a_dhl[1]), y.Bp, y.HLp));
+    for (int l = y.L - 1; l >= 0; --l) {
+        for (int d = 0; d < 2; ++d) {
+            const int pl = 2 * l + d;
+            const LayerLayout& ly = y.layer[pl];
+            const int GHp = y.G * ly.Hp;
+            RecArgs a = rec_args(h, pl);
+            if (h->fill_done && sbr_rec_cluster_ok(a)) {
+                a.sentinel_done = 1;
+                SBR_HIP(hipStreamWaitEvent(s, h->ev_fill, 0));
+            }
+            a.dh_last = l == y.L - 1 ? h->A(y.a_dhl[d]) : nullptr;
+            a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
+            const int nblk = sbr_rec_bwd_blocks(a, simple_rec(h));
+            SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
+            if (l == 0 && d == 1) mark(h, 4);
+            SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+                                                  h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
+            // dW_hid = hs^T . d hid_input (hs slot t = the state before step t)
+            if (y.cfg.cell == SBR_CELL_GRU) {
+                SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, 2 * ly.Hp, TB, nullptr,
+                                       ws, y.ws_floats, sg));
+                SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dhi, ly.Hp, 1, h->Gd(ly.p_Whid) + 2 * ly.Hp, GHp, ly.Hp, ly.Hp, TB,
+                                       nullptr, ws, y.ws_floats, sg));
+            } else {
+                SBR_LAUNCH(launch_gemm(s, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, h->Gd(ly.p_Whid), GHp, ly.Hp, GHp, TB, nullptr, ws,
+                                       y.ws_floats, sg));
+            }
+            if (l == 0 && !y.E) {   // index input: scatter-add with this direction's ids (the backwards one sorted its reversed ids)
+                if (d == 0) mark(h, 5);
+                const int* idx = d ? (const int*)h->A(y.a_Xr) : h->bX;
+                if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
+                    SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, idx, a.len, y.T, y.Bp, y.F, GHp));
+                } else {
+                    SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));
+                    SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(d ? y.a_s2sid : y.a_sid),
+                                                     (const int*)h->A(d ? y.a_s2pos : y.a_spos), (const int*)h->A(d ? y.a_s2off : y.a_soff),
+                                                     y.cfg.input_size, y.T * y.Bp * y.F, GHp, y.Bp));
+                }
+            } else {                // dense input: dW_in = inp^T . dxt, d_inp = dxt . W_in^T (in this direction's time order)
+                const float* inp = l == 0 ? h->A(d ? y.a_embr : y.a_emb) : h->A(d ? y.a_catr[l - 1] : y.a_cat[l - 1]);
+                SBR_LAUNCH(launch_gemm(s, inp, 1, ly.n_in_p, a.dxt, GHp, 1, h->Gd(ly.p_Win), GHp, ly.n_in_p, GHp, TB, nullptr, ws,
+                                       y.ws_floats, sg));
+                SBR_LAUNCH(launch_gemm(s, a.dxt, GHp, 1, h->P(ly.p_Win), 1, GHp, h->A(y.a_dinp[d]), ly.n_in_p, TB, ly.n_in_p, GHp, nullptr,
+                                       nullptr, 0, sg));
+            }
+        }
+        if (l > 0) {        // gradient wrt the level below: forward half in forward time, backwards half in reversed time
+            const LayerLayout& lf = y.layer[2 * (l - 1)]; const LayerLayout& lb = y.layer[2 * (l - 1) + 1];
+            SBR_LAUNCH(launch_uncat(s, h->A(y.a_dinp[0]), h->A(y.a_dinp[1]), h->blen, h->A(lf.a_dhext), h->A(lb.a_dhext), y.T, y.Bp,
+                                    2 * lf.Hp, lf.Hp));
+        } else if (y.E) {   // embedding table: both directions' input gradients, back in forward time, scatter-added by index
+            mark(h, 5);
+            SBR_LAUNCH(launch_uncat(s, h->A(y.a_dinp[0]), h->A(y.a_dinp[1]), h->blen, h->A(y.a_demb), nullptr, y.T, y.Bp, y.F * y.Ep, 0));
+            SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));
+            SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(y.p_Emb), h->A(y.a_demb), (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                             (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, y.Ep, y.Bp));
+        }
+        if (l == 0) mark(h, 6);
+    }
+    if (!h->in_train_step && !h->deferred_join) return side_join(h);
+    return SBR_OK;
+}
+
 extern "C" int sbr_forward(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     sbr_gemm_set_exact_f32((h->lay.cfg.flags & SBR_FLAG_F32_MFMA) != 0);
     if (!h->have_batch) { sbr_set_error("sbr_forward: no batch set"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream;
+    if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
         const int GHp = y.G * ly.Hp;
@@ -465,7 +618,8 @@ extern "C" int sbr_forward(sbr_handle* h) {
 }
 
 static float* h_last(sbr_handle* h) {   // hid_out[-1] (sparse_lstm.py:485-486) = slot T of the top layer
-    const Layout& y = h->lay; const LayerLayout& ly = y.layer[y.L - 1];
+    const Layout& y = h->lay; const LayerLayout& ly = y.layer[(y.L - 1) * y.D];
+    if (y.D == 2) return h->A(y.a_hcat);                 // [forward final | backwards final], filled by forward_bi
     return h->A(ly.a_hs) + (size_t)y.T * y.Bp * ly.Hp;
 }
 
@@ -486,7 +640,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     sbr_gemm_set_exact_f32((h->lay.cfg.flags & SBR_FLAG_F32_MFMA) != 0);
     if (!h->fwd_done) { sbr_set_error("sbr_loss_backward_output: call sbr_forward first"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
-    const int R = h->n_rows, Hp = y.HLp, N = y.N;
+    const int R = h->n_rows, Hp = y.HLt, N = y.N;      // Hp: the output layer's input width (both directions with --r_bi)
     const bool sg = simple_gemm(h);
     h->grads_clean = false;
     float* hl = h_last(h);
@@ -500,7 +654,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     h->fill_done = false;
     if (!simple_rec(h)) {   // cluster BPTT kernels: the sentinel fill of their exchange arrays runs beside the output phase
         bool any = false;
-        for (int l = 0; l < y.L; ++l) {
+        for (int l = 0; l < y.L * y.D; ++l) {
             RecArgs a = rec_args(h, l);
             if (sbr_rec_cluster_ok(a)) { SBR_LAUNCH(sbr_rec_bwd_cl_fill(sd, a)); any = true; }
         }
@@ -511,6 +665,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                        y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
                                        (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
+        if (y.D == 2 && !y.E)   // the backwards direction scatters with the reversed ids (a_Xr was written by forward_bi)
+            SBR_LAUNCH(launch_scatter_sort(sd, (const int*)h->A(y.a_Xr), h->blen, y.T, y.Bp, y.F, y.cfg.input_size,
+                                           (int*)h->A(y.a_s2cnt), (int*)h->A(y.a_s2off), (int*)h->A(y.a_s2cur),
+                                           (int*)h->A(y.a_s2sid), (int*)h->A(y.a_s2pos), 0));
         SBR_HIP(hipEventRecord(h->ev_sort, sd));
     }
     if (y.cfg.loss == SBR_LOSS_CCE) {
@@ -565,6 +723,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
     const Layout& y = h->lay; hipStream_t s = h->stream, sd = h->side;
     const bool sg = simple_gemm(h);
     h->grads_clean = false;
+    if (y.D == 2) return backward_bi(h);
     float* ws = h->A(y.a_ws);
     float* ws2 = h->A(y.a_ws2);
     const int TB = y.T * y.Bp;
@@ -701,10 +860,10 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         // (recorded long ago), updates all ranges except the W_hid blocks, joins, then updates those.
         SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
         size_t pos = 0;
-        for (int l = 0; l < y.L; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
+        for (int l = 0; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
         SBR_LAUNCH(upd(pos, y.n_params));
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
-        for (int l = 0; l < y.L; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
+        for (int l = 0; l < y.L * y.D; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
     } else {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(upd(0, y.n_params));
@@ -759,7 +918,7 @@ static int full_scores(sbr_handle* h, int do_softmax) {
     // scoring always runs the exact-f32 kernel: a row's scores (hence its ranked ids) must not depend on how many rows
     // share the call (the bf16x6 kernel takes over at >= 96 rows and rounds differently)
     sbr_gemm_set_exact_f32(true);
-    SBR_LAUNCH(launch_gemm(h->stream, h_last(h), y.HLp, 1, h->P(y.p_WoutT), 1, y.HLp, lg, y.N, h->n_rows, y.N, y.HLp, nullptr,
+    SBR_LAUNCH(launch_gemm(h->stream, h_last(h), y.HLt, 1, h->P(y.p_WoutT), 1, y.HLt, lg, y.N, h->n_rows, y.N, y.HLt, nullptr,
                            nullptr, 0, simple_gemm(h)));
     SBR_LAUNCH(launch_softmax_rows(h->stream, lg, h->P(y.p_bout), h->n_rows, y.N, do_softmax));
     return SBR_OK;
@@ -805,9 +964,9 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     const Layout& y = h->lay;
     const std::string nm(name);
     const size_t tb = (size_t)y.T * y.Bp;
-    if (nm == "h_last") { *dev_ptr = h_last(h); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
+    if (nm == "h_last") { *dev_ptr = h_last(h); *n_floats = (size_t)y.Bp * y.HLt; return SBR_OK; }
     if (nm == "logits") { *dev_ptr = h->A(y.a_logits); *n_floats = (size_t)y.Bp * y.N; return SBR_OK; }
-    if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLp; return SBR_OK; }
+    if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLt; return SBR_OK; }
     if (nm == "batch_X") { *dev_ptr = (void*)h->bX; *n_floats = (size_t)y.Bp * y.T * y.F; return SBR_OK; }
     if (nm == "batch_lengths") { *dev_ptr = (void*)h->blen; *n_floats = y.Bp; return SBR_OK; }
     if (nm == "batch_target") { *dev_ptr = (void*)h->btgt; *n_floats = y.S > 0 ? y.Bg : y.Bp; return SBR_OK; }
@@ -858,7 +1017,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         RecArgs a = rec_args(h, 0);
         *value = (y.E == 0 && y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(a, simple_rec(h))) ? 1 : 0;
     } else if (w == "rows_per_workgroup") *value = h->rpt;
-    else if (w == "cluster") { RecArgs a = rec_args(h, y.L - 1); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
+    else if (w == "cluster") { RecArgs a = rec_args(h, (y.L - 1) * y.D); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
     else if (w == "side_stream") *value = (int64_t)(intptr_t)h->side;
     else { sbr_set_error("unknown query '%s'", what); return SBR_EINVAL; }

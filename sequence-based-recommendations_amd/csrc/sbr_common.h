@@ -53,11 +53,20 @@ struct LayerLayout {
 struct Layout {
     sbr_config cfg;
     int L, G, T, B, Bp, N, F, Bg, S, C;   // C = Bg + S sampled columns
-    int HLp;                              // padded width of the top layer
+    int HLp;                              // padded width of one direction of the top layer
+    int D, HLt;                           // directions per level (2 with --r_bi) and the output layer's input width D * HLp
+    // --r_bi only (the backwards direction runs the ordinary kernels on per-row time-reversed copies of its input):
+    size_t a_Xr;                          // [Bp][T][F] ints: item ids reversed inside each row's valid length
+    size_t a_embr;                        // [T][Bp][F*Ep] reversed flattened embeddings (--r_emb)
+    size_t a_cat[SBR_MAX_LAYERS], a_catr[SBR_MAX_LAYERS];   // [T][Bp][2*Hp_l] concatenated outputs of level l (forward time / reversed)
+    size_t a_hcat;                        // [Bp][2*HLp] final states of both directions
+    size_t a_dhl[2];                      // [Bp][HLp] halves of dh_last
+    size_t a_dinp[2];                     // [T][Bp][max dense n_in_p] gradient wrt a dense level's input, per direction
+    size_t a_s2cnt, a_s2off, a_s2cur, a_s2sid, a_s2pos;     // scatter sort workspace of the reversed ids
     int E, Ep;                            // --r_emb: embedding width and its stored width (multiple of 4); 0 = none
     size_t p_Emb;                         // [input_size][Ep]
     size_t a_emb, a_demb;                 // [T][Bp][F*Ep] flattened embeddings = dense input of layer 0, and its gradient
-    LayerLayout layer[SBR_MAX_LAYERS];
+    LayerLayout layer[2 * SBR_MAX_LAYERS];   // [l * D + d]: d = 0 forward, 1 backwards (--r_bi)
     size_t p_WoutT, p_bout;               // [N][HLp], [N]
     size_t n_params;                      // floats in the parameter section
     size_t p_split;                       // == p_WoutT : output-layer part starts here
@@ -149,6 +158,17 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
                                int* offs, int* cur, int* sid, int* spos, int concat = 0);
 // emb[t][b][f*Ep + e] = W_emb[X[b][t][f]][e]          (lasagne EmbeddingLayer + flatten(outdim=3), recurrent_layers.py:48)
 hipError_t launch_gather_concat(hipStream_t s, const float* Wemb, const int* X, float* out, int T, int Bp, int F, int Ep);
+// --r_bi helpers (sbr_misc.hip).  rev(t, len) = t < len ? len-1-t : t (padding stays in place).
+hipError_t launch_rev_rows_int(hipStream_t s, const int* X, const int* len, int* Xr, int T, int Bp, int F);
+hipError_t launch_rev_rows(hipStream_t s, const float* src, const int* len, float* dst, int T, int Bp, int W);   // dst[t][b] = src[rev(t)][b]
+// cat[t][b] = [hs_f[t+1][b] | hs_b[rev(t)+1][b]]   (hs_*: [T+1][Bp][Hp], slot t+1 = state after step t of that scan)
+hipError_t launch_cat_outputs(hipStream_t s, const float* hs_f, const float* hs_b, const int* len, float* cat, int T, int Bp, int Hp);
+hipError_t launch_hcat(hipStream_t s, const float* hf, const float* hb, float* out, int Bp, int Hp);            // [hf | hb]
+hipError_t launch_split_cols(hipStream_t s, const float* src, float* a, float* b, int rows, int Hp);             // src [rows][2Hp] -> a, b
+// d[t][b] = f[t][b] + r[rev(t)][b] over W columns; then out_f[t][b] = d[t][b][0:Hp], out_b[t][b] = d[rev(t)][b][Hp:2Hp]
+// (out_b == NULL: W arbitrary, only the sum d is written to out_f -- the embedding case)
+hipError_t launch_uncat(hipStream_t s, const float* f, const float* r, const int* len, float* out_f, float* out_b, int T, int Bp,
+                        int W, int Hp);
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp);
 

@@ -76,6 +76,102 @@ hipError_t launch_gather_concat(hipStream_t s, const float* Wemb, const int* X, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// --r_bi helpers.  The backwards layer of a level (Lasagne go_backwards=True over the left-aligned, masked sequence:
+// the padded steps come first and copy hid_init, then the valid steps in reverse) is run as an ordinary forward scan
+// over the row's valid steps REVERSED IN PLACE: rev(t) = len-1-t for t < len, t otherwise.  State after scan step s of
+// the reversed row = the backwards layer's output at time len-1-s; its final state = the output at time 0, which is what
+// only_return_final takes (sparse_lstm.py:485-486).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int rev_t(int t, int len) { return t < len ? len - 1 - t : t; }
+
+__global__ void rev_rows_int_kernel(const int* __restrict__ X, const int* __restrict__ len, int* __restrict__ Xr, int T, int Bp, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * T * F) return;
+    const int f = i % F, t = (i / F) % T, b = i / (F * T);
+    Xr[i] = X[((size_t)b * T + rev_t(t, len[b])) * F + f];
+}
+hipError_t launch_rev_rows_int(hipStream_t s, const int* X, const int* len, int* Xr, int T, int Bp, int F) {
+    const int n = Bp * T * F;
+    rev_rows_int_kernel<<<(n + 255) / 256, 256, 0, s>>>(X, len, Xr, T, Bp, F);
+    return hipGetLastError();
+}
+
+__global__ void rev_rows_kernel(const f32x4* __restrict__ src, const int* __restrict__ len, f32x4* __restrict__ dst, int T, int Bp, int W4) {
+    const size_t total = (size_t)T * Bp * W4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W4);
+        const size_t pos = i / W4;
+        const int b = (int)(pos % Bp), t = (int)(pos / Bp);
+        dst[i] = src[((size_t)rev_t(t, len[b]) * Bp + b) * W4 + w];
+    }
+}
+hipError_t launch_rev_rows(hipStream_t s, const float* src, const int* len, float* dst, int T, int Bp, int W) {
+    const size_t total = (size_t)T * Bp * (W / 4);
+    rev_rows_kernel<<<(int)min((size_t)4096, (total + 255) / 256), 256, 0, s>>>((const f32x4*)src, len, (f32x4*)dst, T, Bp, W / 4);
+    return hipGetLastError();
+}
+
+__global__ void cat_outputs_kernel(const f32x4* __restrict__ hf, const f32x4* __restrict__ hb, const int* __restrict__ len,
+                                   f32x4* __restrict__ cat, int T, int Bp, int H4) {
+    const size_t total = (size_t)T * Bp * 2 * H4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % (2 * H4));
+        const size_t pos = i / (2 * H4);
+        const int b = (int)(pos % Bp), t = (int)(pos / Bp);
+        cat[i] = w < H4 ? hf[((size_t)(t + 1) * Bp + b) * H4 + w]
+                        : hb[((size_t)(rev_t(t, len[b]) + 1) * Bp + b) * H4 + (w - H4)];
+    }
+}
+hipError_t launch_cat_outputs(hipStream_t s, const float* hs_f, const float* hs_b, const int* len, float* cat, int T, int Bp, int Hp) {
+    const size_t total = (size_t)T * Bp * 2 * (Hp / 4);
+    cat_outputs_kernel<<<(int)min((size_t)4096, (total + 255) / 256), 256, 0, s>>>((const f32x4*)hs_f, (const f32x4*)hs_b, len,
+                                                                                 (f32x4*)cat, T, Bp, Hp / 4);
+    return hipGetLastError();
+}
+
+__global__ void hcat_kernel(const float* __restrict__ hf, const float* __restrict__ hb, float* __restrict__ out, int Bp, int Hp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp * 2 * Hp) return;
+    const int w = i % (2 * Hp), b = i / (2 * Hp);
+    out[i] = w < Hp ? hf[(size_t)b * Hp + w] : hb[(size_t)b * Hp + w - Hp];
+}
+hipError_t launch_hcat(hipStream_t s, const float* hf, const float* hb, float* out, int Bp, int Hp) {
+    hcat_kernel<<<(Bp * 2 * Hp + 255) / 256, 256, 0, s>>>(hf, hb, out, Bp, Hp);
+    return hipGetLastError();
+}
+__global__ void split_cols_kernel(const float* __restrict__ src, float* __restrict__ a, float* __restrict__ b, int rows, int Hp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 2 * Hp) return;
+    const int w = i % (2 * Hp), r = i / (2 * Hp);
+    if (w < Hp) a[(size_t)r * Hp + w] = src[i]; else b[(size_t)r * Hp + w - Hp] = src[i];
+}
+hipError_t launch_split_cols(hipStream_t s, const float* src, float* a, float* b, int rows, int Hp) {
+    split_cols_kernel<<<(rows * 2 * Hp + 255) / 256, 256, 0, s>>>(src, a, b, rows, Hp);
+    return hipGetLastError();
+}
+
+__global__ void uncat_kernel(const float* __restrict__ f, const float* __restrict__ r, const int* __restrict__ len,
+                             float* __restrict__ out_f, float* __restrict__ out_b, int T, int Bp, int W, int Hp) {
+    const size_t total = (size_t)T * Bp * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const size_t pos = i / W;
+        const int b = (int)(pos % Bp), t = (int)(pos / Bp);
+        const int tr = rev_t(t, len[b]);
+        const float d = f[i] + r[((size_t)tr * Bp + b) * W + w];                   // gradient wrt the level's input at time t
+        if (!out_b) out_f[i] = d;
+        else if (w < Hp) out_f[((size_t)t * Bp + b) * Hp + w] = d;                     // forward direction: its own time
+        else out_b[((size_t)tr * Bp + b) * Hp + (w - Hp)] = d;                         // backwards direction: reversed time
+    }
+}
+hipError_t launch_uncat(hipStream_t s, const float* f, const float* r, const int* len, float* out_f, float* out_b, int T, int Bp,
+                        int W, int Hp) {
+    const size_t total = (size_t)T * Bp * W;
+    uncat_kernel<<<(int)min((size_t)4096, (total + 255) / 256), 256, 0, s>>>(f, r, len, out_f, out_b, T, Bp, W, Hp);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, const int* X, float* xt, int T, int Bp,
                             int F, int GHp, int) {
     const int R4 = GHp / 4;

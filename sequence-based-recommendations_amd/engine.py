@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 2
+SBR_ABI_VERSION = 3
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
@@ -43,7 +43,7 @@ class SbrConfig(ctypes.Structure):
                 ("loss", ctypes.c_int32), ("n_samples", ctypes.c_int32), ("updater", ctypes.c_int32),
                 ("learning_rate", ctypes.c_float), ("rho", ctypes.c_float), ("beta1", ctypes.c_float),
                 ("beta2", ctypes.c_float), ("regularization", ctypes.c_float), ("grad_clip", ctypes.c_float),
-                ("flags", ctypes.c_int32), ("embedding_size", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("embedding_size", ctypes.c_int32), ("bidirectional", ctypes.c_int32)]
 
 
 # every symbol include/sbr_rnn.h declares (tests check the library exports all of them)
@@ -215,7 +215,7 @@ class RNNEngine(object):
     def __init__(self, cell="GRU", layers=(50,), n_items=None, max_length=30, batch_size=16, loss="CCE",
                  n_samples=0, updater="adam", learning_rate=0.001, rho=0.9, beta1=0.9, beta2=0.999,
                  regularization=0.0, grad_clip=100.0, input_size=None, n_feat=1, local_batch=None, row_offset=0,
-                 flags=0, device=None, embedding_size=0):
+                 flags=0, device=None, embedding_size=0, bidirectional=False):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("RNNEngine needs a HIP device (MI355X); there is no CPU fallback")
@@ -249,6 +249,7 @@ class RNNEngine(object):
         cfg.grad_clip = grad_clip
         cfg.flags = int(flags)
         cfg.embedding_size = max(0, int(embedding_size))     # --r_emb: a size < 1 means no embedding layer
+        cfg.bidirectional = 1 if bidirectional else 0        # --r_bi
         if len(layers) > SBR_MAX_LAYERS:
             raise ValueError("at most %d recurrent layers" % SBR_MAX_LAYERS)
         self.cfg = cfg

@@ -47,8 +47,6 @@ class RNNBase(object):
         if self.use_movies_features or self.use_users_features:
             # the reference dereferences feature tables that are always None (rnn_base.py:27-29,572,607)
             raise NotImplementedError("movie/user features (--mf/--uf) are unusable in the reference and unsupported here")
-        if self.recurrent_layer.bidirectional:
-            raise NotImplementedError("--r_bi is not part of the round-1 hot path")
         self._input_type = "int32"
         self.name = "RNN base"
         self.metrics = {"recall": {"direction": 1}, "sps": {"direction": 1}, "user_coverage": {"direction": 1},
@@ -73,7 +71,7 @@ class RNNBase(object):
         kw = dict(cell=self.recurrent_layer.layer_type, layers=self.recurrent_layer.layers, n_items=self.n_items,
                   max_length=self.max_length, batch_size=self.batch_size, grad_clip=float(self.recurrent_layer.grad_clip),
                   input_size=self.n_items + self._n_optional_features(), n_feat=self._input_size(),
-                  embedding_size=self.recurrent_layer.embedding_size)
+                  embedding_size=self.recurrent_layer.embedding_size, bidirectional=self.recurrent_layer.bidirectional)
         kw.update(self.updater.engine_kwargs())
         kw.update(self._engine_kwargs())
         self.engine = RNNEngine(**kw)

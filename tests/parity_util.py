@@ -33,17 +33,17 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0, emb=0):
+def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0, emb=0, bi=False):
     if scale is None:      # a tanh-only cell with wide layers is chaotic at large weights: keep it well conditioned
         scale = 0.3 if (cell != "Vanilla" or max(layers) <= 64) else 0.05
     rng = np.random.default_rng(seed)
-    params = O.init_params(cell, layers, N, rng, n_in0=N + n_opt, embedding=emb, n_feat=F)
+    params = O.init_params(cell, layers, N, rng, n_in0=N + n_opt, embedding=emb, n_feat=F, bidirectional=bi)
     for p in params:                      # move every parameter (biases, inits, peepholes) off zero
         p += rng.normal(0, scale, size=p.shape)
     params = [p.astype(np.float32).astype(np.float64) for p in params]
     batch = make_batch(rng, B, T, N, S=S, F=F, n_in0=N + n_opt, full=full)
     batch["pop"] = (batch["pop"] * popscale).astype(np.float32)
-    cfg = dict(cell=cell, layers=list(layers), loss=loss, regularization=0.0, embedding=emb)
+    cfg = dict(cell=cell, layers=list(layers), loss=loss, regularization=0.0, embedding=emb, bidirectional=bi)
     return params, cfg, batch
 
 
@@ -53,7 +53,7 @@ def engine_for(cfg, N, B, T, S=0, F=1, n_opt=0, updater="adam", lr=0.01, flags=0
     return RNNEngine(cell=cfg["cell"], layers=cfg["layers"], n_items=N, max_length=T, batch_size=B, loss=cfg["loss"],
                      n_samples=S, updater=updater, learning_rate=lr, rho=0.9, beta1=0.9, beta2=0.999,
                      regularization=reg, input_size=N + n_opt, n_feat=F, flags=flags, local_batch=local_batch,
-                     row_offset=row_offset, embedding_size=cfg.get("embedding", 0))
+                     row_offset=row_offset, embedding_size=cfg.get("embedding", 0), bidirectional=cfg.get("bidirectional", False))
 
 
 def oracle_batch(batch):
@@ -63,10 +63,10 @@ def oracle_batch(batch):
 
 
 def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
-                 reg=0.0, steps=2, popscale=1.0, scale=None, emb=0):
+                 reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False):
     """Returns dict of relative errors (engine float32 vs oracle float64)."""
     params, cfg, batch = build_case(cell, layers, loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, full=full,
-                                    popscale=popscale, scale=scale, emb=emb)
+                                    popscale=popscale, scale=scale, emb=emb, bi=bi)
     cfg["regularization"] = reg
     eng = engine_for(cfg, N, B, T, S=S, F=F, n_opt=n_opt, updater=updater, flags=flags, reg=reg)
     out = {}
@@ -79,11 +79,15 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
         cost = eng.forward_backward()
         ocost, ograds, aux = O.cost_and_grads(params, cfg, oracle_batch(batch))
         Hp = eng.debug_buffer("h_last").size // (((B + 15) // 16) * 16)
-        hl = eng.debug_buffer("h_last").reshape(-1, Hp)[:B, :layers[-1]]
+        hl = eng.debug_buffer("h_last").reshape(-1, Hp)[:B]
+        if bi:      # [forward H | pad | backwards H | pad]
+            hl = np.concatenate([hl[:, :layers[-1]], hl[:, Hp // 2:Hp // 2 + layers[-1]]], axis=1)
+        else:
+            hl = hl[:, :layers[-1]]
         out["h_last"] = rel_err(hl, aux["h"])
         out["cost"] = abs(cost - ocost) / (abs(ocost) + 1e-12)
         grads = eng.get_all_grad_values()
-        names = [n for n, _ in O.model_param_shapes(cell, layers, N, N + n_opt, emb, F)]
+        names = [n for n, _ in O.model_param_shapes(cell, layers, N, N + n_opt, emb, F, bi)]
         worst = 0.0
         for n, g, og in zip(names, grads, ograds):
             e = rel_err(g, og) if np.abs(og).max() > 0 else float(np.abs(g).max())

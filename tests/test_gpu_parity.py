@@ -113,6 +113,19 @@ def test_embedding_layer_option(cell):
     check(PU.compare_step(cell, [20, 12], "CCE", N=41, B=19, T=7, F=2, n_opt=10, emb=5))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_bidirectional_option(cell):
+    # --r_bi (recurrent_layers.py:70-76): a forward and a backwards layer per level, concatenated.  The backwards one
+    # runs the ordinary kernels on per-row time-reversed copies of its input; ragged lengths make the reversal non-trivial
+    check(PU.compare_step(cell, [20], "CCE", N=61, B=37, T=9, bi=True))
+    check(PU.compare_step(cell, [20, 12], "CCE", N=41, B=19, T=7, bi=True, seed=2))
+
+
+def test_bidirectional_with_embedding_sampled_head_and_two_indices():
+    check(PU.compare_step("GRU", [16, 16], "BPR", N=41, B=19, T=7, S=8, bi=True, emb=6, F=2, n_opt=10, seed=3))
+    check(PU.compare_step("LSTM", [128], "CCE", N=61, B=21, T=8, bi=True, seed=4))
+
+
 def test_embedding_layer_with_sampled_head_and_wide_layer():
     check(PU.compare_step("GRU", [128], "BPR", N=61, B=37, T=9, S=8, emb=16))
 

@@ -43,6 +43,7 @@ def make_dataset(root, n_users=40, n_items=30, seed=0):
 
 @pytest.mark.parametrize("extra", [["--loss", "CCE", "--r_t", "GRU", "--r_l", "16"],
                                    ["--loss", "CCE", "--r_t", "GRU", "--r_l", "16", "--r_emb", "8"],
+                                   ["--loss", "CCE", "--r_t", "LSTM", "--r_l", "12-8", "--r_bi"],
                                    ["--loss", "BPR", "--r_t", "LSTM", "--r_l", "12", "--sampling", "8", "--u_m", "adagrad", "--u_l", "0.1"]])
 def test_train_cli_end_to_end(tmp_path, extra):
     from sbr_amd import train as T
