@@ -188,6 +188,10 @@ class Evaluator(object):
 
     def __init__(self, dataset, k=10):
         self.instances, self.dataset, self.k = [], dataset, k
+        # evaluation.py:24-35: the names test.py's --metrics accepts
+        self.metrics = {"sps": self.sps, "recall": self.average_recall, "precision": self.average_precision,
+                        "ndcg": self.average_ndcg, "item_coverage": self.item_coverage, "user_coverage": self.user_coverage,
+                        "blockbuster_share": self.blockbuster_share, "novelty": self.average_novelty, "assr": self.assr}
 
     def add_instance(self, goal, predictions):
         self.instances.append([list(goal), list(predictions)])
@@ -230,6 +234,30 @@ class Evaluator(object):
 
     def item_coverage(self):
         return len(set(self.get_correct_predictions()))
+
+    def average_novelty(self):
+        """evaluation.py:90-101 ("Auralist"): -mean log2(popularity share) of the recommended items."""
+        total = float(np.sum(self.dataset.item_popularity))
+        nov = 0.0
+        for _, p in self.instances:
+            if len(p) > 0:
+                top = np.asarray(self._top(p), dtype=np.int64)
+                nov += float(np.sum(np.log2(self.dataset.item_popularity[top] / total))) / min(len(p), self.k)
+        return -nov / len(self.instances)
+
+    def get_rank_comparison(self):
+        """evaluation.py:196-205: (position in the goal list, position in the recommendation list) pairs; needs full
+        recommendation lists (test.py --save_rank)."""
+        out = []
+        for goal, prediction in self.instances:
+            pos = np.argsort(prediction)[goal]
+            out.extend(list(enumerate(pos)))
+        return out
+
+    def assr(self):
+        """evaluation.py:207-216: average search-space reduction (1 without the clustering head)."""
+        nb = getattr(self, "nb_of_dp", 0)
+        return self.dataset.n_items / nb if nb and nb > 0 else 1
 
     def blockbuster_share(self):
         correct = self.get_correct_predictions()

@@ -105,3 +105,31 @@ def test_batched_validation_ranks_exactly_like_one_row_calls(tmp_path):
     for m in ("average_recall", "sps", "average_ndcg", "user_coverage", "item_coverage", "blockbuster_share"):
         assert getattr(ev1, m)() == getattr(ev2, m)()
     predictor.engine.close()
+
+
+def test_test_cli_scores_saved_models_like_the_one_by_one_loop(tmp_path):
+    # test.py mirror: trains, saves two checkpoints, `python -m sbr_amd.test` finds them by the training options, ranks the
+    # test users in batches and appends the results file; metrics equal the reference-style per-user loop
+    from sbr_amd import test as Te, train as T, options as parse
+    from sbr_amd.data import DataHandler, Evaluator
+    root = make_dataset(str(tmp_path / "ds"), n_users=60)
+    base = ["-d", root, "-b", "8", "--max_length", "6", "--r_t", "GRU", "--r_l", "16"]
+    T.main(base + ["--max_iter", "40", "--progress", "20", "--save", "All"])
+    res = Te.main(base + ["--save", "--metrics", "sps,recall,ndcg,item_coverage,user_coverage,blockbuster_share,precision"])
+    assert len(res) == 2
+    out = glob.glob(root + "results/*")
+    assert len(out) == 1 and len(open(out[0]).read().strip().split("\n")) == 2
+    assert Te.main(base + ["--save"]) == []                       # both checkpoints already in the results file
+    # reference-style loop on the last checkpoint
+    args = parse.command_parser(parse.predictor_command_parser, Te.test_command_parser, argv=base)
+    predictor = parse.get_predictor(args)
+    dataset = DataHandler(dirname=root)
+    predictor.prepare_model(dataset)
+    predictor.load(res[-1][0])
+    ev = Evaluator(dataset, k=10)
+    for sequence, user_id in dataset.test_set(epochs=1):
+        nv = int(len(sequence) / 2)
+        ev.add_instance([i[0] for i in sequence[nv:]], predictor.top_k_recommendations(sequence[:nv], user_id=user_id, k=10))
+    for m, v in res[-1][1].items():
+        assert ev.metrics[m]() == v, m
+    predictor.engine.close()
