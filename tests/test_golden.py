@@ -31,7 +31,9 @@ def test_fixtures_exist():
 def test_oracle_reproduces_golden(path):
     from oracle import rnn_oracle as O
     z, p0, g, q = load(path)
-    cfg = dict(cell=str(z["cell"]), layers=[int(h) for h in z["layers"]], loss=str(z["loss"]), regularization=0.0)
+    cfg = dict(cell=str(z["cell"]), layers=[int(h) for h in z["layers"]], loss=str(z["loss"]), regularization=0.0,
+               embedding=int(z["embedding"]) if "embedding" in z else 0,
+               bidirectional=bool(int(z["bidirectional"])) if "bidirectional" in z else False)
     batch = dict(X=z["X"], mask=z["mask"], target=z["target"], samples=z["samples"], pop=z["pop"].astype(np.float64))
     params = [p.astype(np.float64) for p in p0]
     cost, grads, aux = O.cost_and_grads(params, cfg, batch)
@@ -54,7 +56,8 @@ def test_engine_matches_golden(path):
     N, B, T, S, F, n_opt = (int(z[k]) for k in ("N", "B", "T", "S", "F", "n_opt"))
     eng = RNNEngine(cell=cell, layers=layers, n_items=N, max_length=T, batch_size=B, loss=loss, n_samples=S,
                     updater=str(z["updater"]), learning_rate=0.01, rho=0.9, beta1=0.9, beta2=0.999,
-                    input_size=N + n_opt, n_feat=F)
+                    input_size=N + n_opt, n_feat=F, embedding_size=int(z["embedding"]) if "embedding" in z else 0,
+                    bidirectional=bool(int(z["bidirectional"])) if "bidirectional" in z else False)
     try:
         eng.set_all_param_values(p0)
         smp = z["samples"] if loss != "CCE" else None
@@ -62,7 +65,12 @@ def test_engine_matches_golden(path):
         cost = eng.forward_backward()
         assert abs(cost - float(z["cost"])) <= 1e-5 * abs(float(z["cost"]))
         Bp = (B + 15) // 16 * 16
-        hl = eng.debug_buffer("h_last").reshape(Bp, -1)[:B, :layers[-1]]
+        hl = eng.debug_buffer("h_last").reshape(Bp, -1)[:B]
+        if "bidirectional" in z and int(z["bidirectional"]):      # [forward H | pad | backwards H | pad]
+            half = hl.shape[1] // 2
+            hl = np.concatenate([hl[:, :layers[-1]], hl[:, half:half + layers[-1]]], axis=1)
+        else:
+            hl = hl[:, :layers[-1]]
         assert rel(hl, z["h_last"]) <= TOL_LOGITS
         if loss == "CCE":
             pass    # "logits" now holds dlogits; the logits themselves are checked through predict below

@@ -6,7 +6,7 @@ torch-autograd restatement and finite differences (tests/test_oracle.py).  They 
 oracle's behaviour (a later edit that changes results fails tests/test_golden.py) and give the
 GPU tests known answers that do not depend on importing the oracle's code path at all.
 
-    python tools/make_golden.py        # rewrites tests/golden/
+    python tools/make_golden.py [names]   # default: the option fixtures; name the originals explicitly to rewrite them
 """
 import os
 import sys
@@ -30,11 +30,21 @@ CASES = {
     "lstm20x12_cce_adadelta": ("LSTM", [20, 12], "CCE", 35, 6, 6, 0, "adadelta", 1, 0),
     "lstm8_cce_rf_adam": ("LSTM", [8], "CCE", 25, 5, 6, 0, "adam", 2, 10),
 }
+# option fixtures added later: (..., embedding, bidirectional); the eight above are never regenerated
+OPTION_CASES = {
+    "gru12_cce_emb6_adam": ("GRU", [12], "CCE", 40, 7, 8, 0, "adam", 1, 0, 6, False),
+    "lstm10x8_cce_bi_adagrad": ("LSTM", [10, 8], "CCE", 35, 7, 7, 0, "adagrad", 1, 0, 0, True),
+    "gru8_bpr_bi_emb5_rf_adam": ("GRU", [8], "BPR", 30, 6, 6, 5, "adam", 2, 10, 5, True),
+}
 
 
 def make(name):
-    cell, layers, loss, N, B, T, S, updater, F, n_opt = CASES[name]
-    params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=sum(map(ord, name)), F=F, n_opt=n_opt)
+    if name in CASES:
+        cell, layers, loss, N, B, T, S, updater, F, n_opt = CASES[name]
+        emb, bi = 0, False
+    else:
+        cell, layers, loss, N, B, T, S, updater, F, n_opt, emb, bi = OPTION_CASES[name]
+    params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=sum(map(ord, name)), F=F, n_opt=n_opt, emb=emb, bi=bi)
     ob = PU.oracle_batch(batch)
     cost, grads, aux = O.cost_and_grads(params, cfg, ob)
     upd = O.Updater(updater, 0.01, rho=0.9, beta1=0.9, beta2=0.999)
@@ -51,6 +61,7 @@ def make(name):
         top = np.sort(row)[::-1][:k + 1]
         assert np.all(np.diff(top) < -1e-6 * top[0]), (name, b, top)
     out = dict(cell=cell, layers=np.array(layers), loss=loss, N=N, B=B, T=T, S=S, updater=updater, F=F, n_opt=n_opt,
+               embedding=emb, bidirectional=int(bi),
                X=batch["X"], mask=batch["mask"], target=batch["target"], samples=batch["samples"], pop=batch["pop"],
                cost=cost, h_last=aux["h"], act=aux["act"], costs3=np.array(costs), scores=scores, topk=ids, n_params=len(params))
     for i, (p0, g, pn) in enumerate(zip(params, grads, p2)):
@@ -60,5 +71,6 @@ def make(name):
 
 
 if __name__ == "__main__":
-    for n in CASES:
+    names = sys.argv[1:] or list(OPTION_CASES)       # default: only the option fixtures (the originals stay frozen)
+    for n in names:
         make(n)
