@@ -13,6 +13,13 @@
 // next tile prefetched into registers while the MFMAs of the current one run.  LDS holds each operand as three bf16
 // planes [128 rows][32 k] with an 80-byte row stride (conflict-free ds_read_b128 / ds_write_b128).  Each wave owns a
 // 64x64 sub-tile = 4x4 MFMA tiles.  Split-K over grid.z writes partial slabs (summed by gemm_splitk_reduce).
+//
+// Measured on C4's weight-gradient shape (M=256 N=1024 K=51200, 189 us = 142 TFLOP/s f32-equivalent): with 1/6 of the
+// MFMAs the kernel still takes 123 us, i.e. the matrix pipe runs at full rate when it runs and ~65 % of the time is the
+// serial split / LDS-write / barrier / LDS-read part of each k-step (two workgroups per CU overlap it only partly).
+// Tried and rejected: a second stage of global prefetch (no change: latency is already covered); double-buffered
+// LDS with the split interleaved into the MFMA stream at one workgroup per CU (311 us: 376 registers push operands
+// into AGPRs and a single wave per SIMD cannot keep the pipe fed -- the same lesson as rec_fwd_x6s NT=2).
 #include "sbr_cell.h"
 
 #define XM 128

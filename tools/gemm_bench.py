@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sbr_amd.engine import load_library
-lib = load_library()
+lib = load_library(os.environ.get("SBR_LIB"))
 dev = torch.device("cuda")
 SHAPES = [("c4 logits  NT", 256, 26744, 256, False, True), ("c4 dh      NN", 256, 256, 26744, False, False),
           ("c4 dW_out  TN", 26744, 256, 256, True, False), ("c4 wgrad   TN", 256, 1024, 51200, True, False),
