@@ -130,7 +130,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
     lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
     lay.a_fault = take(64);
-    lay.a_clx = take((size_t)Bp * 2 + 64);
+    lay.a_clx = take((size_t)Bp * 8 + 64);      // handshake slots: up to Bp/4 tiles x 32 members
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
     lay.a_ws = take(lay.ws_floats);
     lay.ws2_floats = 4 * lay.ws_floats;          // up to 256 weight-gradient slabs

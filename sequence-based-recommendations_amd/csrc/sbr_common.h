@@ -13,14 +13,15 @@
 static inline size_t sbr_align(size_t n_floats) { return (n_floats + SBR_ALIGN_FLOATS - 1) / SBR_ALIGN_FLOATS * SBR_ALIGN_FLOATS; }
 static inline int sbr_gates(int cell) { return cell == SBR_CELL_LSTM ? 4 : (cell == SBR_CELL_GRU ? 3 : 1); }
 // Hidden size padded for the MFMA tiling: 16/32/64/128 (W_hid register-resident single-workgroup kernels), 256 for
-// anything in (128, 256] (the cluster kernels of sbr_rec_cl.hip: a 150-wide layer padded to 256 runs ~6x faster there
-// than at 192 on the streamed f32 kernels), above that the next multiple of 64 (streamed-W kernels).
+// anything in (128, 256] and 512 for (256, 512] (the cluster kernels of sbr_rec_cl.hip: a 150-wide layer padded to 256
+// runs ~6x faster there than at 192 on the streamed f32 kernels), above that the next multiple of 64 (streamed-W kernels).
 static inline int sbr_pad_hidden(int H) {
     if (H <= 16) return 16;
     if (H <= 32) return 32;
     if (H <= 64) return 64;
     if (H <= 128) return 128;
     if (H <= 256) return 256;
+    if (H <= 512) return 512;
     return (H + 63) / 64 * 64;
 }
 
@@ -218,6 +219,7 @@ struct RecArgs {
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
 bool sbr_rec_cluster_ok(const RecArgs& a);
+int sbr_rec_cluster_bwd_rows(const RecArgs& a);
 hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a);

@@ -1426,7 +1426,7 @@ static bool uses_x6_bwd(const RecArgs& a) {
 }
 int sbr_rec_bwd_blocks(const RecArgs& a, bool simple) {
     if (simple) return a.Bp / 16;                 // simple kernels accumulate into block 0, others zeroed
-    if (sbr_rec_cluster_ok(a)) return a.Bp / SBR_CL_ROWS;
+    if (sbr_rec_cluster_ok(a)) return a.Bp / sbr_rec_cluster_bwd_rows(a);
     return uses_x6_bwd(a) ? a.Bp / a.rpt : a.Bp / 16;
 }
 

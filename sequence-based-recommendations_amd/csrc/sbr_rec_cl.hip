@@ -576,39 +576,458 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// General cluster kernels (Hp = 512): UT unit tiles per workgroup, K split KS ways over the waves (UT * KS = 4 waves),
+// R live rows per tile (R = 8: lanes j, j+8 share a row and finish 2 units each; R = 4: four copies, 1 unit each).
+// C = Hp / (16 * UT) members per cluster; with UT = 1 at Hp = 512 a cluster is 32 workgroups = one whole XCD.
+// Same exchange protocol, same layouts as rec_fwd_cl / rec_bwd_cl above (which stay as the tuned Hp = 256 instances).
+// Sizing at LSTM-512: forward (UT 1, KS 4, R 8): W planes 1,2 = 128 VGPRs per wave, plane 3 = 64 KB LDS, h planes 25 KB;
+// backward (UT 1, KS 4, R 4): K = 2048 columns, 128 VGPRs, 64 KB, dhi planes 49.5 KB (8 rows would need 99 KB).
+// ---------------------------------------------------------------------------------------
+template <int N> struct VecN { float v[N]; };
+template <int N> __device__ __forceinline__ VecN<N> ldn(const float* p) {
+    VecN<N> r;
+    if (N == 2) { const f32x2 t = *(const f32x2*)p; r.v[0] = t[0]; r.v[N - 1] = t[1]; }
+    else r.v[0] = p[0];
+    return r;
+}
+template <int N> __device__ __forceinline__ void stn(float* p, const VecN<N>& x) {
+    if (N == 2) *(f32x2*)p = f32x2{x.v[0], x.v[N - 1]};
+    else p[0] = x.v[0];
+}
+template <int N> __device__ __forceinline__ void cl_storen(float* p, const VecN<N>& x, bool fast) {
+    if (N == 2) { cl_store2(p, f32x2{x.v[0], x.v[N - 1]}, fast); return; }
+    if (fast) p[0] = x.v[0];
+    else __hip_atomic_store(p, x.v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float pick4f(const f32x4 v, int c) { return c == 0 ? v[0] : (c == 1 ? v[1] : (c == 2 ? v[2] : v[3])); }
+
+template <int CELL, int HP, int UT, int KS, int R>
+__global__ void __launch_bounds__(256) rec_fwd_clg(RecArgs a) {
+    static_assert(UT * KS == 4 && (R == 8 || R == 4), "4 waves; 8 or 4 live rows");
+    constexpr int G = Gates<CELL>::G, C = HP / (16 * UT), KW = HP / KS, KBW = KW / 32, GHP = G * HP, EPL = R / 4;
+    constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW;
+    constexpr int W3_BYTES = G * KBW * 4 * 1024;
+    constexpr int NP = R * HP / 4 / 256;
+    static_assert(R * HP / 4 % 256 == 0 && NP >= 1, "piece count");
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [G][KBW][4 waves][64 lanes][16 B]
+    char* hpl = smem_c + W3_BYTES;                       // [3 planes][R rows][HROW]
+    char* red = hpl + 3 * PLANEB;                        // [KS-1][UT][G][64 lanes][16 B]
+    int tile, mem;
+    if (!cl_ids(a, C, a.Bp / R, tile, mem)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = wave % UT, kq = wave / UT;
+    const int j = lane & 15, q = lane >> 4;
+    const int rl = j & (R - 1), eh = j / R;              // tile-local row; which EPL of the lane's 4 units this copy finishes
+    const int row = tile * R + rl;
+    const int T = a.T, Bp = a.Bp;
+    const int ub = (mem * UT + ut) * 16;                 // first unit of this wave's tile
+    const int u = ub + q * 4 + eh * EPL;
+    const int k0 = kq * KW;
+    const bool fin = kq == 0;
+    bool dead = false;
+    const bool fast = cl_same_xcc(a, C, tile, mem, (int*)red, dead);
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < R; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    bf16x8 W1[G][KBW], W2[G][KBW];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+            bf16x8 w3v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 b1, b2, b3;
+                split3(a.Whid[(size_t)(k0 + kb * 32 + 8 * q + e) * GHP + g * HP + ub + j], b1, b2, b3);
+                W1[g][kb][e] = b1; W2[g][kb][e] = b2; w3v[e] = b3;
+            }
+            *(bf16x8*)(w3 + ((g * KBW + kb) * 4 + wave) * 1024 + lane * 16) = w3v;
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    typedef VecN<EPL> V;
+    V h, c, pi, pf, po;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { h.v[e] = 0.f; c.v[e] = 0.f; pi.v[e] = 0.f; pf.v[e] = 0.f; po.v[e] = 0.f; }
+    if (fin) {
+        h = ldn<EPL>(&a.hinit[u]);
+        if (CELL == CELL_LSTM) {
+            c = ldn<EPL>(&a.cinit[u]);
+            pi = ldn<EPL>(&a.peep[u]); pf = ldn<EPL>(&a.peep[HP + u]); po = ldn<EPL>(&a.peep[2 * HP + u]);
+            stn<EPL>(&a.cs[(size_t)row * HP + u], c);
+        }
+        cl_storen<EPL>(&a.hs[(size_t)row * HP + u], h, fast);
+    }
+    const bool fuse = a.gX != nullptr;
+    V x[G], xn[G], bias[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { bias[g].v[e] = 0.f; x[g].v[e] = 0.f; xn[g].v[e] = 0.f; }
+        if (fuse && fin) bias[g] = ldn<EPL>(&a.gbias[g * HP + u]);
+    }
+    auto load_id = [&](int t) -> int { return fuse ? a.gX[(size_t)row * T + (t < T ? t : T - 1)] : 0; };
+    auto load_x = [&](int t, int id, V (&d)[G]) {
+        const float* src = fuse ? a.gWin + (size_t)id * GHP + u : a.xt + ((size_t)(t < T ? t : T - 1) * Bp + row) * GHP + u;
+#pragma unroll
+        for (int g = 0; g < G; ++g) d[g] = ldn<EPL>(&src[g * HP]);
+    };
+    int id_next = 0, id_nn = 0;
+    if (fin) { id_next = load_id(1); load_x(0, load_id(0), x); }
+    __syncthreads();                                     // W plane 3 visible
+
+    const f32x4 z = f32x4{0, 0, 0, 0};
+    auto mfma_phase = [&](f32x4 (&acc)[G]) {
+        const char* hb = hpl + rl * HROW + k0 * 2 + q * 16;
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = z;
+        bf16x8 hp[2][3], wp[2][G];
+        auto load_ops = [&](int kb, int s) {
+            hp[s][0] = *(const bf16x8*)(hb + kb * 64);
+            hp[s][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
+            hp[s][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+#pragma unroll
+            for (int g = 0; g < G; ++g) wp[s][g] = *(const bf16x8*)(w3 + ((g * KBW + kb) * 4 + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KBW) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(wp[s][g], hp[s][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][2], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W2[g][kb], hp[s][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][1], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(W1[g][kb], hp[s][0], acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15");
+    };
+    auto exchange = [&](int t) {
+        f32x4 v[NP];
+        const float* base = a.hs + ((size_t)t * Bp + (size_t)tile * R) * HP;
+        (void)cl_fetch<NP>(v, [&](int r, int col) { return base + (size_t)r * HP + col; }, HP, fast, dead, a.fault);
+        cl_publish<NP>(v, hpl, HP, HROW, PLANEB);
+    };
+
+    if (fin) {
+        for (int t = 0; t < tmax; ++t) {
+            load_x(t + 1, id_next, xn);
+            id_nn = load_id(t + 2);
+            exchange(t);
+            __syncthreads();
+            f32x4 acc[G];
+            mfma_phase(acc);
+            __syncthreads();                             // partials of the other K parts visible; hpl free again
+            V sv[4];
+            float as[G][EPL];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f32x4 s4 = acc[g];
+#pragma unroll
+                for (int p = 0; p < KS - 1; ++p) s4 += *(const f32x4*)(red + (((p * UT + ut) * G + g) * 64 + lane) * 16);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) as[g][e] = pick4f(s4, eh * EPL + e);
+            }
+            const bool m = t < mylen;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float xs[G], ag[G], s[4];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { xs[g] = x[g].v[e] + bias[g].v[e]; ag[g] = as[g][e]; }
+                float hh = h.v[e], cc = c.v[e];
+                cell_forward<CELL, true>(xs, ag, m, hh, cc, pi.v[e], pf.v[e], po.v[e], s);
+                h.v[e] = hh; c.v[e] = cc;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k].v[e] = s[k];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = xn[g];
+            id_next = id_nn;
+            __builtin_amdgcn_sched_barrier(0);
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
+            cl_storen<EPL>(&a.hs[o], h, fast);           // first: the other members are waiting for it
+            if (CELL == CELL_LSTM) stn<EPL>(&a.cs[o], c);
+            if (CELL != CELL_VANILLA) {
+                const size_t og = sbr_blocked_index(t, row, u, Bp, HP);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) stn<EPL>(&a.g[k][og], sv[k]);
+            }
+        }
+        for (int t = tmax; t < T; ++t) {
+            const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
+            stn<EPL>(&a.hs[o], h);
+            if (CELL == CELL_LSTM) stn<EPL>(&a.cs[o], c);
+        }
+    } else {
+        for (int t = 0; t < tmax; ++t) {
+            exchange(t);
+            __syncthreads();
+            f32x4 acc[G];
+            mfma_phase(acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) *(f32x4*)(red + ((((kq - 1) * UT + ut) * G + g) * 64 + lane) * 16) = acc[g];
+            __syncthreads();
+        }
+    }
+}
+
+template <int CELL, int HP, int UT, int KS, int R>
+__global__ void __launch_bounds__(256) rec_bwd_clg(RecArgs a) {
+    static_assert(UT * KS == 4 && (R == 8 || R == 4), "4 waves; 8 or 4 live rows");
+    constexpr int G = Gates<CELL>::G, C = HP / (16 * UT), GHP = G * HP, KW = GHP / KS, KBW = KW / 32, EPL = R / 4;
+    constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW;
+    constexpr int W3_BYTES = KBW * 4 * 1024;
+    constexpr int NP = R * GHP / 4 / 256;
+    static_assert(R * GHP / 4 % 256 == 0 && NP >= 1, "piece count");
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* w3 = smem_c;                                   // [KBW][4 waves][64][16 B]
+    char* dpl = smem_c + W3_BYTES;                       // [3][R][DROW]
+    char* red = dpl + 3 * PLANEB;                        // [KS-1][UT][64 lanes][16 B]
+    int tile, mem;
+    if (!cl_ids(a, C, a.Bp / R, tile, mem)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = wave % UT, kq = wave / UT;
+    const int j = lane & 15, q = lane >> 4;
+    const int rl = j & (R - 1), eh = j / R;
+    const int row = tile * R + rl;
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+    const int ub = (mem * UT + ut) * 16;
+    const int u = ub + q * 4 + eh * EPL;
+    const int k0 = kq * KW;
+    const bool fin = kq == 0;
+    bool dead = false;
+    const bool fast = cl_same_xcc(a, C, tile, mem, (int*)red, dead);
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+#pragma unroll
+    for (int o = 1; o < R; o <<= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+
+    bf16x8 W1[KBW], W2[KBW];
+#pragma unroll
+    for (int kb = 0; kb < KBW; ++kb) {
+        const float* src = a.Whid + (size_t)(ub + j) * GHP + k0 + kb * 32 + 8 * q;
+        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        bf16x8 w3v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 b1, b2, b3;
+            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
+            W1[kb][e] = b1; W2[kb][e] = b2; w3v[e] = b3;
+        }
+        *(bf16x8*)(w3 + (kb * 4 + wave) * 1024 + lane * 16) = w3v;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    typedef VecN<EPL> V;
+    V dh, dc, pi, pf, po, sdb[G], sdp[3], sv[4], hprev, cprev, cnew, hnew;
+    auto zero = [](V& x) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) x.v[e] = 0.f;
+    };
+    zero(dh); zero(dc); zero(pi); zero(pf); zero(po); zero(hprev); zero(cprev); zero(cnew); zero(hnew);
+#pragma unroll
+    for (int g = 0; g < G; ++g) zero(sdb[g]);
+    zero(sdp[0]); zero(sdp[1]); zero(sdp[2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zero(sv[k]);
+    if (fin && a.dh_last) dh = ldn<EPL>(&a.dh_last[(size_t)row * HP + u]);
+    if (CELL == CELL_LSTM) { pi = ldn<EPL>(&a.peep[u]); pf = ldn<EPL>(&a.peep[HP + u]); po = ldn<EPL>(&a.peep[2 * HP + u]); }
+    auto load_saved = [&](int t) {
+        const size_t o = ((size_t)t * Bp + row) * HP + u;
+        hprev = ldn<EPL>(&a.hs[o]);
+        if (CELL != CELL_VANILLA) {
+            const size_t og = sbr_blocked_index(t, row, u, Bp, HP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = ldn<EPL>(&a.g[k][og]);
+        }
+        if (CELL == CELL_LSTM) cprev = ldn<EPL>(&a.cs[o]);
+    };
+    __syncthreads();                                     // W plane 3 visible
+
+    const f32x4 z4 = f32x4{0, 0, 0, 0};
+    auto mfma_phase = [&]() -> f32x4 {
+        const char* db = dpl + rl * DROW + k0 * 2 + q * 16;
+        f32x4 acc[3] = {z4, z4, z4};
+        bf16x8 dp[2][3], wp[2];
+        auto load_ops = [&](int kb, int s) {
+            dp[s][0] = *(const bf16x8*)(db + kb * 64);
+            dp[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
+            dp[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+            wp[s] = *(const bf16x8*)(w3 + (kb * 4 + wave) * 1024 + lane * 16);
+        };
+        load_ops(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+            const int s = kb & 1;
+            if (kb + 1 < KBW) load_ops(kb + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = MFMA_BF16(wp[s], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][2], acc[1]);
+            acc[2] = MFMA_BF16(W2[kb], dp[s][1], acc[2]);
+            acc[0] = MFMA_BF16(W2[kb], dp[s][0], acc[0]);
+            acc[1] = MFMA_BF16(W1[kb], dp[s][1], acc[1]);
+            acc[2] = MFMA_BF16(W1[kb], dp[s][0], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15");
+        return acc[0] + acc[1] + acc[2];
+    };
+    auto exchange = [&](int t) {
+        f32x4 v[NP];
+        const float* bx = a.dxt + ((size_t)t * Bp + (size_t)tile * R) * GHP;
+        const float* bc = a.dhi + ((size_t)t * Bp + (size_t)tile * R) * HP;
+        (void)cl_fetch<NP>(v, [&](int r, int col) {
+            return (CELL == CELL_GRU && col >= 2 * HP) ? bc + (size_t)r * HP + (col - 2 * HP) : bx + (size_t)r * GHP + col;
+        }, GHP, fast, dead, a.fault);
+        cl_publish<NP>(v, dpl, GHP, DROW, PLANEB);
+    };
+
+    if (fin) {
+        for (int t = T - 1; t >= tmax; --t) {
+            if (a.dh_ext) { const V e = ldn<EPL>(&a.dh_ext[((size_t)t * Bp + row) * HP + u]);
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) dh.v[i] += e.v[i]; }
+            V zz; zero(zz);
+#pragma unroll
+            for (int g = 0; g < G; ++g) stn<EPL>(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u], zz);
+            if (CELL == CELL_GRU) stn<EPL>(&a.dhi[((size_t)t * Bp + row) * HP + u], zz);
+        }
+        if (tmax > 0) {
+            load_saved(tmax - 1);
+            const size_t o1 = ((size_t)tmax * Bp + row) * HP + u;
+            if (CELL == CELL_LSTM) cnew = ldn<EPL>(&a.cs[o1]);
+            if (CELL == CELL_VANILLA) hnew = ldn<EPL>(&a.hs[o1]);
+        }
+        for (int t = tmax - 1; t >= 0; --t) {
+            if (a.dh_ext) { const V e = ldn<EPL>(&a.dh_ext[((size_t)t * Bp + row) * HP + u]);
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) dh.v[i] += e.v[i]; }
+            const bool m = t < mylen;
+            V vxi[G], vhi[G];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float s[4] = {sv[0].v[e], sv[1].v[e], sv[2].v[e], sv[3].v[e]};
+                float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+                float dhh = dh.v[e], dcc = dc.v[e];
+                cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev.v[e], cprev.v[e], cnew.v[e], hnew.v[e], pi.v[e], pf.v[e],
+                                          po.v[e], dxi, dhi, dp);
+                dh.v[e] = dhh; dc.v[e] = dcc;
+#pragma unroll
+                for (int g = 0; g < G; ++g) { vxi[g].v[e] = dxi[g]; vhi[g].v[e] = dhi[g]; sdb[g].v[e] += dxi[g]; }
+                sdp[0].v[e] += dp[0]; sdp[1].v[e] += dp[1]; sdp[2].v[e] += dp[2];
+            }
+            if (CELL == CELL_LSTM) cnew = cprev;
+            if (CELL == CELL_VANILLA) hnew = hprev;
+            __builtin_amdgcn_sched_barrier(0);
+            load_saved(t > 0 ? t - 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) cl_storen<EPL>(&a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u], vxi[g], fast);
+            if (CELL == CELL_GRU) cl_storen<EPL>(&a.dhi[((size_t)t * Bp + row) * HP + u], vhi[2], fast);
+            exchange(t);
+            __syncthreads();
+            f32x4 sum = mfma_phase();
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < KS - 1; ++p) sum += *(const f32x4*)(red + ((p * UT + ut) * 64 + lane) * 16);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dh.v[e] += pick4f(sum, eh * EPL + e);
+        }
+        float* part = a.part + (size_t)tile * (GHP + 5 * HP);
+        V v[G + 5];
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[g] = sdb[g];
+        v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2];
+        v[G + 3] = dc; v[G + 4] = dh;
+#pragma unroll
+        for (int k = 0; k < G + 5; ++k)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float sum = v[k].v[e];
+#pragma unroll
+                for (int o = 1; o < R; o <<= 1) sum += __shfl_xor(sum, o);
+                v[k].v[e] = sum;
+            }
+        if (rl == 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) stn<EPL>(&part[g * HP + u], v[g]);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) stn<EPL>(&part[GHP + k * HP + u], v[G + k]);
+        }
+    } else {
+        for (int t = tmax - 1; t >= 0; --t) {
+            exchange(t);
+            __syncthreads();
+            const f32x4 sum = mfma_phase();
+            *(f32x4*)(red + (((kq - 1) * UT + ut) * 64 + lane) * 16) = sum;
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 bool sbr_rec_cluster_ok(const RecArgs& a) {
-    return a.cluster && !a.f32_mfma && a.Hp == 256 && a.Bp % SBR_CL_ROWS == 0;
+    return a.cluster && !a.f32_mfma && (a.Hp == 256 || a.Hp == 512) && a.Bp % SBR_CL_ROWS == 0;
 }
+// rows per tile of the backward launch (part[] has Bp / rows blocks)
+int sbr_rec_cluster_bwd_rows(const RecArgs& a) { return a.Hp == 512 ? 4 : SBR_CL_ROWS; }
 
-static inline int cl_grid(const RecArgs& a, int C) {
-    const int ntiles = a.Bp / SBR_CL_ROWS;
+static inline int cl_grid(const RecArgs& a, int C, int R) {
+    const int ntiles = a.Bp / R;
     return a.cl_linear ? ntiles * C : (ntiles + 7) / 8 * 8 * C;
 }
 
-#define CL_LAUNCH(KERNEL, C, LDS) do { \
+#define CL_LAUNCH(KERNEL, C, R, LDS) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
-        KERNEL<<<cl_grid(a, C), 256, LDS, s>>>(a); } while (0)
+        KERNEL<<<cl_grid(a, C, R), 256, LDS, s>>>(a); } while (0)
 
 template <int CELL, int HP>
 static hipError_t fwd_cl(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G, R = SBR_CL_ROWS;
-    const size_t lds = (size_t)G * (HP / 64) * 4 * 1024 + 3 * (size_t)R * (HP * 2 + 32) + 2 * G * 1024;
     hipError_t e = hipMemsetAsync(a.hs, 0xFF, (size_t)(a.T + 1) * a.Bp * HP * sizeof(float), s);   // sentinel: see the header
     if (e != hipSuccess) return e;
-    CL_LAUNCH((rec_fwd_cl<CELL, HP, R>), HP / 32, lds);
+    if (HP == 256) {
+        const size_t lds = (size_t)G * (HP / 64) * 4 * 1024 + 3 * (size_t)R * (HP * 2 + 32) + 2 * G * 1024;
+        CL_LAUNCH((rec_fwd_cl<CELL, 256, R>), 256 / 32, R, lds);
+    } else {   // 512: one unit tile per workgroup, K in four parts, a cluster = 32 workgroups
+        const size_t lds = (size_t)G * (HP / 4 / 32) * 4 * 1024 + 3 * (size_t)R * (HP * 2 + 32) + 3 * G * 1024;
+        CL_LAUNCH((rec_fwd_clg<CELL, 512, 1, 4, R>), 512 / 16, R, lds);
+    }
     return hipGetLastError();
 }
 template <int CELL, int HP>
 static hipError_t bwd_cl(hipStream_t s, const RecArgs& a) {
-    constexpr int G = Gates<CELL>::G, R = SBR_CL_ROWS, GHP = G * HP;
-    const size_t lds = (size_t)(GHP / 64) * 4 * 1024 + 3 * (size_t)R * (GHP * 2 + 32) + 2 * 1024;
+    constexpr int G = Gates<CELL>::G, GHP = G * HP;
     if (!a.sentinel_done) {                               // else: sbr_rec_bwd_cl_fill ran on the side stream during the output phase
         const hipError_t e = sbr_rec_bwd_cl_fill(s, a);
         if (e != hipSuccess) return e;
     }
-    CL_LAUNCH((rec_bwd_cl<CELL, HP, R>), HP / 32, lds);
+    if (HP == 256) {
+        constexpr int R = SBR_CL_ROWS;
+        const size_t lds = (size_t)(GHP / 64) * 4 * 1024 + 3 * (size_t)R * (GHP * 2 + 32) + 2 * 1024;
+        CL_LAUNCH((rec_bwd_cl<CELL, 256, R>), 256 / 32, R, lds);
+    } else {
+        constexpr int R = 4;
+        const size_t lds = (size_t)(GHP / 4 / 32) * 4 * 1024 + 3 * (size_t)R * (GHP * 2 + 32) + 3 * 1024;
+        CL_LAUNCH((rec_bwd_clg<CELL, 512, 1, 4, R>), 512 / 16, R, lds);
+    }
     return hipGetLastError();
 }
 
@@ -619,17 +1038,13 @@ hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a) {
     return e;
 }
 
-hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a) {
-    switch (a.cell) {
-        case SBR_CELL_LSTM: return fwd_cl<CELL_LSTM, 256>(s, a);
-        case SBR_CELL_GRU: return fwd_cl<CELL_GRU, 256>(s, a);
-        default: return fwd_cl<CELL_VANILLA, 256>(s, a);
-    }
-}
-hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a) {
-    switch (a.cell) {
-        case SBR_CELL_LSTM: return bwd_cl<CELL_LSTM, 256>(s, a);
-        case SBR_CELL_GRU: return bwd_cl<CELL_GRU, 256>(s, a);
-        default: return bwd_cl<CELL_VANILLA, 256>(s, a);
-    }
-}
+#define CL_DISPATCH(FN) \
+    if (a.Hp == 512) { \
+        switch (a.cell) { case SBR_CELL_LSTM: return FN<CELL_LSTM, 512>(s, a); case SBR_CELL_GRU: return FN<CELL_GRU, 512>(s, a); \
+                          default: return FN<CELL_VANILLA, 512>(s, a); } \
+    } \
+    switch (a.cell) { case SBR_CELL_LSTM: return FN<CELL_LSTM, 256>(s, a); case SBR_CELL_GRU: return FN<CELL_GRU, 256>(s, a); \
+                      default: return FN<CELL_VANILLA, 256>(s, a); }
+
+hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a) { CL_DISPATCH(fwd_cl) }
+hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a) { CL_DISPATCH(bwd_cl) }

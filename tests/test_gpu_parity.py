@@ -33,8 +33,21 @@ def test_exact_f32_mfma_kernels(cell, H):                  # SBR_FLAG_F32_MFMA: 
 
 
 @pytest.mark.parametrize("cell", ["GRU", "LSTM"])
-def test_streamed_whid_kernels(cell):                      # Hp = 320: W_hid fragments streamed from L2 (f32 MFMA kernels)
-    check(PU.compare_step(cell, [300], "CCE", N=61, B=21, T=8, scale=0.05), tol_h=2e-4)
+def test_streamed_whid_kernels(cell):                      # Hp = 576: W_hid fragments streamed from L2 (f32 MFMA kernels)
+    check(PU.compare_step(cell, [520], "CCE", N=61, B=21, T=6, scale=0.03), tol_h=2e-4)
+
+
+@pytest.mark.parametrize("linear", ["0", "1"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_cluster_kernels_512_wide(cell, linear, monkeypatch):
+    # Hp = 512 (config C5's width): clusters of 32 workgroups (one unit tile each, K in four parts); forward on 8-row
+    # tiles, backward on 4-row tiles; linear=1 spreads a cluster over all XCDs
+    monkeypatch.setenv("SBR_CL_LINEAR", linear)
+    check(PU.compare_step(cell, [512], "CCE", N=61, B=37, T=7, scale=0.04), tol_h=2e-4)
+
+
+def test_cluster_kernels_512_padded_two_layers_ragged():
+    check(PU.compare_step("LSTM", [300, 300], "CCE", N=41, B=19, T=20, seed=3, scale=0.04), tol_h=2e-4)
 
 
 def test_width_between_128_and_256_takes_the_cluster_kernels():
