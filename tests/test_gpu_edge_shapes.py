@@ -1,0 +1,18 @@
+"""Degenerate shapes against the oracle: T = 1 and 2, a single row, one hidden unit, two items, every kernel family
+(single-workgroup bf16x6, cluster 256 / 512), with the embedding and bidirectional options."""
+import pytest
+
+import parity_util as PU
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("GRU", [8], 5, 3, 1, {}), ("LSTM", [8], 5, 3, 2, {}), ("GRU", [1], 4, 2, 3, {}), ("LSTM", [3, 2], 2, 1, 2, {}),
+         ("Vanilla", [128], 9, 1, 1, {}), ("GRU", [256], 7, 2, 1, {"scale": 0.05}), ("LSTM", [128], 6, 33, 1, {"bi": True}),
+         ("GRU", [16], 6, 5, 2, {"emb": 1}), ("LSTM", [512], 5, 3, 2, {"scale": 0.04})]
+
+
+@pytest.mark.parametrize("case", CASES, ids=["%s%s_N%d_B%d_T%d" % (c[0], "x".join(map(str, c[1])), c[2], c[3], c[4]) for c in CASES])
+def test_degenerate_shapes(case):
+    cell, layers, N, B, T, kw = case
+    r = PU.compare_step(cell, layers, "CCE", N=N, B=B, T=T, **kw)
+    assert r["param_roundtrip"] == 0 and r["h_last"] < 2e-4 and r["grad_worst"] < 2e-4 and r["topk_mismatch"] == 0, r
