@@ -255,10 +255,13 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     }
     sbr_param_descs(h->lay, h->descs);
     h->rpt = 16;
-    {   // rows per workgroup of the bf16x6 recurrent kernels: spread the batch over up to ~64 CUs
+    {   // rows per workgroup of the bf16x6 recurrent kernels: the per-step latency of the chain does not depend on the
+        // tile height, so take the smallest tile whose workgroups still fit the 256 CUs in one round (measured, GRU-128
+        // T=200: B=512 548k seq/s at 4 rows vs 444k at 8; B=1024 856k vs 766k at 8 / 643k at 16; B=2048 1078k at 8 vs
+        // 922k at 4 (two rounds) / 1047k at 16; B=4096 1380k at 16 vs 1124k at 8)
         const char* e = getenv("SBR_RPT");
         int r = e ? atoi(e) : 0;
-        if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) { r = 16; while (r > 4 && h->lay.Bp / r < 64) r >>= 1; }
+        if (r != 1 && r != 2 && r != 4 && r != 8 && r != 16) { r = 4; while (r < 16 && h->lay.Bp / r > 256) r <<= 1; }
         h->rpt = r;
     }
     {
