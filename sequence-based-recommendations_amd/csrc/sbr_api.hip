@@ -279,6 +279,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->wgrad_x6 = wx ? atoi(wx) != 0 : 1;
         const char* xs = getenv("SBR_X6_SPLIT");
         h->x6_split = xs ? atoi(xs) != 0 : 1;
+        const char* xp = getenv("SBR_X6_PIPE");
+        h->x6_pipe = xp ? atoi(xp) : 2;   // 0: barrier kernels (x6s), 1: pipelined without the matrix-pipe gate, 2: with it
         const char* fg = getenv("SBR_FUSE_GATHER");
         h->fuse_gather = fg ? atoi(fg) != 0 : 1;
     }
@@ -432,6 +434,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     const Layout& y = h->lay; const LayerLayout& ly = y.layer[l];
     RecArgs a; memset(&a, 0, sizeof(a));
     a.cell = y.cfg.cell; a.T = y.T; a.Bp = y.Bp; a.H = ly.H; a.Hp = ly.Hp; a.G = y.G;
+    a.n_in = ly.n_in_p;
     a.clip = y.cfg.grad_clip;
     a.len = h->blen;
     a.xt = h->A(ly.a_xt); a.Whid = h->P(ly.p_Whid); a.peep = h->P(ly.p_peep);
@@ -440,7 +443,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     for (int k = 0; k < 4; ++k) a.g[k] = h->A(ly.a_g[k]);
     a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
     a.xt_blocked = 0;
-    a.rpt = h->rpt; a.x6_split = h->x6_split;
+    a.rpt = h->rpt; a.x6_split = h->x6_split; a.x6_pipe = h->x6_pipe;
     a.t_lo = 0; a.t_hi = y.T; a.chunk = 0; a.state = h->A(ly.a_state);
     a.f32_mfma = (y.cfg.flags & SBR_FLAG_F32_MFMA) ? 1 : 0;
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;

@@ -114,6 +114,7 @@ struct sbr_handle {
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
     int x6_split, fuse_gather;
+    int x6_pipe;         // per-k-block publish counters instead of a workgroup barrier per step (SBR_X6_PIPE, default 1; Hp = 128)
     int wgrad_x6;        // weight gradients through the bf16x6 GEMM instead of the dedicated f32 kernel (SBR_WGRAD_X6, default 1; the f32 kernel serves Hp < 96 and SBR_FLAG_F32_MFMA)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
@@ -203,9 +204,11 @@ struct RecArgs {
     int rpt;                // live batch rows per workgroup of the bf16x6 kernels (16, 8, 4, 2, 1); part[] has Bp/rpt blocks
     int xt_blocked;         // xt is tile-blocked (layer 0: written by the gather) or row-major (GEMM output)
     int x6_split;           // 4-row tiles use the split-gate-math kernels (SBR_X6_SPLIT, default 1)
+    int x6_pipe;            // Hp = 128: waves synchronise per k-block through LDS counters, no per-step barrier (SBR_X6_PIPE)
     // layer 0, one index per step: the embedding gather is fused into the forward kernel (xt is never written)
     const int* gX;          // [Bp][T] item ids, or NULL: read xt
     const float* gWin;      // [input_size][G*Hp]
+    int n_in;               // rows of W_in (the pipelined kernels address them with 32-bit byte offsets)
     const float* gbias;     // [G*Hp]
     int f32_mfma;           // SBR_FLAG_F32_MFMA: exact-f32 v_mfma_f32_16x16x4_f32 kernels instead of bf16x6
     unsigned long long* prof; // SBR_FLAG_PROFILE_REC: [nblk][waves][4] cycle counters, else NULL
@@ -222,6 +225,9 @@ bool sbr_rec_cluster_ok(const RecArgs& a);
 int sbr_rec_cluster_bwd_rows(const RecArgs& a);
 hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
+// sbr_rec_p.hip: pipelined bf16x6 kernels for Hp = 128 on 4-row tiles
+bool sbr_rec_x6p_ok(const RecArgs& a);
+hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
 hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 // true when the forward launch for these args can gather its input rows itself (RecArgs.gX/gWin/gbias)

@@ -1303,6 +1303,7 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         return hipGetLastError();
     }
     if (sbr_rec_cluster_ok(a)) return launch_rec_forward_cl(s, a);
+    if (sbr_rec_x6p_ok(a)) return launch_rec_forward_x6p(s, a);
     const int nblk = a.Bp / 16;
 #define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \

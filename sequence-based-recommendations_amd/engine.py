@@ -64,7 +64,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("SBR_LIB") or LIB_PATH      # SBR_LIB: another build of the library (kernel experiments)
     try:        # torch bundles its own libamdhip64: it must be the one already loaded when the extension binds to HIP,
         import torch  # noqa: F401  otherwise two runtimes coexist and this library sees no device
     except ImportError:

@@ -17,11 +17,23 @@ for _ in range(3):
 raw = eng.debug_buffer("prof").view(np.uint64).reshape(2, B // 16, 16, 8)
 for k, name in enumerate(("rec_fwd", "rec_bwd")):
     p = raw[k].astype(np.float64)
-    nw = int((p[0, :, 0] > 0).sum())
+    nw = min(8, int((p[0, :, 0] > 0).sum()))
     tot, real, work, bar = (p[:, :nw, i] for i in range(4))
     mhz = tot / real * 100.0
     print("%s: waves/block %d | kernel %.1f us (realtime) | shader clock %.0f MHz (min %.0f max %.0f)" % (
         name, nw, real.mean() / 100.0, mhz.mean(), mhz.min(), mhz.max()))
+    if k == 0 and raw[0, 0, 8, 0] > 0:       # pipelined kernels: step-100 timeline of block 0, slots of "waves" 8..15
+        tl = raw[0, 0, 8:16, :].astype(np.int64)
+        t0 = tl[:, 0].min()
+        print("   step-100 timeline of block 0 (cycles after the first wave's loop top): top, k-block 0..3 operands ready, MFMAs done, published, next top")
+        for w in range(8):
+            print("     wave %d: %s" % (w, (tl[w] - t0).tolist()))
+        print("   waiting for the partner's pipe turn, per step: %s" % np.round(p[0, :8, 4] / T).astype(int).tolist())
+        print("   loop top -> first MFMA %s | MFMA phase %s | gate math + publish %s" % tuple(
+            np.round(p[0, :8, i] / T).astype(int).tolist() for i in (5, 6, 7)))
+        p = p[:, :8]
+        nw = 8
+        tot, real, work, bar = (p[:, :nw, i] for i in range(4))
     if k == 1:
         print("   bwd split by wave of block 0: gate-math %s  store/LDS-write/prefetch issue %s  LDS-read+MFMA %s" % (
             np.round(p[0, :nw, 4] / T).astype(int).tolist(), np.round(p[0, :nw, 5] / T).astype(int).tolist(),
