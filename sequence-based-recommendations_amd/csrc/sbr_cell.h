@@ -23,6 +23,11 @@ __device__ __forceinline__ float tanh_fast(float x) {   // 2*sigmoid(2x) - 1, ab
 template <bool FAST> __device__ __forceinline__ float sg(float x) { return FAST ? sigm_fast(x) : sigm(x); }
 template <bool FAST> __device__ __forceinline__ float th(float x) { return FAST ? tanh_fast(x) : tanhf(x); }
 __device__ __forceinline__ float clipf(float x, float c) { return c > 0.0f ? fminf(fmaxf(x, -c), c) : x; }
+// one v_med3_f32 per clip instead of max + min + select: ce = clip_bound(c), hoisted out of the step loops
+__device__ __forceinline__ float clip_bound(float c) { return c > 0.0f ? c : 3.402823466e38f; }
+template <bool FAST> __device__ __forceinline__ float clipb(float x, float c, float ce) {
+    return FAST ? __builtin_amdgcn_fmed3f(x, -ce, ce) : clipf(x, c);
+}
 template <int CELL> struct Gates { static constexpr int G = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1); };
 
 // ---------------------------------------------------------------------------------------
@@ -63,6 +68,8 @@ __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, flo
                                               float cprev, float cnew, float hnew, float pi, float pf, float po,
                                               float* dxi, float* dhi, float* dpeep) {
     float dhn = m ? dh : 0.0f, dhp = m ? 0.0f : dh;
+    const float ce = clip_bound(clip);
+#define CLIP(X) clipb<FAST>(X, clip, ce)
     if (CELL == CELL_LSTM) {
         float i = sv[0], f = sv[1], g = sv[2], o = sv[3];
         float dcn = m ? dc : 0.0f, dcp = m ? 0.0f : dc;
@@ -73,31 +80,42 @@ __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, flo
         float dzf = dcn * cprev * f * (1.0f - f);
         float dac = dcn * i * (1.0f - g * g);
         dpeep[0] = dzi * cprev; dpeep[1] = dzf * cprev; dpeep[2] = dzo * cnew;
-        dxi[0] = dhi[0] = clipf(dzi, clip); dxi[1] = dhi[1] = clipf(dzf, clip);
-        dxi[2] = dhi[2] = clipf(dac, clip); dxi[3] = dhi[3] = clipf(dzo, clip);
+        dxi[0] = dhi[0] = CLIP(dzi); dxi[1] = dhi[1] = CLIP(dzf);
+        dxi[2] = dhi[2] = CLIP(dac); dxi[3] = dhi[3] = CLIP(dzo);
         dc = dcp + dcn * f + dzi * pi + dzf * pf;
         dh = dhp;
     } else if (CELL == CELL_GRU) {
         float r = sv[0], u = sv[1], cc = sv[2], hic = sv[3];
         float du = dhn * (cc - hprev);
-        float dq = clipf(dhn * u * (1.0f - cc * cc), clip);
+        float dq = CLIP(dhn * u * (1.0f - cc * cc));
         float dzr = dq * hic * r * (1.0f - r);
         float dzu = du * u * (1.0f - u);
-        dxi[0] = clipf(dzr, clip); dxi[1] = clipf(dzu, clip); dxi[2] = clipf(dq, clip);
-        dhi[0] = dxi[0]; dhi[1] = dxi[1]; dhi[2] = clipf(dq * r, clip);
+        dxi[0] = CLIP(dzr); dxi[1] = CLIP(dzu); dxi[2] = CLIP(dq);
+        dhi[0] = dxi[0]; dhi[1] = dxi[1]; dhi[2] = CLIP(dq * r);
         dh = dhp + dhn * (1.0f - u);
     } else {
-        float dq = clipf(dhn * (1.0f - hnew * hnew), clip);
-        dxi[0] = dhi[0] = clipf(dq, clip);
+        float dq = CLIP(dhn * (1.0f - hnew * hnew));
+        dxi[0] = dhi[0] = CLIP(dq);
         dh = dhp;
     }
 }
+#undef CLIP
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split3(float v, __bf16& b1, __bf16& b2, __bf16& b3) {
     b1 = (__bf16)v; float r = v - (float)b1; b2 = (__bf16)r; r -= (float)b2; b3 = (__bf16)r;
+}
+// Truncating split for values published every step: hi 16 bits of v, of the remainder, of its remainder (2 VALU per
+// level instead of 3-4 for the round-to-nearest form).  Still exact (8 + 8 + 8 mantissa bits); the terms are up to
+// twice as large as the rounded ones, so against round-to-nearest weight planes the products the bf16x6 scheme
+// drops stay <= 2^-23 of the result.  Returns the three planes in the HIGH halves of b1, b2, b3.
+__device__ __forceinline__ void split3_trunc(float v, unsigned& b1, unsigned& b2, unsigned& b3) {
+    b1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(b1);
+    b2 = __float_as_uint(r1) & 0xFFFF0000u;
+    b3 = __float_as_uint(r1 - __uint_as_float(b2));
 }
 __device__ __forceinline__ void split3x4(const f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
 #pragma unroll

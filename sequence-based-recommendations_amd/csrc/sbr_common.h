@@ -228,6 +228,7 @@ hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 // sbr_rec_p.hip: pipelined bf16x6 kernels for Hp = 128 on 4-row tiles
 bool sbr_rec_x6p_ok(const RecArgs& a);
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
+hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a);
 hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 // true when the forward launch for these args can gather its input rows itself (RecArgs.gX/gWin/gbias)

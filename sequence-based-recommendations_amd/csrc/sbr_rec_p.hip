@@ -119,10 +119,12 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
     const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16);     // A operand: tile row m = j holds batch row j >> 2
     auto publish_h = [&](int buf) {
-        __bf16 p1, p2, p3;
-        split3(h, p1, p2, p3);
+        unsigned p1, p2, p3;
+        split3_trunc(h, p1, p2, p3);
         char* base = hbuf + buf * BUFB + lds_pub;
-        *(__bf16*)(base) = p1; *(__bf16*)(base + PLANEB) = p2; *(__bf16*)(base + 2 * PLANEB) = p3;
+        *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
+        *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
+        *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
     };
     publish_h(0);
 
@@ -293,6 +295,234 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// backward (GRU / Vanilla).  Same lane <-> (row, unit) mapping, counters and pipe gate as the forward kernel.
+//   dh_{t-1}[row][unit] += sum_k dhi_t[row][k] * W_hid[unit][k],  k over the G*HP gate columns (12 k-blocks at GRU)
+// A operand = dhi planes (LDS, published by the gate math of all eight waves), B operand = W_hid rows of the wave's 16
+// units (three planes, registers).  K is three times the forward's, so the operand planes cannot all be fetched up
+// front: k-block i+1 is read while k-block i's six MFMAs run.  k-blocks are visited producer-group-major: first the
+// six whose columns belong to units 0-63 (waves 0-3), then the six of waves 4-7, which waves 0-3 reach just after
+// their partner has published them.
+// Chunked BPTT protocol (t_lo / t_hi / state / part) as in rec_bwd_x6s.
+// ---------------------------------------------------------------------------------------
+namespace {
+template <int IMM>
+__device__ __forceinline__ void st_si(const void* ubase, unsigned boff, float v) {
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(boff), "v"(v), "s"(ubase), "n"(IMM) : "memory");
+}
+}  // namespace
+
+template <int CELL, bool EXT, bool PROF>
+__global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
+    constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate
+    static_assert(G <= 3, "W_hid plane 3 does not fit the register file with four gates");
+    constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW, BUFB = 3 * PLANEB;
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    char* dbuf = smem_p;                                 // [2][3 planes][R rows][DROW]
+    int* cnt = (int*)(dbuf + 2 * BUFB);
+    int* tok = cnt + 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * R + q;
+    const int u = wave * 16 + j;
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    const bool roleA = wave < 4;
+    const unsigned lds_cnt_mine = (unsigned)(size_t)(cnt + (roleA ? 0 : 1)), lds_tok = (unsigned)(size_t)(tok + (wave & 3));
+    const int one = 1;
+
+    const int mylen = a.len[row];
+    int tmax = mylen;
+    tmax = max(tmax, __shfl_xor(tmax, 16));
+    tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));
+
+    bf16x8 W1[KB], W2[KB], W3[KB];                       // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const float* src = a.Whid + (size_t)u * GHP + kb * 32 + 8 * q;
+        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 b1, b2, b3;
+            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
+            W1[kb][e] = b1; W2[kb][e] = b2; W3[kb][e] = b3;
+        }
+    }
+
+    const unsigned bo_h = (unsigned)(row * HP + u) * 4u;
+    const unsigned bo_g = (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;
+    const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;
+    const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;
+    const unsigned lds_pub = (unsigned)(q * DROW + u * 2), lds_rd = (unsigned)((j >> 2) * DROW + q * 16);
+
+    const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
+    float dh = 0.f, dc = 0.f;
+    if (first) { if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u]; }
+    else dh = a.state[(size_t)row * HP + u];
+    float sdb[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) sdb[g] = 0.f;
+
+    float sv[4] = {0.f, 0.f, 0.f, 0.f}, hprev = 0.f, hnew = 0.f, dhe = 0.f;
+    auto load_saved = [&](size_t o) {                            // activations of the step at byte offset o = t * st_h
+        hprev = ldf((const char*)a.hs + o, bo_h);
+        if (CELL != CELL_VANILLA) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = ldf((const char*)a.g[k] + o, bo_g);
+        }
+        if (EXT) dhe = ldf((const char*)a.dh_ext + o, bo_h);
+    };
+    unsigned long long p_c0 = 0, p_r0 = 0, p_spin = 0, p_tok = 0;
+    if (PROF) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+    __syncthreads();
+
+    const int t_live = min(a.t_hi, tmax);                         // steps [t_live, t_hi) are masked for the whole tile
+    for (int t = a.t_hi - 1; t >= max(t_live, a.t_lo); --t) {     // zero rows; dh_ext still accumulates
+        if (EXT) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = 0.f;
+        if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = 0.f;
+    }
+    if (t_live > a.t_lo) {
+        load_saved((size_t)(t_live - 1) * st_h);
+        if (CELL == CELL_VANILLA) hnew = a.hs[(size_t)t_live * Bp * HP + (size_t)row * HP + u];
+    }
+    // k-blocks in the order they are visited: columns of units 0-63 (all gates), then of units 64-127
+    constexpr int NH = KB / 2;
+    auto korder = [](int i) { return (i % NH) / 2 * KU + (i % NH) % 2 + (i / NH) * 2; };
+    size_t off_h = (size_t)(t_live - 1) * st_h, off_x = (size_t)(t_live - 1) * st_x;   // of step t
+    int n = 0;                                                    // steps done
+    for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
+        // ---- N: gate math of step t (needs dh complete), publish dhi, stores, loads for step t-1
+        if (EXT) dh += dhe;
+        char* lds = dbuf + (n & 1) * BUFB;
+        float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, 0.f, 0.f, hnew, 0.f, 0.f, 0.f, dxi, dhi, dp);
+#pragma unroll
+        for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            unsigned p1, p2, p3;
+            split3_trunc(dhi[g], p1, p2, p3);
+            char* base = lds + lds_pub + g * HP * 2;
+            *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
+            *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
+            *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+        }
+        lds_inc(lds_cnt_mine, one);
+        if (CELL == CELL_VANILLA) hnew = hprev;
+        {
+            const char* dx_t = (const char*)a.dxt + off_x;
+            st_si<0>(dx_t, bo_x, dxi[0]);
+            if (G > 1) st_si<HP * 4>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
+            if (G > 2) st_si<2 * HP * 4>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
+            if (CELL == CELL_GRU) st_si<0>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_saved(t > a.t_lo ? off_h - st_h : off_h);            // step t-1: unconditional, clamped
+        __builtin_amdgcn_sched_barrier(0);
+        off_h -= st_h; off_x -= st_x;
+        // ---- operands of the first k-block, the pipe gate
+        const char* db = lds + lds_rd;
+        bf16x8 dpl[2][3];
+        int fl[2];
+        auto load_kb = [&](int i, int s) {
+            const int kb = korder(i);
+            dpl[s][0] = *(const bf16x8*)(db + kb * 64);
+            dpl[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
+            dpl[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+        };
+        auto load_flag = [&](int half) {
+            fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+        };
+        auto ensure_half = [&](int half, int i, int s) {          // the half's producers have published; planes of k-block i in dpl[s]
+            if (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1)) {
+                unsigned long long w0 = 0;
+                if (PROF) w0 = clock64();
+                int spins = 0;
+#pragma clang loop unroll(disable)
+                do {
+                    asm volatile("" ::: "memory");
+                    load_flag(half);
+                    load_kb(i, s);
+                    if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 2); break; }
+                } while (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1));
+                if (PROF) p_spin += clock64() - w0;
+            }
+            asm volatile("" :: "v"(dpl[s][0]), "v"(dpl[s][1]), "v"(dpl[s][2]));
+        };
+        load_flag(0); load_kb(0, 0);
+        if (!roleA) load_flag(1);
+        ensure_half(0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (roleA && a.x6_pipe >= 2) {                            // the matrix-pipe gate, see rec_fwd_x6p
+            unsigned long long w0 = 0;
+            if (PROF) w0 = clock64();
+            int v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
+#pragma clang loop unroll(disable)
+            while (__builtin_amdgcn_readfirstlane(v) < n) {
+                v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 4); break; }
+            }
+            if (PROF) p_tok += clock64() - w0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M
+        const f32x4 z4 = f32x4{0, 0, 0, 0};
+        f32x4 acc[3] = {z4, z4, z4};
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int s = i & 1, kb = korder(i);
+            if (i + 1 < KB) {
+                if (i + 1 == NH) load_flag(1);                    // (waves 4-7 looked before the gate; harmless to look again)
+                load_kb(i + 1, s ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = MFMA_BF16(dpl[s][0], W3[kb], acc[0]);
+            acc[1] = MFMA_BF16(dpl[s][2], W1[kb], acc[1]);
+            acc[2] = MFMA_BF16(dpl[s][1], W2[kb], acc[2]);
+            acc[0] = MFMA_BF16(dpl[s][0], W2[kb], acc[0]);
+            acc[1] = MFMA_BF16(dpl[s][1], W1[kb], acc[1]);
+            acc[2] = MFMA_BF16(dpl[s][0], W1[kb], acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 == NH) ensure_half(1, i + 1, s ^ 1);
+            else if (i + 1 < KB) asm volatile("" :: "v"(dpl[s ^ 1][0]), "v"(dpl[s ^ 1][1]), "v"(dpl[s ^ 1][2]));
+        }
+        if (!roleA) lds_inc(lds_tok, one);
+        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
+        __builtin_amdgcn_s_setprio(3);
+        dh += acc[0][0] + acc[1][0] + acc[2][0];
+    }
+    if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
+        const unsigned long long tot = clock64() - p_c0;
+        o[0] = tot; o[1] = wall_clock64() - p_r0; o[2] = tot - p_spin - p_tok; o[3] = p_spin; o[4] = p_tok;
+    }
+
+    if (!last) a.state[(size_t)row * HP + u] = dh;               // hand dh to the next chunk launch
+    float* part = a.part + ((size_t)a.chunk * gridDim.x + blockIdx.x) * (GHP + 5 * HP);
+    float v[G + 5];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = sdb[g];
+    v[G] = 0.f; v[G + 1] = 0.f; v[G + 2] = 0.f; v[G + 3] = 0.f;
+    v[G + 4] = last ? dh : 0.f;                                   // init-state gradient comes from the last chunk only
+#pragma unroll
+    for (int k = 0; k < G + 5; ++k) {
+        float sum = v[k];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);                               // over the tile's 4 rows (q)
+        v[k] = sum;
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) part[g * HP + u] = v[g];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) part[GHP + k * HP + u] = v[G + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes() { return 2 * 3 * R * (size_t)(HP * 2 + 32) + 64; }
@@ -316,6 +546,25 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
     else { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false>)); }
 #undef X6P_LAUNCH
     return hipGetLastError();
+}
+
+template <int CELL>
+static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
+    constexpr int G = Gates<CELL>::G;
+    const size_t lds = 2 * 3 * R * (size_t)(G * HP * 2 + 32) + 64;
+    const int nb = a.Bp / R;
+#define X6P_LAUNCH(KERNEL) do { \
+        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
+    const bool ext = a.dh_ext != nullptr;
+    if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true>)); }
+    else { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false>)); }
+#undef X6P_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a) {
+    return a.cell == SBR_CELL_GRU ? launch_bwd_p<CELL_GRU>(s, a) : launch_bwd_p<CELL_VANILLA>(s, a);
 }
 
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a) {
