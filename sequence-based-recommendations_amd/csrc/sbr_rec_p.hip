@@ -20,6 +20,8 @@
 #include "sbr_cell.h"
 
 #define X6P_SPIN_LIMIT (1 << 21)
+#define X6P_NLOG2E (-1.4426950408889634f)
+#include <type_traits>
 #ifndef X6P_DBG
 #define X6P_DBG 0        // timing experiments only (tools/probes/x6p_variants.sh): wrong results by design
 #endif
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const int T = a.T, Bp = a.Bp;
     if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
     const bool roleA = wave < 4;                         // waves w and w + 4 share a SIMD; the older one owns the pipe
-    const unsigned lds_cnt_mine = (unsigned)(size_t)(cnt + (roleA ? 0 : 1)), lds_tok = (unsigned)(size_t)(tok + (wave & 3));
+    const unsigned lds_tok = (unsigned)(size_t)(tok + (wave & 3));
     const int one = 1;
 
     const int mylen = a.len[row];
@@ -103,7 +105,8 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 __bf16 b1, b2, b3;
-                split3(a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + u], b1, b2, b3);
+                const float sc = (CELL == CELL_GRU && g < 2) ? X6P_NLOG2E : 1.0f;     // sigmoid gates: see the gate math
+                split3(sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + u], b1, b2, b3);
                 W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b3;
             }
 
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const unsigned bo_id = (unsigned)(row * T) * 4u;                                           // ids of this row
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;                      // bytes per time step
 
-    float h = a.hinit[u], cst = 0.f;
+    float h = a.hinit[u];
     stf(a.hs, bo_h, h);
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
     const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16);     // A operand: tile row m = j holds batch row j >> 2
@@ -140,6 +143,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     for (int g = 0; g < G; ++g) {
         float b = FUSE ? a.gbias[g * HP + u] : 0.f;
         if (CELL == CELL_GRU && g == 2) { bias_c = b; b = 0.f; }
+        if (CELL == CELL_GRU && g < 2) b *= X6P_NLOG2E;
         biasv[g] = f32x4{b, b, b, b};
     }
     auto load_id = [&](int t) -> int { return FUSE ? ldi((const char*)a.gX + (size_t)min(t, T - 1) * 4, bo_id) : 0; };
@@ -163,6 +167,14 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
     size_t off_t = 0;                                              // t * st_h
+    int tmin = mylen;                                              // steps below it: no row of the tile is masked
+    tmin = min(tmin, __shfl_xor(tmin, 16));
+    tmin = __builtin_amdgcn_readfirstlane(min(tmin, __shfl_xor(tmin, 32)));
+    const unsigned lds_cnt0 = (unsigned)(size_t)cnt;              // LDS addresses of the two publish counters
+    // One loop per role (waves 0-3 / 4-7): a role test inside the loop costs VALU instructions in every step, some
+    // of them between MFMAs, and values defined under it get copies at the join (see sbr_rec_cl.hip).
+    auto steps = [&](auto role_tag) {
+    constexpr bool RA = decltype(role_tag)::value;
     for (int t = 0; t < tmax; ++t) {
         if (PROF) p_ta = clock64();
         if (PROF && tl && (t == 100 || t == 101)) tl[t == 100 ? 0 : 7] = p_ta;
@@ -198,16 +210,16 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                                "v"(hp[2 * half + 1][0]), "v"(hp[2 * half + 1][1]), "v"(hp[2 * half + 1][2]));
         };
         load_half(0);
-        if (!roleA) load_half(1);
+        if (!RA) load_half(1);
         ensure_half(0);
-        if (!roleA) ensure_half(1);
+        if (!RA) ensure_half(1);
         __builtin_amdgcn_s_setprio(0);
         // The matrix pipe serves the OLDER wave of a SIMD pair first, strictly (tools/probes/mfma_share_probe.hip: two
         // MFMA streams on one SIMD run 1160 / 2321 cycles per 72, not 1740 / 1740).  A wave 0-3 that started its step
         // as soon as its own group's k-blocks were there would starve its partner's last MFMAs, whose results
         // everybody waits for: so it holds back until the partner has issued its whole step.  Waves 4-7 need no gate,
         // they only ever get the gaps.
-        if (roleA && a.x6_pipe >= 2 && !(X6P_DBG & 32)) {
+        if (RA && a.x6_pipe >= 2 && !(X6P_DBG & 32)) {
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
             int v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
@@ -225,50 +237,52 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 #define X6P_TERM(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(HOP, WOP, acc[g]);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            if (kb == KB / 2 && roleA) ensure_half(1);
+            if (kb == KB / 2 && RA) ensure_half(1);
             __builtin_amdgcn_sched_barrier(0);
             if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-            if (!((X6P_DBG & 8) && !roleA) && !((X6P_DBG & 16) && roleA)) {
             if (kb == 0) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(hp[kb][0], W3[g][kb], biasv[g]);
             } else { X6P_TERM(hp[kb][0], W3[g][kb]) }
             X6P_TERM(hp[kb][2], W1[g][kb])
             X6P_TERM(hp[kb][1], W2[g][kb])
-            } else if (kb == 0) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = biasv[g];
-            }
-            if (kb == KB / 2 - 1 && roleA) {                      // late enough for the partner's gate math to have
+            if (kb == KB / 2 - 1 && RA) {                         // late enough for the partner's gate math to have
                 __builtin_amdgcn_sched_barrier(0);                // published, early enough to hide the LDS latency
                 load_half(1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!((X6P_DBG & 8) && !roleA) && !((X6P_DBG & 16) && roleA)) {
             X6P_TERM(hp[kb][0], W2[g][kb])
             X6P_TERM(hp[kb][1], W1[g][kb])
             X6P_TERM(hp[kb][0], W1[g][kb])
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef X6P_TERM
-        if (!roleA) lds_inc(lds_tok, one);
+        if (!RA) lds_inc(lds_tok, one);
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard (see rec_fwd_mfma)
         __builtin_amdgcn_s_setprio(3);
         if (PROF) { const unsigned long long tc = clock64(); p_seg[1] += tc - p_tb; p_tb = tc; }
         if (PROF && tl && t == 100) tl[5] = p_tb;
-        // ---- N2
+        // ---- N2: gate math (sparse_lstm.py:780-803 / :1133-1150).  For GRU the r and u columns of W_hid and their
+        // bias were scaled by -log2(e) when the planes were built, so a sigmoid is fma, exp2, add, rcp.
         {
-            float as[G], xc[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { as[g] = acc[g][0]; xc[g] = x[g]; }
-            if (CELL == CELL_GRU) xc[G - 1] += bias_c;
-            if (X6P_DBG & 1) { h = 0.5f * h + 0.01f * (as[0] + xc[0] + as[G - 1] * xc[G - 1]); sv[0] = as[0]; sv[1] = xc[0]; }
-            else cell_forward<CELL, true>(xc, as, t < mylen, h, cst, 0.f, 0.f, 0.f, sv);
+            float hn;
+            if (CELL == CELL_GRU) {
+                constexpr int IU = G > 1 ? 1 : 0, IC = G > 2 ? 2 : 0;
+                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(x[0], X6P_NLOG2E, acc[0][0])));
+                const float ug = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(x[IU], X6P_NLOG2E, acc[IU][0])));
+                const float hc = acc[IC][0];
+                const float cc = tanh_fast(fmaf(rg, hc, x[IC] + bias_c));
+                hn = fmaf(ug, cc - h, h);                         // (1 - u) h + u c
+                sv[0] = rg; sv[1] = ug; sv[2] = cc; sv[3] = hc;
+            } else {
+                hn = tanh_fast(x[0] + acc[0][0]);
+            }
+            if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; }            // uniform branch: no select while no row is masked
+            else h = t < mylen ? hn : h;
         }
         if (t + 1 < tmax) {
             publish_h((t + 1) & 1);
-            lds_inc(lds_cnt_mine, one);
+            lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
             if (PROF) p_seg[2] += clock64() - p_tb;
             if (PROF && tl && t == 100) tl[6] = clock64();
         }
@@ -282,6 +296,8 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         off_t += st_h;
         if (!(X6P_DBG & 2)) { load_x(t + 1, id_next); id_next = load_id(t + 2); }
     }
+    };
+    if (roleA) steps(std::true_type{}); else steps(std::false_type{});
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
         off_t += st_h;
@@ -328,7 +344,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     const float clip = a.clip;
     if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
     const bool roleA = wave < 4;
-    const unsigned lds_cnt_mine = (unsigned)(size_t)(cnt + (roleA ? 0 : 1)), lds_tok = (unsigned)(size_t)(tok + (wave & 3));
+    const unsigned lds_tok = (unsigned)(size_t)(tok + (wave & 3));
     const int one = 1;
 
     const int mylen = a.len[row];
@@ -391,6 +407,9 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     constexpr int NH = KB / 2;
     auto korder = [](int i) { return (i % NH) / 2 * KU + (i % NH) % 2 + (i / NH) * 2; };
     size_t off_h = (size_t)(t_live - 1) * st_h, off_x = (size_t)(t_live - 1) * st_x;   // of step t
+    const unsigned lds_cnt0 = (unsigned)(size_t)cnt;
+    auto steps = [&](auto role_tag) {                             // one loop per role, see rec_fwd_x6p
+    constexpr bool RA = decltype(role_tag)::value;
     int n = 0;                                                    // steps done
     for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
         // ---- N: gate math of step t (needs dh complete), publish dhi, stores, loads for step t-1
@@ -409,7 +428,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
             *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
         }
-        lds_inc(lds_cnt_mine, one);
+        lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
         if (CELL == CELL_VANILLA) hnew = hprev;
         {
             const char* dx_t = (const char*)a.dxt + off_x;
@@ -453,10 +472,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             asm volatile("" :: "v"(dpl[s][0]), "v"(dpl[s][1]), "v"(dpl[s][2]));
         };
         load_flag(0); load_kb(0, 0);
-        if (!roleA) load_flag(1);
+        if (!RA) load_flag(1);
         ensure_half(0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if (roleA && a.x6_pipe >= 2) {                            // the matrix-pipe gate, see rec_fwd_x6p
+        if (RA && a.x6_pipe >= 2) {                               // the matrix-pipe gate, see rec_fwd_x6p
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
             int v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
@@ -489,11 +508,13 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             if (i + 1 == NH) ensure_half(1, i + 1, s ^ 1);
             else if (i + 1 < KB) asm volatile("" :: "v"(dpl[s ^ 1][0]), "v"(dpl[s ^ 1][1]), "v"(dpl[s ^ 1][2]));
         }
-        if (!roleA) lds_inc(lds_tok, one);
+        if (!RA) lds_inc(lds_tok, one);
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
         dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
+    };
+    if (roleA) steps(std::true_type{}); else steps(std::false_type{});
     if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         const unsigned long long tot = clock64() - p_c0;
