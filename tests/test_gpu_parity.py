@@ -71,6 +71,23 @@ def test_unfused_gather_agrees(monkeypatch):
     check(PU.compare_step("LSTM", [50], "CCE", N=61, B=37, T=9))
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+def test_pipelined_kernel_modes(cell, mode, monkeypatch):
+    # default (2): rec_*_x6p for GRU / Vanilla at 128 units: LDS counters instead of a per-step barrier + the matrix-pipe
+    # gate between the two waves of a SIMD (every other 128-wide test); 1 = without the gate, 0 = the barrier kernels
+    monkeypatch.setenv("SBR_X6_PIPE", mode)
+    check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
+    check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12))
+
+
+def test_pipelined_kernels_long_ragged_rows_and_chunks(monkeypatch):
+    # rows of every length in one tile (masked tail, carried state), BPTT in time chunks, dense second layer (dh_ext)
+    monkeypatch.setenv("SBR_BWD_CHUNKS", "3")
+    check(PU.compare_step("GRU", [128, 128], "CCE", N=61, B=7, T=70, scale=0.05))
+    check(PU.compare_step("Vanilla", [128], "Blackout", N=61, B=21, T=33, S=8))
+
+
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_general_kernel_on_four_row_tiles(cell, monkeypatch):
     monkeypatch.setenv("SBR_X6_SPLIT", "0")
