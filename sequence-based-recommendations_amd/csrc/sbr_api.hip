@@ -886,10 +886,11 @@ extern "C" int sbr_read_cost(sbr_handle* h, float* cost_host) {
     CHECK_ARG(h && cost_host, "null argument");
     SBR_HIP(hipMemcpyAsync(cost_host, h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
     int fault = 0;
-    if (h->cluster) SBR_HIP(hipMemcpyAsync(&fault, h->A(h->lay.a_fault), sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipMemcpyAsync(&fault, h->A(h->lay.a_fault), sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SBR_HIP(hipStreamSynchronize(h->stream));
-    if (fault) {
-        sbr_set_error("a cluster exchange wait of the wide-layer recurrent kernels timed out (results invalid); rerun with SBR_CLUSTER=0");
+    if (fault) {   // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip)
+        sbr_set_error("a bounded wait inside the recurrent kernels gave up (flag %d, results invalid); rerun with %s", fault,
+                      (fault & 1) ? "SBR_CLUSTER=0" : "SBR_X6_PIPE=0");
         return SBR_EHIP;
     }
     return SBR_OK;
