@@ -123,6 +123,12 @@ int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* lengths, const
 /* train_function(*batch) -> cost (rnn_base.py:290): zero grads, forward, loss, backward,
  * update.  cost_host may be NULL (cost stays on device: sbr_read_cost). */
 int sbr_train_step(sbr_handle* h, float* cost_host);
+/* The training loop's form of the same call (rnn_base.py:285-300 reads the cost of every iteration): enqueues the step
+ * and a copy of its cost, and hands back the cost of the PREVIOUS call once that is ready, so the host never waits for
+ * the step it has just enqueued.  *have_prev = 0 on the first call.  sbr_lagged_flush waits for and returns the cost of
+ * the last enqueued step (call it before reading parameters, validating, or leaving the loop). */
+int sbr_train_step_lagged(sbr_handle* h, float* prev_cost, int* have_prev);
+int sbr_lagged_flush(sbr_handle* h, float* cost, int* have);
 /* The same in phases (data-parallel: all-reduce the gradient section between them). */
 int sbr_zero_grads(sbr_handle* h);
 int sbr_forward(sbr_handle* h);

@@ -290,6 +290,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
+    h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
     // every "overlapped" kernel serialised: +150 us per step in the data-parallel path).  Streams of another priority
@@ -306,7 +307,10 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_chunk[3], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_chunk[3], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_lag[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_lag[1], hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&h->lag_host, 4 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         sbr_set_error("side stream creation failed"); sbr_destroy(h); return SBR_EHIP;
     }
     // parameters, gradients, optimizer state and batch buffers start as zeros
@@ -330,6 +334,8 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
     if (h->ev_og) (void)hipEventDestroy(h->ev_og);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
+    for (int c = 0; c < 2; ++c) if (h->ev_lag[c]) (void)hipEventDestroy(h->ev_lag[c]);
+    if (h->lag_host) (void)hipHostFree(h->lag_host);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -912,6 +918,43 @@ extern "C" int sbr_train_step(sbr_handle* h, float* cost_host) {
     if (h->timing) h->ring_used += 1;
     if (cost_host) return sbr_read_cost(h, cost_host);
     return SBR_OK;
+}
+
+static int lagged_collect(sbr_handle* h, float* cost, int* have) {
+    *have = 0;
+    if (h->lag_pending < 0) return SBR_OK;
+    const int s = h->lag_pending;
+    h->lag_pending = -1;
+    SBR_HIP(hipEventSynchronize(h->ev_lag[s]));
+    *cost = h->lag_host[s];
+    *have = 1;
+    int fault = 0;
+    memcpy(&fault, &h->lag_host[2 + s], sizeof(int));
+    if (fault) {
+        sbr_set_error("a bounded wait inside the recurrent kernels gave up (flag %d, results invalid); rerun with %s", fault,
+                      (fault & 1) ? "SBR_CLUSTER=0" : "SBR_X6_PIPE=0");
+        return SBR_EHIP;
+    }
+    return SBR_OK;
+}
+
+extern "C" int sbr_train_step_lagged(sbr_handle* h, float* prev_cost, int* have_prev) {
+    CHECK_ARG(h && prev_cost && have_prev, "null argument");
+    int rc = sbr_train_step(h, nullptr);
+    if (rc != SBR_OK) return rc;
+    const int s = h->lag_slot;
+    SBR_HIP(hipMemcpyAsync(&h->lag_host[s], h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipMemcpyAsync(&h->lag_host[2 + s], h->A(h->lay.a_fault), sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipEventRecord(h->ev_lag[s], h->stream));
+    rc = lagged_collect(h, prev_cost, have_prev);          // the step before this one: normally long finished
+    h->lag_pending = s;
+    h->lag_slot = s ^ 1;
+    return rc;
+}
+
+extern "C" int sbr_lagged_flush(sbr_handle* h, float* cost, int* have) {
+    CHECK_ARG(h && cost && have, "null argument");
+    return lagged_collect(h, cost, have);
 }
 
 // ---------------------------------------------------------------------------------------

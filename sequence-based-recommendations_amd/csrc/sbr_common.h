@@ -114,6 +114,9 @@ struct sbr_handle {
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
     int x6_split, fuse_gather;
+    float* lag_host;     // pinned: [2] cost, [2] fault flag (sbr_train_step_lagged)
+    hipEvent_t ev_lag[2];
+    int lag_slot, lag_pending;
     int x6_pipe;         // per-k-block publish counters instead of a workgroup barrier per step (SBR_X6_PIPE, default 1; Hp = 128)
     int wgrad_x6;        // weight gradients through the bf16x6 GEMM instead of the dedicated f32 kernel (SBR_WGRAD_X6, default 1; the f32 kernel serves Hp < 96 and SBR_FLAG_F32_MFMA)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's

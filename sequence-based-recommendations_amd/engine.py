@@ -49,7 +49,7 @@ class SbrConfig(ctypes.Structure):
 # every symbol include/sbr_rnn.h declares (tests check the library exports all of them)
 EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create", "sbr_destroy", "sbr_num_params",
            "sbr_param_shape", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
-           "sbr_train_step", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
+           "sbr_train_step", "sbr_train_step_lagged", "sbr_lagged_flush", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm",
@@ -87,6 +87,8 @@ def load_library(path=None):
                                 ctypes.POINTER(ctypes.c_size_t)]
     lib.sbr_set_batch.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int]
     lib.sbr_train_step.argtypes = [vp, f32p]
+    lib.sbr_train_step_lagged.argtypes = [vp, f32p, i32p]
+    lib.sbr_lagged_flush.argtypes = [vp, f32p, i32p]
     for fn in (lib.sbr_zero_grads, lib.sbr_forward, lib.sbr_loss_backward_output, lib.sbr_backward_recurrent,
                lib.sbr_apply_update, lib.sbr_synchronize):
         fn.argtypes = [vp]
@@ -407,6 +409,18 @@ class RNNEngine(object):
             return float(cost.value)
         self._check(self.lib.sbr_train_step(self.h, None))
         return None
+
+    def train_step_lagged(self):
+        """Enqueue a step; returns the cost of the PREVIOUS lagged call (None on the first): the training loop's
+        form, the host never waits for the step it has just enqueued.  flush_lagged() returns the last one."""
+        cost, have = ctypes.c_float(), ctypes.c_int32()
+        self._check(self.lib.sbr_train_step_lagged(self.h, ctypes.byref(cost), ctypes.byref(have)))
+        return float(cost.value) if have.value else None
+
+    def flush_lagged(self):
+        cost, have = ctypes.c_float(), ctypes.c_int32()
+        self._check(self.lib.sbr_lagged_flush(self.h, ctypes.byref(cost), ctypes.byref(have)))
+        return float(cost.value) if have.value else None
 
     def forward_backward(self):
         """Gradients without the update (parity tests, data-parallel)."""

@@ -240,19 +240,26 @@ class RNNBase(object):
         train_costs, current_train_cost, epochs = [], [], []
         metrics = {name: [] for name in self.metrics.keys()}
         filename = {}
+        def take(cost):                 # rnn_base.py:290-293; with device batches the cost arrives one iteration late
+            if cost is not None:
+                if np.isnan(cost):
+                    raise ValueError("Cost is NaN")
+                current_train_cost.append(cost)
+
         try:
             while time() - start_time < max_time and iterations < max_iter:
                 try:
                     batch = next(batch_generator)
-                    cost = self.engine.train_step() if native is not None else self.train_function(*batch)
-                    if np.isnan(cost):
-                        raise ValueError("Cost is NaN")
+                    # device batches: the step is enqueued and the PREVIOUS step's cost comes back (no wait for the step
+                    # just enqueued); the last one is collected before anything reads the costs or the parameters
+                    take(self.engine.train_step_lagged() if native is not None else self.train_function(*batch))
                 except StopIteration:
                     break
-                current_train_cost.append(cost)
                 iterations += 1
                 progress_indicator = int(time() - start_time) if time_based_progress else iterations
                 if progress_indicator >= next_save:
+                    if native is not None:
+                        take(self.engine.flush_lagged())
                     if progress_indicator >= min_iterations:
                         epochs.append(epochs_offset + dataset.training_set.epochs)
                         train_costs.append(np.mean(current_train_cost))
@@ -283,6 +290,8 @@ class RNNBase(object):
                         next_save += min(max_progress_interval, next_save * (progress - 1))
         except KeyboardInterrupt:
             print("Training interrupted")
+        if native is not None:
+            take(self.engine.flush_lagged())
         if not metrics[validation_metrics[0]]:
             return {}, time() - start_time, None
         best_run = int(np.argmax(np.array(metrics[validation_metrics[0]]) * self.metrics[validation_metrics[0]]["direction"]))

@@ -150,3 +150,37 @@ def test_training_from_native_batches_matches_host_batches_in_quality(tmp_path, 
                                  "--save", "None", "--r_t", "GRU", "--r_l", "32", "--u_l", "0.01"])
         res[native] = metrics["sps"]
     assert res["1"] > 0.2 and res["0"] > 0.2, res
+
+
+def test_lagged_train_step_returns_the_same_costs_one_call_late():
+    # the training loop's pipelined form (sbr_train_step_lagged): same steps, each cost handed back one call later
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(3, 40, size=40)
+    B, T, n = 16, 12, 9
+
+    def run(lagged):
+        eng, ds, _, _ = make(lengths, B, T)
+        try:
+            from oracle import rnn_oracle as O
+            eng.set_all_param_values(O.init_params("GRU", [16], 1 + 64 * len(lengths), np.random.default_rng(7), dtype=np.float32))
+            nb = ds.plan_pass(None, B)
+            costs = []
+            for i in range(n):
+                eng.build_batch(ds, i % nb, seed=50 + i)
+                c = eng.train_step_lagged() if lagged else eng.train_step()
+                if c is not None:
+                    costs.append(c)
+            if lagged:
+                assert len(costs) == n - 1
+                costs.append(eng.flush_lagged())
+                assert eng.flush_lagged() is None
+            return np.array(costs), eng.get_all_param_values()
+        finally:
+            ds.close(); eng.close()
+
+    c0, p0 = run(False)
+    c1, p1 = run(True)
+    # (not bitwise: the scatter adds the few segments that straddle chunk seams with float atomics)
+    assert np.allclose(c0, c1, rtol=1e-5, atol=0)
+    assert all(np.allclose(a, b, rtol=1e-4, atol=1e-6) for a, b in zip(p0, p1))
+    assert c0[-1] < c0[0]
