@@ -1,22 +1,39 @@
-// Pipelined bf16x6 recurrent kernels for Hp = 128 on 4-row tiles ("x6p"): the kernels of BASELINE config C2.
+// Pipelined bf16x6 recurrent kernels for GRU / Vanilla layers of 128 units on 4-row tiles ("x6p"): the kernels of
+// BASELINE config C2.  Same arithmetic and global data layout as rec_fwd_x6s / rec_bwd_x6s (sbr_rec.hip: one workgroup
+// of eight waves, two per SIMD, per 4-row tile for all T steps; f32 operands split exactly into three bf16 planes, six
+// MFMA terms); the schedule inside the workgroup is rebuilt around three facts measured on the MI355X
+// (tools/probes/mfma_share_probe.hip, valu_beside_mfma_probe.hip, lds_mask_probe.hip):
 //
-// Same arithmetic, data layout and LDS operand planes as rec_fwd_x6s / rec_bwd_x6s (sbr_rec.hip: one workgroup of
-// eight waves per 4-row tile, W_hid planes 1-2 in registers and plane 3 in LDS, every lane finishes ONE (row, unit)
-// pair on the duplicate MFMA columns).  Two things differ:
+//   a. Waves w and w + 4 share a SIMD, and its matrix pipe serves the OLDER one first, strictly: two MFMA streams on
+//      one SIMD finish in 1160 / 2321 cycles per 72 MFMAs, not 1740 / 1740.  s_setprio does not change that.
+//   b. Beside a partner wave that streams MFMAs, a VALU instruction of the other wave costs ~20 cycles (one issue slot
+//      per partner MFMA; 2.6 - 8.5 cycles alone), whichever wave is older.  Scalar, LDS and memory instructions cost
+//      what they always cost.
+//   c. A ds_read_b128 occupies the LDS pipe ~5 cycles whatever the exec mask.
 //
-// 1. No workgroup barrier in the step loop.  The two waves that own the 32 units of k-block kb bump an LDS counter
-//    after publishing their slice of h_{t+1} (forward) / dhi_t (backward); a consumer reads counter then planes (the
-//    LDS executes one wave's instructions in order, so planes read after a counter value >= target are the published
-//    ones) and re-reads both while the counter is short.  The waves of a SIMD pair drift apart by about half a step
-//    (measured with the timeline counters below), so one wave's gate math issues while its partner keeps the matrix
-//    pipe busy.  Double buffering still suffices: a wave overwrites the buffer of step t only after its step-(t+1)
-//    MFMAs, which needed every wave's step-(t+1) slice, which each wave published after its own step-t operand reads.
+// So a step is two serial MFMA phases per SIMD (2 x 1160 cycles) with every wave's other work running under its
+// partner's phase, and it lasts max(both phases, one wave's phase + its other work at 20 cycles per VALU instruction).
+// With a barrier per step (x6s) all eight waves do their gate math at the same time while the pipe idles: 3760 cycles.
 //
-// 2. The step loop is written for instruction count.  With two waves per SIMD the VALU issue port carries 144 MFMAs
-//    (576 issue cycles of the 2304 the pipe is busy) plus both waves' non-MFMA instructions at 4+ cycles each; the
-//    x6s loop spends ~250 of those per wave and step, most of them 64-bit address arithmetic, and that, not the matrix
-//    pipe, set its 3760 cycles per step.  Here every global access is (uniform base advanced on the scalar unit) +
-//    (32-bit per-lane byte offset computed once), profiling is a template parameter, and so is the fused gather.
+//   1. No workgroup barrier in the step loop: LDS counters per group of four producer waves; a consumer reads counter
+//      then planes (the LDS keeps a wave's order, so planes read after a sufficient counter value are the published
+//      ones) and re-reads both while the counter is short.  Double buffering still suffices: a wave overwrites the
+//      buffer of step t only after its step-(t+1) MFMAs, which needed every wave's step-(t+1) slice, which each wave
+//      published after its own step-t operand reads.  Every spin is bounded and raises the fault flag
+//      (sbr_read_cost reports it) instead of hanging the GPU.
+//   2. A gate on the matrix pipe: waves 0-3 start their MFMA phase only when their partner has issued its own (fact a:
+//      otherwise they starve the partner's last MFMAs, whose results everybody waits for).
+//   3. All three W_hid planes in registers (144 VGPRs; a fourth gate does not fit: LSTM keeps x6s); activations are the
+//      A operand with every batch row filling four tile rows, so lane (j, q) finishes (row q, unit j) from accumulator
+//      element 0 without a select; biases ride in as the MFMA C operand; sigmoid gates are pre-scaled by -log2(e).
+//   4. Everything outside the MFMA phase is written for VALU count (fact b): scalar-advanced addresses, single-
+//      instruction stores and counter updates, v_med3 clip, truncating bf16 split, one loop per role, no packed-f32
+//      (SLP) gate math, a uniform branch instead of a select while no row is masked.
+//
+// Measured at C2 (cycles per step, 2320 = MFMA issue): forward 3760 -> 2750, backward 4100 -> 3190.  Tried and
+// rejected: all operands fetched before the MFMA phase by every wave (LDS burst, +35 us), a three-deep operand ring in
+// the backward (+15 us), a delay or an early signal at the gate (+5 .. +35 us), splitting the backward over K instead
+// of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
 #include "sbr_cell.h"
 
 #define X6P_SPIN_LIMIT (1 << 21)
