@@ -232,6 +232,10 @@ hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 bool sbr_rec_x6p_ok(const RecArgs& a);
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a);
+// sbr_rec_q.hip: the same step loop for Hp = 32 / 64 (one wave per SIMD)
+bool sbr_rec_x6q_ok(const RecArgs& a);
+hipError_t launch_rec_forward_x6q(hipStream_t s, const RecArgs& a);
+hipError_t launch_rec_backward_x6q(hipStream_t s, const RecArgs& a);
 hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 // true when the forward launch for these args can gather its input rows itself (RecArgs.gX/gWin/gbias)

@@ -1304,6 +1304,7 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
     }
     if (sbr_rec_cluster_ok(a)) return launch_rec_forward_cl(s, a);
     if (sbr_rec_x6p_ok(a)) return launch_rec_forward_x6p(s, a);
+    if (sbr_rec_x6q_ok(a)) return launch_rec_forward_x6q(s, a);
     const int nblk = a.Bp / 16;
 #define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
@@ -1382,7 +1383,8 @@ static hipError_t launch_bwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
         return e;
     }
     if (sbr_rec_cluster_ok(a)) return launch_rec_backward_cl(s, a);
-    if (sbr_rec_x6p_ok(a) && a.x6_pipe < 8) return launch_rec_backward_x6p(s, a);   // SBR_X6_PIPE=10: pipelined forward only
+    if (sbr_rec_x6p_ok(a)) return launch_rec_backward_x6p(s, a);
+    if (sbr_rec_x6q_ok(a)) return launch_rec_backward_x6q(s, a);
     if (!a.f32_mfma && (Hp == 32 || Hp == 64 || Hp == 128)) {
         const size_t w3b = (size_t)(GHp / 32) * (Hp / 16) * 1024, one6 = 3 * (size_t)a.rpt * (GHp * 2 + 32);
         const int db6 = (w3b + 2 * one6 <= 160 * 1024) ? 1 : 0;

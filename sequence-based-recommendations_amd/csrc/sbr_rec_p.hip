@@ -34,27 +34,13 @@
 // rejected: all operands fetched before the MFMA phase by every wave (LDS burst, +35 us), a three-deep operand ring in
 // the backward (+15 us), a delay or an early signal at the gate (+5 .. +35 us), splitting the backward over K instead
 // of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
-#include "sbr_cell.h"
+#include "sbr_rec_p.h"
 
-#define X6P_SPIN_LIMIT (1 << 21)
-#define X6P_NLOG2E (-1.4426950408889634f)
-#include <type_traits>
 #ifndef X6P_DBG
 #define X6P_DBG 0        // timing experiments only (tools/probes/x6p_variants.sh): wrong results by design
 #endif
 
 namespace {
-
-// uniform base + 32-bit per-lane byte offset (+ immediate): one global_load/store with an SGPR base, no VALU
-__device__ __forceinline__ float ldf(const void* base, unsigned boff, int imm = 0) {
-    return *(const float*)((const char*)base + (size_t)boff + imm);
-}
-__device__ __forceinline__ int ldi(const void* base, unsigned boff, int imm = 0) {
-    return *(const int*)((const char*)base + (size_t)boff + imm);
-}
-__device__ __forceinline__ void stf(void* base, unsigned boff, float v, int imm = 0) {
-    *(float*)((char*)base + (size_t)boff + imm) = v;
-}
 
 constexpr int HP = 128, R = 4, KBH = HP / 32;
 
@@ -79,17 +65,6 @@ constexpr int HP = 128, R = 4, KBH = HP / 32;
 // MFMA, tools/probes/valu_beside_mfma_probe.hip) and a scalar one ~4: per-step addresses advance on the SALU, stores
 // and counter updates are single instructions with scalar bases / precomputed operands.
 // ---------------------------------------------------------------------------------------
-namespace {
-// one lane adds 1 to an LDS counter: exec is all ones around every call site
-__device__ __forceinline__ void lds_inc(unsigned addr, int one) {
-    asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(one) : "memory");
-}
-// store with a scalar base: the compiler's own form adds the per-step offset on the VALU
-__device__ __forceinline__ void st_s(const void* ubase, unsigned boff, float v) {
-    asm volatile("global_store_dword %0, %1, %2" :: "v"(boff), "v"(v), "s"(ubase) : "memory");
-}
-}  // namespace
-
 template <int CELL, bool FUSE, bool PROF>
 __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     constexpr int G = Gates<CELL>::G, KB = KBH, GHP = G * HP;
@@ -337,13 +312,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 // their partner has published them.
 // Chunked BPTT protocol (t_lo / t_hi / state / part) as in rec_bwd_x6s.
 // ---------------------------------------------------------------------------------------
-namespace {
-template <int IMM>
-__device__ __forceinline__ void st_si(const void* ubase, unsigned boff, float v) {
-    asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(boff), "v"(v), "s"(ubase), "n"(IMM) : "memory");
-}
-}  // namespace
-
 template <int CELL, bool EXT, bool PROF>
 __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate

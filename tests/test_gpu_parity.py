@@ -81,6 +81,21 @@ def test_pipelined_kernel_modes(cell, mode, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12))
 
 
+@pytest.mark.parametrize("H", [20, 50])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_small_layer_barrier_kernels_agree(cell, H, monkeypatch):
+    # default for Hp = 32 / 64: rec_*_x6q (LDS counter instead of a barrier, every other small-layer test);
+    # SBR_X6_PIPE=0 keeps the barrier kernels rec_*_x6s
+    monkeypatch.setenv("SBR_X6_PIPE", "0")
+    check(PU.compare_step(cell, [H], "CCE", N=61, B=37, T=9))
+
+
+def test_small_layer_kernels_two_layers_ragged_and_chunks(monkeypatch):
+    monkeypatch.setenv("SBR_BWD_CHUNKS", "3")
+    check(PU.compare_step("LSTM", [50, 20], "CCE", N=61, B=7, T=70, scale=0.05))
+    check(PU.compare_step("GRU", [20, 50], "Blackout", N=61, B=21, T=33, S=8))
+
+
 def test_pipelined_kernels_long_ragged_rows_and_chunks(monkeypatch):
     # rows of every length in one tile (masked tail, carried state), BPTT in time chunks, dense second layer (dh_ext)
     monkeypatch.setenv("SBR_BWD_CHUNKS", "3")
