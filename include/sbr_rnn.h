@@ -174,7 +174,9 @@ int sbr_synchronize(sbr_handle* h);
 int sbr_enable_timing(sbr_handle* h, int on);
 /* Which kernels this handle's shapes select (tooling: bench.py names the kernels it prices):
  * "fused_gather" (layer-0 input rows gathered inside the forward kernel), "rows_per_workgroup",
- * "cluster" (multi-workgroup recurrent kernels for the top layer), "arena_bytes", "side_stream" (hipStream_t). */
+ * "cluster" (multi-workgroup recurrent kernels for the top layer), "rec_kernel" (kernel family of the top layer:
+ * 0 triage, 1 cluster, 2 counter-synchronised 128-unit, 3 counter-synchronised 32/64-unit, 4 barrier / general),
+ * "arena_bytes", "side_stream" (hipStream_t). */
 int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 

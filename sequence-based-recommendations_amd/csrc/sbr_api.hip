@@ -1068,6 +1068,10 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         *value = (y.E == 0 && y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(a, simple_rec(h))) ? 1 : 0;
     } else if (w == "rows_per_workgroup") *value = h->rpt;
     else if (w == "cluster") { RecArgs a = rec_args(h, (y.L - 1) * y.D); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
+    else if (w == "rec_kernel") {   // family serving the top layer: 0 triage, 1 cluster, 2 x6p (128 units), 3 x6q (32/64), 4 other
+        RecArgs a = rec_args(h, (y.L - 1) * y.D);
+        *value = simple_rec(h) ? 0 : sbr_rec_cluster_ok(a) ? 1 : sbr_rec_x6p_ok(a) ? 2 : sbr_rec_x6q_ok(a) ? 3 : 4;
+    }
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
     else if (w == "side_stream") *value = (int64_t)(intptr_t)h->side;
     else { sbr_set_error("unknown query '%s'", what); return SBR_EINVAL; }

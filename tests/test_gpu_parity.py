@@ -71,6 +71,19 @@ def test_unfused_gather_agrees(monkeypatch):
     check(PU.compare_step("LSTM", [50], "CCE", N=61, B=37, T=9))
 
 
+def test_benchmark_configs_take_their_fast_kernels():
+    # a silent fallback to the barrier kernels would keep every parity test green and lose 20-25 % of the step
+    from sbr_amd.engine import RNNEngine
+    for cell, layers, n_items, want in (("GRU", [128], 3706, 2), ("LSTM", [20], 3706, 3), ("GRU", [50], 3706, 3),
+                                        ("LSTM", [256], 26744, 1), ("LSTM", [128], 3706, 4)):
+        eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=200, batch_size=256, loss="CCE")
+        try:
+            assert eng.query("rec_kernel") == want, (cell, layers)
+            assert eng.query("fused_gather") == 1
+        finally:
+            eng.close()
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
 def test_pipelined_kernel_modes(cell, mode, monkeypatch):
