@@ -32,7 +32,7 @@
 //
 // Measured at C2 (cycles per step, 2320 = MFMA issue): forward 3760 -> 2750, backward 4100 -> 3190.  Tried and
 // rejected: all operands fetched before the MFMA phase by every wave (LDS burst, +35 us), a three-deep operand ring in
-// the backward (+15 us), a delay or an early signal at the gate (+5 .. +35 us), splitting the backward over K instead
+// the backward (+15 us), a delay at the gate or a signal more than one MFMA term early (+5 .. +35 us; one term early is what runs, -4 us), splitting the backward over K instead
 // of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
 #include "sbr_rec_p.h"
 
@@ -245,11 +245,15 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             }
             X6P_TERM(hp[kb][0], W2[g][kb])
             X6P_TERM(hp[kb][1], W1[g][kb])
+            // The partner needs >= ~100 cycles to notice the counter (LDS add + its polling read): tell it G MFMAs (48
+            // cycles at GRU) before the last one is issued, so that less of that reaction time is idle matrix pipe.  Not
+            // earlier: an older wave that starts while this one still has MFMAs to issue stalls them for its whole first
+            // half (measured: 2 G MFMAs early gains nothing in the forward, 3 terms early loses 5 us).
+            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             X6P_TERM(hp[kb][0], W1[g][kb])
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef X6P_TERM
-        if (!RA) lds_inc(lds_tok, one);
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard (see rec_fwd_mfma)
         __builtin_amdgcn_s_setprio(3);
         if (PROF) { const unsigned long long tc = clock64(); p_seg[1] += tc - p_tb; p_tb = tc; }
@@ -486,6 +490,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             acc[0] = MFMA_BF16(dpl[s][0], W3[kb], acc[0]);
             acc[1] = MFMA_BF16(dpl[s][2], W1[kb], acc[1]);
             acc[2] = MFMA_BF16(dpl[s][1], W2[kb], acc[2]);
+            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
             acc[0] = MFMA_BF16(dpl[s][0], W2[kb], acc[0]);
             acc[1] = MFMA_BF16(dpl[s][1], W1[kb], acc[1]);
             acc[2] = MFMA_BF16(dpl[s][0], W1[kb], acc[2]);
@@ -493,7 +498,6 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             if (i + 1 == NH) ensure_half(1, i + 1, s ^ 1);
             else if (i + 1 < KB) asm volatile("" :: "v"(dpl[s ^ 1][0]), "v"(dpl[s ^ 1][1]), "v"(dpl[s ^ 1][2]));
         }
-        if (!RA) lds_inc(lds_tok, one);
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
         dh += acc[0][0] + acc[1][0] + acc[2][0];
