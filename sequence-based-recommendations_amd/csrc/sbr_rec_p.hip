@@ -205,7 +205,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (!RA) load_half(1);
         ensure_half(0);
         if (!RA) ensure_half(1);
-        __builtin_amdgcn_s_setprio(0);
         // The matrix pipe serves the OLDER wave of a SIMD pair first, strictly (tools/probes/mfma_share_probe.hip: two
         // MFMA streams on one SIMD run 1160 / 2321 cycles per 72, not 1740 / 1740).  A wave 0-3 that started its step
         // as soon as its own group's k-blocks were there would starve its partner's last MFMAs, whose results
@@ -254,8 +253,9 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef X6P_TERM
-        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard (see rec_fwd_mfma)
-        __builtin_amdgcn_s_setprio(3);
+        // MFMA D -> VALU read hazard: hipcc pads it inside a basic block (the accumulators are read right below); the
+        // profiling build has branches in between and pads by hand (see rec_fwd_mfma)
+        if (PROF) asm volatile("s_nop 15");
         if (PROF) { const unsigned long long tc = clock64(); p_seg[1] += tc - p_tb; p_tb = tc; }
         if (PROF && tl && t == 100) tl[5] = p_tb;
         // ---- N2: gate math (sparse_lstm.py:780-803 / :1133-1150).  For GRU the r and u columns of W_hid and their
