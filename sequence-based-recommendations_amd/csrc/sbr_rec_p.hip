@@ -430,12 +430,13 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         load_saved(t > a.t_lo ? off_h - st_h : off_h);            // step t-1: unconditional, clamped
         __builtin_amdgcn_sched_barrier(0);
         off_h -= st_h; off_x -= st_x;
-        // ---- operands of the first k-block, the pipe gate
+        // ---- operands: a ring of NS k-block slots, fetched LA k-blocks ahead of their MFMAs; the pipe gate
+        constexpr int NS = 2, LA = 1;          // measured: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
         const char* db = lds + lds_rd;
-        bf16x8 dpl[2][3];
+        bf16x8 dpl[NS][3];
         int fl[2];
-        auto load_kb = [&](int i, int s) {
-            const int kb = korder(i);
+        auto load_kb = [&](int i) {
+            const int kb = korder(i), s = i % NS;
             dpl[s][0] = *(const bf16x8*)(db + kb * 64);
             dpl[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
             dpl[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
@@ -444,7 +445,9 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
         };
-        auto ensure_half = [&](int half, int i, int s) {          // the half's producers have published; planes of k-block i in dpl[s]
+        auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][2])); };
+        // the half's producers have published this step; else re-read the counter and the k-blocks [i0, i1) fetched on spec
+        auto ensure_half = [&](int half, int i0, int i1) {
             if (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1)) {
                 unsigned long long w0 = 0;
                 if (PROF) w0 = clock64();
@@ -453,16 +456,19 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 do {
                     asm volatile("" ::: "memory");
                     load_flag(half);
-                    load_kb(i, s);
+#pragma unroll
+                    for (int i = i0; i < i1; ++i) load_kb(i);
                     if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 2); break; }
                 } while (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1));
                 if (PROF) p_spin += clock64() - w0;
             }
-            asm volatile("" :: "v"(dpl[s][0]), "v"(dpl[s][1]), "v"(dpl[s][2]));
+            use(i0);
         };
-        load_flag(0); load_kb(0, 0);
+        load_flag(0);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) load_kb(i);
         if (!RA) load_flag(1);
-        ensure_half(0, 0, 0);
+        ensure_half(0, 0, LA);
         __builtin_amdgcn_s_setprio(0);
         if (RA && a.x6_pipe >= 2) {                               // the matrix-pipe gate, see rec_fwd_x6p
             unsigned long long w0 = 0;
@@ -481,10 +487,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         f32x4 acc[3] = {z4, z4, z4};
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
-            const int s = i & 1, kb = korder(i);
-            if (i + 1 < KB) {
-                if (i + 1 == NH) load_flag(1);                    // (waves 4-7 looked before the gate; harmless to look again)
-                load_kb(i + 1, s ^ 1);
+            const int s = i % NS, kb = korder(i);
+            if (i + LA < KB) {
+                if (i + LA == NH) load_flag(1);                   // (waves 4-7 looked before the gate; harmless to look again)
+                load_kb(i + LA);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = MFMA_BF16(dpl[s][0], W3[kb], acc[0]);
@@ -495,8 +501,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             acc[1] = MFMA_BF16(dpl[s][1], W1[kb], acc[1]);
             acc[2] = MFMA_BF16(dpl[s][0], W1[kb], acc[2]);
             __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 == NH) ensure_half(1, i + 1, s ^ 1);
-            else if (i + 1 < KB) asm volatile("" :: "v"(dpl[s ^ 1][0]), "v"(dpl[s ^ 1][1]), "v"(dpl[s ^ 1][2]));
+            if (i + 1 == NH) ensure_half(1, NH, NH + LA < KB ? NH + LA : KB);
+            else if (i + 1 < KB) use(i + 1);
         }
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
