@@ -154,8 +154,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
             X6Q_TERM(hp[kb][0], W1[g][kb])
         }
 #undef X6Q_TERM
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard (see rec_fwd_mfma)
+        __builtin_amdgcn_sched_barrier(0);                        // (the MFMA D -> VALU read hazard right below is padded by hipcc: same basic block)
         {
             float hn, cn = cst;
             if (CELL == CELL_GRU) {                               // sparse_lstm.py:780-803; r, u columns pre-scaled by -log2(e)
@@ -356,8 +355,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
             acc[1] = MFMA_BF16(dpl[kb][1], W1[kb], acc[1]);
             acc[2] = MFMA_BF16(dpl[kb][0], W1[kb], acc[2]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
+        __builtin_amdgcn_sched_barrier(0);                        // (MFMA D -> VALU read hazard: padded by hipcc, same basic block)
         dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
 
