@@ -133,3 +133,24 @@ def test_test_cli_scores_saved_models_like_the_one_by_one_loop(tmp_path):
     for m, v in res[-1][1].items():
         assert ev.metrics[m]() == v, m
     predictor.engine.close()
+
+
+def test_raw_file_to_trained_model_through_preprocess(tmp_path):
+    # the whole user journey with this package only: raw interactions -> sbr_amd.preprocess -> train CLI -> test CLI
+    from sbr_amd import preprocess as P, train as T, test as Te
+    rng = np.random.default_rng(5)
+    lines, t = [], 10 ** 9
+    for u in range(70):
+        start, L = int(rng.integers(0, 30)), int(rng.integers(8, 20))
+        for k in range(L):
+            t += int(rng.integers(1, 100))
+            lines.append("%d::%d::%d::%d" % (1000 + u, 500 + (start + 2 * k + int(rng.integers(0, 2))) % 30, 4, t))
+    rng.shuffle(lines)
+    (tmp_path / "ratings.dat").write_text("\n".join(lines) + "\n")
+    root = P.main(["-f", str(tmp_path / "ratings.dat"), "--columns", "uirt", "--sep", "::", "--yes", "--min_item_pop", "2"])
+    argv = ["-d", root, "-b", "8", "--max_length", "10", "--r_t", "GRU", "--r_l", "16", "--max_iter", "150", "--progress", "75",
+            "--save", "All"]
+    metrics, _, best_file = T.main(argv)
+    assert best_file is not None and 0.0 <= metrics["sps"] <= 1.0 and np.isfinite(metrics["ndcg"])
+    res = Te.main(["-d", root, "-b", "8", "--max_length", "10", "--r_t", "GRU", "--r_l", "16", "--save", "--metrics", "sps,recall"])
+    assert len(res) == 2 and len(glob.glob(root + "results/rnn_*")) == 1
