@@ -74,7 +74,7 @@ def map_ids(data, dirname):
     data = data.copy()
     for col, name in (("u", "user_id_mapping"), ("i", "item_id_mapping")):
         originals, codes = np.unique(data[col].to_numpy(), return_inverse=True)
-        pd.DataFrame({"new_id": np.arange(len(originals)), "original_id": originals}).to_csv(
+        pd.DataFrame({"original_id": originals, "new_id": np.arange(len(originals))}).to_csv(
             dirname + "data/" + name, sep="\t", index=False)
         data[col] = codes
     return data

@@ -77,9 +77,9 @@ def test_filters_ids_and_chronology(tmp_path):
     assert all(len(v) < 2 for u, v in want.items() if u not in got)
     # the mapping files
     rows = [l.split("\t") for l in open(root + "data/user_id_mapping").read().splitlines()[1:]]
-    assert {r[1]: int(r[0]) for r in rows} == umap
+    assert {r[0]: int(r[1]) for r in rows} == umap
     rows = [l.split("\t") for l in open(root + "data/item_id_mapping").read().splitlines()[1:]]
-    assert {int(r[1]): int(r[0]) for r in rows} == imap
+    assert {int(r[0]): int(r[1]) for r in rows} == imap
 
 
 def test_stats_triplets_and_extended_training_file(tmp_path):
@@ -128,3 +128,15 @@ def test_not_enough_users(tmp_path):
     path, _ = raw_file(tmp_path, n_users=6)
     with pytest.raises(ValueError):
         P.main(["-f", path, "--columns", "uirt", "--sep", "::", "--yes", "--val_size", "4", "--test_size", "4"])
+
+
+def test_matches_the_reference_outputs_byte_for_byte(tmp_path):
+    # tests/golden/preprocess/: written by the reference's own preprocess.py (tools/make_preprocess_golden.py)
+    import shutil
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess")
+    shutil.copy(os.path.join(gold, "ratings.dat"), tmp_path)
+    root = P.main(["-f", str(tmp_path / "ratings.dat"), "--yes"] + open(os.path.join(gold, "ARGS")).read().split())
+    names = [n for n in sorted(os.listdir(gold)) if n not in ("ARGS", "ratings.dat")]
+    assert len(names) == 10
+    for name in names:
+        assert open(root + "data/" + name).read() == open(os.path.join(gold, name)).read(), name
