@@ -1,12 +1,25 @@
 """CPU oracle for the `train.py -m RNN` hot path  --  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the reference (rdevooght/sequence-based-recommendations) ships no
-tests, golden vectors or fixtures for this path, and Theano/Lasagne (which hold the
-arithmetic) cannot be installed here (no network, python2-only code).  This file is a
-float64 NumPy restatement of the algorithm, with hand-derived BPTT; it is cross-checked
-against an independent torch-autograd restatement (oracle/torch_ref.py) and against
-central finite differences (tests/test_oracle.py).  Nothing in the product path may
-import it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+PINNING: the reference (rdevooght/sequence-based-recommendations) ships no tests, golden
+vectors or fixtures for this path, and Theano/Lasagne cannot be installed here (no
+network, python2-only code), so the reference cannot be RUN as a whole.  What pins this
+file instead:
+  * the reference's OWN layer and cost source (sparse_lstm.py get_output_for of the three
+    index-input cells, BlackoutLayer, rnn_one_hot.py / rnn_sampling.py _prepare_networks
+    and loss functions, recurrent_layers.py wiring) executed through an eager stand-in for
+    the Theano / Lasagne calls it makes (tools/theano_on_torch.py): cost, every parameter
+    gradient (incl. cases where grad_clip decides the result), recurrent output, scores
+    and the parameter order agree with this file to 1e-12
+    (tests/golden/reference_layers/, tests/test_reference_layers.py);
+  * an independent torch-autograd restatement (oracle/torch_ref.py) and central finite
+    differences (tests/test_oracle.py) -- these also cover what the above cannot:
+STILL UNPINNED ("parity unpinned" for these parts): the library code the reference calls
+but does not contain -- Lasagne's stock LSTMLayer / GRULayer / RecurrentLayer (stacked
+layers, layers after --r_emb), EmbeddingLayer, lasagne.updates.* -- restated here from
+their published formulas.
+This file is a float64 NumPy restatement of the algorithm with hand-derived BPTT.  Nothing
+in the product path may import it; only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg do.
 
 Every function cites the reference file:line it follows (paths relative to the
 reference checkout).  "[3P]" marks semantics that live in Theano/Lasagne (not vendored

@@ -1,7 +1,8 @@
 """Pins the CPU oracle (oracle/rnn_oracle.py).  The reference has no tests or golden
-vectors for this path ("parity unpinned"), so the oracle is pinned by
+vectors for this path, so the oracle is pinned by
+(0) the reference's own layer / cost source executed through a Theano stand-in (tests/test_reference_layers.py),
 (1) an independent torch-autograd restatement, (2) central finite differences,
-(3) the committed golden fixtures (tests/test_golden.py)."""
+(3) the committed golden fixtures (tests/test_golden.py).  (1)-(3) are this file and test_golden.py."""
 import numpy as np
 import pytest
 

@@ -1,0 +1,104 @@
+"""The reference's OWN layer and cost code as the known answer: tests/golden/reference_layers/*.npz hold the cost, the
+gradient of every parameter, the recurrent output and the deterministic scores computed by
+/root/reference/neural_networks/{sparse_lstm,rnn_one_hot,rnn_sampling,recurrent_layers}.py themselves, executed through
+an eager stand-in for the Theano / Lasagne calls they make (tools/theano_on_torch.py, tools/make_reference_layer_golden.py).
+CPU: the oracle agrees with them to float64 round-off (so the oracle is pinned by the reference's code on this part of
+the path).  GPU: the HIP engine, through the C-ABI, agrees within the parity bar."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_layers", "*.npz")))
+IDS = [os.path.basename(p)[:-4] for p in GOLD]
+TOL_LOGITS = 1e-3      # north_star: within 1e-3 relative on logits
+TOL_GRADS = 1e-4
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    n = int(z["n_params"])
+    cfg = dict(cell=str(z["cell"]), layers=[int(h) for h in z["layers"]], loss=str(z["loss"]),
+               regularization=float(z["regularization"]), embedding=0, bidirectional=bool(int(z["bidirectional"])))
+    batch = dict(X=z["X"], mask=z["mask"], target=z["target"], samples=z["samples"], pop=z["pop"])
+    return z, cfg, batch, [z["p%d" % i] for i in range(n)], [z["g%d" % i] for i in range(n)]
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def test_fixtures_cover_every_cell_and_head():
+    seen = set()
+    for path in GOLD:
+        z = np.load(path)
+        seen.add((str(z["cell"]), str(z["loss"])))
+    assert {c for c, _ in seen} == {"GRU", "LSTM", "Vanilla"} and {l for _, l in seen} == {"CCE", "Blackout", "BPR", "TOP1"}
+    assert len(GOLD) >= 14
+    assert sum(float(np.load(p)["clip_changes"]) > 0.5 for p in GOLD) >= 4        # cases where the gradient clip decides the result
+
+
+@pytest.mark.parametrize("path", GOLD, ids=IDS)
+def test_oracle_agrees_with_the_reference_code(path):
+    from oracle import rnn_oracle as O
+    z, cfg, batch, p0, g = load(path)
+    N, F, n_opt = int(z["N"]), int(z["F"]), int(z["n_opt"])
+    names = [n for n, _ in O.model_param_shapes(cfg["cell"], cfg["layers"], N, N + n_opt, 0, F, cfg["bidirectional"])]
+    ref_names = [str(n) for n in z["names"]]
+    assert len(names) == len(ref_names)
+    for mine, ref in zip(names, ref_names):        # same parameter, same place in the checkpoint list
+        assert mine.split(".")[-1] == ref or mine.endswith(ref), (mine, ref)
+    params = [p.astype(np.float64) for p in p0]
+    ob = dict(batch); ob["pop"] = batch["pop"].astype(np.float64)
+    cost, grads, aux = O.cost_and_grads(params, cfg, ob)
+    assert abs(cost - float(z["cost"])) <= 1e-12 * abs(float(z["cost"]))
+    assert rel(aux["h"], z["h_last"]) <= 1e-12
+    for n, a, b in zip(ref_names, grads, g):
+        assert a.shape == b.shape, n
+        assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1e-3), n
+    scores, logits = O.predict_scores(params, cfg, batch["X"], batch["mask"])
+    assert rel(scores, z["scores"]) <= 1e-12                   # predict_function: probabilities (CCE) / raw scores (sampled heads)
+    # test function: softmax, viewed items zeroed (rnn_base.py:196-209, rnn_sampling.py:140-156) -> ordered top-k ids
+    excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(len(batch["X"]))]
+    k = 5
+    ids = O.test_function(params, cfg, batch["X"], batch["mask"], excl, k=k)
+    want = np.argsort(-z["test_scores"], axis=1, kind="stable")[:, :k]
+    top = -np.sort(-z["test_scores"], axis=1)[:, :k + 1]
+    assert np.all(np.diff(top, axis=1) < 0)                    # no ties among the ranked items: the ids are well defined
+    assert np.array_equal(ids, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLD, ids=IDS)
+def test_engine_agrees_with_the_reference_code(path):
+    from sbr_amd.engine import RNNEngine
+    z, cfg, batch, p0, g = load(path)
+    N, B, T, S, F, n_opt = (int(z[k]) for k in ("N", "B", "T", "S", "F", "n_opt"))
+    H = cfg["layers"][-1]
+    eng = RNNEngine(cell=cfg["cell"], layers=cfg["layers"], n_items=N, max_length=T, batch_size=B, loss=cfg["loss"],
+                    n_samples=S, updater="adam", learning_rate=0.01, regularization=cfg["regularization"],
+                    input_size=N + n_opt, n_feat=F, bidirectional=cfg["bidirectional"])
+    try:
+        eng.set_all_param_values(p0)
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], batch["samples"] if cfg["loss"] != "CCE" else None, batch["pop"])
+        cost = eng.forward_backward()
+        assert abs(cost - float(z["cost"])) <= 1e-5 * abs(float(z["cost"]))
+        Bp = (B + 15) // 16 * 16
+        hl = eng.debug_buffer("h_last").reshape(Bp, -1)[:B]
+        if cfg["bidirectional"]:
+            half = hl.shape[1] // 2
+            hl = np.concatenate([hl[:, :H], hl[:, half:half + H]], axis=1)
+        else:
+            hl = hl[:, :H]
+        assert rel(hl, z["h_last"]) <= TOL_LOGITS
+        for n, a, b in zip(z["names"], eng.get_all_grad_values(), g):
+            assert np.abs(a - b).max() <= TOL_GRADS * max(np.abs(b).max(), 1e-3), str(n)
+        assert rel(eng.predict_function(batch["X"], batch["mask"]), z["scores"]) <= TOL_LOGITS
+        k = 5
+        top = -np.sort(-z["test_scores"], axis=1)[:, :k + 1]
+        if np.all(top[:, :-1] - top[:, 1:] > 1e-5 * top[:, :1]):          # ranked items well separated: ids are bit-exact
+            ids = eng.test_function((batch["X"], batch["mask"]), k=k)
+            assert np.array_equal(ids, np.argsort(-z["test_scores"], axis=1, kind="stable")[:, :k])
+    finally:
+        eng.close()

@@ -1,0 +1,139 @@
+"""Forward values and gradients of the REFERENCE's own layer and cost code (/root/reference/neural_networks), executed
+through tools/theano_on_torch.py (an eager stand-in for the Theano / Lasagne calls that code makes, on torch float64
+with autograd).  Runs only in this container; the fixtures are committed under tests/golden/reference_layers/.
+
+For every case the reference builds its predictor from a command line (helpers/command_parser.py), `_prepare_networks`
+runs (rnn_one_hot.py:36-78 / rnn_sampling.py:96-138: recurrent_layers.py picks the layer classes, sparse_lstm.py's
+get_output_for computes the recurrence, the cost lines compute the cost), and we record
+    parameter names / shapes in lasagne.layers.get_all_params order      (pins the checkpoint layout)
+    cost, d cost / d every parameter (theano.grad -> autograd)           (pins the forward AND where grad_clip sits)
+    the recurrent stack's output, the deterministic output (rnn_base.py:192 / rnn_sampling.py:144)
+for seeded parameters and batches in the format of the other fixtures (tests/golden/*.npz).
+What this does NOT pin: Theano's and Lasagne's own library code (dot, scan, the stock LSTMLayer / GRULayer used for
+stacked layers and after an embedding, lasagne.updates.*) -- those are restated in the stand-in / the oracle.
+
+    python tools/make_reference_layer_golden.py
+"""
+import builtins
+import os
+import pickle
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import parity_util as PU                   # noqa: E402   (seeded parameters and batches, same helper as the other fixtures)
+import theano_on_torch as E                # noqa: E402
+
+# name: (cell, hidden, loss, N items, B, T, S samples, F indices per step, n_opt, bidirectional, extra argv)
+CASES = {
+    "gru16_cce": ("GRU", 16, "CCE", 40, 7, 9, 0, 1, 0, False, []),
+    "lstm12_cce": ("LSTM", 12, "CCE", 45, 9, 8, 0, 1, 0, False, []),
+    "vanilla8_cce": ("Vanilla", 8, "CCE", 30, 5, 6, 0, 1, 0, False, []),
+    "gru12_blackout": ("GRU", 12, "Blackout", 40, 6, 7, 5, 1, 0, False, []),
+    "lstm10_bpr": ("LSTM", 10, "BPR", 40, 6, 7, 5, 1, 0, False, []),
+    "gru10_top1": ("GRU", 10, "TOP1", 40, 6, 7, 5, 1, 0, False, []),
+    "lstm8_cce_rf": ("LSTM", 8, "CCE", 25, 5, 6, 0, 2, 10, False, ["--rf"]),
+    "gru8_cce_bi": ("GRU", 8, "CCE", 30, 6, 7, 0, 1, 0, True, ["--r_bi"]),
+    "lstm6_blackout_bi": ("LSTM", 6, "Blackout", 30, 5, 6, 4, 1, 0, True, ["--r_bi"]),
+    "gru12_cce_reg": ("GRU", 12, "CCE", 35, 6, 7, 0, 1, 0, False, ["-r", "0.05"]),
+    # targets with a tiny popularity weight -> gate gradients far beyond the clip at 100 (recurrent_layers.py:18): it bites
+    "gru12_cce_clip": ("GRU", 12, "CCE", 35, 6, 8, 0, 1, 0, False, []),
+    "lstm8_cce_clip": ("LSTM", 8, "CCE", 35, 6, 8, 0, 1, 0, False, []),
+    "vanilla8_cce_clip": ("Vanilla", 8, "CCE", 35, 6, 8, 0, 1, 0, False, []),
+    "gru8_bpr_clip_bi": ("GRU", 8, "BPR", 35, 6, 8, 4, 1, 0, True, ["--r_bi"]),
+}
+POPSCALE = {"gru12_cce_clip": 3e-5, "lstm8_cce_clip": 3e-5, "vanilla8_cce_clip": 3e-5, "gru8_bpr_clip_bi": 1e-5}
+
+
+def main():
+    builtins.xrange = range
+    sys.modules["cPickle"] = pickle
+    _map = map
+    builtins.map = lambda *a: list(_map(*a))
+
+    class _Cast(dict):
+        def __missing__(self, k):
+            return lambda x: np.asarray(x, dtype=k)[()]
+    if not hasattr(np, "cast"):
+        np.cast = _Cast()
+    E.install()
+    sys.path[:0] = ["/root/reference"] + ["/root/reference/" + d for d in
+                                          ("neural_networks", "helpers", "factorization", "lazy", "word2vec")]
+    import helpers.command_parser as cp
+    import train as reftrain
+    import lasagne
+    import theano
+
+    outdir = os.path.join(ROOT, "tests", "golden", "reference_layers")
+    os.makedirs(outdir, exist_ok=True)
+    for name, (cell, H, loss, N, B, T, S, F, n_opt, bi, extra) in CASES.items():
+        seed = sum(map(ord, name))
+        params, cfg, batch = PU.build_case(cell, [H], loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, bi=bi,
+                                           popscale=POPSCALE.get(name, 1.0))
+        if loss != "CCE":
+            assert len(batch["samples"]) == S
+        def predictor():
+            sys.argv = ["train.py", "-d", "/tmp/x/", "-b", str(B), "--max_length", str(T), "--r_t", cell, "--r_l", str(H),
+                        "--loss", loss, "--sampling", str(S or 32)] + extra
+            args = cp.command_parser(cp.predictor_command_parser, reftrain.training_command_parser, cp.early_stopping_command_parser)
+            return args, cp.get_predictor(args)
+        args, p = predictor()
+        assert p._input_size() == F
+        exclude = np.zeros((B, N))
+        for b in range(B):
+            exclude[b, batch["X"][b, :int(batch["mask"][b].sum()), 0]] = 1
+        feed = dict(inputs=[batch["X"], batch["mask"].astype(np.float64)], target_output=batch["target"],
+                    target_popularity=batch["pop"].astype(np.float64), samples=batch["samples"], excluded_items=exclude)
+        # pass 1: the reference's own initialisers -> names and shapes in get_all_params order
+        E.new_network(feed)
+        p._prepare_networks(N)
+        layout = [(q.pname, tuple(q.shape)) for q in lasagne.layers.get_all_params(p.l_out)]
+        assert [s for _, s in layout] == [q.shape for q in params], (layout, [q.shape for q in params])
+        assert len(lasagne.layers.get_all_params(p.l_out, trainable=True)) == len(layout)      # learn_init=True: all trained
+        # pass 2: our seeded values (creation order == get_all_params order, checked by the shapes above and the names below)
+        E.new_network(feed, params)
+        p._prepare_networks(N)
+        assert E.leftovers() == 0
+        all_params = lasagne.layers.get_all_params(p.l_out, trainable=True)        # rnn_base.py:182
+        assert [(q.pname, tuple(q.shape)) for q in all_params] == layout
+        cost = p.cost
+        grads = theano.grad(cost, all_params)
+        clip_changes = 0.0
+        if name in POPSCALE:                             # the same network without the clip: it has to make a difference
+            real_clip = theano.gradient.grad_clip
+            theano.gradient.grad_clip = lambda x, lo, hi: x
+            try:
+                E.new_network(feed, params)
+                _, p2 = predictor()
+                p2._prepare_networks(N)
+                free = theano.grad(p2.cost, lasagne.layers.get_all_params(p2.l_out, trainable=True))
+            finally:
+                theano.gradient.grad_clip = real_clip
+            assert abs(float(p2.cost) - float(cost)) < 1e-12 * abs(float(cost))
+            clip_changes = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(grads, free))
+            assert clip_changes > 0.05, clip_changes
+        h_last = lasagne.layers.get_output(p.l_out.input_layer)
+        det = lasagne.layers.get_output(p.l_out, deterministic=True)               # predict_function, rnn_base.py:192
+        test_scores = det if loss == "CCE" else theano.tensor.nnet.softmax(det)    # test function, rnn_base.py:200 / rnn_sampling.py:144
+        if p.interactions_are_unique:
+            test_scores = test_scores * (1 - theano.tensor.fmatrix("excluded_items"))   # rnn_base.py:201-202
+        out = dict(cell=cell, layers=np.array([H]), loss=loss, N=N, B=B, T=T, S=S, F=F, n_opt=n_opt, bidirectional=int(bi),
+                   regularization=float(args.regularization), grad_clip=float(args.gradient_clipping) if hasattr(args, "gradient_clipping") else 100.0,
+                   X=batch["X"], mask=batch["mask"], target=batch["target"], samples=batch["samples"], pop=batch["pop"],
+                   cost=float(cost), h_last=h_last.detach().numpy(), scores=det.detach().numpy(),
+                   test_scores=test_scores.detach().numpy(), n_params=len(params), clip_changes=clip_changes,
+                   names=np.array([n for n, _ in layout]), model_file=p._get_model_filename(1.0))
+        for i, (q, g) in enumerate(zip(params, grads)):
+            out["p%d" % i] = q.astype(np.float32)
+            out["g%d" % i] = g.detach().numpy()
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+        print("%-20s cost %.6f  |g|max %.3e  %d params  clip changes grads by %.2f" % (
+            name, float(cost), max(float(g.abs().max()) for g in grads), len(params), clip_changes))
+
+
+if __name__ == "__main__":
+    main()
