@@ -35,7 +35,7 @@ def test_fixtures_cover_every_cell_and_head():
         z = np.load(path)
         seen.add((str(z["cell"]), str(z["loss"])))
     assert {c for c, _ in seen} == {"GRU", "LSTM", "Vanilla"} and {l for _, l in seen} == {"CCE", "Blackout", "BPR", "TOP1"}
-    assert len(GOLD) >= 14
+    assert len(GOLD) >= 16
     assert sum(float(np.load(p)["clip_changes"]) > 0.5 for p in GOLD) >= 4        # cases where the gradient clip decides the result
 
 
@@ -60,7 +60,8 @@ def test_oracle_agrees_with_the_reference_code(path):
     scores, logits = O.predict_scores(params, cfg, batch["X"], batch["mask"])
     assert rel(scores, z["scores"]) <= 1e-12                   # predict_function: probabilities (CCE) / raw scores (sampled heads)
     # test function: softmax, viewed items zeroed (rnn_base.py:196-209, rnn_sampling.py:140-156) -> ordered top-k ids
-    excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(len(batch["X"]))]
+    excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] if int(z["unique"]) else []
+            for b in range(len(batch["X"]))]
     k = 5
     ids = O.test_function(params, cfg, batch["X"], batch["mask"], excl, k=k)
     want = np.argsort(-z["test_scores"], axis=1, kind="stable")[:, :k]
@@ -98,7 +99,7 @@ def test_engine_agrees_with_the_reference_code(path):
         k = 5
         top = -np.sort(-z["test_scores"], axis=1)[:, :k + 1]
         if np.all(top[:, :-1] - top[:, 1:] > 1e-5 * top[:, :1]):          # ranked items well separated: ids are bit-exact
-            ids = eng.test_function((batch["X"], batch["mask"]), k=k)
+            ids = eng.test_function((batch["X"], batch["mask"]), k=k, exclude_seen=bool(int(z["unique"])))
             assert np.array_equal(ids, np.argsort(-z["test_scores"], axis=1, kind="stable")[:, :k])
     finally:
         eng.close()

@@ -40,6 +40,8 @@ CASES = {
     "gru8_cce_bi": ("GRU", 8, "CCE", 30, 6, 7, 0, 1, 0, True, ["--r_bi"]),
     "lstm6_blackout_bi": ("LSTM", 6, "Blackout", 30, 5, 6, 4, 1, 0, True, ["--r_bi"]),
     "gru12_cce_reg": ("GRU", 12, "CCE", 35, 6, 7, 0, 1, 0, False, ["-r", "0.05"]),
+    "vanilla10_cce_l1": ("Vanilla", 10, "CCE", 35, 6, 7, 0, 1, 0, False, ["-r", "-0.05"]),          # negative -r: L1 on the bias
+    "lstm8_top1_ri": ("LSTM", 8, "TOP1", 30, 5, 6, 4, 1, 0, False, ["--repeated_interactions"]),     # nothing excluded at test time
     # targets with a tiny popularity weight -> gate gradients far beyond the clip at 100 (recurrent_layers.py:18): it bites
     "gru12_cce_clip": ("GRU", 12, "CCE", 35, 6, 8, 0, 1, 0, False, []),
     "lstm8_cce_clip": ("LSTM", 8, "CCE", 35, 6, 8, 0, 1, 0, False, []),
@@ -126,6 +128,7 @@ def main():
                    X=batch["X"], mask=batch["mask"], target=batch["target"], samples=batch["samples"], pop=batch["pop"],
                    cost=float(cost), h_last=h_last.detach().numpy(), scores=det.detach().numpy(),
                    test_scores=test_scores.detach().numpy(), n_params=len(params), clip_changes=clip_changes,
+                   unique=int(p.interactions_are_unique),
                    names=np.array([n for n, _ in layout]), model_file=p._get_model_filename(1.0))
         for i, (q, g) in enumerate(zip(params, grads)):
             out["p%d" % i] = q.astype(np.float32)
