@@ -119,7 +119,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
             lay.a_s2sid = take((size_t)T * Bp * lay.F); lay.a_s2pos = take((size_t)T * Bp * lay.F);
         }
     }
-    lay.a_logits = take((size_t)Bp * lay.N);
+    lay.a_logits = take((size_t)Bp * ((lay.N + 3) & ~3));
     lay.a_dhlast = take((size_t)Bp * lay.HLt);
     lay.a_rowcost = take(Bp);
     if (lay.S > 0) {
@@ -685,19 +685,20 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     }
     if (y.cfg.loss == SBR_LOSS_CCE) {
         float* lg = h->A(y.a_logits);
+        const int Nl = (N + 3) & ~3;               // row stride of the logits / dlogits buffer
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
-        SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, N, R, N, Hp, nullptr, nullptr, 0, sg));
-        SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, y.Bg));
+        SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg));
+        SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, Nl, y.Bg));
         SBR_HIP(hipEventRecord(h->ev_lg, s));
         // critical path: dh = dlogits . W_out^T feeds the BPTT chain
-        SBR_LAUNCH(launch_gemm(s, lg, N, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
+        SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
         // beside it: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg, 0));
         SBR_LAUNCH(launch_sum_cost(sd, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
-        SBR_LAUNCH(launch_colsum_bias(sd, lg, R, N, N, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
-        SBR_LAUNCH(launch_gemm(sd, lg, 1, N, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws2, y.ws2_floats, sg));
+        SBR_LAUNCH(launch_colsum_bias(sd, lg, R, N, Nl, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
+        SBR_LAUNCH(launch_gemm(sd, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws2, y.ws2_floats, sg));
         SBR_HIP(hipEventRecord(h->ev_og, sd)); h->og_recorded = true;   // output-layer gradients + cost complete
     } else {
         const int C = y.C;
@@ -1015,7 +1016,7 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     const std::string nm(name);
     const size_t tb = (size_t)y.T * y.Bp;
     if (nm == "h_last") { *dev_ptr = h_last(h); *n_floats = (size_t)y.Bp * y.HLt; return SBR_OK; }
-    if (nm == "logits") { *dev_ptr = h->A(y.a_logits); *n_floats = (size_t)y.Bp * y.N; return SBR_OK; }
+    if (nm == "logits") { *dev_ptr = h->A(y.a_logits); *n_floats = (size_t)y.Bp * ((y.N + 3) & ~3); return SBR_OK; }
     if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLt; return SBR_OK; }
     if (nm == "batch_X") { *dev_ptr = (void*)h->bX; *n_floats = (size_t)y.Bp * y.T * y.F; return SBR_OK; }
     if (nm == "batch_lengths") { *dev_ptr = (void*)h->blen; *n_floats = y.Bp; return SBR_OK; }

@@ -75,7 +75,8 @@ struct Layout {
     // arena sections (float offsets from the arena base)
     size_t s_params, s_grads, s_state, s_act, s_end;
     // misc activation-section buffers
-    size_t a_logits;                      // [Bp][N]
+    size_t a_logits;                      // [Bp][Nl], Nl = N rounded up to 4 floats in the training step (16-byte rows for the
+                                          // bf16x6 GEMMs that read dlogits); [rows][N] in predict / top-k
     size_t a_dhlast;                      // [Bp][HLp]
     size_t a_rowcost;                     // [Bp]
     size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
@@ -261,7 +262,7 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
 // bf16x6 GEMM (sbr_gemm_x6.hip): false = shape not supported, use the f32 kernel
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0);
+                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0, bool small = false);
 void sbr_gemm_set_exact_f32(bool on);
 
 // slabs are [z][slab_stride] with row stride ws_ld: a GEMM may fill only a column range of wider slabs
@@ -278,9 +279,9 @@ hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int 
 bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const float* dhc, float* slabs, int Hp, int GHp,
                         int npos, int nslices, hipError_t* err);
 
-// full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N) in, dlogits out in place
+// full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N), row stride ld, in; dlogits out in place
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
-                              float* rowcost, int rows, int N, int Bglobal);
+                              float* rowcost, int rows, int N, long ld, int Bglobal);
 hipError_t launch_softmax_rows(hipStream_t s, float* logits, const float* bout, int rows, int N, int do_softmax);
 // db[n] = sum_rows d[r][n] + reg term ; cost += reg term
 hipError_t launch_colsum_bias(hipStream_t s, const float* d, int rows, int N, long ld, float* db, const float* b,

@@ -207,20 +207,28 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
         gemm_naive<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g);
         return hipGetLastError();
     }
-    if (!g_gemm_exact_f32 && a_blk_Bp == 0 && b_blk_Bp == 0 && M >= 96 && N >= 96 && K >= 32) {
-        const int t = ((M + 127) / 128) * ((N + 127) / 128);
-        int ns = 1;
-        if (ws && K >= 512) {
-            ns = std::max(1, 512 / t);
-            ns = std::min(ns, K / 128);
-            ns = (int)std::min<size_t>((size_t)ns, ws_floats / ((size_t)M * N));
-            ns = std::max(ns, 1);
-        }
-        int kc = ((K + ns - 1) / ns + 31) / 32 * 32;
-        ns = std::max(1, (K + kc - 1) / kc);
+    if (!g_gemm_exact_f32 && a_blk_Bp == 0 && b_blk_Bp == 0 && M >= 48 && N >= 48 && K >= 32) {
+        static const int small_below = getenv("SBR_GEMM_SMALL_BELOW") ? atoi(getenv("SBR_GEMM_SMALL_BELOW")) : 128;
+        auto plan = [&](int tile, int& ns, int& kc) {
+            const int t = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
+            ns = 1;
+            if (ws && K >= 512) {
+                ns = std::max(1, 512 / t);
+                ns = std::min(ns, K / 128);
+                ns = (int)std::min<size_t>((size_t)ns, ws_floats / ((size_t)M * N));
+                ns = std::max(ns, 1);
+            }
+            kc = ((K + ns - 1) / ns + 31) / 32 * 32;
+            ns = std::max(1, (K + kc - 1) / kc);
+            return t * ns;
+        };
+        int ns, kc;
+        // fewer than ~128 workgroups of the 128x128 tile: 64x64 tiles put four times as many on the chip
+        const bool small = plan(128, ns, kc) < small_below || M < 96 || N < 96;
+        if (small) plan(64, ns, kc);
         hipError_t e = hipSuccess;
         if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ns > 1 ? ws : C, ns > 1 ? (long)N : ldc, M, N, K, bias, ns, kc,
-                           (size_t)M * N, &e)) {
+                           (size_t)M * N, &e, nullptr, 0, 0, small)) {
             if (e == hipSuccess && ns > 1) {
                 const size_t n = (size_t)M * N;
                 gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, ns, M, N, C, ldc, bias);

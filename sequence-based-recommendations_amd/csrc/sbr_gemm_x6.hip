@@ -22,11 +22,6 @@
 // into AGPRs and a single wave per SIMD cannot keep the pipe fed -- the same lesson as rec_fwd_x6s NT=2).
 #include "sbr_cell.h"
 
-#define XM 128
-#define XN 128
-#define XK 32
-#define XROW 80                       // bytes per LDS row: 32 bf16 + 16 pad
-#define XPLANE (128 * XROW)
 
 struct GemmX6Args {
     const float* A; long sam, sak;
@@ -73,26 +68,31 @@ __device__ __forceinline__ void x6_load(const float* __restrict__ p, long stride
             v[i][kk] = (i < nr && kk < nk) ? (RFAST ? p[(long)kk * stride + i] : p[(long)i * stride + kk]) : 0.0f;
 }
 
-template <int VA, bool RA, int VB, bool RB>
+// TW = MFMA tiles per wave and dimension, KH = 32-wide k blocks per step: <4, 1> is the 128x128x32 workgroup tile
+// described above; <2, 2> is a 64x64x64 tile for problems that would put fewer than ~128 of the large tiles on the chip
+// (C2's logits 256 x 3706 x 128 and dh 256 x 128 x 3706: 58 / 56 workgroups of the large tile, ~230 of the small one).
+// Either way 128 threads load one operand tile, 4 rows x 8 k each.
+template <int VA, bool RA, int VB, bool RB, int TW, int KH>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
-    __shared__ __attribute__((aligned(16))) char sA[3 * XPLANE];
-    __shared__ __attribute__((aligned(16))) char sB[3 * XPLANE];
+    constexpr int TM = 32 * TW, TK = 32 * KH, ROW = 64 * KH + 16, PLANE = TM * ROW, KC = 4 * KH;
+    __shared__ __attribute__((aligned(16))) char sA[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) char sB[3 * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int j = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * XM, n0 = blockIdx.x * XN;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
     const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
 
     // loader role: A tile (waves 0,1) or B tile (waves 2,3); rows rg*4..+3, k-chunk kc*8..+7
     const bool ldB = tid >= 128;
-    const int lt = tid & 127, rg = lt >> 2, kc = lt & 3;
+    const int lt = tid & 127, rg = lt / KC, kc = lt % KC;
     const int r0 = (ldB ? n0 : m0) + rg * 4;
     const int nr = max(0, min(4, (ldB ? g.N : g.M) - r0));
     long srow = ldB ? g.sbn : g.sam, sk = ldB ? g.sbk : g.sak;
-    const float* src = (ldB ? g.B : g.A) + (long)r0 * srow + (long)(kbeg + kc * 8) * sk;   // advanced by 32 k per step
+    const float* src = (ldB ? g.B : g.A) + (long)r0 * srow + (long)(kbeg + kc * 8) * sk;   // advanced by TK k per step
     if (ldB && g.B2 && r0 >= g.n_split) { sk = g.sbk2; src = g.B2 + (long)(r0 - g.n_split) * srow + (long)(kbeg + kc * 8) * sk; }
-    const long kstep = 32 * sk;
-    char* sdst = (ldB ? sB : sA) + (rg * 4) * XROW + kc * 16;
+    const long kstep = TK * sk;
+    char* sdst = (ldB ? sB : sA) + (rg * 4) * ROW + kc * 16;
 
     float v[4][8];
     auto load = [&](int k0) {
@@ -102,51 +102,54 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         src += kstep;
     };
     const f32x4 z = f32x4{0, 0, 0, 0};
-    f32x4 acc[4][4];
+    f32x4 acc[TW][TW];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TW; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = z;
+        for (int b = 0; b < TW; ++b) acc[a][b] = z;
 
     if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += XK) {
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bf16x8 p1, p2, p3;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) { __bf16 a, b, c; split3(v[i][kk], a, b, c); p1[kk] = a; p2[kk] = b; p3[kk] = c; }
-            *(bf16x8*)(sdst + i * XROW) = p1;
-            *(bf16x8*)(sdst + i * XROW + XPLANE) = p2;
-            *(bf16x8*)(sdst + i * XROW + 2 * XPLANE) = p3;
+            *(bf16x8*)(sdst + i * ROW) = p1;
+            *(bf16x8*)(sdst + i * ROW + PLANE) = p2;
+            *(bf16x8*)(sdst + i * ROW + 2 * PLANE) = p3;
         }
         __syncthreads();
-        if (k0 + XK < kend) load(k0 + XK);                 // in flight while this tile's MFMAs run
-        bf16x8 a[3][4], b[3][4];
+        if (k0 + TK < kend) load(k0 + TK);                 // in flight while this tile's MFMAs run
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int kh = 0; kh < KH; ++kh) {
+            bf16x8 a[3][TW], b[3][TW];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[p][t] = *(const bf16x8*)(sA + p * XPLANE + (wm * 64 + t * 16 + j) * XROW + q * 16);
-                b[p][t] = *(const bf16x8*)(sB + p * XPLANE + (wn * 64 + t * 16 + j) * XROW + q * 16);
-            }
-        // smallest terms first: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1; 16 independent accumulators per term
-#define X6_TERM(PA, PB) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
-            acc[mi][ni] = MFMA_BF16(a[PA][mi], b[PB][ni], acc[mi][ni]);
-        X6_TERM(0, 2) X6_TERM(2, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0)
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < TW; ++t) {
+                    a[p][t] = *(const bf16x8*)(sA + p * PLANE + (wm * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
+                    b[p][t] = *(const bf16x8*)(sB + p * PLANE + (wn * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
+                }
+            // smallest terms first: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1; TW*TW independent accumulators per term
+#define X6_TERM(PA, PB) _Pragma("unroll") for (int mi = 0; mi < TW; ++mi) _Pragma("unroll") for (int ni = 0; ni < TW; ++ni) \
+                acc[mi][ni] = MFMA_BF16(a[PA][mi], b[PB][ni], acc[mi][ni]);
+            X6_TERM(0, 2) X6_TERM(2, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0)
 #undef X6_TERM
+        }
         __syncthreads();
     }
 
     float* out = g.C + (size_t)blockIdx.z * g.slab_stride;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < TW; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 64 + mi * 16 + 4 * q + r;
+            const int m = m0 + wm * 16 * TW + mi * 16 + 4 * q + r;
             if (m >= g.M) continue;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = n0 + wn * 64 + ni * 16 + j;
+            for (int ni = 0; ni < TW; ++ni) {
+                const int n = n0 + wn * 16 * TW + ni * 16 + j;
                 if (n < g.N) out[(long)m * g.ldc + n] = acc[mi][ni][r] + (g.bias ? g.bias[n] : 0.0f);
             }
         }
@@ -162,18 +165,22 @@ static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte 
 // C + z*slab_stride, row stride ldc.
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2, long sbk2, int n_split) {
-    if (M < 96 || N < 96 || K < 32) return false;
+                    const float* B2, long sbk2, int n_split, bool small) {
+    if (M < (small ? 48 : 96) || N < (small ? 48 : 96) || K < 32) return false;
     if (B2 && (sbn != 1 || (n_split & 3) || !x6_aligned(B2, sbk2))) return false;
     if (!(sam == 1 || sak == 1) || !(sbk == 1 || sbn == 1)) return false;
     const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
     if (!x6_aligned(A, ra ? sak : sam) || !x6_aligned(B, rb ? sbk : sbn)) return false;
     GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split};
-    const dim3 grid((N + XN - 1) / XN, (M + XM - 1) / XM, nsplit);
-    if (ra && rb) gemm_x6_kernel<4, true, 4, true><<<grid, 256, 0, s>>>(g);
-    else if (ra) gemm_x6_kernel<4, true, 4, false><<<grid, 256, 0, s>>>(g);
-    else if (rb) gemm_x6_kernel<4, false, 4, true><<<grid, 256, 0, s>>>(g);
-    else gemm_x6_kernel<4, false, 4, false><<<grid, 256, 0, s>>>(g);
+    const int tile = small ? 64 : 128;
+    const dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, nsplit);
+#define X6_GO(TW, KH) do { \
+        if (ra && rb) gemm_x6_kernel<4, true, 4, true, TW, KH><<<grid, 256, 0, s>>>(g); \
+        else if (ra) gemm_x6_kernel<4, true, 4, false, TW, KH><<<grid, 256, 0, s>>>(g); \
+        else if (rb) gemm_x6_kernel<4, false, 4, true, TW, KH><<<grid, 256, 0, s>>>(g); \
+        else gemm_x6_kernel<4, false, 4, false, TW, KH><<<grid, 256, 0, s>>>(g); } while (0)
+    if (small) X6_GO(2, 2); else X6_GO(4, 1);
+#undef X6_GO
     *err = hipGetLastError();
     return true;
 }

@@ -418,10 +418,10 @@ hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, con
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) softmax_cce_kernel(float* __restrict__ logits, const float* __restrict__ bout,
                                                           const int* __restrict__ target, const float* __restrict__ pop,
-                                                          float* __restrict__ rowcost, int N, int Bglobal) {
+                                                          float* __restrict__ rowcost, int N, long ld, int Bglobal) {
     __shared__ float red[4];
     const int r = blockIdx.x;
-    float* x = logits + (size_t)r * N;
+    float* x = logits + (size_t)r * ld;
     float mx = -INFINITY;
     for (int n = threadIdx.x; n < N; n += 256) { const float v = x[n] + bout[n]; x[n] = v; mx = fmaxf(mx, v); }
     mx = block_max(mx, red);
@@ -444,11 +444,11 @@ __global__ void __launch_bounds__(256) softmax_cce_kernel(float* __restrict__ lo
 // of the logits instead of three reads and two writes, 1024 threads per row, hardware exp2.  C4 (N = 26744): 133 -> ~30 us.
 __global__ void __launch_bounds__(1024) softmax_cce_lds_kernel(float* __restrict__ logits, const float* __restrict__ bout,
                                                                const int* __restrict__ target, const float* __restrict__ pop,
-                                                               float* __restrict__ rowcost, int N, int Bglobal) {
+                                                               float* __restrict__ rowcost, int N, long ld, int Bglobal) {
     extern __shared__ float row[];
     __shared__ float red[16];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float* x = logits + (size_t)r * N;
+    float* x = logits + (size_t)r * ld;
     float mx = -INFINITY;
     for (int n = tid; n < N; n += 1024) { const float v = x[n] + bout[n]; row[n] = v; mx = fmaxf(mx, v); }
 #pragma unroll
@@ -479,15 +479,15 @@ __global__ void __launch_bounds__(1024) softmax_cce_lds_kernel(float* __restrict
 }
 
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
-                              float* rowcost, int rows, int N, int Bglobal) {
+                              float* rowcost, int rows, int N, long ld, int Bglobal) {
     if (rows <= 0) return hipSuccess;
     const size_t lds = (size_t)N * sizeof(float);
     if (lds <= 150 * 1024) {
         (void)hipFuncSetAttribute((const void*)softmax_cce_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        softmax_cce_lds_kernel<<<rows, 1024, lds, s>>>(logits, bout, target, pop, rowcost, N, Bglobal);
+        softmax_cce_lds_kernel<<<rows, 1024, lds, s>>>(logits, bout, target, pop, rowcost, N, ld, Bglobal);
         return hipGetLastError();
     }
-    softmax_cce_kernel<<<rows, 256, 0, s>>>(logits, bout, target, pop, rowcost, N, Bglobal);
+    softmax_cce_kernel<<<rows, 256, 0, s>>>(logits, bout, target, pop, rowcost, N, ld, Bglobal);
     return hipGetLastError();
 }
 

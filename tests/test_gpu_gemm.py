@@ -50,7 +50,11 @@ SHAPES = [
     (128, 384, 51200, True, False, 1 << 22),     # dW_hid = hs^T . dhi             (TN, K = T*B positions)
     (200, 130, 97, False, False, 0),             # ragged everything, odd leading dimensions (4-byte loads)
     (131, 257, 64, True, True, 0),
-    (96, 96, 32, False, True, 0),                # smallest shape the bf16x6 kernel takes
+    (96, 96, 32, False, True, 0),                # smallest shape the 128x128 bf16x6 tile takes
+    (48, 48, 32, False, True, 0),                # smallest shape of the 64x64 tile
+    (64, 200, 160, True, False, 0),              # 64x64 tiles, k tail of 32 inside a 64-wide step
+    (256, 128, 3712, False, False, 1 << 20),     # dh with 16-byte aligned rows: 64x64 tiles + split-K
+    (80, 3706, 128, False, True, 0),             # logits of a small batch
     (512, 1024, 256, False, False, 0),           # layer >= 2 input projection
 ]
 

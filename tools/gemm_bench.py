@@ -9,6 +9,7 @@ dev = torch.device("cuda")
 SHAPES = [("c4 logits  NT", 256, 26744, 256, False, True), ("c4 dh      NN", 256, 256, 26744, False, False),
           ("c4 dW_out  TN", 26744, 256, 256, True, False), ("c4 wgrad   TN", 256, 1024, 51200, True, False),
           ("c2 logits  NT", 256, 3706, 128, False, True), ("c2 wgrad   TN", 128, 384, 51200, True, False),
+          ("c2 dh      NN", 256, 128, 3712, False, False), ("c2 dW_out  TN", 3706, 128, 256, True, False),
           ("c3 l2 proj NN", 51200, 1024, 256, False, False)]
 ws = torch.empty(1 << 26, device=dev)
 for name, M, N, K, at, bt in SHAPES:
