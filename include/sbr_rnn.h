@@ -168,8 +168,10 @@ int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr, size_t* n_
 int sbr_copy_to_host(sbr_handle* h, const void* dev_ptr, float* host, size_t n_floats);
 int sbr_synchronize(sbr_handle* h);
 
-/* Per-phase device time of the last sbr_train_step in microseconds (hipEvents on the
- * handle's stream): gather, rec_fwd, output, rec_bwd, wgrad, scatter, update, total. */
+/* Per-phase device time of the train steps since sbr_enable_timing, in microseconds (hipEvents on the
+ * handle's stream): gather, rec_fwd, output, rec_bwd, wgrad, scatter, update, total.
+ * on = 0: off; 1: every phase (eight event records per step: each costs the stream a few microseconds, ~40 us per
+ * C2 step); 2 + p: only phase p (two records; the others read 0) -- what bench.py uses inside its timed region. */
 #define SBR_N_PHASES 8
 int sbr_enable_timing(sbr_handle* h, int on);
 /* Which kernels this handle's shapes select (tooling: bench.py names the kernels it prices):

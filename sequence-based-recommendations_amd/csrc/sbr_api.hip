@@ -285,7 +285,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->fuse_gather = fg ? atoi(fg) != 0 : 1;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
-    h->grads_clean = false;
+    h->grads_clean = false; h->timing_marks = 0;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
@@ -460,7 +460,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
 static inline bool simple_gemm(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_GEMM; }
 static inline void mark(sbr_handle* h, int i) {
-    if (h->timing && h->ev[h->ring_cur][i]) (void)hipEventRecord(h->ev[h->ring_cur][i], h->stream);
+    if (h->timing && ((h->timing_marks >> i) & 1) && h->ev[h->ring_cur][i]) (void)hipEventRecord(h->ev[h->ring_cur][i], h->stream);
 }
 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
@@ -660,28 +660,39 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     float* ws2 = h->A(y.a_ws2);
     const int* tgt = h->btgt;
     if (R < y.Bp) SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));   // padded rows carry no gradient
-    SBR_HIP(hipEventRecord(h->ev_fork, s));
-    SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     h->side_pending = true;
     h->fill_done = false;
-    if (!simple_rec(h)) {   // cluster BPTT kernels: the sentinel fill of their exchange arrays runs beside the output phase
-        bool any = false;
-        for (int l = 0; l < y.L * y.D; ++l) {
-            RecArgs a = rec_args(h, l);
-            if (sbr_rec_cluster_ok(a)) { SBR_LAUNCH(sbr_rec_bwd_cl_fill(sd, a)); any = true; }
+    // Work on the side stream that needs only the batch: the sentinel fill of the cluster BPTT kernels' exchange arrays and
+    // the sort for the embedding scatter-add (the scatter kernel waits for ev_sort).  With cluster kernels it starts now,
+    // beside the output phase (its own fork event); otherwise it rides behind the ev_lg wait the side stream needs anyway
+    // -- every event record costs the main stream a few microseconds.
+    bool fill_needed = false;
+    if (!simple_rec(h))
+        for (int l = 0; l < y.L * y.D; ++l) fill_needed = fill_needed || sbr_rec_cluster_ok(rec_args(h, l));
+    auto side_batch_work = [&]() -> int {
+        if (fill_needed) {
+            for (int l = 0; l < y.L * y.D; ++l) {
+                RecArgs a = rec_args(h, l);
+                if (sbr_rec_cluster_ok(a)) SBR_LAUNCH(sbr_rec_bwd_cl_fill(sd, a));
+            }
+            SBR_HIP(hipEventRecord(h->ev_fill, sd)); h->fill_done = true;
         }
-        if (any) { SBR_HIP(hipEventRecord(h->ev_fill, sd)); h->fill_done = true; }
-    }
-    if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E) {
-        // batch-only work for the embedding scatter-add; the scatter kernel waits for ev_sort
-        SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
-                                       y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
-                                       (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
-        if (y.D == 2 && !y.E)   // the backwards direction scatters with the reversed ids (a_Xr was written by forward_bi)
-            SBR_LAUNCH(launch_scatter_sort(sd, (const int*)h->A(y.a_Xr), h->blen, y.T, y.Bp, y.F, y.cfg.input_size,
-                                           (int*)h->A(y.a_s2cnt), (int*)h->A(y.a_s2off), (int*)h->A(y.a_s2cur),
-                                           (int*)h->A(y.a_s2sid), (int*)h->A(y.a_s2pos), 0));
-        SBR_HIP(hipEventRecord(h->ev_sort, sd));
+        if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E) {
+            SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
+                                           y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
+                                           (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
+            if (y.D == 2 && !y.E)   // the backwards direction scatters with the reversed ids (a_Xr was written by forward_bi)
+                SBR_LAUNCH(launch_scatter_sort(sd, (const int*)h->A(y.a_Xr), h->blen, y.T, y.Bp, y.F, y.cfg.input_size,
+                                               (int*)h->A(y.a_s2cnt), (int*)h->A(y.a_s2off), (int*)h->A(y.a_s2cur),
+                                               (int*)h->A(y.a_s2sid), (int*)h->A(y.a_s2pos), 0));
+            SBR_HIP(hipEventRecord(h->ev_sort, sd));
+        }
+        return SBR_OK;
+    };
+    if (fill_needed) {
+        SBR_HIP(hipEventRecord(h->ev_fork, s));
+        SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
+        const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
     }
     if (y.cfg.loss == SBR_LOSS_CCE) {
         float* lg = h->A(y.a_logits);
@@ -694,6 +705,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
         // beside it: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg, 0));
+        if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(launch_sum_cost(sd, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
@@ -715,6 +727,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
         SBR_HIP(hipEventRecord(h->ev_og, s)); h->og_recorded = true;
+        if (!fill_needed) {      // the sampled heads keep the main stream: the batch-only side work follows this record
+            SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
+            const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
+        }
     }
     mark(h, 3);
     if (h->deferred_join && !h->in_train_step) {
@@ -871,12 +887,20 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         // The last thing the side stream produces is dW_hid (weight-gradient GEMM + slab reduction, 240 us at C4).  Every
         // other parameter is updated while it finishes: the main stream waits only for the output-layer gradients
         // (recorded long ago), updates all ranges except the W_hid blocks, joins, then updates those.
-        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
-        size_t pos = 0;
-        for (int l = 0; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
-        SBR_LAUNCH(upd(pos, y.n_params));
-        { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
-        for (int l = 0; l < y.L * y.D; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
+        if (y.L * y.D == 1 && y.n_params - y.layer[0].p_peep <= ((size_t)1 << 20)) {
+            // small output layer (C2: 0.47 M floats): two launches instead of three; a large one (C4: 6.8 M) is better
+            // updated while dW_hid finishes
+            SBR_LAUNCH(upd(0, y.layer[0].p_Whid));                         // W_in, b: main-stream gradients only
+            { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+            SBR_LAUNCH(upd(y.layer[0].p_Whid, y.n_params));               // W_hid, peepholes, initial states, output layer
+        } else {
+            SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
+            size_t pos = 0;
+            for (int l = 0; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
+            SBR_LAUNCH(upd(pos, y.n_params));
+            { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+            for (int l = 0; l < y.L * y.D; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
+        }
     } else {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(upd(0, y.n_params));
@@ -1084,7 +1108,9 @@ extern "C" int sbr_enable_timing(sbr_handle* h, int on) {
     if (on)
         for (int r = 0; r < sbr_handle::kRing; ++r)
             for (int i = 0; i < SBR_N_PHASES; ++i) if (!h->ev[r][i]) SBR_HIP(hipEventCreate(&h->ev[r][i]));
+    CHECK_ARG(on >= 0 && on <= SBR_N_PHASES, "on = %d: 0 off, 1 every phase, 2 + p only phase p", on);
     h->timing = on != 0; h->ring_used = 0; h->ring_cur = 0;
+    h->timing_marks = on == 1 ? 0xffu : on >= 2 ? (3u << (on - 2)) : 0u;      // a phase lies between marks p and p + 1
     return SBR_OK;
 }
 
@@ -1098,6 +1124,7 @@ extern "C" int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]) {
     for (int r = 0; r < n; ++r)
         for (int i = 0; i < SBR_N_PHASES - 1; ++i) {
             float ms = 0.f;
+            if (((h->timing_marks >> i) & 3) != 3) continue;          // this phase was not bracketed
             if (hipEventElapsedTime(&ms, h->ev[r][i], h->ev[r][i + 1]) != hipSuccess) ms = 0.f;
             us[i] += ms * 1000.f / n;
         }

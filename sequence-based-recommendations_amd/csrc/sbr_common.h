@@ -127,6 +127,7 @@ struct sbr_handle {
     bool have_batch, fwd_done;
     bool grads_clean;    // the gradient section is all zero (fresh arena, or the update kernel cleared it)
     bool timing;
+    unsigned timing_marks;   // which of the SBR_N_PHASES event marks a step records (sbr_enable_timing)
     // ring of per-step event sets, read back after the timed region (no per-step sync)
     static const int kRing = 64;
     hipEvent_t ev[kRing][SBR_N_PHASES];

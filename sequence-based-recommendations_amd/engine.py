@@ -498,8 +498,11 @@ class RNNEngine(object):
     def synchronize(self):
         self._check(self.lib.sbr_synchronize(self.h))
 
-    def enable_timing(self, on=True):
-        self._check(self.lib.sbr_enable_timing(self.h, 1 if on else 0))
+    def enable_timing(self, on=True, only=None):
+        """on: record the per-phase events of every train step; only="rec_bwd": just the two events around that phase
+        (every event record costs the stream a few microseconds)."""
+        mode = 0 if not on else 1 if only is None else 2 + PHASE_NAMES.index(only)
+        self._check(self.lib.sbr_enable_timing(self.h, mode))
 
     def phase_times(self):
         us = (ctypes.c_float * SBR_N_PHASES)()

@@ -16,3 +16,32 @@ def test_degenerate_shapes(case):
     cell, layers, N, B, T, kw = case
     r = PU.compare_step(cell, layers, "CCE", N=N, B=B, T=T, **kw)
     assert r["param_roundtrip"] == 0 and r["h_last"] < 2e-4 and r["grad_worst"] < 2e-4 and r["topk_mismatch"] == 0, r
+
+
+def test_phase_timing_modes():
+    # sbr_enable_timing: every phase, or only the two events around one phase (what bench.py keeps in its timed region)
+    import numpy as np
+    params, cfg, batch = PU.build_case("GRU", [16], "CCE", 30, 6, 8)
+    eng = PU.engine_for(cfg, 30, 6, 8)
+    try:
+        eng.set_all_param_values(params)
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], None, batch["pop"])
+        eng.enable_timing(True)
+        for _ in range(3):
+            eng.train_step(sync=True)
+        full = eng.phase_times()
+        assert all(full[k] > 0 for k in ("rec_fwd", "output", "rec_bwd", "update"))
+        assert full["total"] == pytest.approx(sum(v for k, v in full.items() if k != "total"), rel=1e-5)
+        eng.enable_timing(True, only="rec_bwd")
+        for _ in range(3):
+            eng.train_step(sync=True)
+        one = eng.phase_times()
+        assert one["rec_bwd"] > 0 and one["total"] == pytest.approx(one["rec_bwd"], rel=1e-5)
+        assert all(one[k] == 0 for k in ("gather", "rec_fwd", "output", "wgrad", "scatter", "update"))
+        assert 0.3 < one["rec_bwd"] / full["rec_bwd"] < 3.0
+        eng.enable_timing(False)
+        eng.train_step(sync=True)
+        with pytest.raises(RuntimeError):
+            eng.phase_times()
+    finally:
+        eng.close()
