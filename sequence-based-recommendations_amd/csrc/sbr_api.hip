@@ -285,7 +285,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         h->fuse_gather = fg ? atoi(fg) != 0 : 1;
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
-    h->grads_clean = false; h->timing_marks = 0;
+    h->grads_clean = false; h->timing_marks = 0; h->marks_shared = 0; h->tail_swapped = false;
+    { const char* e = getenv("SBR_SWAP_TAIL"); h->swap_tail = e ? atoi(e) != 0 : true; }
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
@@ -459,8 +460,23 @@ static RecArgs rec_args(sbr_handle* h, int l) {
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
 static inline bool simple_gemm(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_GEMM; }
-static inline void mark(sbr_handle* h, int i) {
-    if (h->timing && ((h->timing_marks >> i) & 1) && h->ev[h->ring_cur][i]) (void)hipEventRecord(h->ev[h->ring_cur][i], h->stream);
+static inline void mark_on(sbr_handle* h, int i, hipStream_t st) {
+    if (i == 0) h->marks_shared = 0;
+    if ((h->marks_shared >> i) & 1) return;              // this step's mark i was recorded by record_shared
+    if (h->timing && ((h->timing_marks >> i) & 1) && h->ev[h->ring_cur][i]) (void)hipEventRecord(h->ev[h->ring_cur][i], st);
+}
+static inline void mark(sbr_handle* h, int i) { mark_on(h, i, h->stream); }
+// An event record costs the stream ~6 us before its next kernel starts (measured: profiles/round1_i_timeline.txt), so
+// where a cross-stream event and a timing mark fall on the same point of the main stream ONE record serves both: the
+// side stream waits on the timing event.  Returns the event to wait on.
+static inline hipEvent_t record_shared(sbr_handle* h, hipEvent_t plain, int mk) {
+    if (mk >= 0 && h->timing && ((h->timing_marks >> mk) & 1) && h->ev[h->ring_cur][mk]) {
+        (void)hipEventRecord(h->ev[h->ring_cur][mk], h->stream);
+        h->marks_shared |= 1u << mk;
+        return h->ev[h->ring_cur][mk];
+    }
+    (void)hipEventRecord(plain, h->stream);
+    return plain;
 }
 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
@@ -700,11 +716,11 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, Nl, y.Bg));
-        SBR_HIP(hipEventRecord(h->ev_lg, s));
         // critical path: dh = dlogits . W_out^T feeds the BPTT chain
         SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
-        // beside it: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h
-        SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg, 0));
+        // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
+        // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
+        SBR_HIP(hipStreamWaitEvent(sd, record_shared(h, h->ev_lg, 3), 0));
         if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(launch_sum_cost(sd, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
@@ -782,12 +798,19 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             static const int wgs = getenv("SBR_WGRAD_X6_WGS") ? atoi(getenv("SBR_WGRAD_X6_WGS")) : 512;
             nsl = std::max(1, std::min(nsl, wgs / (((ly.Hp + 127) / 128) * ((GHp + 127) / 128)) / nc));
         }
+        // Tail of a single-layer step with one BPTT launch: the main stream keeps the longer branch (dW_hid GEMM + slab
+        // reduction + its updates) and the side stream takes the bias partials, the embedding scatter-add and their
+        // updates -- the main stream then ends the step without waiting ~13 us for a cross-stream event behind the
+        // branch that finishes last (profiles/round1_i_timeline.txt).
+        const bool swap = h->swap_tail && h->in_train_step && side_wgrad && nc == 1 && y.L == 1 && !y.E &&
+                          !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER);   // (phase-by-phase callers order their collectives behind the side stream)
+        hipStream_t sw = swap ? s : sd;      // weight-gradient GEMM
+        hipStream_t sm = swap ? sd : s;      // partials + scatter
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
                 SBR_LAUNCH(launch_rec_backward(s, a, false));
-                SBR_HIP(hipEventRecord(h->ev_chunk[c], s));
-                SBR_HIP(hipStreamWaitEvent(sd, h->ev_chunk[c], 0));
+                SBR_HIP(hipStreamWaitEvent(sd, record_shared(h, h->ev_chunk[c], (l == 0 && c == nc - 1) ? 4 : -1), 0));
                 // dW_hid [Hp][G*Hp] += hs[t]^T . dhi[t] over the chunk's positions (hs slot t = h_{t-1})
                 const float* hsc = h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp;
                 const int Kc = (a.t_hi - a.t_lo) * y.Bp;
@@ -796,22 +819,23 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 const float* dxc = a.dxt + (size_t)a.t_lo * y.Bp * GHp;
                 const float* dhcc = gru ? a.dhi + (size_t)a.t_lo * y.Bp * ly.Hp : nullptr;
                 hipError_t we = hipSuccess;
-                if (!wg_gemm && launch_wgrad_slabs(sd, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
+                if (!wg_gemm && launch_wgrad_slabs(sw, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
                     SBR_LAUNCH(we);
-                } else if (gru && launch_gemm_slabs_x6(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab, dhcc, ly.Hp,
+                } else if (gru && launch_gemm_slabs_x6(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab, dhcc, ly.Hp,
                                                        2 * ly.Hp, &we)) {
                     SBR_LAUNCH(we);     // one bf16x6 GEMM: columns [0, 2Hp) from dxt, the candidate-gate columns from the compact array
                 } else if (gru) {   // hid_input grad = [dxt_r | dxt_u | dhi_c]
-                    SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, 2 * ly.Hp, Kc, slabs, nsl, GHp, slab));
-                    SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dhcc, ly.Hp, 1, ly.Hp, ly.Hp, Kc, slabs + 2 * ly.Hp, nsl, GHp, slab));
+                    SBR_LAUNCH(launch_gemm_slabs(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, 2 * ly.Hp, Kc, slabs, nsl, GHp, slab));
+                    SBR_LAUNCH(launch_gemm_slabs(sw, hsc, 1, ly.Hp, dhcc, ly.Hp, 1, ly.Hp, ly.Hp, Kc, slabs + 2 * ly.Hp, nsl, GHp, slab));
                 } else {
-                    SBR_LAUNCH(launch_gemm_slabs(sd, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab));
+                    SBR_LAUNCH(launch_gemm_slabs(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab));
                 }
             }
-            SBR_LAUNCH(launch_splitk_reduce(sd, ws2, nc * nsl, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
+            SBR_LAUNCH(launch_splitk_reduce(sw, ws2, nc * nsl, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
             h->side_pending = true;
             if (l == 0) mark(h, 4);
-            SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nc * nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+            if (swap) h->tail_swapped = true;
+            SBR_LAUNCH(launch_rec_reduce_partials(sm, a.part, nc * nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
                                                   h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
         } else {
             SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
@@ -841,15 +865,15 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                              (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, y.Ep, y.Bp));
             mark(h, 6);
         } else         if (l == 0) {
-            mark(h, 5);
+            mark_on(h, 5, sm);
             if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
                 SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, h->bX, a.len, y.T, y.Bp, y.F, GHp));
             } else {
-                SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));
-                SBR_LAUNCH(launch_scatter_reduce(s, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                if (sm == s) SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));      // (the sort ran on the side stream)
+                SBR_LAUNCH(launch_scatter_reduce(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                  (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp, y.Bp));
             }
-            mark(h, 6);
+            mark_on(h, 6, sm);
         } else {
             const LayerLayout& lo = y.layer[l - 1];
             const float* xin = h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp;     // input at step t = h^{l-1}_t = slot t+1
@@ -883,7 +907,19 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         return launch_update(h->stream, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1 ? s1 + lo : nullptr, hi - lo,
                              y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
     };
-    if (h->side_pending && h->og_recorded) {
+    if (h->side_pending && h->tail_swapped) {
+        // side stream: W_in, b | peepholes, initial states (its own scatter / partials); main stream: W_hid (its own GEMM) |
+        // output layer (gradients complete since ev_og); then the main stream joins the side stream, normally long done
+        const LayerLayout& l0 = y.layer[0];
+        auto upd2 = [&](hipStream_t st, size_t lo, size_t n1, size_t skip, size_t n2) -> hipError_t {
+            return launch_update(st, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1 ? s1 + lo : nullptr, n1 + n2,
+                                 y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count, n1, skip);
+        };
+        SBR_LAUNCH(upd2(h->side, 0, l0.p_Whid, l0.p_peep - l0.p_Whid, y.p_WoutT - l0.p_peep));
+        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
+        SBR_LAUNCH(upd2(h->stream, l0.p_Whid, l0.p_peep - l0.p_Whid, y.p_WoutT - l0.p_peep, y.n_params - y.p_WoutT));
+        { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+    } else if (h->side_pending && h->og_recorded) {
         // The last thing the side stream produces is dW_hid (weight-gradient GEMM + slab reduction, 240 us at C4).  Every
         // other parameter is updated while it finishes: the main stream waits only for the output-layer gradients
         // (recorded long ago), updates all ranges except the W_hid blocks, joins, then updates those.
@@ -905,7 +941,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(upd(0, y.n_params));
     }
-    h->og_recorded = false;
+    h->og_recorded = false; h->tail_swapped = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;

@@ -128,6 +128,9 @@ struct sbr_handle {
     bool grads_clean;    // the gradient section is all zero (fresh arena, or the update kernel cleared it)
     bool timing;
     unsigned timing_marks;   // which of the SBR_N_PHASES event marks a step records (sbr_enable_timing)
+    bool swap_tail;      // SBR_SWAP_TAIL: after the BPTT chain the main stream keeps dW_hid, the side stream takes the scatter
+    bool tail_swapped;   // ... done for this step (sbr_apply_update splits its ranges accordingly)
+    unsigned marks_shared;   // marks of this step already recorded as a cross-stream event (record_shared)
     // ring of per-step event sets, read back after the timed region (no per-step sync)
     static const int kRing = 64;
     hipEvent_t ev[kRing][SBR_N_PHASES];
@@ -297,8 +300,9 @@ hipError_t launch_sampled_loss(hipStream_t s, float* act, const float* bc, const
 hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float* dWc, const float* dbc,
                                 const int* cells, int C, int Hp);
 // optimizers (lasagne.updates.* [3P], update_manager.py:24-82)
+// n elements starting at p / g / s0 / s1, skipping gap_len elements after the first gap_at (two ranges, one launch)
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
-                         float lr, float rho, float b1, float b2, long t);
+                         float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);
 // top-k (rnn_base.py:196-211)
 hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F,
                                int N);

@@ -690,8 +690,11 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
 // (update_manager.py:24-82), applied densely to the whole flat parameter section.
 // ---------------------------------------------------------------------------------------
 __global__ void update_kernel(int updater, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
-                              float* __restrict__ s1, size_t n, float lr, float rho, float b1, float b2, float a_t) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+                              float* __restrict__ s1, size_t n, float lr, float rho, float b1, float b2, float a_t,
+                              size_t gap_at, size_t gap_len) {
+    // n elements of [0, gap_at) u [gap_at + gap_len, ...): two parameter ranges in one launch
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = k < gap_at ? k : k + gap_len;
         const float gi = g[i];
         g[i] = 0.0f;                                      // the gradient section is clean for the next step (no memset)
         float pi = p[i];
@@ -720,12 +723,13 @@ __global__ void update_kernel(int updater, float* __restrict__ p, float* __restr
 }
 
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n, float lr,
-                         float rho, float b1, float b2, long t) {
+                         float rho, float b1, float b2, long t, size_t gap_at, size_t gap_len) {
+    if (n == 0) return hipSuccess;
     float a_t = 0.0f;
     if (updater == SBR_UPD_ADAM)
         a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
     const int grid = (int)min((size_t)256 * 16, (n + 255) / 256);
-    update_kernel<<<grid, 256, 0, s>>>(updater, p, g, s0, s1, n, lr, rho, b1, b2, a_t);
+    update_kernel<<<grid, 256, 0, s>>>(updater, p, g, s0, s1, n, lr, rho, b1, b2, a_t, gap_at, gap_len);
     return hipGetLastError();
 }
 
