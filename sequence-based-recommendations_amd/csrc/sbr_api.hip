@@ -908,16 +908,14 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
                              y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
     };
     if (h->side_pending && h->tail_swapped) {
-        // side stream: W_in, b | peepholes, initial states (its own scatter / partials); main stream: W_hid (its own GEMM) |
-        // output layer (gradients complete since ev_og); then the main stream joins the side stream, normally long done
+        // side stream: everything but W_hid (W_in, b from its own scatter / partials; the output layer's gradients are its
+        // own too); main stream: W_hid (its own GEMM) -- no event wait in front of it; then the main stream joins the side
+        // stream, normally done by then
         const LayerLayout& l0 = y.layer[0];
-        auto upd2 = [&](hipStream_t st, size_t lo, size_t n1, size_t skip, size_t n2) -> hipError_t {
-            return launch_update(st, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1 ? s1 + lo : nullptr, n1 + n2,
-                                 y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count, n1, skip);
-        };
-        SBR_LAUNCH(upd2(h->side, 0, l0.p_Whid, l0.p_peep - l0.p_Whid, y.p_WoutT - l0.p_peep));
-        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
-        SBR_LAUNCH(upd2(h->stream, l0.p_Whid, l0.p_peep - l0.p_Whid, y.p_WoutT - l0.p_peep, y.n_params - y.p_WoutT));
+        SBR_LAUNCH(launch_update(h->side, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, l0.p_Whid + (y.n_params - l0.p_peep),
+                                 y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count, l0.p_Whid,
+                                 l0.p_peep - l0.p_Whid));
+        SBR_LAUNCH(upd(l0.p_Whid, l0.p_peep));
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
     } else if (h->side_pending && h->og_recorded) {
         // The last thing the side stream produces is dW_hid (weight-gradient GEMM + slab reduction, 240 us at C4).  Every

@@ -148,6 +148,45 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce(const float* __restric
     C[(long)m * ldc + n] = s + (bias ? bias[n] : 0.0f);
 }
 
+// The same for many slabs (the weight gradients: 170 slabs of 128 x 384): 16-byte loads, 64 outputs x 16 slab groups per
+// workgroup, 4 loads in flight per thread, fixed summation order.  Needs M*N % 4 == 0 and 16-byte aligned slabs.
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_v4(const f32x4* __restrict__ ws, int nsplit, int M, int N,
+                                                             float* __restrict__ C, long ldc, const float* __restrict__ bias) {
+    __shared__ f32x4 red[16][16];
+    const size_t MN4 = (size_t)M * N / 4;
+    const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i4 = (size_t)blockIdx.x * 16 + j;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    if (i4 < MN4) {
+        int z = grp;
+        for (; z + 48 < nsplit; z += 64) {
+            s0 += ws[(size_t)z * MN4 + i4]; s1 += ws[(size_t)(z + 16) * MN4 + i4];
+            s2 += ws[(size_t)(z + 32) * MN4 + i4]; s3 += ws[(size_t)(z + 48) * MN4 + i4];
+        }
+        for (; z < nsplit; z += 16) s0 += ws[(size_t)z * MN4 + i4];
+    }
+    red[grp][j] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int jj = threadIdx.x >> 2, e = threadIdx.x & 3;             // one output element per thread
+    const size_t i = ((size_t)blockIdx.x * 16 + jj) * 4 + e;
+    if (i >= (size_t)M * N) return;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][jj][e];
+    const int m = (int)(i / N), n = (int)(i % N);
+    C[(long)m * ldc + n] = t + (bias ? bias[n] : 0.0f);
+}
+
+static hipError_t splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc, const float* bias) {
+    const size_t n = (size_t)M * N;
+    if (nslabs >= 32 && (n & 3) == 0 && ((uintptr_t)ws & 15) == 0)
+        gemm_splitk_reduce_v4<<<(unsigned)((n / 4 + 15) / 16), 256, 0, s>>>((const f32x4*)ws, nslabs, M, N, C, ldc, bias);
+    else
+        gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, nslabs, M, N, C, ldc, bias);
+    return hipGetLastError();
+}
+
 // triage: one thread per output element
 __global__ void gemm_naive(GemmArgs g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,9 +231,7 @@ bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, con
 }
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias) {
-    const size_t n = (size_t)M * N;
-    gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, nslabs, M, N, C, ldc, bias);
-    return hipGetLastError();
+    return splitk_reduce(s, ws, nslabs, M, N, C, ldc, bias);
 }
 
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
@@ -230,9 +267,7 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
         if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ns > 1 ? ws : C, ns > 1 ? (long)N : ldc, M, N, K, bias, ns, kc,
                            (size_t)M * N, &e, nullptr, 0, 0, small)) {
             if (e == hipSuccess && ns > 1) {
-                const size_t n = (size_t)M * N;
-                gemm_splitk_reduce<<<(unsigned)((n + 63) / 64), 256, 0, s>>>(ws, ns, M, N, C, ldc, bias);
-                e = hipGetLastError();
+                e = splitk_reduce(s, ws, ns, M, N, C, ldc, bias);
             }
             return e;
         }
