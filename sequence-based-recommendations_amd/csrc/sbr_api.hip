@@ -803,6 +803,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // updates -- the main stream then ends the step without waiting ~13 us for a cross-stream event behind the
         // branch that finishes last (profiles/round1_i_timeline.txt).
         const bool swap = h->swap_tail && h->in_train_step && side_wgrad && nc == 1 && y.L == 1 && !y.E &&
+                          y.n_params <= ((size_t)4 << 20) &&      // large models (C4: 34 M parameters) measured 2 % slower this way
                           !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER);   // (phase-by-phase callers order their collectives behind the side stream)
         hipStream_t sw = swap ? s : sd;      // weight-gradient GEMM
         hipStream_t sm = swap ? sd : s;      // partials + scatter
