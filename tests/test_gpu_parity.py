@@ -94,6 +94,16 @@ def test_pipelined_kernel_modes(cell, mode, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12))
 
 
+@pytest.mark.parametrize("env", [("SBR_SWAP_TAIL", "0"), ("SBR_GEMM_SMALL_BELOW", "0")])
+def test_step_scheduling_switches(env, monkeypatch):
+    # defaults (every other test): after the BPTT chain the main stream keeps dW_hid and the side stream takes the scatter
+    # and most updates; GEMMs that would put < 128 large tiles on the chip use 64x64 tiles.  Here: the older arrangements.
+    monkeypatch.setenv(*env)
+    check(PU.compare_step("GRU", [128], "CCE", N=300, B=64, T=12))
+    check(PU.compare_step("LSTM", [20], "CCE", N=120, B=37, T=9))
+    check(PU.compare_step("GRU", [50], "BPR", N=200, B=48, T=9, S=16))
+
+
 @pytest.mark.parametrize("H", [20, 50])
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_small_layer_barrier_kernels_agree(cell, H, monkeypatch):
