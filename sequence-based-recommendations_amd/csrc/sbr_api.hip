@@ -802,9 +802,10 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // reduction + its updates) and the side stream takes the bias partials, the embedding scatter-add and their
         // updates -- the main stream then ends the step without waiting ~13 us for a cross-stream event behind the
         // branch that finishes last (profiles/round1_i_timeline.txt).
-        const bool swap = h->swap_tail && h->in_train_step && side_wgrad && nc == 1 && y.L == 1 && !y.E &&
+        const bool swap = h->swap_tail && side_wgrad && nc == 1 && y.L == 1 && !y.E &&
                           y.n_params <= ((size_t)4 << 20) &&      // large models (C4: 34 M parameters) measured 2 % slower this way
-                          !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER);   // (phase-by-phase callers order their collectives behind the side stream)
+                          !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER);   // phase-by-phase callers (data parallel) join the side stream
+                                                                      // before their collective: same split of the tail
         hipStream_t sw = swap ? s : sd;      // weight-gradient GEMM
         hipStream_t sm = swap ? sd : s;      // partials + scatter
         if (nc > 1 || side_wgrad) {
