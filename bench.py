@@ -64,6 +64,25 @@ def synth_batches(n_batches, B, T, n_items, n_samples, lengths_mode, seed):
     return out
 
 
+def initial_parameters(shapes, cell, rng):
+    """Random-init weights of the architecture, in the engine's parameter order (= Lasagne's get_all_param_values order):
+    gate weights and peepholes Normal(std 0.1), biases and initial states 0, output W GlorotUniform, output b 0 -- the
+    initialisers the reference's layers name (sparse_lstm.py:143-171, rnn_one_hot.py:65)."""
+    per_layer, n_gate = {"LSTM": (17, 12), "GRU": (10, 9), "Vanilla": (4, 3)}[cell]
+    last = len(shapes) - 2
+    out = []
+    for i, shp in enumerate(shapes):
+        k = i % per_layer
+        if i == last:
+            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            out.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+        elif i < last and ((k < n_gate and k % 3 != 2) or (cell == "LSTM" and 12 <= k < 15)):
+            out.append(rng.normal(0.0, 0.1, size=shp).astype(np.float32))
+        else:
+            out.append(np.zeros(shp, dtype=np.float32))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,7 +104,6 @@ def main():
     T0 = time.perf_counter()
     import torch
     import torch.distributed as dist
-    from oracle import rnn_oracle as O          # parameter init law + the cpu_baseline leg only
     from sbr_amd.engine import RNNEngine
     from sbr_amd.parallel import DataParallel
     log("imports done")
@@ -108,7 +126,7 @@ def main():
     Bg = B * world
     eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=Bg, local_batch=B,
                     row_offset=rank * B, loss=loss, n_samples=n_samples, updater="adam", learning_rate=1e-3)
-    params = O.init_params(cell, layers, n_items, np.random.default_rng(42), dtype=np.float32)   # Lasagne init law
+    params = initial_parameters(eng.param_shapes, cell, np.random.default_rng(42))
     eng.set_all_param_values(params)
 
     # synthetic batches, resident in HBM before the timed region
@@ -264,6 +282,7 @@ def main():
         result["kernels"] = kernels
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import rnn_oracle as O          # the oracle: only this leg of the bench touches it
         from oracle import torch_ref as R
         ncores = os.cpu_count() or 1
         nthr = args.cpu_threads or min(ncores, 16)
