@@ -34,6 +34,8 @@
 // rejected: all operands fetched before the MFMA phase by every wave (LDS burst, +35 us), a three-deep operand ring in
 // the backward (+15 us), a delay at the gate or a signal more than one MFMA term early (+5 .. +35 us; one term early is what runs, -4 us), splitting the backward over K instead
 // of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
+// The backward's 36 operand reads per wave and step (K = 384; the forward has 12) are not what holds it back: with half
+// of them skipped (X6P_DBG 64) rec_bwd takes 256 instead of 263 us, with three quarters skipped (128) 250 us.
 #include "sbr_rec_p.h"
 
 #ifndef X6P_DBG
@@ -437,6 +439,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         int fl[2];
         auto load_kb = [&](int i) {
             const int kb = korder(i), s = i % NS;
+            if ((X6P_DBG & 64) && (i & 1)) { dpl[s][0] = dpl[s ^ 1][0]; dpl[s][1] = dpl[s ^ 1][1]; dpl[s][2] = dpl[s ^ 1][2]; return; }   // half the LDS reads
+            if ((X6P_DBG & 128) && (i % 4)) { dpl[s][0] = dpl[s ^ 1][0]; dpl[s][1] = dpl[s ^ 1][1]; dpl[s][2] = dpl[s ^ 1][2]; return; }  // a quarter
             dpl[s][0] = *(const bf16x8*)(db + kb * 64);
             dpl[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
             dpl[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
