@@ -46,6 +46,28 @@ namespace {
 
 constexpr int HP = 128, R = 4, KBH = HP / 32;
 
+// "f16x3": an f32 operand as a1 + a2 / 2048 with a1 = fp16(a), a2 = fp16((a - a1) * 2048) (the scale keeps the low part
+// out of fp16's subnormal range), a product as a1 b1 + (a1 b2 + a2 b1) / 2048: three MFMAs instead of bf16x6's six, two
+// accumulators.  Measured against fp64 on K = 128 dot products of recurrent-step operands (tools/probes/
+// mfma_f16x3_probe.hip): rms error 1.1e-7 of the rms value (bf16x6 1.5e-7, a plain f32 FMA chain 2.1e-7), the same for
+// activations of magnitude 1e-4; the matrix pipe keeps fp16 subnormal inputs.  Range: |a| < 65504 -- hidden states are
+// in [-1, 1], weights far below; relative precision decays below |a| ~ 1e-4 * 2^-13 (absolute floor 1.5e-11), which is
+// why only the FORWARD chain uses it: gradients span too many binades without a per-row scale.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16_LO = 2048.0f;
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) { return MFMA_BF16(a, b, c); }
+__device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// v must be a value the compiler cannot look through (callers pin it with an empty asm): when it can see the expression
+// that produced v, it forms a1 twice -- v_fma_mixlo_f16 straight from that expression (one rounding) for the subtraction,
+// v_cvt_pk_f16_f32 of the f32-rounded value for the stored plane -- and the two differ in one element of ~2^13 (double
+// rounding), each worth an fp16 ulp of that operand (found as a 30x larger error in one hidden unit of GRU [64, 128]).
+__device__ __forceinline__ void split2_f16(float v, _Float16& a1, _Float16& a2) {
+    a1 = (_Float16)v;
+    a2 = (_Float16)((v - (float)a1) * F16_LO);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -67,8 +89,10 @@ constexpr int HP = 128, R = 4, KBH = HP / 32;
 // MFMA, tools/probes/valu_beside_mfma_probe.hip) and a scalar one ~4: per-step addresses advance on the SALU, stores
 // and counter updates are single instructions with scalar bases / precomputed operands.
 // ---------------------------------------------------------------------------------------
-template <int CELL, bool FUSE, bool PROF>
+template <int CELL, bool FUSE, bool PROF, bool F16>
 __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
+    using OPV = std::conditional_t<F16, f16x8, bf16x8>;      // operand fragment: fp16 (two planes) or bf16 (three planes)
+    constexpr int NP = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, KB = KBH, GHP = G * HP;
     static_assert(G <= 3, "W_hid plane 3 does not fit the register file with four gates");
     constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW, BUFB = 3 * PLANEB;
@@ -91,17 +115,25 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, 16));
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));  // workgroup-uniform: all four rows
 
-    bf16x8 W1[G][KB], W2[G][KB], W3[G][KB];              // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
+    OPV W1[G][KB], W2[G][KB], W3[G][KB];                 // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                __bf16 b1, b2, b3;
                 const float sc = (CELL == CELL_GRU && g < 2) ? X6P_NLOG2E : 1.0f;     // sigmoid gates: see the gate math
-                split3(sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + u], b1, b2, b3);
-                W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b3;
+                float w = sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + u];
+                if constexpr (F16) {
+                    _Float16 b1, b2;
+                    if (!(X6P_DBG & 256)) asm volatile("" : "+v"(w));   // see split2_f16 (256: timing experiment without it)
+                    split2_f16(w, b1, b2);
+                    W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b2;          // (W3 unused)
+                } else {
+                    __bf16 b1, b2, b3;
+                    split3(w, b1, b2, b3);
+                    W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b3;
+                }
             }
 
     // per-lane byte offsets, computed once; the per-step part of every address is uniform and advances on the SALU
@@ -116,12 +148,19 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
     const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16);     // A operand: tile row m = j holds batch row j >> 2
     auto publish_h = [&](int buf) {
-        unsigned p1, p2, p3;
-        split3_trunc(h, p1, p2, p3);
         char* base = hbuf + buf * BUFB + lds_pub;
-        *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
-        *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
-        *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+        if constexpr (F16) {
+            _Float16 h1, h2;
+            split2_f16(h, h1, h2);
+            *(_Float16*)(base) = h1;
+            *(_Float16*)(base + PLANEB) = h2;
+        } else {
+            unsigned p1, p2, p3;
+            split3_trunc(h, p1, p2, p3);
+            *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
+            *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
+            *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+        }
     };
     publish_h(0);
 
@@ -174,16 +213,16 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (PROF && tl && (t == 100 || t == 101)) tl[t == 100 ? 0 : 7] = p_ta;
         // ---- N1
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
-        bf16x8 hp[KB][3];
+        OPV hp[KB][3];
         int fl[2];
         auto load_half = [&](int half) {                          // counter first, then planes: the LDS keeps a wave's order
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 2 * half; kb < 2 * half + 2; ++kb) {
-                hp[kb][0] = *(const bf16x8*)(hb + kb * 64);
-                hp[kb][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
-                hp[kb][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+                hp[kb][0] = *(const OPV*)(hb + kb * 64);
+                hp[kb][1] = *(const OPV*)(hb + kb * 64 + PLANEB);
+                hp[kb][2] = NP == 3 ? *(const OPV*)(hb + kb * 64 + 2 * PLANEB) : hp[kb][1];
             }
         };
         auto ensure_half = [&](int half) {                        // the four producers of this half have published h_t
@@ -226,8 +265,35 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (PROF) { p_tb = clock64(); p_seg[0] += p_tb - p_ta; }
         // ---- M
-        f32x4 acc[G];
-#define X6P_TERM(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(HOP, WOP, acc[g]);
+        f32x4 acc[G], acl[G];                                     // acl: the low-order products of the fp16 form
+#define X6P_TERM(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = mfma16(HOP, WOP, acc[g]);
+#define X6P_TERL(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acl[g] = mfma16(HOP, WOP, acl[g]);
+        if constexpr (F16) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb == KB / 2 && RA) ensure_half(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (PROF && tl && t == 100) tl[1 + kb] = clock64();
+                if (kb == 0) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acl[g] = mfma16(hp[kb][1], W1[g][kb], f32x4{0.f, 0.f, 0.f, 0.f});
+                } else { X6P_TERL(hp[kb][1], W1[g][kb]) }
+                if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                X6P_TERL(hp[kb][0], W2[g][kb])
+                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (kb == 0) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W1[g][kb], biasv[g]);
+                } else { X6P_TERM(hp[kb][0], W1[g][kb]) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acl[g][0], 1.0f / F16_LO, acc[g][0]);
+        } else {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             if (kb == KB / 2 && RA) ensure_half(1);
@@ -235,7 +301,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             if (PROF && tl && t == 100) tl[1 + kb] = clock64();
             if (kb == 0) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(hp[kb][0], W3[g][kb], biasv[g]);
+                for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W3[g][kb], biasv[g]);
             } else { X6P_TERM(hp[kb][0], W3[g][kb]) }
             X6P_TERM(hp[kb][2], W1[g][kb])
             X6P_TERM(hp[kb][1], W2[g][kb])
@@ -254,7 +320,9 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             X6P_TERM(hp[kb][0], W1[g][kb])
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
 #undef X6P_TERM
+#undef X6P_TERL
         // MFMA D -> VALU read hazard: hipcc pads it inside a basic block (the accumulators are read right below); the
         // profiling build has branches in between and pads by hand (see rec_fwd_mfma)
         if (PROF) asm volatile("s_nop 15");
@@ -276,7 +344,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 hn = tanh_fast(x[0] + acc[0][0]);
             }
             if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; }            // uniform branch: no select while no row is masked
-            else h = t < mylen ? hn : h;
+            else { h = t < mylen ? hn : h; if (F16) asm volatile("" : "+v"(h)); }   // (pinned for split2_f16 either way)
         }
         if (t + 1 < tmax) {
             publish_h((t + 1) & 1);
@@ -562,8 +630,11 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool fuse = a.gX != nullptr;
-    if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true>)); }
-    else { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false>)); }
+    const char* fe = getenv("SBR_X6_F16");                         // read per launch: the tests flip it
+    const bool f16 = fe ? atoi(fe) != 0 : true;                    // forward products as fp16 x3 (see split2_f16)
+    if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, false>)); }
+    else if (f16) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, true>)); }
+    else { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, false>)); }
 #undef X6P_LAUNCH
     return hipGetLastError();
 }

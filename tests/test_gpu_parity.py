@@ -94,6 +94,24 @@ def test_pipelined_kernel_modes(cell, mode, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+def test_forward_chain_with_bf16x6_products(cell, monkeypatch):
+    # default (every other 128-wide GRU / Vanilla test): the forward chain's products as a 2-way fp16 split, 3 MFMAs
+    # (rec_fwd_x6p<.., F16>); SBR_X6_F16=0: the 3-way bf16 split, 6 MFMAs, as the backward chain and the GEMMs use
+    monkeypatch.setenv("SBR_X6_F16", "0")
+    check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
+    check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12, scale=0.05))
+
+
+def test_fp16_forward_products_keep_f32_accuracy_over_long_chains():
+    # the forward state after 200 dependent steps: as close to the float64 oracle as the bf16x6 / f32 kernels get
+    # (tolerances of the other tests), with weights up to |w| ~ 1.5 and initial states beyond 1
+    r = PU.compare_step("GRU", [128], "CCE", N=300, B=8, T=200, scale=0.2)
+    assert r["h_last"] < 5e-5 and r["grad_worst"] < 2e-4 and r["topk_mismatch"] == 0, r
+    r = PU.compare_step("GRU", [64, 128], "CCE", N=61, B=9, T=1, scale=0.3)      # the case that exposed a double rounding
+    assert r["h_last"] < 2e-6 and r["grad_worst"] < 3e-6, r
+
+
 @pytest.mark.parametrize("env", [("SBR_SWAP_TAIL", "0"), ("SBR_GEMM_SMALL_BELOW", "0")])
 def test_step_scheduling_switches(env, monkeypatch):
     # defaults (every other test): after the BPTT chain the main stream keeps dW_hid and the side stream takes the scatter
