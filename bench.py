@@ -209,7 +209,10 @@ def main():
         "config": {"workload": "%s: train.py -m RNN --r_t %s --r_l %s --max_length %d -b %d --loss %s --u_m adam, "
                                "N=%d items, Zipf(1.0) ids, lengths=%s, %d rows per GPU"
                                % (args.config, cell, "-".join(map(str, layers)), T, B, loss, n_items, args.lengths, B),
-                   "global_batch": Bg, "seq_len": T, "parallelism": "dp%d" % world, "last_cost": round(cost, 5)},
+                   "global_batch": Bg, "seq_len": T, "parallelism": "dp%d" % world, "last_cost": round(cost, 5),
+                   "arithmetic": "f32 tensors and accumulation; matrix products of f32 operands as exact splits on the bf16 / fp16 "
+                                 "matrix pipe (bf16x6: backward chain and GEMMs, fp16x3: forward chain of 128-unit GRU / Vanilla) "
+                                 "with f32-class error, DESIGN.md section 3"},
     }
 
     if rank == 0 and phases is not None:

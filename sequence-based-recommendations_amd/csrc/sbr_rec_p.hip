@@ -30,7 +30,9 @@
 //      instruction stores and counter updates, v_med3 clip, truncating bf16 split, one loop per role, no packed-f32
 //      (SLP) gate math, a uniform branch instead of a select while no row is masked.
 //
-// Measured at C2 (cycles per step, 2320 = MFMA issue): forward 3760 -> 2650, backward 4100 -> 3150.  Tried and
+//   5. Forward only: products as a 2-way fp16 split, three MFMAs instead of six (f16x3, see split2_f16 below): 228 -> 196 us.
+//
+// Measured at C2 (cycles per step, 2320 = MFMA issue of bf16x6): forward 3760 -> 2650 (-> 2250 with f16x3), backward 4100 -> 3150.  Tried and
 // rejected: all operands fetched before the MFMA phase by every wave (LDS burst, +35 us), a three-deep operand ring in
 // the backward (+15 us), a delay at the gate or a signal more than one MFMA term early (+5 .. +35 us; one term early is what runs, -4 us), splitting the backward over K instead
 // of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
