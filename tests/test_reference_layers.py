@@ -35,7 +35,7 @@ def test_fixtures_cover_every_cell_and_head():
         z = np.load(path)
         seen.add((str(z["cell"]), str(z["loss"])))
     assert {c for c, _ in seen} == {"GRU", "LSTM", "Vanilla"} and {l for _, l in seen} == {"CCE", "Blackout", "BPR", "TOP1"}
-    assert len(GOLD) >= 16
+    assert len(GOLD) >= 19
     assert sum(float(np.load(p)["clip_changes"]) > 0.5 for p in GOLD) >= 4        # cases where the gradient clip decides the result
 
 

@@ -42,6 +42,11 @@ CASES = {
     "gru12_cce_reg": ("GRU", 12, "CCE", 35, 6, 7, 0, 1, 0, False, ["-r", "0.05"]),
     "vanilla10_cce_l1": ("Vanilla", 10, "CCE", 35, 6, 7, 0, 1, 0, False, ["-r", "-0.05"]),          # negative -r: L1 on the bias
     "lstm8_top1_ri": ("LSTM", 8, "TOP1", 30, 5, 6, 4, 1, 0, False, ["--repeated_interactions"]),     # nothing excluded at test time
+    # the widths of the benchmark kernels (rec_*_x6p with fp16 / bf16 split products, rec_*_x6s): scale 0.1 keeps 128-wide
+    # layers well conditioned
+    "gru128_cce": ("GRU", 128, "CCE", 30, 6, 8, 0, 1, 0, False, []),
+    "vanilla128_blackout": ("Vanilla", 128, "Blackout", 30, 5, 7, 4, 1, 0, False, []),
+    "lstm128_cce": ("LSTM", 128, "CCE", 30, 5, 6, 0, 1, 0, False, []),
     # targets with a tiny popularity weight -> gate gradients far beyond the clip at 100 (recurrent_layers.py:18): it bites
     "gru12_cce_clip": ("GRU", 12, "CCE", 35, 6, 8, 0, 1, 0, False, []),
     "lstm8_cce_clip": ("LSTM", 8, "CCE", 35, 6, 8, 0, 1, 0, False, []),
@@ -75,7 +80,7 @@ def main():
     for name, (cell, H, loss, N, B, T, S, F, n_opt, bi, extra) in CASES.items():
         seed = sum(map(ord, name))
         params, cfg, batch = PU.build_case(cell, [H], loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, bi=bi,
-                                           popscale=POPSCALE.get(name, 1.0))
+                                           popscale=POPSCALE.get(name, 1.0), scale=0.1 if H >= 128 else None)
         if loss != "CCE":
             assert len(batch["samples"]) == S
         def predictor():
