@@ -30,9 +30,9 @@
 //      instruction stores and counter updates, v_med3 clip, truncating bf16 split, one loop per role, no packed-f32
 //      (SLP) gate math, a uniform branch instead of a select while no row is masked.
 //
-//   5. Forward only: products as a 2-way fp16 split, three MFMAs instead of six (f16x3, see split2_f16 below): 228 -> 196 us.
+//   5. Forward only: products as a 2-way fp16 split, three MFMAs instead of six (f16x3, see split2_f16 below): 228 -> 175 us.
 //
-// Measured at C2 (cycles per step, 2320 = MFMA issue of bf16x6): forward 3760 -> 2650 (-> 2250 with f16x3), backward 4100 -> 3150.  Tried and
+// Measured at C2 (cycles per step, 2320 = MFMA issue of bf16x6): forward 3760 -> 2650 (-> 2000 with f16x3), backward 4100 -> 3150.  Tried and
 // rejected: all operands fetched before the MFMA phase by every wave (LDS burst, +35 us), a three-deep operand ring in
 // the backward (+15 us), a delay at the gate or a signal more than one MFMA term early (+5 .. +35 us; one term early is what runs, -4 us), splitting the backward over K instead
 // of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 float w = sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + u];
                 if constexpr (F16) {
                     _Float16 b1, b2;
-                    if (!(X6P_DBG & 256)) asm volatile("" : "+v"(w));   // see split2_f16 (256: timing experiment without it)
+                    if (!(X6P_DBG & 256)) asm("" : "+v"(w));            // see split2_f16.  NOT volatile: volatile asms keep their order and
+                                                                        // serialised the 96 loads of this prologue (+20 us per launch)
                     split2_f16(w, b1, b2);
                     W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b2;          // (W3 unused)
                 } else {
@@ -145,6 +146,11 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const unsigned bo_id = (unsigned)(row * T) * 4u;                                           // ids of this row
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;                      // bytes per time step
 
+    // X6P_DBG 1024 / 2048 / 512: values kept alive across the kernel only to move the operand tuples to other registers
+    // (same instructions, see DESIGN.md: 177 vs 198 us between two register assignments)
+    double dbg_pair = 0.0; float dbg_one = 0.f;
+    if (X6P_DBG & 1024) { dbg_pair = (double)blockIdx.x; asm volatile("" : "+v"(dbg_pair)); }
+    if (X6P_DBG & 2048) { dbg_one = (float)blockIdx.x; asm volatile("" : "+v"(dbg_one)); }
     float h = a.hinit[u];
     stf(a.hs, bo_h, h);
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
@@ -210,6 +216,10 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     // of them between MFMAs, and values defined under it get copies at the join (see sbr_rec_cl.hip).
     auto steps = [&](auto role_tag) {
     constexpr bool RA = decltype(role_tag)::value;
+    // X6P_DBG 4096 / 8192 / 16384: position of the loop in the instruction stream (256-byte boundary, + 32, + 64 bytes)
+    if (X6P_DBG & 4096) asm volatile(".p2align 8");
+    if (X6P_DBG & 8192) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
+    if (X6P_DBG & 16384) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
     for (int t = 0; t < tmax; ++t) {
         if (PROF) p_ta = clock64();
         if (PROF && tl && (t == 100 || t == 101)) tl[t == 100 ? 0 : 7] = p_ta;
@@ -370,6 +380,9 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         stf((char*)a.hs + off_t + st_h, bo_h, h);
         off_t += st_h;
     }
+    if ((X6P_DBG & 512) && T < 0) a.fault[1] = (int)threadIdx.x;  // keeps the live-in v0 where it is
+    if (X6P_DBG & 1024) asm volatile("" :: "v"(dbg_pair));
+    if (X6P_DBG & 2048) asm volatile("" :: "v"(dbg_one));
     if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         const unsigned long long tot = clock64() - p_c0;
