@@ -278,3 +278,21 @@ def test_native_batch_plan_rejects_bad_arguments(lib):
         plan_pass_host([5, 6], [0, 7], 4, lib=lib)            # user id out of range
     seg, nb, pend = plan_pass_host([1, 2, 2], None, 4, lib=lib)    # nothing long enough: no rows at all
     assert len(seg) == 0 and nb == 0 and pend == []
+
+
+def test_bench_initial_parameters_follow_the_init_law():
+    # bench.py draws its own random-init weights (the oracle is only its cpu_baseline leg): same zero / non-zero pattern and
+    # scales as the oracle's Lasagne-law initialiser, for every cell and for stacked layers
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for cell, layers in (("GRU", [128]), ("LSTM", [20]), ("Vanilla", [8]), ("LSTM", [512, 512])):
+        N = 50
+        ref = O.init_params(cell, layers, N, np.random.default_rng(0), dtype=np.float32)
+        got = bench.initial_parameters([p.shape for p in ref], cell, np.random.default_rng(1))
+        assert [g.shape for g in got] == [p.shape for p in ref] and all(g.dtype == np.float32 for g in got)
+        for a, b in zip(got, ref):
+            assert (np.abs(a).max() > 0) == (np.abs(b).max() > 0)
+            if np.abs(b).max() > 0 and b.size > 500:
+                assert 0.7 < a.std() / b.std() < 1.4
