@@ -296,3 +296,25 @@ def test_bench_initial_parameters_follow_the_init_law():
             assert (np.abs(a).max() > 0) == (np.abs(b).max() > 0)
             if np.abs(b).max() > 0 and b.size > 500:
                 assert 0.7 < a.std() / b.std() < 1.4
+
+
+def test_documented_switches_exist_in_the_sources():
+    # every SBR_* switch README.md names is read somewhere in the package sources, and every getenv("SBR_...") of the
+    # library is documented (README.md, or DESIGN.md for the experiment-only ones)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    readme = open(os.path.join(root, "README.md")).read()
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    pkg = os.path.join(root, "sequence-based-recommendations_amd")
+    src = ""
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".hip", ".h", ".py")):
+                src += open(os.path.join(d, f)).read()
+    src += open(os.path.join(root, "include", "sbr_rnn.h")).read()
+    named = set(re.findall(r"`(SBR_[A-Z0-9_]+)", readme))
+    assert len(named) >= 15
+    for n in sorted(named):
+        assert n in src, n + " is documented but nothing reads it"
+    read = set(re.findall(r'getenv\("(SBR_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ\.get\("(SBR_[A-Z0-9_]+)"', src))
+    for n in sorted(read):
+        assert n in readme or n in design, n + " is read but not documented"
