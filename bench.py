@@ -64,23 +64,11 @@ def synth_batches(n_batches, B, T, n_items, n_samples, lengths_mode, seed):
     return out
 
 
-def initial_parameters(shapes, cell, rng):
-    """Random-init weights of the architecture, in the engine's parameter order (= Lasagne's get_all_param_values order):
-    gate weights and peepholes Normal(std 0.1), biases and initial states 0, output W GlorotUniform, output b 0 -- the
-    initialisers the reference's layers name (sparse_lstm.py:143-171, rnn_one_hot.py:65)."""
-    per_layer, n_gate = {"LSTM": (17, 12), "GRU": (10, 9), "Vanilla": (4, 3)}[cell]
-    last = len(shapes) - 2
-    out = []
-    for i, shp in enumerate(shapes):
-        k = i % per_layer
-        if i == last:
-            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
-            out.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
-        elif i < last and ((k < n_gate and k % 3 != 2) or (cell == "LSTM" and 12 <= k < 15)):
-            out.append(rng.normal(0.0, 0.1, size=shp).astype(np.float32))
-        else:
-            out.append(np.zeros(shp, dtype=np.float32))
-    return out
+def initial_parameters(cfg, rng):
+    """Random-init weights of the architecture, in the engine's parameter order (= Lasagne's get_all_param_values order), by
+    the initialisers the reference's layers name (engine.initial_values; sparse_lstm.py:143-171, rnn_one_hot.py:65)."""
+    from sbr_amd.engine import describe_params, initial_values
+    return initial_values(describe_params(cfg), rng)
 
 
 def main():
@@ -126,7 +114,7 @@ def main():
     Bg = B * world
     eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=Bg, local_batch=B,
                     row_offset=rank * B, loss=loss, n_samples=n_samples, updater="adam", learning_rate=1e-3)
-    params = initial_parameters(eng.param_shapes, cell, np.random.default_rng(42))
+    params = initial_parameters(eng.cfg, np.random.default_rng(42))
     eng.set_all_param_values(params)
 
     # synthetic batches, resident in HBM before the timed region

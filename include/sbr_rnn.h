@@ -98,6 +98,11 @@ void sbr_destroy(sbr_handle* h);
  * out.W (H,N), out.b (N,)  (sparse_lstm.py:240-279, :660-676). */
 int sbr_num_params(const sbr_handle* h);
 int sbr_param_shape(const sbr_handle* h, int i, int64_t dims[2], int* ndim);
+/* Name and shape of array i of that list for a configuration -- host only, no device or handle needed (tooling: which
+ * arrays are weights / biases / initial states, for the init laws of the Lasagne layers).  "l0.W_in_to_ingate", "emb.W",
+ * "out.W" ...; a Vanilla layer with dense input is the stock RecurrentLayer and lists hid_init, input_to_hidden.W,
+ * input_to_hidden.b, hidden_to_hidden.W (recurrent_layers.py:94-104).  i past the end: SBR_EINVAL. */
+int sbr_describe_param(const sbr_config* cfg, int i, char* name, size_t name_cap, int64_t dims[2], int* ndim);
 int sbr_set_params(sbr_handle* h, int n, const float* const* host_arrays);
 int sbr_get_params(sbr_handle* h, int n, float* const* host_arrays);
 /* Same layout, gradients of the last forward/backward (parity tests). */
@@ -152,7 +157,8 @@ int sbr_join_side(sbr_handle* h);
 int sbr_predict_scores(sbr_handle* h, int probs, float* out_host);
 /* test_function(theano_inputs, k) (rnn_base.py:196-211): ordered top-k ids per row of
  * softmax * (1 - exclude) where exclude = the row's own input items when exclude_seen
- * (interactions_are_unique, rnn_base.py:200-201).  Ties break to the lowest id. */
+ * (interactions_are_unique, rnn_base.py:200-201).  Ties break to the lowest id.  A row with fewer than k rankable items
+ * (more than N - k items excluded, or NaN scores) gets -1 in the places it cannot fill. */
 int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_host);
 
 /* The dense GEMM of the hot path on caller-provided DEVICE buffers (parity tests of the kernels themselves):

@@ -52,13 +52,20 @@ def _clip(x):
 # --------------------------------------------------------------------------------------
 # Parameter creation (Lasagne init laws [3P]; order = get_all_param_values)
 # --------------------------------------------------------------------------------------
-def recurrent_param_shapes(cell, n_in, H):
+def recurrent_param_shapes(cell, n_in, H, dense=False):
     """Per-layer parameter (name, shape) list in Lasagne creation order.
 
     LSTM: sparse_lstm.py:240-279 (ingate, forgetgate, cell, outgate triples, then the
     three peepholes, cell_init, hid_init).  GRU: sparse_lstm.py:660-676 (updategate,
     resetgate, hidden_update triples, hid_init).  Vanilla: sparse_lstm.py:1030-1042.
+    dense=True: the layer is a stock Lasagne layer over a dense input (recurrent_layers.py:94-104: every layer above
+    layer 0, and layer 0 behind --r_emb).  LSTMLayer / GRULayer create their parameters in the order above [3P];
+    RecurrentLayer (= CustomRecurrentLayer over two DenseLayers) lists its own parameter first, then the children's:
+    hid_init, input_to_hidden.W, input_to_hidden.b, hidden_to_hidden.W [3P] (names kept in this file's spelling).
     """
+    if cell == "Vanilla" and dense:
+        return [("hid_init", (1, H)), ("W_in_to_hidden_update", (n_in, H)), ("b_hidden_update", (H,)),
+                ("W_hid_to_hidden_update", (H, H))]
     if cell == "LSTM":
         names = []
         for g in ("ingate", "forgetgate", "cell", "outgate"):
@@ -97,7 +104,7 @@ def model_param_shapes(cell, layers, n_items, n_in0=None, embedding=0, n_feat=1,
         # feature axis; parameters of the forward layer come first
         for d in range(D):
             tag = "l%d." % li if D == 1 else "l%d%s." % (li, "fb"[d])
-            for name, shp in recurrent_param_shapes(cell, n_in, H):
+            for name, shp in recurrent_param_shapes(cell, n_in, H, dense=(li > 0 or embedding > 0)):
                 shapes.append((tag + name, shp))
         n_in = D * H
     shapes += [("out.W", (D * layers[-1], n_items)), ("out.b", (n_items,))]
@@ -108,11 +115,15 @@ def init_params(cell, layers, n_items, rng, n_in0=None, last_layer_init=1.0, dty
                 bidirectional=False):
     """Lasagne default initialisers [3P]: Gate W_in/W_hid/W_cell Normal(std=0.1),
     b Constant(0), cell_init/hid_init Constant(0) (sparse_lstm.py:156-162); output W
-    GlorotUniform(gain) = U(+-gain*sqrt(6/(fan_in+fan_out))), b 0 (rnn_sampling.py:131)."""
+    GlorotUniform(gain) = U(+-gain*sqrt(6/(fan_in+fan_out))), b 0 (rnn_sampling.py:131); the stock RecurrentLayer
+    (dense Vanilla layers) draws W_in_to_hid / W_hid_to_hid from init.Uniform() = U(-0.01, 0.01) [3P]."""
     out = []
     for name, shp in model_param_shapes(cell, layers, n_items, n_in0, embedding, n_feat, bidirectional):
         base = name.split(".")[1]
-        if name == "emb.W":
+        level = 0 if name in ("emb.W", "out.W", "out.b") else int(name.split(".")[0][1:].rstrip("fb"))
+        if cell == "Vanilla" and base.startswith("W_") and name[0] == "l" and (level > 0 or embedding > 0):
+            a = rng.uniform(-0.01, 0.01, size=shp)
+        elif name == "emb.W":
             a = rng.normal(0.0, 0.01, size=shp)          # lasagne EmbeddingLayer default W=init.Normal() (std 0.01) [3P]
         elif name == "out.W":
             lim = last_layer_init * np.sqrt(6.0 / (shp[0] + shp[1]))
@@ -130,9 +141,9 @@ def split_params(params, cell, layers, embedding=0, bidirectional=False):
     extra FIRST entry (params[0]); with --r_bi every layer contributes two dicts (forward, backwards)."""
     per = []
     pos = 1 if embedding else 0
-    for H in layers:
+    for li, H in enumerate(layers):
         for _ in range(2 if bidirectional else 1):
-            names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
+            names = [n for n, _ in recurrent_param_shapes(cell, 1, H, dense=(li > 0 or embedding > 0))]
             per.append(dict(zip(names, params[pos:pos + len(names)])))
             pos += len(names)
     W_out, b_out = params[pos], params[pos + 1]
@@ -171,8 +182,11 @@ def input_projection(layer, cell, inp, index_input):
     return np.transpose(x, (1, 0, 2))              # dimshuffle(1,0,2): sparse_lstm.py:343
 
 
-def recurrent_forward(layer, cell, xt, mask):
+def recurrent_forward(layer, cell, xt, mask, relu=False):
     """Scan over T (sparse_lstm.py:474-481 LSTM, :843-850 GRU, :1190-1197 Vanilla).
+    relu (dense Vanilla layers only): the stock lasagne RecurrentLayer's default nonlinearity is rectify, where the
+    reference's own VanillaLayerOHEInput uses tanh (sparse_lstm.py:1015); its step clips the gradient of the summed
+    pre-activation once [3P] -- the same gradient as the three clips of the index-input layer (clip is idempotent).
 
     xt (T,B,G*H) precomputed input; mask (B,T).  Returns hid_out (T,B,H) and a cache.
     Masked steps copy the previous state (sparse_lstm.py:417-425, :798-805, :1145-1152).
@@ -183,7 +197,7 @@ def recurrent_forward(layer, cell, xt, mask):
     m = np.transpose(mask, (1, 0)).astype(bool)    # (T,B)
     h = np.repeat(layer["hid_init"], B, axis=0)    # T.dot(ones, hid_init): :438-445
     hs = np.zeros((T + 1, B, H)); hs[0] = h
-    cache = {"cell": cell, "xt": xt, "m": m, "hs": hs}
+    cache = {"cell": cell, "xt": xt, "m": m, "hs": hs, "relu": relu}
     if cell == "LSTM":
         c = np.repeat(layer["cell_init"], B, axis=0)
         cs = np.zeros((T + 1, B, H)); cs[0] = c
@@ -219,7 +233,8 @@ def recurrent_forward(layer, cell, xt, mask):
     else:  # Vanilla
         hn = np.zeros((T, B, H))
         for t in range(T):
-            h_new = np.tanh(xt[t] + h @ W_hid)                       # :1122-1143
+            pre = xt[t] + h @ W_hid                                  # :1122-1143
+            h_new = np.maximum(pre, 0.0) if relu else np.tanh(pre)
             hn[t] = h_new
             h = np.where(m[t][:, None], h_new, h)                    # :1150
             hs[t + 1] = h
@@ -293,7 +308,7 @@ def recurrent_backward(layer, cell, cache, dhid_out):
             mt = m[t][:, None]
             hn = cache["hn"][t]
             dh_new = np.where(mt, dh, 0.0); dh_pass = np.where(mt, 0.0, dh)
-            dq = _clip(dh_new * (1 - hn * hn))
+            dq = _clip(dh_new * ((hn > 0) if cache.get("relu") else (1 - hn * hn)))
             dxi = _clip(dq); dhi = _clip(dq)
             dW_hid += hs[t].T @ dhi
             dxt[t] = dxi
@@ -330,7 +345,7 @@ def layer_grads_to_list(layer, cell, inp, index_input, bw):
         g["W_cell_to_ingate"] = bw["dp_i"]; g["W_cell_to_forgetgate"] = bw["dp_f"]
         g["W_cell_to_outgate"] = bw["dp_o"]; g["cell_init"] = bw["dcell_init"]
     g["hid_init"] = bw["dhid_init"]
-    names = [n for n, _ in recurrent_param_shapes(cell, 1, H)]
+    names = [n for n, _ in recurrent_param_shapes(cell, 1, H, dense=not index_input)]
     return [g[n] for n in names], d_inp
 
 
@@ -360,7 +375,7 @@ def network_forward(params, cell, layers, X, mask, embedding=0, bidirectional=Fa
             layer = per[li * D + d]
             src, m = (inp, mask) if d == 0 else (inp[:, ::-1], mask[:, ::-1])
             xt = input_projection(layer, cell, src, index_input=index_input)
-            hid, cache = recurrent_forward(layer, cell, xt, m)
+            hid, cache = recurrent_forward(layer, cell, xt, m, relu=(cell == "Vanilla" and not index_input))
             cache["inp"] = src
             caches.append(cache)
             finals.append(cache["hs"][-1])

@@ -77,11 +77,16 @@ def layer_forward(layer, cell, inp, mask, index_input):
             h_new = (1 - u) * h + u * torch.tanh(q)
             h = torch.where(m[t], h_new, h)
             outs.append(h)
-    else:
+    elif index_input:
         for t in range(T):
             hi = grad_clip(h @ W_hid)
             xi = grad_clip(x[t])
             h_new = torch.tanh(grad_clip(xi + hi))
+            h = torch.where(m[t], h_new, h)
+            outs.append(h)
+    else:       # stock lasagne RecurrentLayer (recurrent_layers.py:94-104): hid_pre = hid.W_hid + input_n, one grad_clip,
+        for t in range(T):                              # default nonlinearity rectify [3P]
+            h_new = torch.relu(grad_clip(h @ W_hid + x[t]))
             h = torch.where(m[t], h_new, h)
             outs.append(h)
     return torch.stack(outs, dim=0)
@@ -89,9 +94,9 @@ def layer_forward(layer, cell, inp, mask, index_input):
 
 def split_params(params, cell, layers, names_fn, embedding=0, bidirectional=False):
     per, pos = [], (1 if embedding else 0)
-    for H in layers:
+    for li, H in enumerate(layers):
         for _ in range(2 if bidirectional else 1):
-            names = [n for n, _ in names_fn(cell, 1, H)]
+            names = [n for n, _ in names_fn(cell, 1, H, dense=(li > 0 or embedding > 0))]
             per.append(dict(zip(names, params[pos:pos + len(names)])))
             pos += len(names)
     return per, params[pos], params[pos + 1]

@@ -163,6 +163,15 @@ void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out) {
         char pre[16];
         if (lay.D == 1) snprintf(pre, sizeof(pre), "l%d.", pl);
         else snprintf(pre, sizeof(pre), "l%d%c.", pl / 2, "fb"[pl & 1]);
+        if (cell == SBR_CELL_VANILLA && (pl / lay.D > 0 || lay.E)) {
+            // dense input: stock lasagne RecurrentLayer = CustomRecurrentLayer over two DenseLayers, whose get_params lists
+            // its own parameter first and then the children's (recurrent_layers.py:94-104 [3P])
+            out.push_back({std::string(pre) + "hid_init", l, 5, 0, 1, y.H, 2});
+            out.push_back({std::string(pre) + "input_to_hidden.W", l, 0, 0, y.n_in, y.H, 2});
+            out.push_back({std::string(pre) + "input_to_hidden.b", l, 2, 0, y.H, 1, 1});
+            out.push_back({std::string(pre) + "hidden_to_hidden.W", l, 1, 0, y.H, y.H, 2});
+            continue;
+        }
         for (int g = 0; g < lay.G; ++g) {
             out.push_back({std::string(pre) + "W_in_to_" + gn[g], l, 0, g, y.n_in, y.H, 2});
             out.push_back({std::string(pre) + "W_hid_to_" + gn[g], l, 1, g, y.H, y.H, 2});
@@ -350,6 +359,19 @@ extern "C" int sbr_param_shape(const sbr_handle* h, int i, int64_t dims[2], int*
     return SBR_OK;
 }
 
+extern "C" int sbr_describe_param(const sbr_config* cfg, int i, char* name, size_t name_cap, int64_t dims[2], int* ndim) {
+    CHECK_ARG(cfg && dims && ndim, "null argument");
+    Layout lay; std::string err;
+    if (sbr_build_layout(*cfg, lay, err) != SBR_OK) { sbr_set_error("%s", err.c_str()); return SBR_EINVAL; }
+    std::vector<ParamDesc> descs;
+    sbr_param_descs(lay, descs);
+    CHECK_ARG(i >= 0 && i < (int)descs.size(), "parameter index %d outside [0,%d)", i, (int)descs.size());
+    const ParamDesc& d = descs[i];
+    if (name && name_cap) snprintf(name, name_cap, "%s", d.name.c_str());
+    dims[0] = d.d0; dims[1] = d.ndim == 2 ? d.d1 : 1; *ndim = d.ndim;
+    return SBR_OK;
+}
+
 extern "C" int sbr_set_params(sbr_handle* h, int n, const float* const* arrays) {
     CHECK_ARG(h && arrays && n == (int)h->descs.size(), "expected %d parameter arrays, got %d", h ? (int)h->descs.size() : -1, n);
     std::vector<float> image(h->lay.n_params, 0.0f);     // padding stays exactly zero
@@ -456,6 +478,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.prof = (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) : nullptr;
     a.cluster = h->cluster; a.cl_linear = h->cl_linear; a.fault = (int*)h->A(y.a_fault);
     a.clx = (int*)h->A(y.a_clx); a.epoch = (++h->cl_epoch) & 0x07FFFFFF;
+    a.relu = (y.cfg.cell == SBR_CELL_VANILLA && (l / y.D > 0 || y.E)) ? 1 : 0;   // stock RecurrentLayer: rectify [3P]
     return a;
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
@@ -949,18 +972,28 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     return SBR_OK;
 }
 
-extern "C" int sbr_read_cost(sbr_handle* h, float* cost_host) {
-    CHECK_ARG(h && cost_host, "null argument");
-    SBR_HIP(hipMemcpyAsync(cost_host, h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
+// The recurrent kernels' bounded spin-waits raise a flag instead of hanging the GPU.  Every call that hands results to the
+// host checks it (training: with the cost; inference: with the ids / scores) and CLEARS it, so that one timeout fails
+// the call it belongs to and not every later call of the handle.
+static int report_fault(sbr_handle* h, int fault) {
+    if (!fault) return SBR_OK;
+    (void)hipMemsetAsync(h->A(h->lay.a_fault), 0, sizeof(int), h->stream);
+    // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip)
+    sbr_set_error("a bounded wait inside the recurrent kernels gave up (flag %d, results of this call invalid); rerun with %s", fault,
+                  (fault & 1) ? "SBR_CLUSTER=0" : "SBR_X6_PIPE=0");
+    return SBR_EHIP;
+}
+static int check_fault(sbr_handle* h) {        // synchronises the stream
     int fault = 0;
     SBR_HIP(hipMemcpyAsync(&fault, h->A(h->lay.a_fault), sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SBR_HIP(hipStreamSynchronize(h->stream));
-    if (fault) {   // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip)
-        sbr_set_error("a bounded wait inside the recurrent kernels gave up (flag %d, results invalid); rerun with %s", fault,
-                      (fault & 1) ? "SBR_CLUSTER=0" : "SBR_X6_PIPE=0");
-        return SBR_EHIP;
-    }
-    return SBR_OK;
+    return report_fault(h, fault);
+}
+
+extern "C" int sbr_read_cost(sbr_handle* h, float* cost_host) {
+    CHECK_ARG(h && cost_host, "null argument");
+    SBR_HIP(hipMemcpyAsync(cost_host, h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return check_fault(h);
 }
 
 extern "C" int sbr_train_step(sbr_handle* h, float* cost_host) {
@@ -991,12 +1024,7 @@ static int lagged_collect(sbr_handle* h, float* cost, int* have) {
     *have = 1;
     int fault = 0;
     memcpy(&fault, &h->lag_host[2 + s], sizeof(int));
-    if (fault) {
-        sbr_set_error("a bounded wait inside the recurrent kernels gave up (flag %d, results invalid); rerun with %s", fault,
-                      (fault & 1) ? "SBR_CLUSTER=0" : "SBR_X6_PIPE=0");
-        return SBR_EHIP;
-    }
-    return SBR_OK;
+    return report_fault(h, fault);
 }
 
 extern "C" int sbr_train_step_lagged(sbr_handle* h, float* prev_cost, int* have_prev) {
@@ -1043,7 +1071,7 @@ extern "C" int sbr_predict_scores(sbr_handle* h, int probs, float* out_host) {
     if (rc != SBR_OK) return rc;
     if (out_host) {
         SBR_HIP(hipMemcpyAsync(out_host, h->A(y.a_logits), (size_t)h->n_rows * y.N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        SBR_HIP(hipStreamSynchronize(h->stream));
+        return check_fault(h);      // a forward that gave up must not hand out scores
     }
     return SBR_OK;
 }
@@ -1063,8 +1091,7 @@ extern "C" int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_hos
     int* ids = (int*)h->A(y.a_topk);
     SBR_LAUNCH(launch_topk(h->stream, lg, h->n_rows, y.N, k, ids));
     SBR_HIP(hipMemcpyAsync(ids_host, ids, (size_t)h->n_rows * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    SBR_HIP(hipStreamSynchronize(h->stream));
-    return SBR_OK;
+    return check_fault(h);          // ... nor rankings (test.py, validation)
 }
 
 // ---------------------------------------------------------------------------------------

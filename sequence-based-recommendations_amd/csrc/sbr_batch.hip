@@ -81,7 +81,9 @@ __global__ void __launch_bounds__(256) bb_split_kernel(const long long* __restri
     const int s = seg_begin + blockIdx.x, tid = threadIdx.x;
     const int user = seg_user[s], k = seg_k[s], row0 = seg_row0[s];
     const int n = (int)(off[user + 1] - off[user]) - 2;
-    const unsigned long long sd = seed ^ mix64(0x5EEDull + (unsigned long long)user);
+    // the segment's first row is part of the seed: a user who owns two segments of one batch (the carried tail of the previous
+    // pass meeting the same user in the new pass) draws independent split points for each, as random.sample does
+    const unsigned long long sd = seed ^ mix64(0x5EEDull + (unsigned long long)user) ^ mix64(0xB0Bull + ((unsigned long long)(unsigned)row0 << 20));
     if (tid == 0) { s_prefix = 0; s_mask = 0; s_remaining = k; }
     __syncthreads();
     if (k < n) {

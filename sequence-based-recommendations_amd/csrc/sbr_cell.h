@@ -35,9 +35,12 @@ template <int CELL> struct Gates { static constexpr int G = CELL == CELL_LSTM ? 
 // ---------------------------------------------------------------------------------------
 // Forward: a[g] = (h_prev . W_hid)[g], x[g] = xt[g].  Updates h/c in place (masked rows copy),
 // writes the values saved for BPTT into sv[0..3].
+// relu (Vanilla only): the layer is a stock lasagne RecurrentLayer (dense input: every Vanilla layer above layer 0 and
+// layer 0 behind --r_emb, recurrent_layers.py:94-104), whose default nonlinearity is rectify [3P]; the reference's own
+// index-input VanillaLayerOHEInput uses tanh (sparse_lstm.py:1015).
 template <int CELL, bool FAST = false>
 __device__ __forceinline__ void cell_forward(const float* x, const float* a, bool m, float& h, float& c,
-                                             float pi, float pf, float po, float* sv) {
+                                             float pi, float pf, float po, float* sv, bool relu = false) {
     if (CELL == CELL_LSTM) {
         float i = sg<FAST>(x[0] + a[0] + c * pi);             // sparse_lstm.py:397-402
         float f = sg<FAST>(x[1] + a[1] + c * pf);
@@ -55,7 +58,8 @@ __device__ __forceinline__ void cell_forward(const float* x, const float* a, boo
         sv[0] = r; sv[1] = u; sv[2] = cc; sv[3] = a[2];
         h = m ? hn : h;                                       // :803
     } else {
-        float hn = th<FAST>(x[0] + a[0]);                     // :1133-1143
+        const float pre = x[0] + a[0];
+        float hn = relu ? fmaxf(pre, 0.0f) : th<FAST>(pre);   // :1133-1143
         h = m ? hn : h;                                       // :1150
     }
 }
@@ -66,7 +70,7 @@ __device__ __forceinline__ void cell_forward(const float* x, const float* a, boo
 template <int CELL, bool FAST = false>
 __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, float& dc, const float* sv, float hprev,
                                               float cprev, float cnew, float hnew, float pi, float pf, float po,
-                                              float* dxi, float* dhi, float* dpeep) {
+                                              float* dxi, float* dhi, float* dpeep, bool relu = false) {
     float dhn = m ? dh : 0.0f, dhp = m ? 0.0f : dh;
     const float ce = clip_bound(clip);
 #define CLIP(X) clipb<FAST>(X, clip, ce)
@@ -94,7 +98,7 @@ __device__ __forceinline__ void cell_backward(bool m, float clip, float& dh, flo
         dhi[0] = dxi[0]; dhi[1] = dxi[1]; dhi[2] = CLIP(dq * r);
         dh = dhp + dhn * (1.0f - u);
     } else {
-        float dq = CLIP(dhn * (1.0f - hnew * hnew));
+        float dq = CLIP(dhn * (relu ? (hnew > 0.0f ? 1.0f : 0.0f) : (1.0f - hnew * hnew)));
         dxi[0] = dhi[0] = CLIP(dq);
         dh = dhp;
     }

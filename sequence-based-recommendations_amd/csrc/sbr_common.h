@@ -227,6 +227,7 @@ struct RecArgs {
     int sentinel_done;      // the backward exchange arrays were already filled with the sentinel (side stream)
     int* clx;               // [tiles][C] start-of-launch handshake: (epoch << 4) | XCC id of every member
     int epoch;              // unique per launch (clx is never cleared)
+    int relu;               // Vanilla layers with dense input = stock lasagne RecurrentLayer: rectify instead of tanh (sbr_cell.h)
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
 bool sbr_rec_cluster_ok(const RecArgs& a);

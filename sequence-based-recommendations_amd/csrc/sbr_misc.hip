@@ -749,7 +749,10 @@ hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const
     return hipGetLastError();
 }
 
-// k rounds of arg-max per row; ties -> lowest id; destroys the row (winners set to -inf)
+// k rounds of arg-max per row; ties -> lowest id; destroys the row (winners set to -inf).  Only finite scores and +inf are
+// candidates (NaN never wins a comparison and -inf is an excluded or already emitted item): when a row runs out of
+// candidates -- a user who has seen more than N - k items with exclude_seen, or NaN scores -- the remaining places are
+// filled with -1 instead of re-emitting an excluded id or an out-of-range one.
 __global__ void __launch_bounds__(256) topk_kernel(float* __restrict__ scores, int N, int k, int* __restrict__ ids) {
     __shared__ float rv[4];
     __shared__ int ri[4];
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(256) topk_kernel(float* __restrict__ scores, i
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int n = threadIdx.x; n < N; n += 256) {
             const float v = x[n];
-            if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+            if (v > bv || (v == bv && n < bi && v > -INFINITY)) { bv = v; bi = n; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -771,7 +774,7 @@ __global__ void __launch_bounds__(256) topk_kernel(float* __restrict__ scores, i
         if (threadIdx.x == 0) {
             for (int w = 1; w < 4; ++w)
                 if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-            ids[(size_t)blockIdx.x * k + it] = bi;
+            ids[(size_t)blockIdx.x * k + it] = bi < N ? bi : -1;
             if (bi < N) x[bi] = -INFINITY;
         }
         __syncthreads();

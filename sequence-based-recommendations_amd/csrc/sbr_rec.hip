@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_fwd_mfma(
 #pragma unroll
                     for (int g = 0; g < G; ++g) { xs[g] = x[n][g][e]; as[g] = acc[n][g][e]; }
                     float hh = h[n][e], cc = c[n][e];
-                    cell_forward<CELL, true>(xs, as, m, hh, cc, pi[n][e], pf[n][e], po[n][e], s);
+                    cell_forward<CELL, true>(xs, as, m, hh, cc, pi[n][e], pf[n][e], po[n][e], s, a.relu != 0);
                     h[n][e] = hh; c[n][e] = cc;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(KS_RES > 0 ? KS_RES * 16 : 1024) rec_bwd_mfma(
                 float dhh = dh[n][e], dcc = dc[n][e];
                 const float cpv = CELL == CELL_LSTM ? cur.cprev[n][e] : 0.f;
                 cell_backward<CELL, true>(m, clip, dhh, dcc, s, cur.hprev[n][e], cpv, cnew[n][e], hnew[n][e], pi[n][e],
-                                          pf[n][e], po[n][e], dxi, dhi, dp);
+                                          pf[n][e], po[n][e], dxi, dhi, dp, a.relu != 0);
                 dh[n][e] = dhh; dc[n][e] = dcc;
 #pragma unroll
                 for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[n][g][e] += dxi[g]; }
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(HP * 4) rec_fwd_x6(RecArgs a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) { xs[g] = x[g][e]; as[g] = acc[g][e]; }
                 float hh = h[e], cc = c[e];
-                cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
+                cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s, a.relu != 0);
                 h[e] = hh; c[e] = cc;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6(RecArgs a, int dbuf) {
                 float dhh = dh[e], dcc = dc[e];
                 const float cpv = CELL == CELL_LSTM ? cur.cprev[0][e] : 0.f;
                 cell_backward<CELL, true>(m, clip, dhh, dcc, s, cur.hprev[0][e], cpv, cnew[e], hnew[e], pi[e], pf[e], po[e],
-                                          dxi, dhi, dp);
+                                          dxi, dhi, dp, a.relu != 0);
                 dh[e] = dhh; dc[e] = dcc;
 #pragma unroll
                 for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[g][e] += dxi[g]; }
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(HP * 4 / NT) rec_fwd_x6s(RecArgs a) {
             float as[G], xb[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) { as[g] = pick4(acc[n][g], c); xb[g] = x[n][g] + bias[n][g]; }
-            cell_forward<CELL, true>(xb, as, t < mylen, h[n], cst[n], pi[n], pf[n], po[n], sv[n]);
+            cell_forward<CELL, true>(xb, as, t < mylen, h[n], cst[n], pi[n], pf[n], po[n], sv[n], a.relu != 0);
         }
         if (t + 1 < tmax) {
 #pragma unroll
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(HP * 4) rec_bwd_x6s(RecArgs a, int dbuf) {
         if (a.dh_ext) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
         char* lds = dbufp + (size_t)(dbuf ? (t & 1) : 0) * 3 * PLANEB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
-        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp);
+        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp, a.relu != 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
         sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2];
@@ -1195,7 +1195,7 @@ __global__ void rec_fwd_step_simple(RecArgs a, int t) {
     }
     float pi = 0.f, pf = 0.f, po = 0.f;
     if (CELL == CELL_LSTM) { pi = a.peep[k]; pf = a.peep[Hp + k]; po = a.peep[2 * Hp + k]; }
-    cell_forward<CELL>(x, acc, t < a.len[row], h, c, pi, pf, po, s);
+    cell_forward<CELL>(x, acc, t < a.len[row], h, c, pi, pf, po, s, a.relu != 0);
     if (CELL != CELL_VANILLA)
         for (int q = 0; q < 4; ++q) a.g[q][gate_index(t, row, k, Bp, Hp)] = s[q];
     a.hs[o1 + k] = h;
@@ -1220,7 +1220,7 @@ __global__ void rec_bwd_elem_simple(RecArgs a, int t, float* dhstate, float* dcs
     float cprev = 0.f, cnew = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
     if (CELL == CELL_LSTM) { cprev = a.cs[o0]; cnew = a.cs[o1]; pi = a.peep[k]; pf = a.peep[Hp + k]; po = a.peep[2 * Hp + k]; }
     float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
-    cell_backward<CELL>(t < a.len[row], a.clip, dh, dc, s, a.hs[o0], cprev, cnew, a.hs[o1], pi, pf, po, dxi, dhi, dp);
+    cell_backward<CELL>(t < a.len[row], a.clip, dh, dc, s, a.hs[o0], cprev, cnew, a.hs[o1], pi, pf, po, dxi, dhi, dp, a.relu != 0);
     for (int g = 0; g < G; ++g) {
         const size_t og = ((size_t)t * Bp + row) * GHp + g * Hp + k;
         a.dxt[og] = dxi[g];

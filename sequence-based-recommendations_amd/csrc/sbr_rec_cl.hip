@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) rec_fwd_cl(RecArgs a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) { xs[g] = x[g][e] + bias[g][e]; as[g] = as2[g][e]; }
                 float hh = h[e], cc = c[e];
-                cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s);
+                cell_forward<CELL, true>(xs, as, m, hh, cc, pi[e], pf[e], po[e], s, a.relu != 0);
                 h[e] = hh; c[e] = cc;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sv[k][e] = s[k];
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) rec_bwd_cl(RecArgs a) {
                 float s[4] = {sv[0][e], sv[1][e], sv[2][e], sv[3][e]};
                 float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
                 float dhh = dh[e], dcc = dc[e];
-                cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[e], pf[e], po[e], dxi, dhi, dp);
+                cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev[e], cprev[e], cnew[e], hnew[e], pi[e], pf[e], po[e], dxi, dhi, dp, a.relu != 0);
                 dh[e] = dhh; dc[e] = dcc;
 #pragma unroll
                 for (int g = 0; g < G; ++g) { vxi[g][e] = dxi[g]; vhi[g][e] = dhi[g]; sdb[g][e] += dxi[g]; }
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(256) rec_fwd_clg(RecArgs a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) { xs[g] = x[g].v[e] + bias[g].v[e]; ag[g] = as[g][e]; }
                 float hh = h.v[e], cc = c.v[e];
-                cell_forward<CELL, true>(xs, ag, m, hh, cc, pi.v[e], pf.v[e], po.v[e], s);
+                cell_forward<CELL, true>(xs, ag, m, hh, cc, pi.v[e], pf.v[e], po.v[e], s, a.relu != 0);
                 h.v[e] = hh; c.v[e] = cc;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sv[k].v[e] = s[k];
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(256) rec_bwd_clg(RecArgs a) {
                 float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
                 float dhh = dh.v[e], dcc = dc.v[e];
                 cell_backward<CELL, true>(m, clip, dhh, dcc, s, hprev.v[e], cprev.v[e], cnew.v[e], hnew.v[e], pi.v[e], pf.v[e],
-                                          po.v[e], dxi, dhi, dp);
+                                          po.v[e], dxi, dhi, dp, a.relu != 0);
                 dh.v[e] = dhh; dc.v[e] = dcc;
 #pragma unroll
                 for (int g = 0; g < G; ++g) { vxi[g].v[e] = dxi[g]; vhi[g].v[e] = dhi[g]; sdb[g].v[e] += dxi[g]; }

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 hn = fmaf(ug, cc - h, h);                         // (1 - u) h + u c
                 sv[0] = rg; sv[1] = ug; sv[2] = cc; sv[3] = hc;
             } else {
-                hn = tanh_fast(x[0] + acc[0][0]);
+                { const float pre = x[0] + acc[0][0]; hn = a.relu ? fmaxf(pre, 0.0f) : tanh_fast(pre); }
             }
             if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; }            // uniform branch: no select while no row is masked
             else { h = t < mylen ? hn : h; if (F16) asm volatile("" : "+v"(h)); }   // (pinned for split2_f16 either way)
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
-        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, 0.f, 0.f, hnew, 0.f, 0.f, 0.f, dxi, dhi, dp);
+        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, 0.f, 0.f, hnew, 0.f, 0.f, 0.f, dxi, dhi, dp, a.relu != 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
 #pragma unroll
@@ -646,7 +646,8 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool fuse = a.gX != nullptr;
     const char* fe = getenv("SBR_X6_F16");                         // read per launch: the tests flip it
-    const bool f16 = fe ? atoi(fe) != 0 : true;                    // forward products as fp16 x3 (see split2_f16)
+    const bool f16 = (fe ? atoi(fe) != 0 : true) && !a.relu;       // forward products as fp16 x3 (see split2_f16); a rectified
+                                                                   // state is unbounded, the fp16 split needs |h| < 65504
     if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, true>)); }
     else { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, false>)); }

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
                 hn = og * tanh_fast(cn);
                 sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og;
             } else {
-                hn = tanh_fast(x[0] + acc[0][0]);
+                { const float pre = x[0] + acc[0][0]; hn = a.relu ? fmaxf(pre, 0.0f) : tanh_fast(pre); }
             }
             if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; cst = cn; }          // uniform branch: no selects
             else { const bool m = t < mylen; h = m ? hn : h; cst = m ? cn : cst; }
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
-        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp);
+        cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp, a.relu != 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
         if (CELL == CELL_LSTM) { sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2]; }

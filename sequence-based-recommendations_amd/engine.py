@@ -48,7 +48,7 @@ class SbrConfig(ctypes.Structure):
 
 # every symbol include/sbr_rnn.h declares (tests check the library exports all of them)
 EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create", "sbr_destroy", "sbr_num_params",
-           "sbr_param_shape", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
+           "sbr_param_shape", "sbr_describe_param", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
            "sbr_train_step", "sbr_train_step_lagged", "sbr_lagged_flush", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
@@ -81,6 +81,8 @@ def load_library(path=None):
     lib.sbr_destroy.restype = None
     lib.sbr_num_params.argtypes = [vp]
     lib.sbr_param_shape.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+    lib.sbr_describe_param.argtypes = [ctypes.POINTER(SbrConfig), ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
     for fn in (lib.sbr_set_params, lib.sbr_get_params, lib.sbr_get_grads):
         fn.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
     lib.sbr_section.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t),
@@ -205,6 +207,84 @@ class DeviceDataset(object):
             pass
 
 
+def make_config(cell="GRU", layers=(50,), n_items=None, max_length=30, batch_size=16, loss="CCE", n_samples=0,
+                updater="adam", learning_rate=0.001, rho=0.9, beta1=0.9, beta2=0.999, regularization=0.0, grad_clip=100.0,
+                input_size=None, n_feat=1, local_batch=None, row_offset=0, flags=0, embedding_size=0, bidirectional=False):
+    """sbr_config for the options RNNBase.__init__ / prepare_model fix (include/sbr_rnn.h)."""
+    if cell not in CELLS:
+        raise ValueError("Unknown layer type")                      # recurrent_layers.py:90
+    if loss not in LOSSES:
+        raise ValueError("Unknown loss for the RNN model")          # command_parser.py:123
+    if updater not in UPDATERS:
+        raise ValueError("Unknown update option")                   # update_manager.py:22
+    layers = [int(h) for h in layers]
+    if len(layers) > SBR_MAX_LAYERS:
+        raise ValueError("at most %d recurrent layers" % SBR_MAX_LAYERS)
+    cfg = SbrConfig()
+    cfg.abi_version = SBR_ABI_VERSION
+    cfg.cell = CELLS[cell]
+    cfg.n_layers = len(layers)
+    for i, hsz in enumerate(layers):
+        cfg.layers[i] = hsz
+    cfg.n_items = int(n_items)
+    cfg.input_size = int(input_size if input_size is not None else n_items)
+    cfg.n_feat = int(n_feat)
+    cfg.max_length = int(max_length)
+    cfg.batch_size = int(batch_size)
+    cfg.local_batch = int(local_batch if local_batch is not None else batch_size)
+    cfg.row_offset = int(row_offset)
+    cfg.loss = LOSSES[loss]
+    cfg.n_samples = int(n_samples) if loss != "CCE" else 0
+    cfg.updater = UPDATERS[updater]
+    cfg.learning_rate, cfg.rho, cfg.beta1, cfg.beta2 = learning_rate, rho, beta1, beta2
+    cfg.regularization = regularization
+    cfg.grad_clip = grad_clip
+    cfg.flags = int(flags)
+    cfg.embedding_size = max(0, int(embedding_size))     # --r_emb: a size < 1 means no embedding layer
+    cfg.bidirectional = 1 if bidirectional else 0        # --r_bi
+    return cfg
+
+
+def describe_params(cfg, lib=None):
+    """[(name, shape)] of lasagne.layers.get_all_param_values(l_out) for a configuration (sbr_describe_param: host only,
+    no GPU needed)."""
+    lib = lib or load_library()
+    out, i = [], 0
+    name = ctypes.create_string_buffer(96)
+    while True:
+        dims, nd = (ctypes.c_int64 * 2)(), ctypes.c_int()
+        if lib.sbr_describe_param(ctypes.byref(cfg), i, name, 96, dims, ctypes.byref(nd)) != 0:
+            if i == 0:
+                raise ValueError(lib.sbr_last_error().decode("utf-8", "replace"))
+            return out
+        out.append((name.value.decode(), tuple(int(d) for d in dims[:nd.value])))
+        i += 1
+
+
+def initial_values(descs, rng, last_layer_init=1.0):
+    """Random-init arrays in get_all_param_values order by the initialisers the reference's layers name [3P]: gate weights
+    and peepholes of the LSTM / GRU / index-input Vanilla layers Normal(std 0.1) (sparse_lstm.py:143-171 Gate defaults),
+    biases and initial states 0, stock RecurrentLayer weights (dense Vanilla layers) init.Uniform() = U(-0.01, 0.01),
+    EmbeddingLayer W init.Normal() = std 0.01, output W GlorotUniform(gain) (rnn_one_hot.py:65, rnn_sampling.py:131),
+    output b 0.  rng: numpy Generator or RandomState."""
+    out = []
+    for name, shp in descs:
+        base = name.split(".", 1)[1]
+        if name == "out.W":
+            lim = last_layer_init * np.sqrt(6.0 / (shp[0] + shp[1]))
+            a = rng.uniform(-lim, lim, size=shp)
+        elif name == "emb.W":
+            a = rng.normal(0.0, 0.01, size=shp)
+        elif base in ("input_to_hidden.W", "hidden_to_hidden.W"):
+            a = rng.uniform(-0.01, 0.01, size=shp)
+        elif base.startswith("W_"):
+            a = rng.normal(0.0, 0.1, size=shp)
+        else:
+            a = np.zeros(shp)
+        out.append(np.asarray(a, dtype=np.float32))
+    return out
+
+
 class RNNEngine(object):
     """Device-resident model + optimizer state behind the reference's callables.
 
@@ -230,30 +310,11 @@ class RNNEngine(object):
         if updater not in UPDATERS:
             raise ValueError("Unknown update option")                   # update_manager.py:22
         layers = [int(h) for h in layers]
-        cfg = SbrConfig()
-        cfg.abi_version = SBR_ABI_VERSION
-        cfg.cell = CELLS[cell]
-        cfg.n_layers = len(layers)
-        for i, hsz in enumerate(layers[:SBR_MAX_LAYERS]):
-            cfg.layers[i] = hsz
-        cfg.n_items = int(n_items)
-        cfg.input_size = int(input_size if input_size is not None else n_items)
-        cfg.n_feat = int(n_feat)
-        cfg.max_length = int(max_length)
-        cfg.batch_size = int(batch_size)
-        cfg.local_batch = int(local_batch if local_batch is not None else batch_size)
-        cfg.row_offset = int(row_offset)
-        cfg.loss = LOSSES[loss]
-        cfg.n_samples = int(n_samples) if loss != "CCE" else 0
-        cfg.updater = UPDATERS[updater]
-        cfg.learning_rate, cfg.rho, cfg.beta1, cfg.beta2 = learning_rate, rho, beta1, beta2
-        cfg.regularization = regularization
-        cfg.grad_clip = grad_clip
-        cfg.flags = int(flags)
-        cfg.embedding_size = max(0, int(embedding_size))     # --r_emb: a size < 1 means no embedding layer
-        cfg.bidirectional = 1 if bidirectional else 0        # --r_bi
-        if len(layers) > SBR_MAX_LAYERS:
-            raise ValueError("at most %d recurrent layers" % SBR_MAX_LAYERS)
+        cfg = make_config(cell=cell, layers=layers, n_items=n_items, max_length=max_length, batch_size=batch_size, loss=loss,
+                          n_samples=n_samples, updater=updater, learning_rate=learning_rate, rho=rho, beta1=beta1, beta2=beta2,
+                          regularization=regularization, grad_clip=grad_clip, input_size=input_size, n_feat=n_feat,
+                          local_batch=local_batch, row_offset=row_offset, flags=flags, embedding_size=embedding_size,
+                          bidirectional=bidirectional)
         self.cfg = cfg
         self.cell, self.layers, self.loss = cell, layers, loss
         self.n_items, self.max_length = cfg.n_items, cfg.max_length
@@ -273,6 +334,7 @@ class RNNEngine(object):
                                             ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
         self.h = handle
         self.n_params = self.lib.sbr_num_params(self.h)
+        self.param_descs = describe_params(cfg, self.lib)
         self.param_shapes = []
         for i in range(self.n_params):
             dims = (ctypes.c_int64 * 2)()

@@ -7,10 +7,11 @@ holds one of these objects keeps working:
     prepare_model(dataset) / train(dataset, ...) / top_k_recommendations(sequence, ...) /
     save(filename) / load(filename) / load_last(save_dir)
 
-Only what the RNN hot path needs is here; `--mf/--uf` (feature tables the
-reference never loads), `--r_bi`, `--r_emb` raise NotImplementedError in this round.
+Only what the RNN hot path needs is here, `--r_bi` and `--r_emb` included; `--mf/--uf`
+(feature tables the reference never loads, rnn_base.py:27-29,572,607) raise NotImplementedError in prepare_model.
 """
 import glob
+import math
 import os
 import pickle
 import random
@@ -44,9 +45,6 @@ class RNNBase(object):
         self.updater = updater if updater is not None else Adagrad()
         self.target_selection = target_selection if target_selection is not None else SelectTargets()
         self.interactions_are_unique = interactions_are_unique
-        if self.use_movies_features or self.use_users_features:
-            # the reference dereferences feature tables that are always None (rnn_base.py:27-29,572,607)
-            raise NotImplementedError("movie/user features (--mf/--uf) are unusable in the reference and unsupported here")
         self._input_type = "int32"
         self.name = "RNN base"
         self.metrics = {"recall": {"direction": 1}, "sps": {"direction": 1}, "user_coverage": {"direction": 1},
@@ -67,6 +65,9 @@ class RNNBase(object):
     def prepare_model(self, dataset):
         """Must be called before train, load or top_k_recommendations (rnn_base.py:106-109)."""
         from .engine import RNNEngine
+        if self.use_movies_features or self.use_users_features:
+            # the reference dereferences feature tables that are always None (rnn_base.py:27-29,572,607)
+            raise NotImplementedError("movie/user features (--mf/--uf) are unusable in the reference and unsupported here")
         self.n_items = dataset.n_items
         kw = dict(cell=self.recurrent_layer.layer_type, layers=self.recurrent_layer.layers, n_items=self.n_items,
                   max_length=self.max_length, batch_size=self.batch_size, grad_clip=float(self.recurrent_layer.grad_clip),
@@ -78,33 +79,12 @@ class RNNBase(object):
         self._init_parameters()
 
     def _init_parameters(self, seed=None):
-        """Lasagne initialisers [3P]: gate weights and peepholes Normal(std 0.1), biases and initial
-        states 0, output W GlorotUniform(gain), output b 0."""
+        """The initialisers the reference's layers name [3P] (engine.initial_values: gate weights and peepholes
+        Normal(std 0.1), biases and initial states 0, stock RecurrentLayer weights U(-0.01, 0.01), embedding Normal(0.01),
+        output W GlorotUniform(gain), output b 0), by parameter name."""
+        from .engine import initial_values
         rng = np.random.RandomState(seed)
-        values = []
-        last = len(self.engine.param_shapes) - 2
-        for i, shp in enumerate(self.engine.param_shapes):
-            if i == last:
-                lim = getattr(self, "last_layer_init", 1.0) * np.sqrt(6.0 / (shp[0] + shp[1]))
-                values.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
-            elif i > last:
-                values.append(np.zeros(shp, dtype=np.float32))
-            else:
-                values.append(None)
-        # recurrent part: which arrays are weights is decided by the Lasagne order
-        cell = self.recurrent_layer.layer_type
-        per_layer = {"LSTM": 17, "GRU": 10, "Vanilla": 4}[cell]
-        n_gate = {"LSTM": 12, "GRU": 9, "Vanilla": 3}[cell]
-        first = 0
-        if self.recurrent_layer.embedding_size > 0:        # EmbeddingLayer W: init.Normal() = std 0.01 [3P]
-            values[0] = rng.normal(0.0, 0.01, size=self.engine.param_shapes[0]).astype(np.float32)
-            first = 1
-        for i in range(first, last):
-            shp = self.engine.param_shapes[i]
-            k = (i - first) % per_layer
-            is_weight = (k < n_gate and k % 3 != 2) or (cell == "LSTM" and 12 <= k < 15)
-            values[i] = (rng.normal(0.0, 0.1, size=shp) if is_weight else np.zeros(shp)).astype(np.float32)
-        self.engine.set_all_param_values(values)
+        self.engine.set_all_param_values(initial_values(self.engine.param_descs, rng, getattr(self, "last_layer_init", 1.0)))
 
     # ------------------------------------------------------------------ filenames (rnn_base.py:111-130)
     def _common_filename(self, epochs):
@@ -132,7 +112,8 @@ class RNNBase(object):
         """[item_id] (+ [n_items + rating bucket] with --rf): rating one-hot index round(r*2)-1."""
         item_id, rating = item
         if self.use_ratings_features:
-            return [item_id, self.n_items + (int(round(rating * 2)) - 1) % 10]
+            # Python 2's round() goes half away from zero (the reference's interpreter); Python 3's goes to even
+            return [item_id, self.n_items + (int(math.floor(rating * 2 + 0.5)) - 1) % 10]
         return [item_id]
 
     def _pack(self, sequences):
@@ -309,7 +290,8 @@ class RNNBase(object):
         def flush():
             ids = self.engine.test_function((np.concatenate(Xs), np.concatenate(masks)), k=k,
                                             exclude_seen=self.interactions_are_unique)
-            out = (list(goals), [ids[i] for i in range(len(goals))])
+            # a row with fewer than k rankable items carries -1 in the places it cannot fill (include/sbr_rnn.h): drop them
+            out = (list(goals), [ids[i][ids[i] >= 0] for i in range(len(goals))])
             del Xs[:], masks[:], goals[:]
             return out
         for batch_input, goal in self._gen_mini_batch(sequence_generator, test=True):

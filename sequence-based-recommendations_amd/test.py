@@ -56,7 +56,7 @@ def run_tests(predictor, model_file, dataset, args, get_full_recommendation_list
             mask[i, :len(viewed)] = 1
         ids = predictor.engine.test_function((X, mask), k=k, exclude_seen=predictor.interactions_are_unique)
         for (n, _, _), row in zip(pending, ids):
-            results[n] = list(row)
+            results[n] = list(row[row >= 0])      # -1 = a place the row had no rankable item for (include/sbr_rnn.h)
         del pending[:]
     for n, (sequence, user_id) in enumerate(dataset.test_set(epochs=1)):
         num_viewed = int(len(sequence) / 2)

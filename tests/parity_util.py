@@ -5,8 +5,17 @@ import numpy as np
 from oracle import rnn_oracle as O
 
 
-def make_batch(rng, B, T, N, S=0, F=1, n_in0=None, full=False, Bg=None):
+def zipf_ids(rng, N, size):
+    """item ids ~ Zipf(1.0) over N through a fixed permutation: the law bench.py draws its batches from."""
+    w = 1.0 / np.arange(1, N + 1)
+    cdf = np.cumsum(w / w.sum())
+    perm = np.random.default_rng(1234).permutation(N)
+    return perm[np.minimum(np.searchsorted(cdf, rng.random(size)), N - 1)]
+
+
+def make_batch(rng, B, T, N, S=0, F=1, n_in0=None, full=False, Bg=None, zipf=False):
     n_in0 = n_in0 or N
+    draw = (lambda n: zipf_ids(rng, N, n)) if zipf else (lambda n: rng.integers(0, N, size=n))
     lens = rng.integers(1, T + 1, size=B)
     if full:
         lens[:] = T
@@ -17,13 +26,13 @@ def make_batch(rng, B, T, N, S=0, F=1, n_in0=None, full=False, Bg=None):
     X = np.zeros((B, T, F), dtype=np.int32)
     mask = np.zeros((B, T), dtype=np.float32)
     for b in range(B):
-        X[b, :lens[b], 0] = rng.integers(0, N, size=lens[b])
+        X[b, :lens[b], 0] = draw(lens[b])
         mask[b, :lens[b]] = 1
         if F > 1:
             X[b, :lens[b], 1] = rng.integers(N, n_in0, size=lens[b])
     if B > 2:
         X[2, :lens[2], 0] = 0          # pad id 0 is a real item; duplicates accumulate
-    return dict(X=X, mask=mask, target=rng.integers(0, N, size=Bg or B).astype(np.int32),
+    return dict(X=X, mask=mask, target=draw(Bg or B).astype(np.int32),
                 samples=rng.integers(0, N, size=max(S, 1)).astype(np.int32),
                 pop=rng.uniform(0.5, 2.0, size=B).astype(np.float32))
 
@@ -33,7 +42,8 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0, emb=0, bi=False):
+def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0, emb=0, bi=False,
+               zipf=False):
     if scale is None:      # a tanh-only cell with wide layers is chaotic at large weights: keep it well conditioned
         scale = 0.3 if (cell != "Vanilla" or max(layers) <= 64) else 0.05
     rng = np.random.default_rng(seed)
@@ -41,7 +51,7 @@ def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=Fals
     for p in params:                      # move every parameter (biases, inits, peepholes) off zero
         p += rng.normal(0, scale, size=p.shape)
     params = [p.astype(np.float32).astype(np.float64) for p in params]
-    batch = make_batch(rng, B, T, N, S=S, F=F, n_in0=N + n_opt, full=full)
+    batch = make_batch(rng, B, T, N, S=S, F=F, n_in0=N + n_opt, full=full, zipf=zipf)
     batch["pop"] = (batch["pop"] * popscale).astype(np.float32)
     cfg = dict(cell=cell, layers=list(layers), loss=loss, regularization=0.0, embedding=emb, bidirectional=bi)
     return params, cfg, batch
@@ -63,10 +73,16 @@ def oracle_batch(batch):
 
 
 def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
-                 reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False):
-    """Returns dict of relative errors (engine float32 vs oracle float64)."""
+                 reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False, zipf=False, k=None, gap=0.0, tweak=None):
+    """Returns dict of relative errors (engine float32 vs oracle float64).
+    k: length of the ranked list compared (default min(5, N - T)); gap > 0: the ranked ids are compared on the rows
+    whose oracle scores (logits) are separated by more than `gap` down to rank k + 1 -- a tie-free fixture by
+    assertion, `topk_rows_compared` reports how many rows that is; tweak(batch): edits the batch in place (e.g. plants
+    duplicate sampled cells)."""
     params, cfg, batch = build_case(cell, layers, loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, full=full,
-                                    popscale=popscale, scale=scale, emb=emb, bi=bi)
+                                    popscale=popscale, scale=scale, emb=emb, bi=bi, zipf=zipf)
+    if tweak is not None:
+        tweak(batch)
     cfg["regularization"] = reg
     eng = engine_for(cfg, N, B, T, S=S, F=F, n_opt=n_opt, updater=updater, flags=flags, reg=reg)
     out = {}
@@ -108,11 +124,20 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
         scores = eng.predict_function(batch["X"], batch["mask"])
         oscores, ologits = O.predict_scores(oparams, cfg, batch["X"], batch["mask"])
         out["predict_scores"] = rel_err(scores, oscores)
-        k = min(5, N - T) if N - T >= 1 else 1
+        if k is None:
+            k = min(5, N - T) if N - T >= 1 else 1
         ids = eng.test_function((batch["X"], batch["mask"]), k=k)
         excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
         oids = O.test_function(oparams, cfg, batch["X"], batch["mask"], excl, k=k)
-        out["topk_mismatch"] = float((ids != oids).sum())
+        rows = np.ones(B, dtype=bool)
+        if gap > 0.0:      # rows whose k + 1 best admissible logits are pairwise further apart than `gap`
+            for b in range(B):
+                row = ologits[b].copy()
+                row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
+                top = -np.sort(-row)[:k + 1]
+                rows[b] = bool(np.all(top[:-1] - top[1:] > gap))
+        out["topk_rows_compared"] = float(rows.sum())
+        out["topk_mismatch"] = float((ids[rows] != oids[rows]).sum())
     finally:
         eng.close()
     return out

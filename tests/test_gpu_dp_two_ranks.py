@@ -1,0 +1,79 @@
+"""The data-parallel step with the REAL engine and world_size 2: two processes share the one GPU of the test box,
+each holds half of the global batch in its own RNNEngine (local_batch = B/2, row_offset), gradients travel through
+`parallel.DataParallel` (gloo on device tensors: RCCL refuses two ranks on one device) with the deferred-join /
+side-stream choreography the 8-GPU run uses.  After two steps both replicas must hold the parameters of the
+single-engine step on the whole batch, and the same costs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import parity_util as PU
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (cell, layers, loss, N, B, T, S, updater)
+    "gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
+    "lstm20_blackout_adagrad": ("LSTM", [20], "Blackout", 200, 32, 12, 8, "adagrad"),
+    "lstm256_bpr_adam": ("LSTM", [256], "BPR", 500, 32, 10, 8, "adam"),
+}
+
+
+def _worker(rank, world, port, name, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbr_amd.parallel import DataParallel
+    cell, layers, loss, N, B, T, S, updater = CASES[name]
+    params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=31, scale=0.05)
+    lo, hi = DataParallel.shard(B, world, rank)
+    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater, local_batch=hi - lo, row_offset=lo)
+    try:
+        eng.set_all_param_values(params)
+        dp = DataParallel(eng, dist)
+        assert dp.side is not None                      # the stream-level path, not the stand-in one
+        smp = batch["samples"] if loss != "CCE" else None
+        if loss != "CCE":      # every rank needs all B targets (Blackout's softmax spans them): all-gather of the local ones
+            tgt = dp.gather_targets(torch.from_numpy(batch["target"][lo:hi]).cuda()).cpu().numpy()
+            assert np.array_equal(tgt, batch["target"])
+        else:
+            tgt = batch["target"][lo:hi]
+        costs = []
+        for _ in range(2):
+            eng.set_batch(batch["X"][lo:hi], batch["mask"][lo:hi], tgt, smp, batch["pop"][lo:hi])
+            dp.train_step()
+            costs.append(eng.read_cost())
+        np.savez(out % rank, costs=np.array(costs), **{"p%d" % i: p for i, p in enumerate(eng.get_all_param_values())})
+    finally:
+        eng.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_two_ranks_on_one_gpu_equal_the_single_engine_step(tmp_path, name):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(2, port, name, out), nprocs=2, join=True)
+    cell, layers, loss, N, B, T, S, updater = CASES[name]
+    params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=31, scale=0.05)
+    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater)
+    try:
+        eng.set_all_param_values(params)
+        smp = batch["samples"] if loss != "CCE" else None
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], smp, batch["pop"])
+        ref_costs = [eng.train_step(sync=True) for _ in range(2)]
+        ref = eng.get_all_param_values()
+    finally:
+        eng.close()
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert np.allclose(r0["costs"], ref_costs, rtol=2e-5), (r0["costs"], ref_costs)
+    assert np.array_equal(r0["costs"], r1["costs"])
+    for i, p in enumerate(ref):
+        assert np.array_equal(r0["p%d" % i], r1["p%d" % i]), i          # replicas stay bit-identical
+        assert PU.rel_err(r0["p%d" % i], p) <= 2e-5, (i, PU.rel_err(r0["p%d" % i], p))

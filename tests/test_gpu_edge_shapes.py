@@ -45,3 +45,29 @@ def test_phase_timing_modes():
             eng.phase_times()
     finally:
         eng.close()
+
+
+def test_topk_with_fewer_rankable_items_than_k():
+    # a user who has seen more than N - k items (exclude_seen): the places that cannot be filled carry -1, never an
+    # excluded or repeated id; NaN scores rank nowhere
+    import numpy as np
+    N, B, T = 12, 3, 10
+    params, cfg, batch = PU.build_case("GRU", [8], "CCE", N, B, T, seed=2)
+    eng = PU.engine_for(cfg, N, B, T)
+    try:
+        eng.set_all_param_values(params)
+        X = np.zeros((B, T, 1), np.int32); mask = np.zeros((B, T), np.float32)
+        X[0, :10, 0] = np.arange(10); mask[0, :10] = 1          # 2 unseen items
+        X[1, :3, 0] = [4, 4, 5]; mask[1, :3] = 1                 # 10 unseen
+        X[2, :1, 0] = [0]; mask[2, :1] = 1
+        ids = eng.test_function((X, mask), k=5)
+        assert sorted(ids[0][:2]) == [10, 11] and list(ids[0][2:]) == [-1, -1, -1]
+        for b in (1, 2):
+            seen = set(X[b, :int(mask[b].sum()), 0])
+            assert len(set(ids[b])) == 5 and ids[b].min() >= 0 and not set(ids[b]) & seen
+        params[-1][3] = np.nan                                   # a NaN bias -> NaN score of item 3 in every row
+        eng.set_all_param_values(params)
+        ids = eng.test_function((X, mask), k=5, exclude_seen=False)
+        assert not (ids == 3).any() and ids.min() >= 0
+    finally:
+        eng.close()

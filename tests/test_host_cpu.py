@@ -287,10 +287,12 @@ def test_bench_initial_parameters_follow_the_init_law():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for cell, layers in (("GRU", [128]), ("LSTM", [20]), ("Vanilla", [8]), ("LSTM", [512, 512])):
+    from sbr_amd.engine import make_config
+    for cell, layers, emb in (("GRU", [128], 0), ("LSTM", [20], 0), ("Vanilla", [8], 0), ("LSTM", [512, 512], 0),
+                              ("Vanilla", [40, 30], 0), ("Vanilla", [32], 16), ("GRU", [20], 6)):
         N = 50
-        ref = O.init_params(cell, layers, N, np.random.default_rng(0), dtype=np.float32)
-        got = bench.initial_parameters([p.shape for p in ref], cell, np.random.default_rng(1))
+        ref = O.init_params(cell, layers, N, np.random.default_rng(0), dtype=np.float32, embedding=emb)
+        got = bench.initial_parameters(make_config(cell=cell, layers=layers, n_items=N, embedding_size=emb), np.random.default_rng(1))
         assert [g.shape for g in got] == [p.shape for p in ref] and all(g.dtype == np.float32 for g in got)
         for a, b in zip(got, ref):
             assert (np.abs(a).max() > 0) == (np.abs(b).max() > 0)

@@ -101,7 +101,8 @@ def test_embedding_layer_option(cell, F, n_opt):
     B, T, N, S, E = 3, 5, 7, 4, 3
     layers = [4, 3]
     params = O.init_params(cell, layers, N, rng, n_in0=N + n_opt, embedding=E, n_feat=F)
-    assert params[0].shape == (N + n_opt, E) and params[1].shape[0] == F * E
+    # (a dense Vanilla layer is the stock RecurrentLayer: hid_init comes first, then W_in)
+    assert params[0].shape == (N + n_opt, E) and params[2 if cell == "Vanilla" else 1].shape[0] == F * E
     for p in params:
         p += rng.normal(0, 0.3, size=p.shape)
     batch = make_batch(rng, B, T, N, S, F=F, n_in0=N + n_opt)

@@ -35,6 +35,9 @@ OPTION_CASES = {
     "gru12_cce_emb6_adam": ("GRU", [12], "CCE", 40, 7, 8, 0, "adam", 1, 0, 6, False),
     "lstm10x8_cce_bi_adagrad": ("LSTM", [10, 8], "CCE", 35, 7, 7, 0, "adagrad", 1, 0, 0, True),
     "gru8_bpr_bi_emb5_rf_adam": ("GRU", [8], "BPR", 30, 6, 6, 5, "adam", 2, 10, 5, True),
+    # dense Vanilla layers = stock lasagne RecurrentLayer: rectify, parameters [hid_init, W_in, b, W_hid]
+    "vanilla12x8_cce_adam": ("Vanilla", [12, 8], "CCE", 35, 7, 7, 0, "adam", 1, 0, 0, False),
+    "vanilla10_blackout_emb6_adagrad": ("Vanilla", [10], "Blackout", 35, 7, 7, 5, "adagrad", 1, 0, 6, False),
 }
 
 
