@@ -75,6 +75,10 @@ typedef struct sbr_config {
 #define SBR_FLAG_F32_MFMA 16      /* recurrent GEMM on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) instead of the bf16x6 split */
 #define SBR_FLAG_PROFILE_REC 8    /* recurrent kernels record s_memtime / s_memrealtime phase counters ("prof" debug buffer) */
 #define SBR_FLAG_ATOMIC_SCATTER 4 /* triage: per-element float atomics instead of the sorted segment reduce */
+/* Row-sparse optimizer (see "Row-sparse blocks" below): by default a block is stepped row by row when a step cannot touch
+ * every row of it anyway (more rows than the batch has item ids / more items than sampled cells). */
+#define SBR_FLAG_SPARSE_UPDATE 32 /* always, for every block that exists (tests) */
+#define SBR_FLAG_DENSE_UPDATE 64  /* never: one dense elementwise pass over every parameter, as lasagne.updates.* does */
 
 typedef struct sbr_handle sbr_handle;
 
@@ -150,6 +154,32 @@ int sbr_read_cost(sbr_handle* h, float* cost_host);
 int sbr_set_deferred_join(sbr_handle* h, int on);
 int sbr_join_side(sbr_handle* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row-sparse blocks.  The reference's updates are dense over every parameter (update_manager.py:24-82, lasagne.updates.*);
+ * only the rows a batch gathers (sparse_lstm.py:368) and the sampled cells (sparse_lstm.py:50-54) receive a non-zero
+ * gradient.  Block kinds: the index-addressed rows of layer 0 (W_in of both directions, or the --r_emb table), and -- for
+ * the sampled heads -- the rows of W_out / b_out.  A sparse block is stepped row by row over the touched rows only:
+ * exact for adagrad (its zero-gradient step is a no-op); for rmsprop / adadelta / nesterov / adam the zero-gradient steps
+ * a row missed are replayed when the row is next read or stepped ("lazy-exact": same results as the dense pass to
+ * float32 rounding).  sbr_get_params, sbr_section(0 / 2), sbr_predict_scores and sbr_topk bring everything they read up to
+ * date themselves; sbr_flush_lazy does it explicitly (e.g. before reading the parameter section through a pointer
+ * obtained earlier). */
+int sbr_flush_lazy(sbr_handle* h);
+/* Data-parallel exchange of a sparse block b (0 .. sbr_query("sparse_blocks") - 1) instead of an all-reduce of the whole
+ * block: after sbr_backward_recurrent,
+ *   sbr_sparse_pack        moves this rank's touched gradient rows into ids_dev [max_local_rows] / rows_dev
+ *                          [max_local_rows][row_floats] (device buffers of the caller, e.g. torch tensors handed to RCCL)
+ *                          and returns their number (synchronises the stream);
+ *   (the ranks all-gather ids and rows)
+ *   sbr_sparse_unpack_add  adds ONE rank's rows into the gradient block; call it for every rank, own rows included, in
+ *                          rank order on every rank, so that the replicas stay bit-identical;
+ * sbr_apply_update then steps the union of the gathered rows.  sbr_dense_ranges lists the [lo, hi) float ranges of the
+ * gradient section (trailing cost included) that still take the dense all-reduce. */
+int sbr_sparse_info(sbr_handle* h, int b, int64_t* n_rows, int64_t* row_floats, int64_t* max_local_rows);
+int sbr_sparse_pack(sbr_handle* h, int b, int32_t* ids_dev, float* rows_dev, int32_t* count_host);
+int sbr_sparse_unpack_add(sbr_handle* h, int b, const int32_t* ids_dev, const float* rows_dev, int count);
+int sbr_dense_ranges(sbr_handle* h, int cap, int64_t* lo, int64_t* hi, int* n);
+
 /* predict_function(X, mask) (rnn_base.py:188-194) on the current batch: scores (rows,N);
  * softmax probabilities for CCE (DenseLayer softmax, rnn_one_hot.py:65), raw activations
  * for the sampled heads (sparse_lstm.py:37-40).  probs != 0 forces softmax (test function of
@@ -184,7 +214,8 @@ int sbr_enable_timing(sbr_handle* h, int on);
  * "fused_gather" (layer-0 input rows gathered inside the forward kernel), "rows_per_workgroup",
  * "cluster" (multi-workgroup recurrent kernels for the top layer), "rec_kernel" (kernel family of the top layer:
  * 0 triage, 1 cluster, 2 counter-synchronised 128-unit, 3 counter-synchronised 32/64-unit, 4 barrier / general),
- * "arena_bytes", "side_stream" (hipStream_t). */
+ * "arena_bytes", "side_stream" (hipStream_t), "sparse_blocks" (row-sparse parameter blocks of this configuration),
+ * "adam_table" (entries of the a_t table of the lazy Adam catch-up). */
 int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 

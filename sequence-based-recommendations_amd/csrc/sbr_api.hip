@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <stdlib.h>
+#include <math.h>
 
 static thread_local std::string g_err;
 void sbr_set_error(const char* fmt, ...) {
@@ -145,6 +146,54 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_scnt = take((size_t)cfg.input_size + 1); lay.a_soff = take((size_t)cfg.input_size + 1);
     lay.a_scur = take((size_t)cfg.input_size + 1);
     lay.a_sid = take((size_t)T * Bp * lay.F); lay.a_spos = take((size_t)T * Bp * lay.F);
+    // Row-sparse blocks (sbr_sparse.hip): the index-addressed rows of layer 0 (or of the embedding table) and, for the sampled
+    // heads, the rows of W_out^T / b_out.  Taken when a step cannot touch every row anyway (more rows than candidates) or
+    // when the flag forces it; SBR_FLAG_DENSE_UPDATE keeps the dense Lasagne-style pass over everything.
+    lay.n_sparse = 0; lay.a_at = 0; lay.n_at = 0; lay.adam_early_exit = 0;
+    if (!(cfg.flags & SBR_FLAG_DENSE_UPDATE)) {
+        const bool force = cfg.flags & SBR_FLAG_SPARSE_UPDATE;
+        const int world = (lay.Bg + lay.B - 1) / lay.B;
+        const long cand0 = (long)T * Bp * lay.F;
+        if (force || (long)cfg.input_size > cand0) {
+            SparseBlockLayout& b = lay.sparse[lay.n_sparse++];
+            b = SparseBlockLayout(); b.kind = 0; b.n_rows = cfg.input_size;
+            if (lay.E) { b.npairs = 1; b.off[0] = lay.p_Emb; b.width[0] = lay.Ep; b.stride[0] = lay.Ep; }
+            else {
+                b.npairs = D;
+                for (int d = 0; d < D; ++d) { b.off[d] = lay.layer[d].p_Win; b.width[d] = G * lay.layer[d].Hp; b.stride[d] = G * lay.layer[d].Hp; }
+            }
+            b.max_local = (int)std::min<long>(b.n_rows, cand0);
+        }
+        if (lay.S > 0 && (force || lay.N > lay.C)) {
+            SparseBlockLayout& b = lay.sparse[lay.n_sparse++];
+            b = SparseBlockLayout(); b.kind = 1; b.n_rows = lay.N; b.npairs = 2;
+            b.off[0] = lay.p_WoutT; b.width[0] = lay.HLt; b.stride[0] = lay.HLt;
+            b.off[1] = lay.p_bout; b.width[1] = 1; b.stride[1] = 1;
+            b.max_local = std::min(lay.N, lay.C);
+        }
+        for (int i = 0; i < lay.n_sparse; ++i) {
+            SparseBlockLayout& b = lay.sparse[i];
+            b.W = 0; for (int k = 0; k < b.npairs; ++k) b.W += b.width[k];
+            b.cand_cap = world * b.max_local + 64;
+            b.a_last = take(b.n_rows); b.a_mark = take(b.n_rows); b.a_cand = take(b.cand_cap); b.a_count = take(64);
+        }
+        if (lay.n_sparse && cfg.updater == SBR_UPD_ADAM) {
+            // a_t = lr sqrt(1 - b2^t) / (1 - b1^t) as the dense launch computes it (double, rounded to float), tabulated until
+            // it has been == (float)lr for a while; the catch-up replays missed steps with their own a_t
+            const double lr = cfg.learning_rate, b1 = cfg.beta1, b2 = cfg.beta2;
+            int t = 1, same = 0; double worst = 0.0, prev = 0.0;
+            const int cap = 1 << 22;
+            for (; t <= cap && same < 256; ++t) {
+                const double a = lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t));
+                same = ((float)a == (float)lr) ? same + 1 : 0;
+                if (t > 1) worst = std::max(worst, a / prev);
+                prev = a;
+            }
+            lay.n_at = t - 1;
+            lay.adam_early_exit = (b2 > 0.0 && worst * b1 / sqrt(b2) < 0.999) ? 1 : 0;
+            lay.a_at = take(lay.n_at);
+        }
+    }
     lay.s_end = lay.s_act + off;
     return SBR_OK;
 }
@@ -328,6 +377,14 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     hipError_t e = hipMemsetAsync(h->arena, 0, h->lay.s_end * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { sbr_set_error("arena initialisation failed: %s", hipGetErrorString(e)); sbr_destroy(h); return SBR_EHIP; }
+    h->sp_exchanged[0] = h->sp_exchanged[1] = 0; h->sp_ncand[0] = h->sp_ncand[1] = 0; h->sp_epoch = 0;
+    if (h->lay.n_at > 0) {
+        std::vector<float> at(h->lay.n_at);
+        const double lr = cfg->learning_rate, b1 = cfg->beta1, b2 = cfg->beta2;
+        for (int t = 1; t <= h->lay.n_at; ++t) at[t - 1] = (float)(lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+        e = hipMemcpy(h->A(h->lay.a_at), at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { sbr_set_error("a_t table upload failed: %s", hipGetErrorString(e)); sbr_destroy(h); return SBR_EHIP; }
+    }
     *out = h;
     return SBR_OK;
 }
@@ -359,6 +416,40 @@ extern "C" int sbr_param_shape(const sbr_handle* h, int i, int64_t dims[2], int*
     return SBR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// row-sparse blocks (sbr_sparse.hip)
+// ---------------------------------------------------------------------------------------
+static SbrSparseRows sparse_rows(sbr_handle* h, int b) {
+    const SparseBlockLayout& sb = h->lay.sparse[b];
+    SbrSparseRows r; memset(&r, 0, sizeof(r));
+    r.npairs = sb.npairs; r.n_rows = sb.n_rows;
+    for (int k = 0; k < sb.npairs; ++k) { r.off[k] = sb.off[k]; r.width[k] = sb.width[k]; r.stride[k] = sb.stride[k]; }
+    r.p = h->P(0); r.g = h->Gd(0); r.s0 = h->St(0, 0); r.s1 = h->lay.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+    r.last = (int*)h->A(sb.a_last);
+    return r;
+}
+static SbrSparseUpd sparse_upd(sbr_handle* h) {
+    const sbr_config& c = h->lay.cfg;
+    SbrSparseUpd u; u.updater = c.updater; u.lr = c.learning_rate; u.rho = c.rho; u.b1 = c.beta1; u.b2 = c.beta2;
+    u.at = h->lay.n_at ? h->A(h->lay.a_at) : nullptr; u.n_at = h->lay.n_at; u.early_exit = h->lay.adam_early_exit;
+    return u;
+}
+// adagrad's zero-gradient step is a no-op: nothing is ever pending
+static inline bool sparse_lazy(const sbr_handle* h) { return h->lay.n_sparse > 0 && h->lay.cfg.updater != SBR_UPD_ADAGRAD; }
+
+// every row of every sparse block current through the last applied step (before parameters are read as a whole)
+static int flush_lazy(sbr_handle* h, int only_kind = -1) {
+    if (!sparse_lazy(h)) return SBR_OK;
+    for (int b = 0; b < h->lay.n_sparse; ++b)
+        if (only_kind < 0 || h->lay.sparse[b].kind == only_kind)
+            SBR_LAUNCH(launch_sparse_flush(h->stream, sparse_rows(h, b), sparse_upd(h), (int)h->step_count));
+    return SBR_OK;
+}
+extern "C" int sbr_flush_lazy(sbr_handle* h) {
+    CHECK_ARG(h, "null handle");
+    return flush_lazy(h);
+}
+
 extern "C" int sbr_describe_param(const sbr_config* cfg, int i, char* name, size_t name_cap, int64_t dims[2], int* ndim) {
     CHECK_ARG(cfg && dims && ndim, "null argument");
     Layout lay; std::string err;
@@ -374,6 +465,7 @@ extern "C" int sbr_describe_param(const sbr_config* cfg, int i, char* name, size
 
 extern "C" int sbr_set_params(sbr_handle* h, int n, const float* const* arrays) {
     CHECK_ARG(h && arrays && n == (int)h->descs.size(), "expected %d parameter arrays, got %d", h ? (int)h->descs.size() : -1, n);
+    { const int rc = flush_lazy(h); if (rc != SBR_OK) return rc; }   // pending zero-gradient steps belong to the old values
     std::vector<float> image(h->lay.n_params, 0.0f);     // padding stays exactly zero
     for (int i = 0; i < n; ++i) {
         CHECK_ARG(arrays[i], "parameter array %d is NULL", i);
@@ -396,13 +488,18 @@ static int get_section(sbr_handle* h, const float* dev, int n, float* const* arr
     }
     return SBR_OK;
 }
-extern "C" int sbr_get_params(sbr_handle* h, int n, float* const* arrays) { return get_section(h, h ? h->P(0) : nullptr, n, arrays); }
+extern "C" int sbr_get_params(sbr_handle* h, int n, float* const* arrays) {
+    CHECK_ARG(h, "null handle");
+    { const int rc = flush_lazy(h); if (rc != SBR_OK) return rc; }
+    return get_section(h, h->P(0), n, arrays);
+}
 extern "C" int sbr_get_grads(sbr_handle* h, int n, float* const* arrays) { return get_section(h, h ? h->Gd(0) : nullptr, n, arrays); }
 
 extern "C" int sbr_section(sbr_handle* h, int which, void** dev_ptr, size_t* n_floats, size_t* split_floats) {
     CHECK_ARG(h && dev_ptr && n_floats, "null argument");
     const Layout& y = h->lay;
     if (split_floats) *split_floats = y.p_split;
+    if (which == 0 || which == 2) { const int rc = flush_lazy(h); if (rc != SBR_OK) return rc; }   // current at the time of the call
     switch (which) {
         case 0: *dev_ptr = h->P(0); *n_floats = y.n_params; return SBR_OK;
         case 1: *dev_ptr = h->Gd(0); *n_floats = y.n_params + 1; return SBR_OK;
@@ -638,6 +735,10 @@ extern "C" int sbr_forward(sbr_handle* h) {
     sbr_gemm_set_exact_f32((h->lay.cfg.flags & SBR_FLAG_F32_MFMA) != 0);
     if (!h->have_batch) { sbr_set_error("sbr_forward: no batch set"); return SBR_ESTATE; }
     const Layout& y = h->lay; hipStream_t s = h->stream;
+    if (sparse_lazy(h))      // the rows this batch gathers must be current before they are read
+        for (int b = 0; b < y.n_sparse; ++b)
+            if (y.sparse[b].kind == 0)
+                SBR_LAUNCH(launch_sparse_catch_up_batch(s, sparse_rows(h, b), sparse_upd(h), h->bX, h->blen, y.T, y.Bp, y.F, (int)h->step_count));
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
@@ -716,7 +817,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             }
             SBR_HIP(hipEventRecord(h->ev_fill, sd)); h->fill_done = true;
         }
-        if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E) {
+        if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
             SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                            y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
                                            (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
@@ -756,6 +857,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         int* cells = (int*)h->A(y.a_cells);
         float *Wc = h->A(y.a_Wc), *bc = h->A(y.a_bc), *act = h->A(y.a_act), *dWc = h->A(y.a_dWc), *dbc = h->A(y.a_dbc);
         SBR_LAUNCH(launch_build_cells(s, tgt, h->bsmp, y.Bg, y.S, cells));
+        if (sparse_lazy(h))      // ... and so must the rows of W_out^T / b_out the sampled cells gather
+            for (int b = 0; b < y.n_sparse; ++b)
+                if (y.sparse[b].kind == 1)
+                    SBR_LAUNCH(launch_sparse_catch_up_list(s, sparse_rows(h, b), sparse_upd(h), cells, nullptr, C, C, (int)h->step_count));
         SBR_LAUNCH(launch_gather_rows(s, h->P(y.p_WoutT), h->P(y.p_bout), cells, C, Hp, Wc, bc));
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, Wc, 1, Hp, act, C, R, C, Hp, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->bpop, h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
@@ -825,7 +930,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // reduction + its updates) and the side stream takes the bias partials, the embedding scatter-add and their
         // updates -- the main stream then ends the step without waiting ~13 us for a cross-stream event behind the
         // branch that finishes last (profiles/round1_i_timeline.txt).
-        const bool swap = h->swap_tail && side_wgrad && nc == 1 && y.L == 1 && !y.E &&
+        const bool swap = h->swap_tail && side_wgrad && nc == 1 && y.L == 1 && !y.E && !y.n_sparse &&
                           y.n_params <= ((size_t)4 << 20) &&      // large models (C4: 34 M parameters) measured 2 % slower this way
                           !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER);   // phase-by-phase callers (data parallel) join the side stream
                                                                       // before their collective: same split of the tail
@@ -922,6 +1027,75 @@ extern "C" int sbr_join_side(sbr_handle* h) {
     return side_join(h);
 }
 
+// ---------------------------------------------------------------------------------------
+// data-parallel exchange of the row-sparse blocks (include/sbr_rnn.h)
+// ---------------------------------------------------------------------------------------
+extern "C" int sbr_sparse_info(sbr_handle* h, int b, int64_t* n_rows, int64_t* row_floats, int64_t* max_local_rows) {
+    CHECK_ARG(h, "null handle");
+    CHECK_ARG(b >= 0 && b < h->lay.n_sparse, "sparse block %d outside [0,%d)", b, h->lay.n_sparse);
+    const SparseBlockLayout& sb = h->lay.sparse[b];
+    if (n_rows) *n_rows = sb.n_rows;
+    if (row_floats) *row_floats = sb.W;
+    if (max_local_rows) *max_local_rows = sb.max_local;
+    return SBR_OK;
+}
+
+extern "C" int sbr_sparse_pack(sbr_handle* h, int b, int32_t* ids_dev, float* rows_dev, int32_t* count_host) {
+    CHECK_ARG(h && ids_dev && rows_dev && count_host, "null argument");
+    CHECK_ARG(b >= 0 && b < h->lay.n_sparse, "sparse block %d outside [0,%d)", b, h->lay.n_sparse);
+    const Layout& y = h->lay; const SparseBlockLayout& sb = y.sparse[b];
+    { const int rc = side_join(h); if (rc != SBR_OK) return rc; }      // the block's gradients come from both streams
+    int* count = (int*)h->A(sb.a_count);
+    const int epoch = ++h->sp_epoch;
+    if (sb.kind == 0) {
+        SBR_LAUNCH(launch_sparse_pack(h->stream, sparse_rows(h, b), (const int*)h->A(y.a_sid), (const int*)h->A(y.a_soff) + y.cfg.input_size, 0,
+                                      y.T * y.Bp * y.F, (int*)h->A(sb.a_mark), epoch, ids_dev, rows_dev, sb.W, count));
+    } else {
+        SBR_LAUNCH(launch_sparse_pack(h->stream, sparse_rows(h, b), (const int*)h->A(y.a_cells), nullptr, y.C, y.C, (int*)h->A(sb.a_mark), epoch,
+                                      ids_dev, rows_dev, sb.W, count));
+    }
+    SBR_HIP(hipMemcpyAsync(count_host, count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    h->sp_exchanged[b] = 1; h->sp_ncand[b] = 0;
+    return SBR_OK;
+}
+
+extern "C" int sbr_sparse_unpack_add(sbr_handle* h, int b, const int32_t* ids_dev, const float* rows_dev, int count) {
+    CHECK_ARG(h && (count == 0 || (ids_dev && rows_dev)), "null argument");
+    CHECK_ARG(b >= 0 && b < h->lay.n_sparse, "sparse block %d outside [0,%d)", b, h->lay.n_sparse);
+    const SparseBlockLayout& sb = h->lay.sparse[b];
+    if (!h->sp_exchanged[b]) { sbr_set_error("sbr_sparse_unpack_add: call sbr_sparse_pack for this step first"); return SBR_ESTATE; }
+    CHECK_ARG(count >= 0 && h->sp_ncand[b] + count <= sb.cand_cap, "%d + %d rows exceed the candidate capacity %d", h->sp_ncand[b], count, sb.cand_cap);
+    SBR_LAUNCH(launch_sparse_unpack_add(h->stream, sparse_rows(h, b), ids_dev, rows_dev, count, sb.W, (int*)h->A(sb.a_cand) + h->sp_ncand[b]));
+    h->sp_ncand[b] += count;
+    h->grads_clean = false;
+    return SBR_OK;
+}
+
+extern "C" int sbr_dense_ranges(sbr_handle* h, int cap, int64_t* lo, int64_t* hi, int* n) {
+    CHECK_ARG(h && lo && hi && n, "null argument");
+    const Layout& y = h->lay;
+    std::vector<std::pair<size_t, size_t>> skip;
+    for (int b = 0; b < y.n_sparse; ++b)
+        for (int k = 0; k < y.sparse[b].npairs; ++k)
+            skip.push_back({y.sparse[b].off[k], y.sparse[b].off[k] + (size_t)y.sparse[b].n_rows * y.sparse[b].stride[k]});
+    std::sort(skip.begin(), skip.end());
+    std::vector<std::pair<size_t, size_t>> out;
+    size_t pos = 0;
+    // ranges never straddle the output-layer split: the part in front of it is complete later than the part behind it
+    auto emit = [&](size_t a, size_t b) {
+        if (b <= a) return;
+        if (a < y.p_split && b > y.p_split) { out.push_back({a, y.p_split}); out.push_back({y.p_split, b}); }
+        else out.push_back({a, b});
+    };
+    for (auto& r : skip) { emit(pos, r.first); pos = r.second; }
+    emit(pos, y.n_params + 1);                        // the batch cost rides behind the last parameter
+    CHECK_ARG((int)out.size() <= cap, "%d ranges, capacity %d", (int)out.size(), cap);
+    for (size_t i = 0; i < out.size(); ++i) { lo[i] = (int64_t)out[i].first; hi[i] = (int64_t)out[i].second; }
+    *n = (int)out.size();
+    return SBR_OK;
+}
+
 extern "C" int sbr_apply_update(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     const Layout& y = h->lay;
@@ -932,7 +1106,35 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         return launch_update(h->stream, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1 ? s1 + lo : nullptr, hi - lo,
                              y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
     };
-    if (h->side_pending && h->tail_swapped) {
+    if (y.n_sparse) {
+        // dense pass over everything outside the sparse blocks, then one row-sparse step per block over the rows this step
+        // touched: the scatter's sorted ids / the sampled cells, or (data parallel) the ids gathered from every rank
+        { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+        std::vector<std::pair<size_t, size_t>> skip;
+        for (int b = 0; b < y.n_sparse; ++b)
+            for (int k = 0; k < y.sparse[b].npairs; ++k)
+                skip.push_back({y.sparse[b].off[k], y.sparse[b].off[k] + (size_t)y.sparse[b].n_rows * y.sparse[b].stride[k]});
+        std::sort(skip.begin(), skip.end());
+        size_t pos = 0;
+        for (auto& r : skip) { SBR_LAUNCH(upd(pos, r.first)); pos = r.second; }
+        SBR_LAUNCH(upd(pos, y.n_params));
+        for (int b = 0; b < y.n_sparse; ++b) {
+            const SparseBlockLayout& sb = y.sparse[b];
+            const SbrSparseRows rows = sparse_rows(h, b);
+            if (h->sp_exchanged[b]) {
+                SBR_LAUNCH(launch_sparse_step_list(h->stream, rows, sparse_upd(h), (const int*)h->A(sb.a_cand), nullptr, h->sp_ncand[b],
+                                                   h->sp_ncand[b], (int)h->step_count));
+            } else if (sb.kind == 0) {
+                const int nmax = y.T * y.Bp * y.F;
+                SBR_LAUNCH(launch_sparse_step_list(h->stream, rows, sparse_upd(h), (const int*)h->A(y.a_sid),
+                                                   (const int*)h->A(y.a_soff) + y.cfg.input_size, 0, nmax, (int)h->step_count));
+            } else {
+                SBR_LAUNCH(launch_sparse_step_list(h->stream, rows, sparse_upd(h), (const int*)h->A(y.a_cells), nullptr, y.C, y.C,
+                                                   (int)h->step_count));
+            }
+            h->sp_exchanged[b] = 0; h->sp_ncand[b] = 0;
+        }
+    } else if (h->side_pending && h->tail_swapped) {
         // side stream: everything but W_hid (W_in, b from its own scatter / partials; the output layer's gradients are its
         // own too); main stream: W_hid (its own GEMM) -- no event wait in front of it; then the main stream joins the side
         // stream, normally done by then
@@ -1053,6 +1255,7 @@ static int full_scores(sbr_handle* h, int do_softmax) {
     const Layout& y = h->lay;
     int rc;
     if (!h->fwd_done && (rc = sbr_forward(h)) != SBR_OK) return rc;
+    if ((rc = flush_lazy(h, 1)) != SBR_OK) return rc;      // every item is scored: all of W_out^T / b_out must be current
     float* lg = h->A(y.a_logits);
     // scoring always runs the exact-f32 kernel: a row's scores (hence its ranked ids) must not depend on how many rows
     // share the call (the bf16x6 kernel takes over at >= 96 rows and rounds differently)
@@ -1161,6 +1364,8 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         *value = simple_rec(h) ? 0 : sbr_rec_cluster_ok(a) ? 1 : sbr_rec_x6p_ok(a) ? 2 : sbr_rec_x6q_ok(a) ? 3 : 4;
     }
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
+    else if (w == "sparse_blocks") *value = y.n_sparse;
+    else if (w == "adam_table") *value = y.n_at;
     else if (w == "side_stream") *value = (int64_t)(intptr_t)h->side;
     else { sbr_set_error("unknown query '%s'", what); return SBR_EINVAL; }
     return SBR_OK;

@@ -51,8 +51,29 @@ struct LayerLayout {
     size_t a_part;   // [SBR_BWD_CHUNKS][Bp][G*Hp + 5*Hp] per-workgroup partial sums (up to one workgroup per row): bias, peepholes, inits
 };
 
+// A row-sparse parameter block: rows of up to two arrays that are touched together (the forward and backwards layer-0
+// W_in under --r_bi; W_out^T and b_out of a sampled head) share one row index space and one `last` array.
+struct SparseBlockLayout {
+    int kind;            // 0: rows indexed by the batch's input ids (layer-0 W_in or the embedding table); 1: by the sampled cells
+    int npairs;
+    size_t off[2];       // offset of row 0 inside the parameter / gradient / state sections
+    int width[2];        // floats of a row that are stored there
+    int stride[2];       // floats between consecutive rows
+    int n_rows;
+    int W;               // packed row width (sum of the widths) in the exchange buffers
+    int max_local;       // most rows one rank can touch per step (capacity of its exchange buffers)
+    size_t a_last;       // [n_rows] ints: step through which the row is current
+    size_t a_mark;       // [n_rows] ints: pack epoch (dedupe of the exchange)
+    size_t a_cand;       // [cand_cap] ints: the step's candidate rows in a data-parallel step (ids of every rank)
+    size_t a_count;      // device int: rows packed by the last sbr_sparse_pack
+    int cand_cap;
+};
+
 struct Layout {
     sbr_config cfg;
+    int n_sparse;                         // row-sparse blocks (0: every parameter takes the dense update)
+    SparseBlockLayout sparse[2];
+    size_t a_at; int n_at; int adam_early_exit;   // adam's a_t table (floats) for the lazy catch-up
     int L, G, T, B, Bp, N, F, Bg, S, C;   // C = Bg + S sampled columns
     int HLp;                              // padded width of one direction of the top layer
     int D, HLt;                           // directions per level (2 with --r_bi) and the output layer's input width D * HLp
@@ -115,6 +136,9 @@ struct sbr_handle {
     int cluster, cl_linear; // cluster recurrent kernels for wide layers (SBR_CLUSTER, SBR_CL_LINEAR)
     int cl_epoch;
     int x6_split, fuse_gather;
+    int sp_exchanged[2]; // data-parallel step: rows of block b were packed / gathered (candidates = a_cand[0 .. sp_ncand[b]))
+    int sp_ncand[2];
+    int sp_epoch;        // pack epoch
     float* lag_host;     // pinned: [2] cost, [2] fault flag (sbr_train_step_lagged)
     hipEvent_t ev_lag[2];
     int lag_slot, lag_pending;
@@ -304,6 +328,19 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
 // n elements starting at p / g / s0 / s1, skipping gap_len elements after the first gap_at (two ranges, one launch)
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);
+// sbr_sparse.hip: row-sparse optimizer steps (lazy catch-up) and gradient exchange for the large-catalogue blocks
+struct SbrSparseRows { int npairs; size_t off[2]; int width[2]; int stride[2]; int n_rows; float *p, *g, *s0, *s1; int* last; };
+struct SbrSparseUpd { int updater; float lr, rho, b1, b2; const float* at; int n_at; int early_exit; };
+hipError_t launch_sparse_catch_up_batch(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* X, const int* len, int T,
+                                        int Bp, int F, int t_to);
+hipError_t launch_sparse_catch_up_list(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* list, const int* n_dev,
+                                       int n_host, int n_max, int t_to);
+hipError_t launch_sparse_flush(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, int t_to);
+hipError_t launch_sparse_step_list(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* list, const int* n_dev,
+                                   int n_host, int n_max, int t_to);
+hipError_t launch_sparse_pack(hipStream_t s, const SbrSparseRows& r, const int* list, const int* n_dev, int n_host, int n_max, int* mark,
+                              int epoch, int* ids_out, float* rows_out, int W, int* count);
+hipError_t launch_sparse_unpack_add(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int n, int W, int* cand);
 // top-k (rnn_base.py:196-211)
 hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F,
                                int N);

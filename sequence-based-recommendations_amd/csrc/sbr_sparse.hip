@@ -1,0 +1,256 @@
+// Row-sparse optimizer steps and gradient exchange for the large-catalogue parameter blocks.
+//
+// The reference applies lasagne.updates.* densely to every parameter (update_manager.py:24-82): at 100 k - 1 M items
+// that is an elementwise pass over the whole item-major W_in [input_size][G*H] (and, for the sampled heads, W_out
+// [N][H] + b_out) per step -- 3.6 GB (C3) to 72 GB (C5) of HBM traffic for rows whose gradient is exactly zero:
+// only the rows the batch gathers (sparse_lstm.py:368) and the sampled cells (sparse_lstm.py:50-54) receive one.
+//
+// What a step does to a row with zero gradient, per updater (same formulas as update_kernel in sbr_misc.hip):
+//   adagrad   nothing (acc += 0, p -= lr * 0 / sqrt(acc + eps))                         -> skipping is EXACT
+//   rmsprop   acc *= rho                                                                -> k skipped steps: acc *= rho^k
+//   adadelta  acc *= rho, delta *= rho, p unchanged                                     -> both *= rho^k
+//   nesterov  v *= rho; p += rho * v                                                    -> geometric sum
+//   adam      m *= b1; v *= b2; p -= a_t * m / (sqrt(v) + eps)   (the row keeps moving) -> replayed step by step
+// Every row of a sparse block carries `last[row]` = the step through which it is current.  Before a row is read
+// (gathered by the forward pass, ranked by predict / top-k, exported by get_params) or stepped with a real gradient, it
+// is CAUGHT UP: the zero-gradient steps it missed are replayed -- Adam literally, one (m, v, p) update per missed step
+// with that step's own a_t, in the dense kernel's arithmetic, until the update is smaller than half an ulp of p and
+// provably stays so (then only m and v still change: one pow each); the others in closed form (a short loop for small k
+// so that the result is the dense kernel's bit for bit, pow for the long gaps).  "Lazy-exact": the dense oracle is
+// matched to float32 rounding over runs that touch rows intermittently (tests/test_gpu_sparse_update.py).
+//
+// Candidates are lists of row ids WITH duplicates (the batch's item ids, the sampled cells, the ids gathered from other
+// ranks): the first wave lane to raise last[id] with atomicMax owns the row, the others skip it.
+#include "sbr_common.h"
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SpUpd {
+    int updater;
+    float lr, rho, b1, b2;
+    const float* at;     // adam: a_t = lr * sqrt(1 - b2^t) / (1 - b1^t) for t = 1..n_at (host double -> float, as the dense launch computes it)
+    int n_at;            // beyond the table a_t == (float)lr
+    int early_exit;      // adam: a missed step's update shrinks monotonically (checked on the host from b1, b2 and the table)
+};
+
+__device__ __forceinline__ float sp_at(const SpUpd& u, long t) { return t <= (long)u.n_at ? u.at[t - 1] : u.lr; }
+
+// k zero-gradient steps t0+1 .. t0+k on one element
+__device__ __forceinline__ void sp_catch_up(const SpUpd& u, float& p, float& s0, float& s1, int k, long t0) {
+    if (k <= 0) return;
+    switch (u.updater) {
+        case SBR_UPD_ADAGRAD: return;
+        case SBR_UPD_RMSPROP:
+            if (k <= 32) { for (int j = 0; j < k; ++j) s0 = u.rho * s0 + (1.0f - u.rho) * 0.0f; }
+            else s0 *= powf(u.rho, (float)k);
+            return;
+        case SBR_UPD_ADADELTA:
+            if (k <= 32) { for (int j = 0; j < k; ++j) { s0 = u.rho * s0; s1 = u.rho * s1; } }
+            else { const float f = powf(u.rho, (float)k); s0 *= f; s1 *= f; }
+            return;
+        case SBR_UPD_NESTEROV:
+            if (k <= 32) { for (int j = 0; j < k; ++j) { const float v = u.rho * s0; s0 = v; p += u.rho * v; } }
+            else {      // p += rho * sum_{j=1..k} rho^j v0 ; v = rho^k v0
+                const float rk = powf(u.rho, (float)k);
+                p += u.rho * s0 * u.rho * (1.0f - rk) / (1.0f - u.rho);
+                s0 *= rk;
+            }
+            return;
+        default: {      // adam
+            float m = s0, v = s1;
+            int j = 0;
+            for (; j < k; ++j) {
+                if (m == 0.0f) break;                                   // never touched (or fully decayed): p is fixed
+                m = u.b1 * m; v = u.b2 * v;
+                const float upd = sp_at(u, t0 + 1 + j) * m / (sqrtf(v) + 1e-8f);
+                p -= upd;
+                if ((u.early_exit && fabsf(upd) < fabsf(p) * 1.4901161e-8f) || j >= 8190) { ++j; break; }   // < 2^-26 |p|: below half an ulp, and shrinking
+            }
+            if (j < k) { const float r = (float)(k - j); m *= powf(u.b1, r); v *= powf(u.b2, r); }
+            s0 = m; s1 = v;
+            return;
+        }
+    }
+}
+
+// one real step (gradient g) -- the dense update_kernel's arithmetic
+__device__ __forceinline__ void sp_step(const SpUpd& u, float& p, float g, float& s0, float& s1, float a_t) {
+    switch (u.updater) {
+        case SBR_UPD_ADAGRAD: { const float acc = s0 + g * g; s0 = acc; p -= u.lr * g / sqrtf(acc + 1e-6f); return; }
+        case SBR_UPD_RMSPROP: { const float acc = u.rho * s0 + (1.0f - u.rho) * g * g; s0 = acc; p -= u.lr * g / sqrtf(acc + 1e-6f); return; }
+        case SBR_UPD_ADADELTA: {
+            const float acc = u.rho * s0 + (1.0f - u.rho) * g * g;
+            const float upd = g * sqrtf(s1 + 1e-6f) / sqrtf(acc + 1e-6f);
+            s0 = acc; p -= u.lr * upd; s1 = u.rho * s1 + (1.0f - u.rho) * upd * upd; return;
+        }
+        case SBR_UPD_NESTEROV: { const float v = u.rho * s0 - u.lr * g; s0 = v; p += u.rho * v - u.lr * g; return; }
+        default: {
+            const float m = u.b1 * s0 + (1.0f - u.b1) * g;
+            const float v = u.b2 * s1 + (1.0f - u.b2) * g * g;
+            s0 = m; s1 = v; p -= a_t * m / (sqrtf(v) + 1e-8f); return;
+        }
+    }
+}
+
+// SRC 0: the current batch (X [Bp][T][F], len [Bp]: entry i = (b, t, f), valid when t < len[b]);
+//     1: an id list of *n_list (device) or n_host entries;   2: every row 0 .. n_rows-1 (flush)
+// STEP false: catch the row up to step t_to;  true: catch it up to t_to - 1, then apply step t_to with its gradient
+// (which is cleared, as the dense kernel clears what it consumes).
+template <int SRC, bool STEP>
+__global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, const int* __restrict__ X, const int* __restrict__ len,
+                                                      int T, int Bp, int F, const int* __restrict__ list, const int* __restrict__ n_list,
+                                                      int n_host, int t_to) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int total = SRC == 0 ? Bp * T * F : SRC == 1 ? (n_list ? *n_list : n_host) : r.n_rows;
+    const float a_t = STEP ? sp_at(u, t_to) : 0.0f;
+    for (int base = wave * 64; base < total; base += nwaves * 64) {
+        const int i = base + lane;
+        int id = -1;
+        if (i < total) {
+            if (SRC == 0) { const int b = i / (T * F), t = (i / F) % T; if (t < len[b]) id = X[i]; }
+            else if (SRC == 1) id = list[i];
+            else id = i;
+        }
+        int old = -1;
+        bool own = false;
+        if (id >= 0 && id < r.n_rows) {
+            old = r.last[id];
+            if (old < t_to) { old = SRC == 2 ? old : atomicMax(&r.last[id], t_to); own = old < t_to; if (SRC == 2) r.last[id] = t_to; }
+        }
+        unsigned long long owners = __ballot(own);
+        while (owners) {
+            const int src = __ffsll((long long)owners) - 1;
+            owners &= owners - 1;
+            const int rid = __shfl(id, src), rold = __shfl(old, src);
+            const int k = (STEP ? t_to - 1 : t_to) - rold;            // zero-gradient steps rold+1 .. rold+k
+            for (int pr = 0; pr < r.npairs; ++pr) {
+                const size_t ro = r.off[pr] + (size_t)rid * r.stride[pr];
+                const int w = r.width[pr];
+                if (w >= 4) {
+                    for (int c = lane * 4; c < w; c += 256) {
+                        f32x4 p = *(const f32x4*)(r.p + ro + c);
+                        f32x4 s0 = *(const f32x4*)(r.s0 + ro + c);
+                        f32x4 s1 = r.s1 ? *(const f32x4*)(r.s1 + ro + c) : f32x4{0, 0, 0, 0};
+                        f32x4 g = f32x4{0, 0, 0, 0};
+                        if (STEP) { g = *(const f32x4*)(r.g + ro + c); *(f32x4*)(r.g + ro + c) = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float pe = p[e], a = s0[e], b = s1[e];
+                            sp_catch_up(u, pe, a, b, k, (long)rold);
+                            if (STEP) sp_step(u, pe, g[e], a, b, a_t);
+                            p[e] = pe; s0[e] = a; s1[e] = b;
+                        }
+                        *(f32x4*)(r.p + ro + c) = p;
+                        *(f32x4*)(r.s0 + ro + c) = s0;
+                        if (r.s1) *(f32x4*)(r.s1 + ro + c) = s1;
+                    }
+                } else if (lane < w) {                                  // bias rows: one float
+                    const size_t o = ro + lane;
+                    float pe = r.p[o], a = r.s0[o], b = r.s1 ? r.s1[o] : 0.0f;
+                    sp_catch_up(u, pe, a, b, k, (long)rold);
+                    if (STEP) { const float g = r.g[o]; r.g[o] = 0.0f; sp_step(u, pe, g, a, b, a_t); }
+                    r.p[o] = pe; r.s0[o] = a; if (r.s1) r.s1[o] = b;
+                }
+            }
+        }
+    }
+}
+
+static SpUpd make_upd(const SbrSparseUpd& c) {
+    SpUpd u; u.updater = c.updater; u.lr = c.lr; u.rho = c.rho; u.b1 = c.b1; u.b2 = c.b2; u.at = c.at; u.n_at = c.n_at;
+    u.early_exit = c.early_exit;
+    return u;
+}
+static inline int sp_grid(long total) { return (int)std::max<long>(1, std::min<long>(2048, (total + 255) / 256)); }
+
+hipError_t launch_sparse_catch_up_batch(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* X, const int* len, int T,
+                                        int Bp, int F, int t_to) {
+    sp_rows_kernel<0, false><<<sp_grid((long)Bp * T * F), 256, 0, s>>>(r, make_upd(c), X, len, T, Bp, F, nullptr, nullptr, 0, t_to);
+    return hipGetLastError();
+}
+hipError_t launch_sparse_catch_up_list(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* list, const int* n_dev,
+                                       int n_host, int n_max, int t_to) {
+    sp_rows_kernel<1, false><<<sp_grid(n_max), 256, 0, s>>>(r, make_upd(c), nullptr, nullptr, 0, 0, 0, list, n_dev, n_host, t_to);
+    return hipGetLastError();
+}
+hipError_t launch_sparse_flush(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, int t_to) {
+    sp_rows_kernel<2, false><<<sp_grid(r.n_rows), 256, 0, s>>>(r, make_upd(c), nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, t_to);
+    return hipGetLastError();
+}
+hipError_t launch_sparse_step_list(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* list, const int* n_dev,
+                                   int n_host, int n_max, int t_to) {
+    sp_rows_kernel<1, true><<<sp_grid(n_max), 256, 0, s>>>(r, make_upd(c), nullptr, nullptr, 0, 0, 0, list, n_dev, n_host, t_to);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Sparse gradient exchange (data parallel): instead of all-reducing the whole block, every rank packs the gradient
+// rows it touched -- (row id, the row of every pair, concatenated) -- the ranks all-gather those, and every rank adds
+// all ranks' rows, in rank order, into its (now empty) gradient block: the replicas stay bit-identical.
+// ---------------------------------------------------------------------------------------
+// list: candidate ids with duplicates; mark[id] = epoch claims a row; count: running number of packed rows
+__global__ void __launch_bounds__(256) sp_pack_kernel(SbrSparseRows r, const int* __restrict__ list, const int* __restrict__ n_list, int n_host,
+                                                      int* __restrict__ mark, int epoch, int* __restrict__ ids_out,
+                                                      float* __restrict__ rows_out, int W, int* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int total = n_list ? *n_list : n_host;
+    for (int base = wave * 64; base < total; base += nwaves * 64) {
+        const int i = base + lane;
+        const int id = i < total ? list[i] : -1;
+        bool own = false;
+        if (id >= 0 && id < r.n_rows && mark[id] != epoch) own = atomicMax(&mark[id], epoch) != epoch;
+        int slot = 0;
+        if (own) { slot = atomicAdd(count, 1); ids_out[slot] = id; }
+        unsigned long long owners = __ballot(own);
+        while (owners) {
+            const int src = __ffsll((long long)owners) - 1;
+            owners &= owners - 1;
+            const int rid = __shfl(id, src), rslot = __shfl(slot, src);
+            float* dst = rows_out + (size_t)rslot * W;
+            int col = 0;
+            for (int pr = 0; pr < r.npairs; ++pr) {
+                float* g = r.g + r.off[pr] + (size_t)rid * r.stride[pr];
+                for (int c = lane; c < r.width[pr]; c += 64) { dst[col + c] = g[c]; g[c] = 0.0f; }
+                col += r.width[pr];
+            }
+        }
+    }
+}
+
+// rows of ONE rank (ids unique): g[id] += row; the ids are appended to the step's candidate list
+__global__ void __launch_bounds__(256) sp_unpack_kernel(SbrSparseRows r, const int* __restrict__ ids, const float* __restrict__ rows, int n,
+                                                        int W, int* __restrict__ cand) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int j = wave; j < n; j += nwaves) {
+        const int id = ids[j];
+        if (lane == 0) cand[j] = id;
+        if (id < 0 || id >= r.n_rows) continue;
+        const float* src = rows + (size_t)j * W;
+        int col = 0;
+        for (int pr = 0; pr < r.npairs; ++pr) {
+            float* g = r.g + r.off[pr] + (size_t)id * r.stride[pr];
+            for (int c = lane; c < r.width[pr]; c += 64) g[c] += src[col + c];
+            col += r.width[pr];
+        }
+    }
+}
+
+hipError_t launch_sparse_pack(hipStream_t s, const SbrSparseRows& r, const int* list, const int* n_dev, int n_host, int n_max, int* mark,
+                              int epoch, int* ids_out, float* rows_out, int W, int* count) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    sp_pack_kernel<<<sp_grid(n_max), 256, 0, s>>>(r, list, n_dev, n_host, mark, epoch, ids_out, rows_out, W, count);
+    return hipGetLastError();
+}
+hipError_t launch_sparse_unpack_add(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int n, int W, int* cand) {
+    if (n <= 0) return hipSuccess;
+    sp_unpack_kernel<<<sp_grid((long)n * 64), 256, 0, s>>>(r, ids, rows, n, W, cand);
+    return hipGetLastError();
+}

@@ -33,6 +33,8 @@ FLAG_SIMPLE_GEMM = 2
 FLAG_ATOMIC_SCATTER = 4
 FLAG_PROFILE_REC = 8
 FLAG_F32_MFMA = 16
+FLAG_SPARSE_UPDATE = 32      # row-sparse optimizer steps for every block that exists (default: where a step cannot touch every row)
+FLAG_DENSE_UPDATE = 64       # never: lasagne's dense pass over every parameter
 
 
 class SbrConfig(ctypes.Structure):
@@ -52,7 +54,8 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_train_step", "sbr_train_step_lagged", "sbr_lagged_flush", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
-           "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm",
+           "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
+           "sbr_sparse_unpack_add", "sbr_dense_ranges",
            "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
@@ -105,6 +108,11 @@ def load_library(path=None):
     lib.sbr_query.argtypes = [vp, ctypes.c_char_p, i64p]
     lib.sbr_debug_gemm.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64,
                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, ctypes.c_size_t, ctypes.c_int32]
+    lib.sbr_flush_lazy.argtypes = [vp]
+    lib.sbr_sparse_info.argtypes = [vp, ctypes.c_int, i64p, i64p, i64p]
+    lib.sbr_sparse_pack.argtypes = [vp, ctypes.c_int, vp, vp, i32p]
+    lib.sbr_sparse_unpack_add.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int]
+    lib.sbr_dense_ranges.argtypes = [vp, ctypes.c_int, i64p, i64p, ctypes.POINTER(ctypes.c_int)]
     lib.sbr_set_deferred_join.argtypes = [vp, ctypes.c_int]
     lib.sbr_join_side.argtypes = [vp]
     lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]
@@ -240,6 +248,9 @@ def make_config(cell="GRU", layers=(50,), n_items=None, max_length=30, batch_siz
     cfg.regularization = regularization
     cfg.grad_clip = grad_clip
     cfg.flags = int(flags)
+    sp = os.environ.get("SBR_SPARSE_UPDATE")             # 1 / 0 force the row-sparse optimizer on / off (include/sbr_rnn.h)
+    if sp is not None and not cfg.flags & (FLAG_SPARSE_UPDATE | FLAG_DENSE_UPDATE):
+        cfg.flags |= FLAG_SPARSE_UPDATE if sp not in ("0", "") else FLAG_DENSE_UPDATE
     cfg.embedding_size = max(0, int(embedding_size))     # --r_emb: a size < 1 means no embedding layer
     cfg.bidirectional = 1 if bidirectional else 0        # --r_bi
     return cfg
@@ -541,6 +552,49 @@ class RNNEngine(object):
         out = np.empty(n.value, dtype=np.float32)
         self._check(self.lib.sbr_copy_to_host(self.h, ptr, ctypes.c_void_p(out.ctypes.data), n.value))
         return out
+
+    # ---------------------------------------------------------------- row-sparse blocks (include/sbr_rnn.h)
+    def flush_lazy(self):
+        """Every lazily stepped row current through the last applied step (sbr_flush_lazy)."""
+        self._check(self.lib.sbr_flush_lazy(self.h))
+
+    def sparse_blocks(self):
+        """[(n_rows, row_floats, max_local_rows)] of the row-sparse parameter blocks of this configuration."""
+        out = []
+        for b in range(self.query("sparse_blocks")):
+            v = [ctypes.c_int64() for _ in range(3)]
+            self._check(self.lib.sbr_sparse_info(self.h, b, *[ctypes.byref(x) for x in v]))
+            out.append(tuple(int(x.value) for x in v))
+        return out
+
+    def sparse_pack(self, b):
+        """This rank's touched gradient rows of block b: (ids int32 [cap], rows float32 [cap, row_floats], count); the
+        first `count` entries are valid.  The tensors are the engine's exchange buffers (reused every step)."""
+        if not hasattr(self, "_sp_buf"):
+            self._sp_buf = {}
+        if b not in self._sp_buf:
+            n_rows, w, cap = self.sparse_blocks()[b]
+            with self.torch.cuda.device(self.device):
+                self._sp_buf[b] = (self.torch.empty(cap, dtype=self.torch.int32, device=self.device),
+                                   self.torch.empty((cap, w), dtype=self.torch.float32, device=self.device))
+        ids, rows = self._sp_buf[b]
+        n = ctypes.c_int32()
+        self._check(self.lib.sbr_sparse_pack(self.h, b, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(rows.data_ptr()),
+                                             ctypes.byref(n)))
+        return ids, rows, int(n.value)
+
+    def sparse_unpack_add(self, b, ids, rows, count):
+        """Adds ONE rank's packed rows into the gradient block (call for every rank in rank order, own rows included)."""
+        if count:
+            assert ids.is_contiguous() and rows.is_contiguous()
+        self._check(self.lib.sbr_sparse_unpack_add(self.h, b, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(rows.data_ptr()),
+                                                   int(count)))
+
+    def dense_ranges(self):
+        """[(lo, hi)] float ranges of the gradient section (trailing cost included) outside the sparse blocks."""
+        lo, hi, n = (ctypes.c_int64 * 16)(), (ctypes.c_int64 * 16)(), ctypes.c_int()
+        self._check(self.lib.sbr_dense_ranges(self.h, 16, lo, hi, ctypes.byref(n)))
+        return [(int(lo[i]), int(hi[i])) for i in range(n.value)]
 
     def set_deferred_join(self, on=True):
         self._check(self.lib.sbr_set_deferred_join(self.h, 1 if on else 0))

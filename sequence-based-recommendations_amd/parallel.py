@@ -48,25 +48,62 @@ class DataParallel(object):
         self.dist.all_gather(parts, local_target, group=self.group)
         return torch.cat(parts)
 
+    def _ranges(self):
+        """(output-layer ranges, recurrent ranges) of the gradient section that take the dense all-reduce."""
+        if not hasattr(self, "_rng"):
+            e = self.engine
+            n = self.grads.numel()
+            ranges = e.dense_ranges() if hasattr(e, "dense_ranges") else [(0, self.split), (self.split, n)]
+            self._rng = ([r for r in ranges if r[0] >= self.split], [r for r in ranges if r[0] < self.split])
+            self._nsparse = len(e.sparse_blocks()) if hasattr(e, "sparse_blocks") else 0
+        return self._rng
+
+    def _exchange_sparse(self, b):
+        """Row-sparse block b: all-gather of (row ids, gradient rows) instead of an all-reduce of the whole block
+        (8.2 GB of W_in at 1 M items against <= T*B_local rows of it per rank).  Every rank then adds all ranks'
+        rows in rank order, so the replicas stay bit-identical."""
+        import torch
+        e, dist = self.engine, self.dist
+        ids, rows, n = e.sparse_pack(b)
+        cnt = torch.tensor([n], dtype=torch.int32, device=ids.device)
+        cnts = [torch.empty_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt, group=self.group)
+        counts = [int(c.item()) for c in cnts]
+        m = max(counts)
+        if m == 0:
+            return
+        ids_m, rows_m = ids[:m].contiguous(), rows[:m].contiguous()
+        gids = [torch.empty_like(ids_m) for _ in range(self.world)]
+        grows = [torch.empty_like(rows_m) for _ in range(self.world)]
+        w1 = dist.all_gather(gids, ids_m, group=self.group, async_op=True)
+        w2 = dist.all_gather(grows, rows_m, group=self.group, async_op=True)
+        w1.wait(); w2.wait()
+        for r in range(self.world):
+            e.sparse_unpack_add(b, gids[r], grows[r], counts[r])
+
     def train_step(self):
         """One step on the batch already set on the engine; returns nothing (cost: read_cost())."""
         e = self.engine
         if self.world == 1 and not self.dist.is_initialized():
             e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()   # joins inside
             return
+        out_r, rec_r = self._ranges()
         e.zero_grads()
         e.forward()
         e.loss_backward_output()
+        red = lambda lo, hi: self.dist.all_reduce(self.grads[lo:hi], group=self.group, async_op=True)
         if self.side is not None:
             import torch
             with torch.cuda.stream(self.side):       # RCCL waits for the side stream only; the main stream runs the chain
-                w_out = self.dist.all_reduce(self.grads[self.split:], group=self.group, async_op=True)
+                works = [red(lo, hi) for lo, hi in out_r]
             e.backward_recurrent()
             e.join_side()                            # weight-gradient kernels of the recurrent part
         else:
-            w_out = self.dist.all_reduce(self.grads[self.split:], group=self.group, async_op=True)
+            works = [red(lo, hi) for lo, hi in out_r]
             e.backward_recurrent()
-        w_rec = self.dist.all_reduce(self.grads[:self.split], group=self.group, async_op=True)
-        w_out.wait()
-        w_rec.wait()
+        works += [red(lo, hi) for lo, hi in rec_r]
+        for b in range(self._nsparse):
+            self._exchange_sparse(b)
+        for w in works:
+            w.wait()
         e.apply_update()

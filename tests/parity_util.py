@@ -1,5 +1,8 @@
 """Shared helpers for the GPU parity tests and tools/gpu_diag.py: build a seeded model + batch,
 run the HIP engine and the CPU oracle on the same inputs, return per-quantity relative errors."""
+import json
+import os
+
 import numpy as np
 
 from oracle import rnn_oracle as O
@@ -136,8 +139,17 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
                 row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
                 top = -np.sort(-row)[:k + 1]
                 rows[b] = bool(np.all(top[:-1] - top[1:] > gap))
+        oids = np.array(oids)
+        for b in range(B):      # a row with fewer than k rankable items: the engine fills the places it cannot rank with -1
+            oids[b, max(0, N - len(set(excl[b]))):] = -1      # (the oracle's argpartition of zeros there is arbitrary)
         out["topk_rows_compared"] = float(rows.sum())
         out["topk_mismatch"] = float((ids[rows] != oids[rows]).sum())
     finally:
         eng.close()
+    log = os.environ.get("SBR_PARITY_LOG")       # tooling: one JSON line per comparison (profiles/round*_config_parity.jsonl)
+    if log:
+        with open(log, "a") as f:
+            f.write(json.dumps(dict(case=dict(cell=cell, layers=list(layers), loss=loss, N=N, B=B, T=T, S=S, updater=updater,
+                                              full=bool(full), zipf=bool(zipf), steps=steps, k=k, gap=gap),
+                                    **{kk: float(v) for kk, v in out.items()})) + "\n")
     return out

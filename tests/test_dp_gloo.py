@@ -60,7 +60,62 @@ class OracleEngine(object):
         return float(self.flat[-1])
 
 
-def _worker(rank, world, port, loss, out):
+class SparseOracleEngine(OracleEngine):
+    """The same stand-in with the engine's row-sparse exchange interface (sparse_blocks / sparse_pack /
+    sparse_unpack_add / dense_ranges): block 0 = the rows of the layer-0 W_in arrays (one (N, H) array per gate, packed
+    side by side), block 1 (sampled heads) = the columns of out.W with out.b.  DataParallel must then all-gather
+    (ids, rows) for those and all-reduce only the rest."""
+
+    def __init__(self, params, cfg, updater, Bglobal, row_offset, cap):
+        OracleEngine.__init__(self, params, cfg, updater, Bglobal, row_offset)
+        offs = np.cumsum([0] + self.sizes)
+        G = O.CELL_GATES[cfg["cell"]]
+        N, H = params[0].shape
+        self.blocks = [[(int(offs[3 * g]), N, H, H, 1) for g in range(G)]]       # (offset, rows, width, row stride, col stride)
+        if cfg["loss"] != "CCE":
+            HL, No = params[-2].shape
+            self.blocks.append([(int(offs[-3]), No, HL, 1, No), (int(offs[-2]), No, 1, 1, 1)])   # out.W is (H, N): a "row" is a column
+        self.cap = cap
+
+    def _view(self, blk, ids):
+        cols = []
+        for off, rows, w, rs, cs in blk:
+            idx = off + np.asarray(ids)[:, None] * rs + np.arange(w)[None, :] * cs
+            cols.append(idx)
+        return np.concatenate(cols, axis=1)
+
+    def sparse_blocks(self):
+        return [(blk[0][1], sum(b[2] for b in blk), self.cap) for blk in self.blocks]
+
+    def sparse_pack(self, b):
+        blk = self.blocks[b]
+        allidx = self._view(blk, np.arange(blk[0][1]))
+        g = self.flat.numpy()
+        ids = np.nonzero(np.abs(g[allidx]).sum(axis=1) > 0)[0]
+        n = len(ids)
+        out_ids = torch.zeros(self.cap, dtype=torch.int32); out_rows = torch.zeros((self.cap, allidx.shape[1]), dtype=torch.float64)
+        out_ids[:n] = torch.from_numpy(ids.astype(np.int32)); out_rows[:n] = torch.from_numpy(g[allidx[ids]])
+        g[allidx[ids].reshape(-1)] = 0.0
+        return out_ids, out_rows, n
+
+    def sparse_unpack_add(self, b, ids, rows, count):
+        if count:
+            idx = self._view(self.blocks[b], ids[:count].numpy())
+            self.flat.numpy()[idx] += rows[:count].numpy()
+
+    def dense_ranges(self):
+        taken = np.zeros(self.flat.numel(), dtype=bool)
+        for blk in self.blocks:
+            taken[self._view(blk, np.arange(blk[0][1])).reshape(-1)] = True
+        edges = np.flatnonzero(np.diff(np.concatenate([[True], taken, [True]]).astype(np.int8)))
+        rs = [(int(a), int(b)) for a, b in zip(edges[::2], edges[1::2])]
+        out = []
+        for a, b in rs:       # never across the output-layer split
+            out += [(a, self.split), (self.split, b)] if a < self.split < b else [(a, b)]
+        return out
+
+
+def _worker(rank, world, port, loss, out, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -69,7 +124,10 @@ def _worker(rank, world, port, loss, out):
     params, cfg, batch = PU.build_case("GRU", [6], loss, N, B, T, S=S, seed=11)
     cfg["regularization"] = 0.03 if loss == "CCE" else 0.0
     lo, hi = DataParallel.shard(B, world, rank)
-    eng = OracleEngine([p.copy() for p in params], cfg, "adam", B, lo)
+    if sparse:
+        eng = SparseOracleEngine([p.copy() for p in params], cfg, "adam", B, lo, cap=N)
+    else:
+        eng = OracleEngine([p.copy() for p in params], cfg, "adam", B, lo)
     dp = DataParallel(eng, dist)
     ob = PU.oracle_batch(batch)
     local_t = torch.from_numpy(ob["target"][lo:hi])
@@ -83,11 +141,12 @@ def _worker(rank, world, port, loss, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("sparse", [False, True], ids=["allreduce", "sparse_exchange"])
 @pytest.mark.parametrize("loss", ["CCE", "Blackout", "BPR"])
-def test_two_rank_step_equals_single_process(tmp_path, loss):
+def test_two_rank_step_equals_single_process(tmp_path, loss, sparse):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(2, port, loss, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, loss, out, sparse), nprocs=2, join=True)
     B, T, N, S = 6, 5, 17, 4
     params, cfg, batch = PU.build_case("GRU", [6], loss, N, B, T, S=S, seed=11)
     cfg["regularization"] = 0.03 if loss == "CCE" else 0.0

@@ -18,7 +18,12 @@ CASES = {
     "gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
     "lstm20_blackout_adagrad": ("LSTM", [20], "Blackout", 200, 32, 12, 8, "adagrad"),
     "lstm256_bpr_adam": ("LSTM", [256], "BPR", 500, 32, 10, 8, "adam"),
+    # row-sparse blocks (forced on these small shapes): all-gather of (ids, rows) instead of the all-reduce of W_in / W_out
+    "sparse_gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
+    "sparse_lstm20_blackout_adagrad": ("LSTM", [20], "Blackout", 200, 32, 12, 8, "adagrad"),
+    "sparse_lstm256_bpr_nesterov": ("LSTM", [256], "BPR", 500, 32, 10, 8, "nesterov"),
 }
+SPARSE_FLAG = 32
 
 
 def _worker(rank, world, port, name, out):
@@ -32,11 +37,14 @@ def _worker(rank, world, port, name, out):
     cell, layers, loss, N, B, T, S, updater = CASES[name]
     params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=31, scale=0.05)
     lo, hi = DataParallel.shard(B, world, rank)
-    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater, local_batch=hi - lo, row_offset=lo)
+    flags = SPARSE_FLAG if name.startswith("sparse") else 0
+    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater, local_batch=hi - lo, row_offset=lo, flags=flags)
     try:
         eng.set_all_param_values(params)
         dp = DataParallel(eng, dist)
         assert dp.side is not None                      # the stream-level path, not the stand-in one
+        if flags:
+            assert len(eng.sparse_blocks()) == (1 if loss == "CCE" else 2)
         smp = batch["samples"] if loss != "CCE" else None
         if loss != "CCE":      # every rank needs all B targets (Blackout's softmax spans them): all-gather of the local ones
             tgt = dp.gather_targets(torch.from_numpy(batch["target"][lo:hi]).cuda()).cpu().numpy()
@@ -62,7 +70,7 @@ def test_two_ranks_on_one_gpu_equal_the_single_engine_step(tmp_path, name):
     mp.spawn(_worker, args=(2, port, name, out), nprocs=2, join=True)
     cell, layers, loss, N, B, T, S, updater = CASES[name]
     params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=31, scale=0.05)
-    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater)
+    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater, flags=64 if name.startswith("sparse") else 0)   # reference: the dense step
     try:
         eng.set_all_param_values(params)
         smp = batch["samples"] if loss != "CCE" else None
