@@ -79,6 +79,11 @@ typedef struct sbr_config {
  * every row of it anyway (more rows than the batch has item ids / more items than sampled cells). */
 #define SBR_FLAG_SPARSE_UPDATE 32 /* always, for every block that exists (tests) */
 #define SBR_FLAG_DENSE_UPDATE 64  /* never: one dense elementwise pass over every parameter, as lasagne.updates.* does */
+/* Output projection h . W_out (DenseLayer rnn_one_hot.py:65 / BlackoutLayer's deterministic branch sparse_lstm.py:37-40) on
+ * plain bf16 operands with f32 accumulation (one v_mfma_f32_16x16x32_bf16 per block): the training forward of the full
+ * softmax and predict / top-k of every head.  Scores then carry bf16 input rounding (~3e-3 of their spread) instead of
+ * float32 rounding; gradients still come from the float32-class kernels. */
+#define SBR_FLAG_BF16_PROJECTION 128
 
 typedef struct sbr_handle sbr_handle;
 
@@ -193,7 +198,8 @@ int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_host);
 
 /* The dense GEMM of the hot path on caller-provided DEVICE buffers (parity tests of the kernels themselves):
  * C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]); ws: split-K workspace (may be NULL).
- * exact_f32 != 0: v_mfma_f32_16x16x4_f32 kernel; 0: bf16x6 kernel where the shape allows it. */
+ * exact_f32 = 1: v_mfma_f32_16x16x4_f32 kernel; 0: bf16x6 kernel where the shape allows it; 2: plain bf16 operands (the
+ * SBR_FLAG_BF16_PROJECTION kernel). */
 int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                    float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* ws, size_t ws_floats,
                    int32_t exact_f32);

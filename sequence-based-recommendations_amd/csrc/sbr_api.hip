@@ -838,7 +838,11 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         float* lg = h->A(y.a_logits);
         const int Nl = (N + 3) & ~3;               // row stride of the logits / dlogits buffer
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
-        SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg));
+        const bool bf16p = (y.cfg.flags & SBR_FLAG_BF16_PROJECTION) && !sg;
+        if (bf16p) sbr_gemm_set_planes(1);
+        const hipError_t ge = launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg);
+        sbr_gemm_set_planes(3);
+        SBR_LAUNCH(ge);
         SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, Nl, y.Bg));
         // critical path: dh = dlogits . W_out^T feeds the BPTT chain
         SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
@@ -1259,9 +1263,14 @@ static int full_scores(sbr_handle* h, int do_softmax) {
     float* lg = h->A(y.a_logits);
     // scoring always runs the exact-f32 kernel: a row's scores (hence its ranked ids) must not depend on how many rows
     // share the call (the bf16x6 kernel takes over at >= 96 rows and rounds differently)
+    // (SBR_FLAG_BF16_PROJECTION: the single-plane bf16 kernel, which serves any number of rows with the same arithmetic)
     sbr_gemm_set_exact_f32(true);
-    SBR_LAUNCH(launch_gemm(h->stream, h_last(h), y.HLt, 1, h->P(y.p_WoutT), 1, y.HLt, lg, y.N, h->n_rows, y.N, y.HLt, nullptr,
-                           nullptr, 0, simple_gemm(h)));
+    const bool bf16p = (y.cfg.flags & SBR_FLAG_BF16_PROJECTION) && !simple_gemm(h);
+    if (bf16p) sbr_gemm_set_planes(1);
+    const hipError_t ge = launch_gemm(h->stream, h_last(h), y.HLt, 1, h->P(y.p_WoutT), 1, y.HLt, lg, y.N, h->n_rows, y.N, y.HLt, nullptr,
+                                      nullptr, 0, simple_gemm(h));
+    sbr_gemm_set_planes(3);
+    SBR_LAUNCH(ge);
     SBR_LAUNCH(launch_softmax_rows(h->stream, lg, h->P(y.p_bout), h->n_rows, y.N, do_softmax));
     return SBR_OK;
 }
@@ -1345,9 +1354,12 @@ extern "C" int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t
                               float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* ws,
                               size_t ws_floats, int32_t exact_f32) {
     CHECK_ARG(A && B && C, "null operand");
-    sbr_gemm_set_exact_f32(exact_f32 != 0);
-    SBR_LAUNCH(launch_gemm((hipStream_t)stream, A, (long)sam, (long)sak, B, (long)sbk, (long)sbn, C, (long)ldc, M, N, K, bias, ws,
-                           ws_floats, false));
+    sbr_gemm_set_exact_f32(exact_f32 == 1);
+    sbr_gemm_set_planes(exact_f32 == 2 ? 1 : 3);
+    const hipError_t ge = launch_gemm((hipStream_t)stream, A, (long)sam, (long)sak, B, (long)sbk, (long)sbn, C, (long)ldc, M, N, K, bias, ws,
+                                      ws_floats, false);
+    sbr_gemm_set_planes(3);
+    SBR_LAUNCH(ge);
     return SBR_OK;
 }
 

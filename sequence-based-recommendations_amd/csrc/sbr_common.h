@@ -291,8 +291,10 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
 // bf16x6 GEMM (sbr_gemm_x6.hip): false = shape not supported, use the f32 kernel
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0, bool small = false);
+                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0, bool small = false, int planes = 3);
 void sbr_gemm_set_exact_f32(bool on);
+// planes = 1: the next launch_gemm calls run on plain bf16 operands (one MFMA per block, no split-K), for any number of rows
+void sbr_gemm_set_planes(int planes);
 
 // slabs are [z][slab_stride] with row stride ws_ld: a GEMM may fill only a column range of wider slabs
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,

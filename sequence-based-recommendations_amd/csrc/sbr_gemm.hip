@@ -205,6 +205,8 @@ __global__ void gemm_naive(GemmArgs g) {
 // SBR_FLAG_F32_MFMA: keep every GEMM on the exact-f32 kernel (set per call by the API layer; a handle is not thread-safe)
 static bool g_gemm_exact_f32 = false;
 void sbr_gemm_set_exact_f32(bool on) { g_gemm_exact_f32 = on; }
+static int g_gemm_planes = 3;
+void sbr_gemm_set_planes(int planes) { g_gemm_planes = planes == 1 ? 1 : 3; }
 
 // split-K partial products only: writes exactly `nsplit` slabs [z][M][N] at ws (no reduction)
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
@@ -243,6 +245,14 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
         const size_t n = (size_t)M * N;
         gemm_naive<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g);
         return hipGetLastError();
+    }
+    if (g_gemm_planes == 1 && a_blk_Bp == 0 && b_blk_Bp == 0) {
+        // plain bf16 operands: one pass over K in a fixed order (no split-K), so that an output element never depends on M
+        hipError_t e = hipSuccess;
+        const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
+        if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, 1, (K + 31) / 32 * 32, (size_t)M * N, &e, nullptr, 0, 0,
+                           t128 < 128 || M < 96, 1))
+            return e;
     }
     if (!g_gemm_exact_f32 && a_blk_Bp == 0 && b_blk_Bp == 0 && M >= 48 && N >= 48 && K >= 32) {
         const char* sb = getenv("SBR_GEMM_SMALL_BELOW");                 // read per call: the tests flip it

@@ -72,11 +72,15 @@ __device__ __forceinline__ void x6_load(const float* __restrict__ p, long stride
 // described above; <2, 2> is a 64x64x64 tile for problems that would put fewer than ~128 of the large tiles on the chip
 // (C2's logits 256 x 3706 x 128 and dh 256 x 128 x 3706: 58 / 56 workgroups of the large tile, ~230 of the small one).
 // Either way 128 threads load one operand tile, 4 rows x 8 k each.
-template <int VA, bool RA, int VB, bool RB, int TW, int KH>
+// NP = bf16 planes per operand: 3 = the exact split above (six MFMA terms); 1 = plain bf16 operands (round to nearest
+// even), ONE v_mfma_f32_16x16x32_bf16 per block with f32 accumulation -- the "bf16 MFMA output projection" of the 1 M-item
+// configuration (BASELINE.json configs[4]; SBR_FLAG_BF16_PROJECTION): logits to ~3e-3 of their spread instead of f32
+// rounding, a sixth of the matrix-pipe time and a third of the LDS traffic.
+template <int VA, bool RA, int VB, bool RB, int TW, int KH, int NP>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     constexpr int TM = 32 * TW, TK = 32 * KH, ROW = 64 * KH + 16, PLANE = TM * ROW, KC = 4 * KH;
-    __shared__ __attribute__((aligned(16))) char sA[3 * PLANE];
-    __shared__ __attribute__((aligned(16))) char sB[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) char sA[NP * PLANE];
+    __shared__ __attribute__((aligned(16))) char sB[NP * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int j = lane & 15, q = lane >> 4;
@@ -113,19 +117,25 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bf16x8 p1, p2, p3;
+            if constexpr (NP == 1) {
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) { __bf16 a, b, c; split3(v[i][kk], a, b, c); p1[kk] = a; p2[kk] = b; p3[kk] = c; }
-            *(bf16x8*)(sdst + i * ROW) = p1;
-            *(bf16x8*)(sdst + i * ROW + PLANE) = p2;
-            *(bf16x8*)(sdst + i * ROW + 2 * PLANE) = p3;
+                for (int kk = 0; kk < 8; ++kk) p1[kk] = (__bf16)v[i][kk];
+                *(bf16x8*)(sdst + i * ROW) = p1;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) { __bf16 a, b, c; split3(v[i][kk], a, b, c); p1[kk] = a; p2[kk] = b; p3[kk] = c; }
+                *(bf16x8*)(sdst + i * ROW) = p1;
+                *(bf16x8*)(sdst + i * ROW + PLANE) = p2;
+                *(bf16x8*)(sdst + i * ROW + 2 * PLANE) = p3;
+            }
         }
         __syncthreads();
         if (k0 + TK < kend) load(k0 + TK);                 // in flight while this tile's MFMAs run
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
-            bf16x8 a[3][TW], b[3][TW];
+            bf16x8 a[NP][TW], b[NP][TW];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     a[p][t] = *(const bf16x8*)(sA + p * PLANE + (wm * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
@@ -134,7 +144,8 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
             // smallest terms first: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1; TW*TW independent accumulators per term
 #define X6_TERM(PA, PB) _Pragma("unroll") for (int mi = 0; mi < TW; ++mi) _Pragma("unroll") for (int ni = 0; ni < TW; ++ni) \
                 acc[mi][ni] = MFMA_BF16(a[PA][mi], b[PB][ni], acc[mi][ni]);
-            X6_TERM(0, 2) X6_TERM(2, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0)
+            if constexpr (NP == 1) { X6_TERM(0, 0) }
+            else { X6_TERM(0, NP - 1) X6_TERM(NP - 1, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0) }
 #undef X6_TERM
         }
         __syncthreads();
@@ -165,8 +176,9 @@ static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte 
 // C + z*slab_stride, row stride ldc.
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2, long sbk2, int n_split, bool small) {
-    if (M < (small ? 48 : 96) || N < (small ? 48 : 96) || K < 32) return false;
+                    const float* B2, long sbk2, int n_split, bool small, int planes) {
+    if (planes == 1) { if (M < 1 || N < 48 || K < 32) return false; }      // any number of rows: a row's scores must not depend on
+    else if (M < (small ? 48 : 96) || N < (small ? 48 : 96) || K < 32) return false;   // how many rows share the call
     if (B2 && (sbn != 1 || (n_split & 3) || !x6_aligned(B2, sbk2))) return false;
     if (!(sam == 1 || sak == 1) || !(sbk == 1 || sbn == 1)) return false;
     const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
@@ -174,12 +186,13 @@ bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const flo
     GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split};
     const int tile = small ? 64 : 128;
     const dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, nsplit);
-#define X6_GO(TW, KH) do { \
-        if (ra && rb) gemm_x6_kernel<4, true, 4, true, TW, KH><<<grid, 256, 0, s>>>(g); \
-        else if (ra) gemm_x6_kernel<4, true, 4, false, TW, KH><<<grid, 256, 0, s>>>(g); \
-        else if (rb) gemm_x6_kernel<4, false, 4, true, TW, KH><<<grid, 256, 0, s>>>(g); \
-        else gemm_x6_kernel<4, false, 4, false, TW, KH><<<grid, 256, 0, s>>>(g); } while (0)
-    if (small) X6_GO(2, 2); else X6_GO(4, 1);
+#define X6_GO(TW, KH, NP) do { \
+        if (ra && rb) gemm_x6_kernel<4, true, 4, true, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
+        else if (ra) gemm_x6_kernel<4, true, 4, false, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
+        else if (rb) gemm_x6_kernel<4, false, 4, true, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
+        else gemm_x6_kernel<4, false, 4, false, TW, KH, NP><<<grid, 256, 0, s>>>(g); } while (0)
+    if (planes == 1) { if (small) X6_GO(2, 2, 1); else X6_GO(4, 1, 1); }
+    else if (small) X6_GO(2, 2, 3); else X6_GO(4, 1, 3);
 #undef X6_GO
     *err = hipGetLastError();
     return true;

@@ -97,6 +97,12 @@ __device__ __forceinline__ void sp_step(const SpUpd& u, float& p, float g, float
 //     1: an id list of *n_list (device) or n_host entries;   2: every row 0 .. n_rows-1 (flush)
 // STEP false: catch the row up to step t_to;  true: catch it up to t_to - 1, then apply step t_to with its gradient
 // (which is cleared, as the dense kernel clears what it consumes).
+// A wave takes SP_CPW candidates at a time and then walks the rows it owns one after the other, all 64 lanes on one row:
+// a row pass is a dependent load -> math -> store chain of ~2 us, so the candidates per wave bound the length of the
+// serial chain (64 per wave measured 600 us for C3's 51 200 candidates, the kernel being nothing but 64-deep chains);
+// up to four 256-float pieces of a row are loaded before the first is used.
+#define SP_CPW 8
+#define SP_NV 4
 template <int SRC, bool STEP>
 __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, const int* __restrict__ X, const int* __restrict__ len,
                                                       int T, int Bp, int F, const int* __restrict__ list, const int* __restrict__ n_list,
@@ -106,10 +112,10 @@ __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, 
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int total = SRC == 0 ? Bp * T * F : SRC == 1 ? (n_list ? *n_list : n_host) : r.n_rows;
     const float a_t = STEP ? sp_at(u, t_to) : 0.0f;
-    for (int base = wave * 64; base < total; base += nwaves * 64) {
+    for (int base = wave * SP_CPW; base < total; base += nwaves * SP_CPW) {
         const int i = base + lane;
         int id = -1;
-        if (i < total) {
+        if (lane < SP_CPW && i < total) {
             if (SRC == 0) { const int b = i / (T * F), t = (i / F) % T; if (t < len[b]) id = X[i]; }
             else if (SRC == 1) id = list[i];
             else id = i;
@@ -126,32 +132,44 @@ __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, 
             owners &= owners - 1;
             const int rid = __shfl(id, src), rold = __shfl(old, src);
             const int k = (STEP ? t_to - 1 : t_to) - rold;            // zero-gradient steps rold+1 .. rold+k
+            if (!STEP && (k <= 0 || u.updater == SBR_UPD_ADAGRAD)) continue;
             for (int pr = 0; pr < r.npairs; ++pr) {
                 const size_t ro = r.off[pr] + (size_t)rid * r.stride[pr];
                 const int w = r.width[pr];
                 if (w >= 4) {
-                    for (int c = lane * 4; c < w; c += 256) {
-                        f32x4 p = *(const f32x4*)(r.p + ro + c);
-                        f32x4 s0 = *(const f32x4*)(r.s0 + ro + c);
-                        f32x4 s1 = r.s1 ? *(const f32x4*)(r.s1 + ro + c) : f32x4{0, 0, 0, 0};
-                        f32x4 g = f32x4{0, 0, 0, 0};
-                        if (STEP) { g = *(const f32x4*)(r.g + ro + c); *(f32x4*)(r.g + ro + c) = f32x4{0, 0, 0, 0}; }
+                    for (int c0 = 0; c0 < w; c0 += 256 * SP_NV) {
+                        f32x4 p[SP_NV], s0[SP_NV], s1[SP_NV], g[SP_NV];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float pe = p[e], a = s0[e], b = s1[e];
-                            sp_catch_up(u, pe, a, b, k, (long)rold);
-                            if (STEP) sp_step(u, pe, g[e], a, b, a_t);
-                            p[e] = pe; s0[e] = a; s1[e] = b;
+                        for (int v = 0; v < SP_NV; ++v) {
+                            const int c = c0 + v * 256 + lane * 4;
+                            const bool in = c < w;
+                            p[v] = in ? *(const f32x4*)(r.p + ro + c) : f32x4{0, 0, 0, 0};
+                            s0[v] = in ? *(const f32x4*)(r.s0 + ro + c) : f32x4{0, 0, 0, 0};
+                            s1[v] = (in && r.s1) ? *(const f32x4*)(r.s1 + ro + c) : f32x4{0, 0, 0, 0};
+                            g[v] = (in && STEP) ? *(const f32x4*)(r.g + ro + c) : f32x4{0, 0, 0, 0};
                         }
-                        *(f32x4*)(r.p + ro + c) = p;
-                        *(f32x4*)(r.s0 + ro + c) = s0;
-                        if (r.s1) *(f32x4*)(r.s1 + ro + c) = s1;
+#pragma unroll
+                        for (int v = 0; v < SP_NV; ++v) {
+                            const int c = c0 + v * 256 + lane * 4;
+                            if (c >= w) continue;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float pe = p[v][e], a = s0[v][e], b = s1[v][e];
+                                sp_catch_up(u, pe, a, b, k, (long)rold);
+                                if (STEP) sp_step(u, pe, g[v][e], a, b, a_t);
+                                p[v][e] = pe; s0[v][e] = a; s1[v][e] = b;
+                            }
+                            *(f32x4*)(r.p + ro + c) = p[v];
+                            *(f32x4*)(r.s0 + ro + c) = s0[v];
+                            if (r.s1) *(f32x4*)(r.s1 + ro + c) = s1[v];
+                            if (STEP) *(f32x4*)(r.g + ro + c) = f32x4{0, 0, 0, 0};
+                        }
                     }
                 } else if (lane < w) {                                  // bias rows: one float
                     const size_t o = ro + lane;
                     float pe = r.p[o], a = r.s0[o], b = r.s1 ? r.s1[o] : 0.0f;
                     sp_catch_up(u, pe, a, b, k, (long)rold);
-                    if (STEP) { const float g = r.g[o]; r.g[o] = 0.0f; sp_step(u, pe, g, a, b, a_t); }
+                    if (STEP) { const float gg = r.g[o]; r.g[o] = 0.0f; sp_step(u, pe, gg, a, b, a_t); }
                     r.p[o] = pe; r.s0[o] = a; if (r.s1) r.s1[o] = b;
                 }
             }
@@ -164,7 +182,8 @@ static SpUpd make_upd(const SbrSparseUpd& c) {
     u.early_exit = c.early_exit;
     return u;
 }
-static inline int sp_grid(long total) { return (int)std::max<long>(1, std::min<long>(2048, (total + 255) / 256)); }
+// one wave per SP_CPW candidates (4 waves per workgroup), at most 16 k workgroups (grid-stride beyond)
+static inline int sp_grid(long total) { return (int)std::max<long>(1, std::min<long>(16384, (total + 4 * SP_CPW - 1) / (4 * SP_CPW))); }
 
 hipError_t launch_sparse_catch_up_batch(hipStream_t s, const SbrSparseRows& r, const SbrSparseUpd& c, const int* X, const int* len, int T,
                                         int Bp, int F, int t_to) {
@@ -199,9 +218,9 @@ __global__ void __launch_bounds__(256) sp_pack_kernel(SbrSparseRows r, const int
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int total = n_list ? *n_list : n_host;
-    for (int base = wave * 64; base < total; base += nwaves * 64) {
+    for (int base = wave * SP_CPW; base < total; base += nwaves * SP_CPW) {
         const int i = base + lane;
-        const int id = i < total ? list[i] : -1;
+        const int id = (lane < SP_CPW && i < total) ? list[i] : -1;
         bool own = false;
         if (id >= 0 && id < r.n_rows && mark[id] != epoch) own = atomicMax(&mark[id], epoch) != epoch;
         int slot = 0;
@@ -251,6 +270,6 @@ hipError_t launch_sparse_pack(hipStream_t s, const SbrSparseRows& r, const int* 
 }
 hipError_t launch_sparse_unpack_add(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int n, int W, int* cand) {
     if (n <= 0) return hipSuccess;
-    sp_unpack_kernel<<<sp_grid((long)n * 64), 256, 0, s>>>(r, ids, rows, n, W, cand);
+    sp_unpack_kernel<<<std::max(1, std::min(16384, (n + 3) / 4)), 256, 0, s>>>(r, ids, rows, n, W, cand);
     return hipGetLastError();
 }

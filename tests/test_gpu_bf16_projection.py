@@ -1,0 +1,59 @@
+"""SBR_FLAG_BF16_PROJECTION: the output projection h . W_out on plain bf16 operands with f32 accumulation (one
+v_mfma_f32_16x16x32_bf16 per block) -- BASELINE.json configs[4] ("bf16 MFMA output projection").  Against the float64
+oracle: logits within 1e-3 of their largest magnitude (north_star), cost to bf16-input rounding, gradients unchanged in
+class (they come from the float32-class kernels, fed with the bf16-rounded softmax), and the ordered top-10 ids exact
+on the rows whose oracle logits are separated by more than six times the measured logit error."""
+import numpy as np
+import pytest
+
+import parity_util as PU
+from oracle import rnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16 = 128
+
+
+@pytest.mark.parametrize("case", [("GRU", [128], "CCE", 3706, 256, 12, 0), ("LSTM", [256], "Blackout", 100000, 64, 8, 32),
+                                  ("LSTM", [512, 512], "BPR", 20000, 33, 6, 16)],
+                         ids=["c2_head", "c3_head_100k", "c5_width"])
+def test_bf16_projection_scores_and_ranking(case):
+    cell, layers, loss, N, B, T, S = case
+    params, cfg, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=41, scale=0.03, zipf=True)
+    eng = PU.engine_for(cfg, N, B, T, S=S, flags=BF16)
+    ref = PU.engine_for(cfg, N, B, T, S=S)
+    try:
+        for e in (eng, ref):
+            e.set_all_param_values(params)
+        # raw logits through top-k's path: probs of the CCE head are softmax(logits); compare logits via log
+        scores = eng.test_probabilities(batch["X"], batch["mask"]).astype(np.float64)
+        _, ologits = O.predict_scores(params, cfg, batch["X"], batch["mask"])
+        lg = np.log(np.maximum(scores, 1e-300))
+        lg = lg - lg.max(axis=1, keepdims=True) + ologits.max(axis=1, keepdims=True)    # softmax fixes logits up to a row shift
+        err = np.abs(lg - ologits).max()
+        assert err <= 1e-3 * np.abs(ologits).max() + 2e-3 * ologits.std(), (err, np.abs(ologits).max(), ologits.std())
+        assert err > 1e-6                      # bf16-class: the flag really changes the kernel
+        # ranking: rows whose top-11 oracle logits are pairwise further apart than 6 x the measured error
+        k = 10
+        ids = eng.test_function((batch["X"], batch["mask"]), k=k)
+        ids_f32 = ref.test_function((batch["X"], batch["mask"]), k=k)
+        excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
+        oids = O.test_function(params, cfg, batch["X"], batch["mask"], excl, k=k)
+        rows = np.zeros(B, dtype=bool)
+        for b in range(B):
+            row = ologits[b].copy(); row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
+            top = -np.sort(-row)[:k + 1]
+            rows[b] = bool(np.all(top[:-1] - top[1:] > 6 * err))
+        assert np.array_equal(ids[rows], oids[rows])
+        # every row: the two engines' lists hold the same items up to swaps among near-ties (>= 8 of 10 in common)
+        common = [len(set(a) & set(b)) for a, b in zip(ids, ids_f32)]
+        assert min(common) >= 6 and np.mean(common) >= 9.0, (min(common), np.mean(common))
+        if loss == "CCE":       # the training forward uses the same kernel: cost to bf16-input rounding, gradients f32-class
+            eng.set_batch(batch["X"], batch["mask"], batch["target"], None, batch["pop"])
+            cost = eng.forward_backward()
+            ocost, ograds, _ = O.cost_and_grads(params, cfg, PU.oracle_batch(batch))
+            assert abs(cost - ocost) <= 2e-4 * abs(ocost)
+            g = eng.get_all_grad_values()
+            assert max(PU.rel_err(a, b) for a, b in zip(g, ograds)) <= 5e-3
+    finally:
+        eng.close(); ref.close()

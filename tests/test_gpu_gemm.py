@@ -34,7 +34,7 @@ def run(M, N, K, a_t, b_t, exact, bias=False, ws_floats=0, seed=0, lda_pad=0, ld
     ws = torch.empty(ws_floats, device=dev) if ws_floats else None
     rc = lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn,
                             C.data_ptr(), N, M, N, K, bv.data_ptr() if bias else None, ws.data_ptr() if ws_floats else None,
-                            ws_floats, 1 if exact else 0)
+                            ws_floats, int(exact))
     assert rc == 0, lib.sbr_last_error()
     torch.cuda.synchronize()
     ref = A64 @ B64 + (bv.cpu().numpy().astype(np.float64)[None, :] if bias else 0.0)
@@ -71,3 +71,32 @@ def test_gemm_unaligned_leading_dimensions():
     for pad in (1, 2, 3):
         assert run(160, 200, 128, False, False, False, lda_pad=pad, ldb_pad=pad) < 3e-6
         assert run(160, 200, 128, True, True, False, lda_pad=pad, ldb_pad=pad) < 3e-6
+
+
+@pytest.mark.parametrize("shape", [(256, 3706, 128, False, True), (1, 5000, 512, False, True), (37, 100000, 256, False, True),
+                                   (256, 26744, 256, False, True), (300, 130, 96, True, False)])
+def test_plain_bf16_projection_kernel(shape):
+    # SBR_FLAG_BF16_PROJECTION's kernel (mode 2): operands rounded to bf16 (2^-9 each), f32 accumulation -- the error of a
+    # K-term dot product of N(0,1) entries is ~2^-8.5 * sqrt(K) * (a small factor for the worst of M*N entries)
+    M, N, K, a_t, b_t = shape
+    err = run(M, N, K, a_t, b_t, 2, bias=True)
+    assert 1e-5 < err < 2.5e-2, (shape, err)          # bf16-class, not f32-class: the flag really selects the one-plane kernel
+
+
+def test_plain_bf16_projection_rows_do_not_depend_on_the_batch():
+    # a row's scores are the same bits whether 1 or 256 rows share the call (ranked ids must not depend on the batch size)
+    import torch
+    from sbr_amd.engine import load_library
+    lib = load_library()
+    rng = np.random.default_rng(3)
+    K, N = 256, 7000
+    A = torch.from_numpy(rng.standard_normal((256, K)).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    outs = []
+    for M in (256, 100, 1):
+        C = torch.empty((M, N), device="cuda")
+        rc = lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), K, 1, B.data_ptr(), 1, K,
+                                C.data_ptr(), N, M, N, K, None, None, 0, 2)
+        assert rc == 0, lib.sbr_last_error()
+        outs.append(C.cpu().numpy())
+    assert np.array_equal(outs[0][:100], outs[1]) and np.array_equal(outs[0][:1], outs[2])

