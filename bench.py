@@ -35,7 +35,9 @@ CONFIGS = {
     "c5": ("LSTM", [512, 512], 1000000, "Blackout", 32),   # configs[4] shape (per-GPU part): 41 GB arena, dense Adam over 2.6 G parameters
 }
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak: what the split products actually occupy
 HBM_PEAK_GBS = 8000.0             # HBM3E spec
+N_CUS = 256
 
 
 def zipf_items(rng, n_items, size, perm):
@@ -85,6 +87,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3, help="max timed CPU-baseline steps")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the port scales to ~16 threads on the GPU box")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the line reports the median region and all of them")
+    ap.add_argument("--pmc-json", default=None, help="HBM counter bytes per launch for roofline.traffic, from a separate rocprofv3 --pmc pass "
+                    "of this same command (tools/pmc_summary.py output); without it traffic is null")
     args = ap.parse_args()
 
     def log(*a):
@@ -160,21 +165,28 @@ def main():
     except Exception as ex:
         log("phase survey skipped:", ex)
     eng.enable_timing(True, only=dom_phase)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+
+    def timed_region(first):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(first + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+    # --repeats regions of EXACTLY --steps steps each, every one bracketed by barrier + synchronize; the headline is the
+    # median region (a DVFS blip in one region cannot move it), all regions are reported
+    region_s = [timed_region(args.warmup + r * args.steps) for r in range(max(1, args.repeats))]
+    dt = float(np.median(region_s))
+    log("timed regions done: %s ms/step" % ", ".join("%.4f" % (x / args.steps * 1e3) for x in region_s))
     cost = eng.read_cost()
     if not np.isfinite(cost):
         raise ValueError("Cost is NaN")            # rnn_base.py:291-292
@@ -193,6 +205,9 @@ def main():
         "metric": "user-sequences/sec training (ML-1M shape, seq200 b256) at 1/2/4/8 GPUs",
         "value": round(value, 1), "unit": "user-sequences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "repeats": {"n": len(region_s), "ms_per_step": [round(x / args.steps * 1e3, 4) for x in region_s],
+                    "stddev_ms": round(float(np.std([x / args.steps * 1e3 for x in region_s])), 5),
+                    "headline": "median region of --steps steps"},
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: train.py -m RNN --r_t %s --r_l %s --max_length %d -b %d --loss %s --u_m adam, "
                                "N=%d items, Zipf(1.0) ids, lengths=%s, %d rows per GPU"
@@ -225,25 +240,78 @@ def main():
             del v["alg"]
         dom = dom_phase if dom_phase in kernels else max(kernels, key=lambda k: phases[k])
         d = kernels[dom]
-        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, gfx950 FETCH_SIZE x2 correction applied; profiles/round1_pmc.json), same config only
-        traffic = None
-        try:
-            if args.config == "c2" and args.lengths == "full" and B == 256 and T == 200:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))["kernels"]
-                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel",
-                       "scatter": "scat_reduce_kernel"}[dom]
+        # what the recurrent kernels put on the matrix pipe: every f32 product is `products` bf16 / fp16 MFMA terms, on 16-column
+        # tiles of which `rows` columns are live batch rows -- against the dense bf16 peak of the WHOLE chip; and the CUs the
+        # launch can occupy at all (one workgroup per CU)
+        for k, sfx in (("rec_fwd", "fwd"), ("rec_bwd", "bwd")):
+            try:
+                prod, rows, wgs = (eng.query("rec_%s_%s" % (q, sfx)) for q in ("products", "rows", "workgroups"))
+            except Exception:
+                continue
+            v = kernels[k]
+            v["active_cus"] = min(N_CUS, wgs)
+            if prod > 0 and v["us"] > 0:
+                issued = rec_flops * prod * 16.0 / rows
+                v["matrix_pipe"] = {"issued_tflops": round(issued / (v["us"] * 1e-6) / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                    "frac": round(issued / (v["us"] * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 5),
+                                    "frac_of_active_cus": round(issued / (v["us"] * 1e-6) / 1e12 / (BF16_MFMA_PEAK_TFLOPS * min(N_CUS, wgs) / N_CUS), 5),
+                                    "terms_per_f32_product": prod, "live_rows_of_16": rows}
+        # HBM bytes per launch of the dominant kernel: only from a counter pass of this same command (rocprofv3 --pmc in its own
+        # run, MI355X_MICROARCH.md; tools/pmc_summary.py writes the file) -- never from a stored number
+        traffic, traffic_src = None, None
+        if args.pmc_json:
+            try:
+                pmc = json.load(open(args.pmc_json))["kernels"]
+                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel", "scatter": "scat_reduce_kernel"}[dom]
                 traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if key in k)
-        except Exception:
-            traffic = None
+                traffic_src = os.path.relpath(args.pmc_json, ROOT)
+            except Exception as ex:
+                log("pmc json unusable:", ex)
         result["roofline"] = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                              "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "launch_us": d["us"],
-                              "note": "algorithmic f32 FLOPs 2*L*H*G*H of the BPTT chain vs the f32 MFMA peak; the chain is "
-                                      "2*T dependent steps on <=64 CUs (DESIGN.md section 3)"}
+                              "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                              "launch_us": d["us"], "matrix_pipe": d.get("matrix_pipe"), "active_cus": d.get("active_cus"),
+                              "note": "achieved = algorithmic f32 FLOPs 2*L*H*G*H of the chain / HIP-event time of the kernel over "
+                                      "the timed regions, vs the f32 MFMA peak; matrix_pipe = the bf16 / fp16 MFMA flops the kernel "
+                                      "really issues vs the 2.5 PF dense peak; the chain is 2*T dependent steps on active_cus CUs "
+                                      "(DESIGN.md section 3)"}
         result["phases_us"] = {k: round(v, 2) for k, v in phases.items() if k != "total"}
         result["phases_us"]["note"] = ("%s: HIP events over the timed region; the other phases: survey pass of %d steps with "
                                        "every phase bracketed (those event records lengthen a step, so the phases do not add "
                                        "up to ms_per_step)" % (dom_phase, min(args.steps, 20)))
+        # the embedding gather (north_star: achieved HBM GB/s on gather AND scatter).  In the step the rows are read inside
+        # rec_fwd (no xt array): its algorithmic bytes over the forward kernel's time is a LOWER bound of the rate the gather runs
+        # at; the stand-alone gather_xt_kernel (the step with SBR_FUSE_GATHER=0) is timed on the same shape beside it.
+        if "gather" not in kernels:
+            gb = Ltot * (row_bytes + 4)
+            kernels["gather_fused"] = {"bound": "hbm", "unit": "GB/s", "us": kernels["rec_fwd"]["us"],
+                                       "achieved": round(gb / (kernels["rec_fwd"]["us"] * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                                       "frac": round(gb / (kernels["rec_fwd"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                       "note": "rows read inside rec_fwd, hidden under the chain: bytes / rec_fwd time"}
+            if world == 1:
+                try:
+                    os.environ["SBR_FUSE_GATHER"] = "0"
+                    e2 = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=B, loss=loss,
+                                   n_samples=n_samples, updater="adam", learning_rate=1e-3)
+                    try:
+                        e2.set_all_param_values(params)
+                        d0 = dev_batches[0]
+                        e2.set_batch_device(d0["X"], d0["lengths"], d0["target"], d0["samples"] if loss != "CCE" else None, d0["pop"], B)
+                        for _ in range(3):
+                            e2.train_step(sync=False)
+                        e2.enable_timing(True, only="gather")
+                        for _ in range(10):
+                            e2.train_step(sync=False)
+                        us = e2.phase_times()["gather"]
+                    finally:
+                        e2.close()
+                        del os.environ["SBR_FUSE_GATHER"]
+                    gb2 = Ltot * (row_bytes * 2 + 4)       # read the row, write xt
+                    kernels["gather_unfused"] = {"bound": "hbm", "unit": "GB/s", "us": round(us, 2),
+                                                 "achieved": round(gb2 / (us * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                                                 "frac": round(gb2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                                 "note": "gather_xt_kernel alone (SBR_FUSE_GATHER=0 engine, same batch): rows in, xt out"}
+                except Exception as ex:
+                    log("unfused gather timing skipped:", ex)
         # the dense output projection on its own (logits = h . W_out^T, rnn_one_hot.py:65): the same kernel the step
         # runs, timed with HIP events on this shape (north_star: MFMA utilisation of the output projection)
         try:
@@ -267,7 +335,29 @@ def main():
             tf = 2.0 * B * n_items * Hl / us / 1e6
             kernels["output_projection"] = {"bound": "mfma", "unit": "TFLOP/s", "us": round(us, 2), "achieved": round(tf, 3),
                                             "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 5),
-                                            "shape": "M=%d N=%d K=%d" % (B, n_items, Hl)}
+                                            "shape": "M=%d N=%d K=%d" % (B, n_items, Hl),
+                                            "matrix_pipe": {"issued_tflops": round(6 * tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                                            "frac": round(6 * tf / BF16_MFMA_PEAK_TFLOPS, 5), "terms_per_f32_product": 6}}
+
+            def proj_bf16():      # SBR_FLAG_BF16_PROJECTION's kernel: plain bf16 operands, one MFMA per block
+                rc = eng.lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), Hl, 1,
+                                            Bm.data_ptr(), 1, Hl, C.data_ptr(), n_items, B, n_items, Hl, None, None, 0, 2)
+                assert rc == 0
+            for _ in range(3):
+                proj_bf16()
+            e0.record()
+            for _ in range(20):
+                proj_bf16()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            tf = 2.0 * B * n_items * Hl / us / 1e6
+            hbm = (n_items * Hl + B * Hl + B * n_items) * 4.0 / (us * 1e-6) / 1e9
+            kernels["output_projection_bf16"] = {"bound": "mfma", "unit": "TFLOP/s", "us": round(us, 2), "achieved": round(tf, 3),
+                                                 "peak": BF16_MFMA_PEAK_TFLOPS, "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 5),
+                                                 "hbm_gbs": round(hbm, 1), "hbm_frac": round(hbm / HBM_PEAK_GBS, 5),
+                                                 "shape": "M=%d N=%d K=%d" % (B, n_items, Hl),
+                                                 "note": "f32 operands converted on the way to LDS: W_out in + logits out at f32 width "
+                                                         "bound it by HBM long before the matrix pipe"}
         except Exception as ex:      # never let the side measurement break the bench line
             log("output projection timing skipped:", ex)
         result["kernels"] = kernels
@@ -291,10 +381,24 @@ def main():
             tr.train_function(cb)
             n += 1
         cdt = (time.perf_counter() - t0) / n
+        # the reference pays its Python batch packing every iteration (rnn_one_hot.py:83-106: B*T list appends + a (B, N)
+        # exclude matrix): restated literally in oracle.prepare_input_one_hot, timed on the same batch, single-threaded as there
+        seqs = [(0, [(int(i), 1.0) for i in hb["X"][b, :hb["lengths"][b], 0]], [(int(hb["target"][b]), 1.0)]) for b in range(B)]
+        pop_table = np.ones(n_items)
+        t0 = time.perf_counter()
+        npk = 0
+        while npk < 3 and (npk == 0 or time.perf_counter() - t0 < 5.0):
+            O.prepare_input_one_hot(seqs, T, n_items, pop_table, 0.0)
+            npk += 1
+        pack = (time.perf_counter() - t0) / npk
         result["cpu_baseline"] = {"value": round(B / cdt, 1), "unit": "user-sequences/s", "cores": nthr,
                                   "kind": "port", "sample": "%d train step(s) of the same %s workload (B=%d, T=%d): torch-CPU "
                                   "float32 port of the reference path (Theano/Lasagne not installable), %.2f s/step, "
-                                  "%d threads of %d host cores" % (n, args.config, B, T, cdt, nthr, ncores)}
+                                  "%d threads of %d host cores" % (n, args.config, B, T, cdt, nthr, ncores),
+                                  "end_to_end": {"value": round(B / (cdt + pack), 1), "unit": "user-sequences/s",
+                                                 "packing_s_per_batch": round(pack, 4),
+                                                 "note": "compute step + reference-style _prepare_input packing of the batch "
+                                                         "(rnn_one_hot.py:83-106 restated in oracle.prepare_input_one_hot), 1 thread"}}
     eng.close()
     if world > 1 or args.force_dp:
         dist.destroy_process_group()

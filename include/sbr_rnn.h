@@ -221,7 +221,10 @@ int sbr_enable_timing(sbr_handle* h, int on);
  * "cluster" (multi-workgroup recurrent kernels for the top layer), "rec_kernel" (kernel family of the top layer:
  * 0 triage, 1 cluster, 2 counter-synchronised 128-unit, 3 counter-synchronised 32/64-unit, 4 barrier / general),
  * "arena_bytes", "side_stream" (hipStream_t), "sparse_blocks" (row-sparse parameter blocks of this configuration),
- * "adam_table" (entries of the a_t table of the lazy Adam catch-up). */
+ * "adam_table" (entries of the a_t table of the lazy Adam catch-up); what the top layer's recurrent kernels put on the
+ * matrix pipe, for roofline reports: "rec_products_fwd" / "rec_products_bwd" (low-precision MFMA terms per f32 product:
+ * 6 = bf16x6, 3 = fp16x3, 0 = exact-f32 MFMA kernels), "rec_rows_fwd" / "_bwd" (live batch rows among the 16 columns of an
+ * MFMA tile), "rec_workgroups_fwd" / "_bwd" (workgroups of the launch = CUs it can occupy). */
 int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 

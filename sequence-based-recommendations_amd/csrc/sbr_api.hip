@@ -1375,6 +1375,23 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         RecArgs a = rec_args(h, (y.L - 1) * y.D);
         *value = simple_rec(h) ? 0 : sbr_rec_cluster_ok(a) ? 1 : sbr_rec_x6p_ok(a) ? 2 : sbr_rec_x6q_ok(a) ? 3 : 4;
     }
+    else if (w.rfind("rec_products_", 0) == 0 || w.rfind("rec_rows_", 0) == 0 || w.rfind("rec_workgroups_", 0) == 0) {
+        // what the recurrent kernel of the TOP layer issues on the matrix pipe (bench.py: roofline.matrix_pipe / active_cus):
+        // products = low-precision MFMA terms per f32 product (bf16x6: 6, fp16x3: 3; 0 = the exact-f32 MFMA kernels, another
+        // pipe rate); rows = live batch rows among the 16 columns of an MFMA tile; workgroups = workgroups of the launch
+        const bool bwd = w.size() > 4 && w.compare(w.size() - 4, 4, "_bwd") == 0;
+        RecArgs a = rec_args(h, (y.L - 1) * y.D);
+        const bool cl = !simple_rec(h) && sbr_rec_cluster_ok(a), xp = sbr_rec_x6p_ok(a), xq = sbr_rec_x6q_ok(a);
+        const bool x6 = cl || xp || xq || (!a.f32_mfma && (a.Hp == 32 || a.Hp == 64 || a.Hp == 128));
+        int products = 0, rows = 16, wgs = y.Bp / 16;
+        if (!simple_rec(h) && x6) {
+            const char* fe = getenv("SBR_X6_F16");
+            products = (!bwd && xp && !cl && !a.relu && (fe ? atoi(fe) != 0 : true)) ? 3 : 6;
+            if (cl) { rows = bwd ? sbr_rec_cluster_bwd_rows(a) : SBR_CL_ROWS; wgs = (y.Bp / rows) * (a.Hp == 256 ? 8 : 32); }
+            else { rows = a.rpt; wgs = y.Bp / a.rpt; }
+        }
+        *value = w.rfind("rec_products_", 0) == 0 ? products : w.rfind("rec_rows_", 0) == 0 ? rows : wgs;
+    }
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
     else if (w == "sparse_blocks") *value = y.n_sparse;
     else if (w == "adam_table") *value = y.n_at;

@@ -36,39 +36,51 @@ struct SpUpd {
 
 __device__ __forceinline__ float sp_at(const SpUpd& u, long t) { return t <= (long)u.n_at ? u.at[t - 1] : u.lr; }
 
-// k zero-gradient steps t0+1 .. t0+k on one element
-__device__ __forceinline__ void sp_catch_up(const SpUpd& u, float& p, float& s0, float& s1, int k, long t0) {
+// k zero-gradient steps t0+1 .. t0+k on the NE elements a lane holds of one row.  The elements advance together, step by
+// step, so that their dependent chains (mul, sqrt, div, sub per step) interleave: one element at a time the replay is
+// latency-bound (measured 264 us for C3's batch rows with gaps <= 25; the loop below issues NE independent chains).
+template <int NE>
+__device__ __forceinline__ void sp_catch_up(const SpUpd& u, float (&p)[NE], float (&s0)[NE], float (&s1)[NE], int k, long t0) {
     if (k <= 0) return;
     switch (u.updater) {
         case SBR_UPD_ADAGRAD: return;
         case SBR_UPD_RMSPROP:
-            if (k <= 32) { for (int j = 0; j < k; ++j) s0 = u.rho * s0 + (1.0f - u.rho) * 0.0f; }
-            else s0 *= powf(u.rho, (float)k);
+            if (k <= 32) { for (int j = 0; j < k; ++j) _Pragma("unroll") for (int e = 0; e < NE; ++e) s0[e] = u.rho * s0[e]; }
+            else { const float f = powf(u.rho, (float)k); _Pragma("unroll") for (int e = 0; e < NE; ++e) s0[e] *= f; }
             return;
         case SBR_UPD_ADADELTA:
-            if (k <= 32) { for (int j = 0; j < k; ++j) { s0 = u.rho * s0; s1 = u.rho * s1; } }
-            else { const float f = powf(u.rho, (float)k); s0 *= f; s1 *= f; }
+            if (k <= 32) { for (int j = 0; j < k; ++j) _Pragma("unroll") for (int e = 0; e < NE; ++e) { s0[e] = u.rho * s0[e]; s1[e] = u.rho * s1[e]; } }
+            else { const float f = powf(u.rho, (float)k); _Pragma("unroll") for (int e = 0; e < NE; ++e) { s0[e] *= f; s1[e] *= f; } }
             return;
         case SBR_UPD_NESTEROV:
-            if (k <= 32) { for (int j = 0; j < k; ++j) { const float v = u.rho * s0; s0 = v; p += u.rho * v; } }
-            else {      // p += rho * sum_{j=1..k} rho^j v0 ; v = rho^k v0
+            if (k <= 32) {
+                for (int j = 0; j < k; ++j)
+                    _Pragma("unroll") for (int e = 0; e < NE; ++e) { const float v = u.rho * s0[e]; s0[e] = v; p[e] += u.rho * v; }
+            } else {    // p += rho * sum_{j=1..k} rho^j v0 ; v = rho^k v0
                 const float rk = powf(u.rho, (float)k);
-                p += u.rho * s0 * u.rho * (1.0f - rk) / (1.0f - u.rho);
-                s0 *= rk;
+                const float f = u.rho * u.rho * (1.0f - rk) / (1.0f - u.rho);
+                _Pragma("unroll") for (int e = 0; e < NE; ++e) { p[e] += s0[e] * f; s0[e] *= rk; }
             }
             return;
-        default: {      // adam
-            float m = s0, v = s1;
+        default: {      // adam: replay until every element's update is below half an ulp of its p (and shrinking) or m is gone
             int j = 0;
             for (; j < k; ++j) {
-                if (m == 0.0f) break;                                   // never touched (or fully decayed): p is fixed
-                m = u.b1 * m; v = u.b2 * v;
-                const float upd = sp_at(u, t0 + 1 + j) * m / (sqrtf(v) + 1e-8f);
-                p -= upd;
-                if ((u.early_exit && fabsf(upd) < fabsf(p) * 1.4901161e-8f) || j >= 8190) { ++j; break; }   // < 2^-26 |p|: below half an ulp, and shrinking
+                const float a_t = sp_at(u, t0 + 1 + j);
+                bool live = false;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const float m = u.b1 * s0[e], v = u.b2 * s1[e];
+                    const float upd = a_t * m / (sqrtf(v) + 1e-8f);
+                    s0[e] = m; s1[e] = v; p[e] -= upd;
+                    live = live || !(m == 0.0f || (u.early_exit && fabsf(upd) < fabsf(p[e]) * 1.4901161e-8f));   // 2^-26 |p|
+                }
+                if (!live || j >= 8190) { ++j; break; }
             }
-            if (j < k) { const float r = (float)(k - j); m *= powf(u.b1, r); v *= powf(u.b2, r); }
-            s0 = m; s1 = v;
+            if (j < k) {
+                const float r = (float)(k - j), f1 = powf(u.b1, r), f2 = powf(u.b2, r);
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { s0[e] *= f1; s1[e] *= f2; }
+            }
             return;
         }
     }
@@ -148,17 +160,25 @@ __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, 
                             s1[v] = (in && r.s1) ? *(const f32x4*)(r.s1 + ro + c) : f32x4{0, 0, 0, 0};
                             g[v] = (in && STEP) ? *(const f32x4*)(r.g + ro + c) : f32x4{0, 0, 0, 0};
                         }
+                        {
+                            float pe[4 * SP_NV], ae[4 * SP_NV], be[4 * SP_NV];
+#pragma unroll
+                            for (int v = 0; v < SP_NV; ++v)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { pe[4 * v + e] = p[v][e]; ae[4 * v + e] = s0[v][e]; be[4 * v + e] = s1[v][e]; }
+                            sp_catch_up<4 * SP_NV>(u, pe, ae, be, k, (long)rold);       // (pieces beyond the row hold zeros: m == 0)
+#pragma unroll
+                            for (int v = 0; v < SP_NV; ++v)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (STEP) sp_step(u, pe[4 * v + e], g[v][e], ae[4 * v + e], be[4 * v + e], a_t);
+                                    p[v][e] = pe[4 * v + e]; s0[v][e] = ae[4 * v + e]; s1[v][e] = be[4 * v + e];
+                                }
+                        }
 #pragma unroll
                         for (int v = 0; v < SP_NV; ++v) {
                             const int c = c0 + v * 256 + lane * 4;
                             if (c >= w) continue;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float pe = p[v][e], a = s0[v][e], b = s1[v][e];
-                                sp_catch_up(u, pe, a, b, k, (long)rold);
-                                if (STEP) sp_step(u, pe, g[v][e], a, b, a_t);
-                                p[v][e] = pe; s0[v][e] = a; s1[v][e] = b;
-                            }
                             *(f32x4*)(r.p + ro + c) = p[v];
                             *(f32x4*)(r.s0 + ro + c) = s0[v];
                             if (r.s1) *(f32x4*)(r.s1 + ro + c) = s1[v];
@@ -167,10 +187,10 @@ __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, 
                     }
                 } else if (lane < w) {                                  // bias rows: one float
                     const size_t o = ro + lane;
-                    float pe = r.p[o], a = r.s0[o], b = r.s1 ? r.s1[o] : 0.0f;
-                    sp_catch_up(u, pe, a, b, k, (long)rold);
-                    if (STEP) { const float gg = r.g[o]; r.g[o] = 0.0f; sp_step(u, pe, gg, a, b, a_t); }
-                    r.p[o] = pe; r.s0[o] = a; if (r.s1) r.s1[o] = b;
+                    float pe[1] = {r.p[o]}, a[1] = {r.s0[o]}, b[1] = {r.s1 ? r.s1[o] : 0.0f};
+                    sp_catch_up<1>(u, pe, a, b, k, (long)rold);
+                    if (STEP) { const float gg = r.g[o]; r.g[o] = 0.0f; sp_step(u, pe[0], gg, a[0], b[0], a_t); }
+                    r.p[o] = pe[0]; r.s0[o] = a[0]; if (r.s1) r.s1[o] = b[0];
                 }
             }
         }

@@ -38,7 +38,27 @@ def test_default_config_line_without_cpu_leg():
     d = run("--no-cpu-baseline")
     check_common(d)
     assert "cpu_baseline" not in d and d["config"]["workload"].startswith("c2:")
-    assert d["roofline"]["kernel"] == "rec_bwd" and isinstance(d["roofline"]["traffic"], int)
+    r = d["roofline"]
+    assert r["kernel"] == "rec_bwd"
+    assert r["traffic"] is None and r["traffic_source"] is None      # only from a counter pass of the same command (--pmc-json)
+    # the matrix pipe runs bf16x6 products on 4 live rows of 16: 24x the algorithmic flops, on the 64 CUs the launch occupies
+    mp = r["matrix_pipe"]
+    assert r["active_cus"] == 64 and mp["terms_per_f32_product"] == 6 and mp["live_rows_of_16"] == 4
+    assert mp["issued_tflops"] == pytest.approx(24 * r["achieved"], rel=1e-2) and 0 < mp["frac"] < mp["frac_of_active_cus"] < 1
+    k = d["kernels"]
+    assert k["rec_fwd"]["matrix_pipe"]["terms_per_f32_product"] == 3          # fp16x3 forward chain
+    for name in ("scatter", "gather_fused", "gather_unfused", "output_projection", "output_projection_bf16"):
+        assert k[name]["us"] > 0 and 0 < k[name]["frac"] < 1, name
+    assert k["gather_unfused"]["bound"] == "hbm" and k["gather_unfused"]["achieved"] > 500      # GB/s
+    rp = d["repeats"]
+    assert rp["n"] == 5 and len(rp["ms_per_step"]) == 5 and sorted(rp["ms_per_step"])[2] == pytest.approx(d["ms_per_step"], rel=1e-3)
+
+
+def test_traffic_comes_only_from_a_counter_file(tmp_path):
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps({"kernels": {"void rec_bwd_x6p<1>(RecArgs)": {"hbm_bytes_per_launch": 123456}}}))
+    d = run("--no-cpu-baseline", "--repeats", "1", "--pmc-json", str(f))
+    assert d["roofline"]["traffic"] == 123456 and d["roofline"]["traffic_source"] and d["repeats"]["n"] == 1
 
 
 def test_cpu_baseline_leg_is_bounded_and_reported():
@@ -47,3 +67,5 @@ def test_cpu_baseline_leg_is_bounded_and_reported():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "user-sequences/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["value"] > 100 * c["value"]
+    e = c["end_to_end"]        # the same step + reference-style batch packing
+    assert 0 < e["value"] < c["value"] and e["packing_s_per_batch"] > 0
