@@ -401,11 +401,19 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 // their partner has published them.
 // Chunked BPTT protocol (t_lo / t_hi / state / part) as in rec_bwd_x6s.
 // ---------------------------------------------------------------------------------------
-template <int CELL, bool EXT, bool PROF>
+// F16: the products as the forward's 2-way fp16 split (three MFMAs per block instead of six).  The A operand is a GRADIENT
+// here; what makes the fp16 range safe is the reference's own clip: every element of dhi has passed grad_clip(+-100)
+// (sparse_lstm.py:768-772, :789-791; recurrent_layers.py:19), so dhi * 2^9 < 65504 always, and the split keeps an absolute
+// floor of 2^-36 / 2^9 = 3e-14 below that (gradients of this path are 1e-12 .. 1e-2: f32-class relative error down to
+// ~1e-9, then absolute).  The launcher takes this form only while 0 < clip <= 100.
+constexpr float F16_DSCALE = 512.0f;
+template <int CELL, bool EXT, bool PROF, bool F16>
 __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
+    using OPV = std::conditional_t<F16, f16x8, bf16x8>;
+    constexpr int NP = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate
     static_assert(G <= 3, "W_hid plane 3 does not fit the register file with four gates");
-    constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW, BUFB = 3 * PLANEB;
+    constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW, BUFB = NP * PLANEB;
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
     char* dbuf = smem_p;                                 // [2][3 planes][R rows][DROW]
     int* cnt = (int*)(dbuf + 2 * BUFB);
@@ -426,16 +434,24 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, 16));
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));
 
-    bf16x8 W1[KB], W2[KB], W3[KB];                       // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
+    OPV W1[KB], W2[KB], W3[F16 ? 1 : KB];               // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const float* src = a.Whid + (size_t)u * GHP + kb * 32 + 8 * q;
         const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            __bf16 b1, b2, b3;
-            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
-            W1[kb][e] = b1; W2[kb][e] = b2; W3[kb][e] = b3;
+            float w = e < 4 ? lo[e & 3] : hi[e & 3];
+            if constexpr (F16) {
+                _Float16 b1, b2;
+                asm("" : "+v"(w));                       // see split2_f16 (not volatile: the loads of this prologue stay unordered)
+                split2_f16(w, b1, b2);
+                W1[kb][e] = b1; W2[kb][e] = b2;
+            } else {
+                __bf16 b1, b2, b3;
+                split3(w, b1, b2, b3);
+                W1[kb][e] = b1; W2[kb][e] = b2; W3[kb][e] = b3;
+            }
         }
     }
 
@@ -495,12 +511,21 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            unsigned p1, p2, p3;
-            split3_trunc(dhi[g], p1, p2, p3);
             char* base = lds + lds_pub + g * HP * 2;
-            *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
-            *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
-            *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+            if constexpr (F16) {
+                float d = dhi[g] * F16_DSCALE;            // |dhi| <= clip <= 100: below fp16's 65504
+                asm volatile("" : "+v"(d));               // pinned for split2_f16
+                _Float16 d1, d2;
+                split2_f16(d, d1, d2);
+                *(_Float16*)(base) = d1;
+                *(_Float16*)(base + PLANEB) = d2;
+            } else {
+                unsigned p1, p2, p3;
+                split3_trunc(dhi[g], p1, p2, p3);
+                *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
+                *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
+                *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+            }
         }
         lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
         if (CELL == CELL_VANILLA) hnew = hprev;
@@ -518,21 +543,21 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         // ---- operands: a ring of NS k-block slots, fetched LA k-blocks ahead of their MFMAs; the pipe gate
         constexpr int NS = 2, LA = 1;          // measured: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
         const char* db = lds + lds_rd;
-        bf16x8 dpl[NS][3];
+        OPV dpl[NS][NP];
         int fl[2];
         auto load_kb = [&](int i) {
             const int kb = korder(i), s = i % NS;
-            if ((X6P_DBG & 64) && (i & 1)) { dpl[s][0] = dpl[s ^ 1][0]; dpl[s][1] = dpl[s ^ 1][1]; dpl[s][2] = dpl[s ^ 1][2]; return; }   // half the LDS reads
-            if ((X6P_DBG & 128) && (i % 4)) { dpl[s][0] = dpl[s ^ 1][0]; dpl[s][1] = dpl[s ^ 1][1]; dpl[s][2] = dpl[s ^ 1][2]; return; }  // a quarter
-            dpl[s][0] = *(const bf16x8*)(db + kb * 64);
-            dpl[s][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
-            dpl[s][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+            if ((X6P_DBG & 64) && (i & 1)) { for (int pp = 0; pp < NP; ++pp) dpl[s][pp] = dpl[s ^ 1][pp]; return; }   // half the LDS reads
+            if ((X6P_DBG & 128) && (i % 4)) { for (int pp = 0; pp < NP; ++pp) dpl[s][pp] = dpl[s ^ 1][pp]; return; }  // a quarter
+            dpl[s][0] = *(const OPV*)(db + kb * 64);
+            dpl[s][1] = *(const OPV*)(db + kb * 64 + PLANEB);
+            if constexpr (NP == 3) dpl[s][2] = *(const OPV*)(db + kb * 64 + 2 * PLANEB);
         };
         auto load_flag = [&](int half) {
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
         };
-        auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][2])); };
+        auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][NP - 1])); };
         // the half's producers have published this step; else re-read the counter and the k-blocks [i0, i1) fetched on spec
         auto ensure_half = [&](int half, int i0, int i1) {
             if (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1)) {
@@ -580,20 +605,28 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 load_kb(i + LA);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = MFMA_BF16(dpl[s][0], W3[kb], acc[0]);
-            acc[1] = MFMA_BF16(dpl[s][2], W1[kb], acc[1]);
-            acc[2] = MFMA_BF16(dpl[s][1], W2[kb], acc[2]);
+            if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
+                acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
+                acc[2] = mfma16(dpl[s][0], W2[kb], acc[2]);
+                acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
+            } else {
+            acc[0] = mfma16(dpl[s][0], W3[kb], acc[0]);
+            acc[1] = mfma16(dpl[s][NP - 1], W1[kb], acc[1]);
+            acc[2] = mfma16(dpl[s][1], W2[kb], acc[2]);
             if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
-            acc[0] = MFMA_BF16(dpl[s][0], W2[kb], acc[0]);
-            acc[1] = MFMA_BF16(dpl[s][1], W1[kb], acc[1]);
-            acc[2] = MFMA_BF16(dpl[s][0], W1[kb], acc[2]);
+            acc[0] = mfma16(dpl[s][0], W2[kb], acc[0]);
+            acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
+            acc[2] = mfma16(dpl[s][0], W1[kb], acc[2]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (i + 1 == NH) ensure_half(1, NH, NH + LA < KB ? NH + LA : KB);
             else if (i + 1 < KB) use(i + 1);
         }
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
-        dh += acc[0][0] + acc[1][0] + acc[2][0];
+        if constexpr (F16) dh += fmaf(acc[1][0] + acc[2][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
+        else dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
     };
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
@@ -664,8 +697,12 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool ext = a.dh_ext != nullptr;
-    if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true>)); }
-    else { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false>)); }
+    const char* fe = getenv("SBR_X6_F16_BWD");                     // read per launch: the tests flip it
+    // fp16 x3 products for the BPTT chain: the operand that carries gradients is bounded by the reference's own gradient clip
+    const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
+    if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
+    else if (f16) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }
+    else { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, false>)); }
 #undef X6P_LAUNCH
     return hipGetLastError();
 }

@@ -62,24 +62,36 @@ __device__ __forceinline__ void sp_catch_up(const SpUpd& u, float (&p)[NE], floa
                 _Pragma("unroll") for (int e = 0; e < NE; ++e) { p[e] += s0[e] * f; s0[e] *= rk; }
             }
             return;
-        default: {      // adam: replay until every element's update is below half an ulp of its p (and shrinking) or m is gone
+        default: {      // adam: replay until every element's update is below half an ulp of its p (and shrinking) or m is gone.
+            // Per missed step and element: m *= b1; the root of v advances by sqrt(b2) (one multiply instead of a square
+            // root: the relative drift after j steps is <= j * 6e-8, on an update that is itself a vanishing share of p); one
+            // hardware reciprocal (1 ulp).  The dense kernel's sqrtf + division cost ~3x the instructions here, where -- unlike
+            // there -- arithmetic and not HBM is the bound.
+            float rt[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) rt[e] = sqrtf(s1[e]);
+            const float rb2 = sqrtf(u.b2);
             int j = 0;
             for (; j < k; ++j) {
                 const float a_t = sp_at(u, t0 + 1 + j);
                 bool live = false;
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    const float m = u.b1 * s0[e], v = u.b2 * s1[e];
-                    const float upd = a_t * m / (sqrtf(v) + 1e-8f);
-                    s0[e] = m; s1[e] = v; p[e] -= upd;
+                    const float m = u.b1 * s0[e];
+                    rt[e] *= rb2;
+                    const float upd = a_t * m * __builtin_amdgcn_rcpf(rt[e] + 1e-8f);
+                    s0[e] = m; p[e] -= upd;
                     live = live || !(m == 0.0f || (u.early_exit && fabsf(upd) < fabsf(p[e]) * 1.4901161e-8f));   // 2^-26 |p|
                 }
                 if (!live || j >= 8190) { ++j; break; }
             }
-            if (j < k) {
-                const float r = (float)(k - j), f1 = powf(u.b1, r), f2 = powf(u.b2, r);
+            const float f2 = powf(u.b2, (float)k);               // v after all k steps, from the exact start value
 #pragma unroll
-                for (int e = 0; e < NE; ++e) { s0[e] *= f1; s1[e] *= f2; }
+            for (int e = 0; e < NE; ++e) s1[e] *= f2;
+            if (j < k) {
+                const float f1 = powf(u.b1, (float)(k - j));
+#pragma unroll
+                for (int e = 0; e < NE; ++e) s0[e] *= f1;
             }
             return;
         }

@@ -103,6 +103,24 @@ def test_forward_chain_with_bf16x6_products(cell, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12, scale=0.05))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+def test_backward_chain_with_bf16x6_products(cell, monkeypatch):
+    # default (every other 128-wide GRU / Vanilla test): the BPTT chain's products as the fp16 split too, the gradient operand
+    # scaled by 2^9 (it is bounded by the clip at 100); SBR_X6_F16_BWD=0: bf16x6
+    monkeypatch.setenv("SBR_X6_F16_BWD", "0")
+    check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
+    check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12, scale=0.05))
+
+
+def test_fp16_backward_products_at_the_clip_boundary_and_with_tiny_gradients():
+    # gate gradients driven beyond +-100 (clip active: the scaled operand reaches 51200 of fp16's 65504), and a batch whose
+    # gradients are ~1e-9 (popularity weights of 1e4: the absolute floor of the scaled split is 3e-14)
+    check(PU.compare_step("GRU", [128], "CCE", N=61, B=37, T=9, popscale=1e-4))
+    check(PU.compare_step("Vanilla", [128], "CCE", N=61, B=37, T=9, popscale=1e-4))
+    check(PU.compare_step("GRU", [128], "CCE", N=61, B=37, T=40, popscale=1e4, scale=0.1), tol_g=2e-4)
+    check(PU.compare_step("GRU", [128, 128], "BPR", N=61, B=9, T=12, S=8, scale=0.05))      # dense lower layer: dh_ext every step
+
+
 def test_fp16_forward_products_keep_f32_accuracy_over_long_chains():
     # the forward state after 200 dependent steps: as close to the float64 oracle as the bf16x6 / f32 kernels get
     # (tolerances of the other tests), with weights up to |w| ~ 1.5 and initial states beyond 1
