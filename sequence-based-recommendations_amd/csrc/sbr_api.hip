@@ -926,6 +926,10 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // the bf16x6 GEMM covers the slab with 128x128 tiles: ~512 workgroups in all is enough (the dedicated f32
         // kernel, one workgroup per slab, wants many thin slabs)
         const bool wg_gemm = (h->wgrad_x6 && !(y.cfg.flags & SBR_FLAG_F32_MFMA) && ly.Hp >= 96) || !(ly.Hp == 32 || ly.Hp == 64 || ly.Hp == 128);
+        // fp16 x3 products for that GEMM: its operands are hidden states (|h| <= 1 behind tanh / sigmoid gates) and gradients
+        // that have passed the clip at +-100 (scaled by 2^9 into fp16's range), see gemm_x6_kernel NP = 2
+        static const int wgf = getenv("SBR_WGRAD_F16") ? atoi(getenv("SBR_WGRAD_F16")) : 1;
+        const bool wg_f16 = wgf && !a.relu && y.cfg.grad_clip > 0.0f && y.cfg.grad_clip <= 100.0f;
         if (wg_gemm && nsl > 1) {
             static const int wgs = getenv("SBR_WGRAD_X6_WGS") ? atoi(getenv("SBR_WGRAD_X6_WGS")) : 512;
             nsl = std::max(1, std::min(nsl, wgs / (((ly.Hp + 127) / 128) * ((GHp + 127) / 128)) / nc));
@@ -955,8 +959,8 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 hipError_t we = hipSuccess;
                 if (!wg_gemm && launch_wgrad_slabs(sw, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
                     SBR_LAUNCH(we);
-                } else if (gru && launch_gemm_slabs_x6(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab, dhcc, ly.Hp,
-                                                       2 * ly.Hp, &we)) {
+                } else if (launch_gemm_slabs_x6(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab, dhcc, ly.Hp,
+                                                gru ? 2 * ly.Hp : 0, &we, wg_f16 ? 2 : 3, 1.0f, wg_f16 ? 512.0f : 1.0f)) {
                     SBR_LAUNCH(we);     // one bf16x6 GEMM: columns [0, 2Hp) from dxt, the candidate-gate columns from the compact array
                 } else if (gru) {   // hid_input grad = [dxt_r | dxt_u | dhi_c]
                     SBR_LAUNCH(launch_gemm_slabs(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, 2 * ly.Hp, Kc, slabs, nsl, GHp, slab));
@@ -1385,8 +1389,9 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         const bool x6 = cl || xp || xq || (!a.f32_mfma && (a.Hp == 32 || a.Hp == 64 || a.Hp == 128));
         int products = 0, rows = 16, wgs = y.Bp / 16;
         if (!simple_rec(h) && x6) {
-            const char* fe = getenv("SBR_X6_F16");
-            products = (!bwd && xp && !cl && !a.relu && (fe ? atoi(fe) != 0 : true)) ? 3 : 6;
+            const char* fe = getenv(bwd ? "SBR_X6_F16_BWD" : "SBR_X6_F16");      // the launchers' own conditions (sbr_rec_p.hip)
+            const bool f16 = xp && !cl && (fe ? atoi(fe) != 0 : true) && (bwd ? (a.clip > 0.0f && a.clip <= 100.0f) : !a.relu);
+            products = f16 ? 3 : 6;
             if (cl) { rows = bwd ? sbr_rec_cluster_bwd_rows(a) : SBR_CL_ROWS; wgs = (y.Bp / rows) * (a.Hp == 256 ? 8 : 32); }
             else { rows = a.rpt; wgs = y.Bp / a.rpt; }
         }

@@ -291,7 +291,8 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
 // bf16x6 GEMM (sbr_gemm_x6.hip): false = shape not supported, use the f32 kernel
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0, bool small = false, int planes = 3);
+                    const float* B2 = nullptr, long sbk2 = 0, int n_split = 0, bool small = false, int planes = 3,
+                    float sa = 1.0f, float sb = 1.0f);      // planes = 2: fp16 x3 with operand scales sa, sb (powers of two)
 void sbr_gemm_set_exact_f32(bool on);
 // planes = 1: the next launch_gemm calls run on plain bf16 operands (one MFMA per block, no split-K), for any number of rows
 void sbr_gemm_set_planes(int planes);
@@ -302,7 +303,7 @@ hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, 
 // same through the bf16x6 kernel only, with the B columns >= n_split taken from B2 (row stride sbk2); false: not launched
 bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
                           int K, float* ws, int nsplit, long ws_ld, size_t slab_stride, const float* B2, long sbk2, int n_split,
-                          hipError_t* err);
+                          hipError_t* err, int planes = 3, float sa = 1.0f, float sb = 1.0f);
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias);
 

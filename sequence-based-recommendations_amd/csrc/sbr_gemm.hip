@@ -226,10 +226,11 @@ hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, 
 }
 bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
                           int K, float* ws, int nsplit, long ws_ld, size_t slab_stride, const float* B2, long sbk2, int n_split,
-                          hipError_t* err) {
+                          hipError_t* err, int planes, float sa, float sb) {
     if (g_gemm_exact_f32 || M <= 0 || N <= 0 || nsplit < 1) return false;
     const int kc = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;
-    return launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, nsplit, kc, slab_stride, err, B2, sbk2, n_split);
+    return launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, nsplit, kc, slab_stride, err, B2, sbk2, n_split, false,
+                          planes, sa, sb);
 }
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias) {

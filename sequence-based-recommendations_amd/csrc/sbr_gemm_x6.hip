@@ -21,6 +21,7 @@
 // LDS with the split interleaved into the MFMA stream at one workgroup per CU (311 us: 376 registers push operands
 // into AGPRs and a single wave per SIMD cannot keep the pipe fed -- the same lesson as rec_fwd_x6s NT=2).
 #include "sbr_cell.h"
+#include <type_traits>
 
 
 struct GemmX6Args {
@@ -30,7 +31,11 @@ struct GemmX6Args {
     int M, N, K, kchunk;
     const float* bias;
     const float* B2; long sbk2; int n_split;   // columns n >= n_split of B come from B2[k*sbk2 + (n - n_split)] (GRU weight gradients)
+    float sa, sb, so;                          // NP == 2 (fp16 x3): power-of-two scales of the operands on the way in, 1 / (sa sb) on the way out
 };
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 x6_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) { return MFMA_BF16(a, b, c); }
+__device__ __forceinline__ f32x4 x6_mfma(const f16x8g& a, const f16x8g& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // 4 rows x 8 k of one operand tile into v[row][k], from p = &operand(r0, k0).  RFAST: unit stride runs along the rows
 // (srow == 1), else along k (sk == 1).  VEC: floats per load instruction (4; the scalar form is kept for the ragged edge path only).  nr / nk: rows
@@ -79,6 +84,7 @@ __device__ __forceinline__ void x6_load(const float* __restrict__ p, long stride
 template <int VA, bool RA, int VB, bool RB, int TW, int KH, int NP>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     constexpr int TM = 32 * TW, TK = 32 * KH, ROW = 64 * KH + 16, PLANE = TM * ROW, KC = 4 * KH;
+    using OPV = std::conditional_t<NP == 2, f16x8g, bf16x8>;
     __shared__ __attribute__((aligned(16))) char sA[NP * PLANE];
     __shared__ __attribute__((aligned(16))) char sB[NP * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,11 +112,12 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         src += kstep;
     };
     const f32x4 z = f32x4{0, 0, 0, 0};
-    f32x4 acc[TW][TW];
+    f32x4 acc[TW][TW], acl[NP == 2 ? TW : 1][NP == 2 ? TW : 1];      // acl: the low-order products of the fp16 form
 #pragma unroll
     for (int a = 0; a < TW; ++a)
 #pragma unroll
-        for (int b = 0; b < TW; ++b) acc[a][b] = z;
+        for (int b = 0; b < TW; ++b) { acc[a][b] = z; if constexpr (NP == 2) acl[a][b] = z; }
+    const float opscale = ldB ? g.sb : g.sa;
 
     if (kbeg < kend) load(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
@@ -121,6 +128,17 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) p1[kk] = (__bf16)v[i][kk];
                 *(bf16x8*)(sdst + i * ROW) = p1;
+            } else if constexpr (NP == 2) {
+                f16x8g h1, h2;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    float x = v[i][kk] * opscale;
+                    asm("" : "+v"(x));                     // one rounding to fp16 for both uses (sbr_rec_p.hip split2_f16)
+                    const _Float16 a1 = (_Float16)x;
+                    h1[kk] = a1; h2[kk] = (_Float16)((x - (float)a1) * 2048.0f);
+                }
+                *(f16x8g*)(sdst + i * ROW) = h1;
+                *(f16x8g*)(sdst + i * ROW + PLANE) = h2;
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) { __bf16 a, b, c; split3(v[i][kk], a, b, c); p1[kk] = a; p2[kk] = b; p3[kk] = c; }
@@ -133,20 +151,24 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         if (k0 + TK < kend) load(k0 + TK);                 // in flight while this tile's MFMAs run
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
-            bf16x8 a[NP][TW], b[NP][TW];
+            OPV a[NP][TW], b[NP][TW];
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
-                    a[p][t] = *(const bf16x8*)(sA + p * PLANE + (wm * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
-                    b[p][t] = *(const bf16x8*)(sB + p * PLANE + (wn * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
+                    a[p][t] = *(const OPV*)(sA + p * PLANE + (wm * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
+                    b[p][t] = *(const OPV*)(sB + p * PLANE + (wn * 16 * TW + t * 16 + j) * ROW + kh * 64 + q * 16);
                 }
             // smallest terms first: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1; TW*TW independent accumulators per term
 #define X6_TERM(PA, PB) _Pragma("unroll") for (int mi = 0; mi < TW; ++mi) _Pragma("unroll") for (int ni = 0; ni < TW; ++ni) \
-                acc[mi][ni] = MFMA_BF16(a[PA][mi], b[PB][ni], acc[mi][ni]);
+                acc[mi][ni] = x6_mfma(a[PA][mi], b[PB][ni], acc[mi][ni]);
+#define X6_TERL(PA, PB) _Pragma("unroll") for (int mi = 0; mi < TW; ++mi) _Pragma("unroll") for (int ni = 0; ni < TW; ++ni) \
+                acl[mi][ni] = x6_mfma(a[PA][mi], b[PB][ni], acl[mi][ni]);
             if constexpr (NP == 1) { X6_TERM(0, 0) }
+            else if constexpr (NP == 2) { X6_TERL(0, 1) X6_TERL(1, 0) X6_TERM(0, 0) }
             else { X6_TERM(0, NP - 1) X6_TERM(NP - 1, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0) }
 #undef X6_TERM
+#undef X6_TERL
         }
         __syncthreads();
     }
@@ -161,7 +183,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
 #pragma unroll
             for (int ni = 0; ni < TW; ++ni) {
                 const int n = n0 + wn * 16 * TW + ni * 16 + j;
-                if (n < g.N) out[(long)m * g.ldc + n] = acc[mi][ni][r] + (g.bias ? g.bias[n] : 0.0f);
+                float val = acc[mi][ni][r];
+                if constexpr (NP == 2) val = fmaf(acl[mi][ni][r], 1.0f / 2048.0f, val) * g.so;
+                if (n < g.N) out[(long)m * g.ldc + n] = val + (g.bias ? g.bias[n] : 0.0f);
             }
         }
 }
@@ -176,14 +200,15 @@ static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte 
 // C + z*slab_stride, row stride ldc.
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2, long sbk2, int n_split, bool small, int planes) {
+                    const float* B2, long sbk2, int n_split, bool small, int planes, float sa, float sb) {
     if (planes == 1) { if (M < 1 || N < 48 || K < 32) return false; }      // any number of rows: a row's scores must not depend on
     else if (M < (small ? 48 : 96) || N < (small ? 48 : 96) || K < 32) return false;   // how many rows share the call
     if (B2 && (sbn != 1 || (n_split & 3) || !x6_aligned(B2, sbk2))) return false;
     if (!(sam == 1 || sak == 1) || !(sbk == 1 || sbn == 1)) return false;
     const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
     if (!x6_aligned(A, ra ? sak : sam) || !x6_aligned(B, rb ? sbk : sbn)) return false;
-    GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split};
+    GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split,
+                 sa, sb, 1.0f / (sa * sb)};
     const int tile = small ? 64 : 128;
     const dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, nsplit);
 #define X6_GO(TW, KH, NP) do { \
@@ -192,6 +217,7 @@ bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const flo
         else if (rb) gemm_x6_kernel<4, false, 4, true, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
         else gemm_x6_kernel<4, false, 4, false, TW, KH, NP><<<grid, 256, 0, s>>>(g); } while (0)
     if (planes == 1) { if (small) X6_GO(2, 2, 1); else X6_GO(4, 1, 1); }
+    else if (planes == 2) { if (small) X6_GO(2, 2, 2); else X6_GO(4, 1, 2); }
     else if (small) X6_GO(2, 2, 3); else X6_GO(4, 1, 3);
 #undef X6_GO
     *err = hipGetLastError();

@@ -314,9 +314,11 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
     return hipGetLastError();
 }
 
-#define SCAT_CHUNK 64
 #define SCAT_FLY 8     // rows in flight per wave
-template <int NV>
+// SCAT_CHUNK sorted entries per wave: 64 puts 800 waves on the chip for C2's 51 200 entries (200 workgroups, one wave per
+// SIMD: latency-bound, 1.6 TB/s of row reads); smaller chunks trade more seam atomics for memory-level parallelism
+// (SBR_SCAT_CHUNK = 16 / 32 / 64).
+template <int NV, int SCAT_CHUNK>
 __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
                                                           int n_ids, float* __restrict__ dWin, int R4, int Bp) {
@@ -375,10 +377,14 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp) {
     const int R4 = GHp / 4;
-    const int chunks = (max_entries + SCAT_CHUNK - 1) / SCAT_CHUNK;
+    static const int chunk_env = getenv("SBR_SCAT_CHUNK") ? atoi(getenv("SBR_SCAT_CHUNK")) : 0;
+    const int chunk = (chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32;
+    const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
-#define SR(NV) scat_reduce_kernel<NV><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp)
+#define SR(NV) do { if (chunk == 16) scat_reduce_kernel<NV, 16><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
+                    else if (chunk == 32) scat_reduce_kernel<NV, 32><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
+                    else scat_reduce_kernel<NV, 64><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); } while (0)
     if (nv <= 1) SR(1); else if (nv <= 2) SR(2); else if (nv <= 4) SR(4); else if (nv <= 8) SR(8); else if (nv <= 16) SR(16);
     else return hipErrorInvalidValue;
 #undef SR

@@ -124,9 +124,10 @@ __device__ __forceinline__ void sp_step(const SpUpd& u, float& p, float g, float
 // A wave takes SP_CPW candidates at a time and then walks the rows it owns one after the other, all 64 lanes on one row:
 // a row pass is a dependent load -> math -> store chain of ~2 us, so the candidates per wave bound the length of the
 // serial chain (64 per wave measured 600 us for C3's 51 200 candidates, the kernel being nothing but 64-deep chains);
-// up to four 256-float pieces of a row are loaded before the first is used.
+// two 256-float pieces of a row are loaded before the first is used and replayed together (four pieces: 256 VGPRs, one
+// wave per SIMD).
 #define SP_CPW 8
-#define SP_NV 4
+#define SP_NV 2
 template <int SRC, bool STEP>
 __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, const int* __restrict__ X, const int* __restrict__ len,
                                                       int T, int Bp, int F, const int* __restrict__ list, const int* __restrict__ n_list,
