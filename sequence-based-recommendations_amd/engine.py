@@ -401,10 +401,11 @@ class RNNEngine(object):
     def section(self, which):
         """torch view of a flat arena section: 'params', 'grads' (last element = cost), 'state'.
         Returns (tensor, split) where split = first float of the output-layer part."""
+        # (always through the library: for 'params' / 'state' the call also brings lazily updated rows up to date)
+        idx = {"params": 0, "grads": 1, "state": 2}[which]
+        ptr, n, split = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+        self._check(self.lib.sbr_section(self.h, idx, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(split)))
         if which not in self._sections:
-            idx = {"params": 0, "grads": 1, "state": 2}[which]
-            ptr, n, split = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
-            self._check(self.lib.sbr_section(self.h, idx, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(split)))
             off = (ptr.value - self.arena.data_ptr()) // 4
             self._sections[which] = (self.arena[off:off + n.value], split.value)
         return self._sections[which]

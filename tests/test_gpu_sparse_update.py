@@ -17,7 +17,7 @@ UPDATERS = ["adagrad", "adadelta", "rmsprop", "nesterov", "adam"]
 
 
 def run_sequence(cell, layers, loss, N, B, T, S, updater, plan, flags, emb=0, bi=False, F=1, n_opt=0, seed=0, oracle=True,
-                 probe_at=None):
+                 probe_at=None, want_sections=False):
     """plan: list of batch seeds, one per step (equal seeds = the same batch again).  Returns engine costs / params /
     probe scores (+ the oracle's)."""
     params, cfg, _ = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, emb=emb, bi=bi)
@@ -47,6 +47,9 @@ def run_sequence(cell, layers, loss, N, B, T, S, updater, plan, flags, emb=0, bi
             if probe_at is not None and i == probe_at:
                 pb = batches[plan[0]]
                 probe = (eng.predict_function(pb["X"], pb["mask"]), eng.test_function((pb["X"], pb["mask"]), k=3))
+        if want_sections:      # the flat arena sections in the engine's own layout (sbr_section brings lazy rows up to date)
+            out["section_state"] = eng.section("state")[0].cpu().numpy().copy()
+            out["section_params"] = eng.section("params")[0].cpu().numpy().copy()
         out.update(costs=np.array(costs), params=eng.get_all_param_values(), probe=probe)
     finally:
         eng.close()
@@ -99,15 +102,30 @@ def test_long_gaps_take_the_closed_forms(updater):
     # the sharp comparison is with the DENSE float32 kernel on the same run; the oracle bounds both
     plan = [0, 0] + [1] * 44 + [0, 1]
     kw = dict(N=40, B=4, T=5, S=4, updater=updater, plan=plan)
+    if updater == "rmsprop":
+        # rmsprop turns every gradient into a step of ~lr whatever its size, so one-ulp differences between the sparse and the
+        # dense kernels' arithmetic (powf against 44 multiplications) flip noise-level gradients and the two runs drift apart
+        # by 1e-2 over 48 steps (two executions of the SAME kernels differ in the fourth digit through the order of their float
+        # atomics).  The closed form itself is therefore checked where that sensitivity cannot reach: on the rows that sat
+        # out the gap -- their gradient is exactly zero meanwhile, so parameter and accumulator depend on the first two steps
+        # only -- read right after the gap (sbr_section flushes).  The whole run is then only bounded loosely.
+        gap = dict(kw, plan=plan[:-2])
+        r = run_sequence("GRU", [8], "TOP1", flags=SPARSE, oracle=False, want_sections=True, **gap)
+        d = run_sequence("GRU", [8], "TOP1", flags=DENSE, oracle=False, want_sections=True, **gap)
+        n = (kw["N"] // 2) * 3 * 16                        # rows [0, N/2) of layer 0's W_in: item-major, 3 gates x Hp = 16
+        for name in ("section_params", "section_state"):
+            a, b = r[name][:n], d[name][:n]
+            assert np.abs(b).max() > 0
+            assert np.allclose(a, b, rtol=1e-4, atol=1e-12), (name, np.abs(a - b).max(), np.abs(b).max())
+        r = run_sequence("GRU", [8], "TOP1", flags=SPARSE, probe_at=30, **kw)
+        assert_matches_oracle(r, tol_p=5e-2, tol_c=5e-2)
+        return
     r = run_sequence("GRU", [8], "TOP1", flags=SPARSE, probe_at=30, **kw)
     d = run_sequence("GRU", [8], "TOP1", flags=DENSE, oracle=False, **kw)
-    # (rmsprop's step divides by the root of an accumulator that has decayed by 0.9^44 = 1e-2: the run is then sensitive enough
-    # that two executions of the SAME kernels differ in the fourth digit through the order of their float atomics)
-    loose = updater == "rmsprop"
-    assert np.allclose(r["costs"], d["costs"], rtol=5e-3 if loose else 1e-4), np.abs(r["costs"] / d["costs"] - 1).max()
+    assert np.allclose(r["costs"], d["costs"], rtol=1e-4), np.abs(r["costs"] / d["costs"] - 1).max()
     worst = max(PU.rel_err(x, y) for x, y in zip(r["params"], d["params"]))
-    assert worst <= (5e-3 if loose else 2e-4), worst
-    assert_matches_oracle(r, tol_p=1e-2 if loose else 2e-3, tol_c=1e-2 if loose else 2e-3)
+    assert worst <= 2e-4, worst
+    assert_matches_oracle(r, tol_p=2e-3, tol_c=2e-3)
 
 
 def test_sparse_steps_with_embedding_bidirectional_and_two_indices():
