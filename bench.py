@@ -232,6 +232,17 @@ def main():
         }
         if eng.query("fused_gather"):      # the rows are gathered inside rec_fwd: this phase is only the gradient memset
             del kernels["gather"]
+        try:
+            tail_chunks = eng.query("tail_chunks")
+        except Exception:
+            tail_chunks = 0
+        if tail_chunks >= 2:
+            # overlapped tail: the scatter phase of the step is the LAST of tail_chunks time chunks (the others ran beside the BPTT
+            # chain on the side stream); its entries are 1 / tail_chunks of the batch, and it re-reads the rows it adds to
+            kernels["scatter"]["alg"] /= tail_chunks
+            kernels["scatter"]["chunks"] = tail_chunks
+            kernels["scatter"]["note"] = ("overlapped tail: time chunk 0 of %d only (the others run beside rec_bwd); "
+                                          "bytes = that chunk's dxt rows + the rows it adds to" % tail_chunks)
         for k, v in kernels.items():
             us = phases[k]
             peak = HBM_PEAK_GBS if v["bound"] == "hbm" else F32_MFMA_PEAK_TFLOPS

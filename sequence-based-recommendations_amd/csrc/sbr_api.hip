@@ -143,9 +143,14 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_cells = take(std::max(lay.C, 1));
     lay.a_pop = take(Bp);
     lay.a_topk = take((size_t)Bp * 64);
-    lay.a_scnt = take((size_t)cfg.input_size + 1); lay.a_soff = take((size_t)cfg.input_size + 1);
-    lay.a_scur = take((size_t)cfg.input_size + 1);
+    // tail overlap (sbr_backward_recurrent): the sort's keys carry a time chunk, its counters cover chunks x ids
+    lay.tail_keys = 1;
+    if (lay.L == 1 && D == 1 && !lay.E && T >= 64 && T < 4096)
+        lay.tail_keys = std::max(1, std::min(8, sbr_scatter_lds_ids() / std::max(1, cfg.input_size)));
+    lay.a_scnt = take((size_t)lay.tail_keys * cfg.input_size + 1); lay.a_soff = take((size_t)lay.tail_keys * cfg.input_size + 1);
+    lay.a_scur = take((size_t)lay.tail_keys * cfg.input_size + 1);
     lay.a_sid = take((size_t)T * Bp * lay.F); lay.a_spos = take((size_t)T * Bp * lay.F);
+    lay.a_prog = take((size_t)Bp * 2 + 192);      // per-wave words, a gap of one line, the monitor's word
     // Row-sparse blocks (sbr_sparse.hip): the index-addressed rows of layer 0 (or of the embedding table) and, for the sampled
     // heads, the rows of W_out^T / b_out.  Taken when a step cannot touch every row anyway (more rows than candidates) or
     // when the flag forces it; SBR_FLAG_DENSE_UPDATE keeps the dense Lasagne-style pass over everything.
@@ -345,6 +350,11 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     h->grads_clean = false; h->timing_marks = 0; h->marks_shared = 0; h->tail_swapped = false;
     { const char* e = getenv("SBR_SWAP_TAIL"); h->swap_tail = e ? atoi(e) != 0 : true; }
+    { const char* e = getenv("SBR_TAIL_OVERLAP"); h->tail_overlap = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_TAIL_CHUNKS"); h->tail_chunks_max = e ? std::max(2, atoi(e)) : 8; }
+    { const char* e = getenv("SBR_TAIL_PUBLISH_EVERY"); h->tail_pub_every = e ? std::max(1, atoi(e)) : 2; }
+    h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr;
+    h->step_open = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
@@ -363,6 +373,9 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipEventCreateWithFlags(&h->ev_lg, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_og, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tail2, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
@@ -400,6 +413,9 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->ev_lg) (void)hipEventDestroy(h->ev_lg);
     if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
     if (h->ev_og) (void)hipEventDestroy(h->ev_og);
+    if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
+    if (h->ev_tail2) (void)hipEventDestroy(h->ev_tail2);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
     for (int c = 0; c < 2; ++c) if (h->ev_lag[c]) (void)hipEventDestroy(h->ev_lag[c]);
     if (h->lag_host) (void)hipHostFree(h->lag_host);
@@ -580,6 +596,26 @@ static RecArgs rec_args(sbr_handle* h, int l) {
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
 static inline bool simple_gemm(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_GEMM; }
+// Overlapped step tail: time chunks for this step (0 = not taken) and steps per chunk.  Taken for a single index-input layer
+// served by rec_bwd_x6p's progress-publishing form, dense updates, the bf16x6 weight-gradient GEMM and one BPTT launch.
+static int tail_plan(sbr_handle* h, int* ch_out) {
+    const Layout& y = h->lay;
+    *ch_out = 0;
+    if (!h->tail_overlap || y.tail_keys < 2 || y.n_sparse || h->bwd_chunks != 1 || !h->wgrad_x6) return 0;
+    if (simple_rec(h) || simple_gemm(h) || (y.cfg.flags & (SBR_FLAG_F32_MFMA | SBR_FLAG_ATOMIC_SCATTER | SBR_FLAG_PROFILE_REC))) return 0;
+    RecArgs a; memset(&a, 0, sizeof(a));
+    a.cell = y.cfg.cell; a.T = y.T; a.Bp = y.Bp; a.H = y.layer[0].H; a.Hp = y.layer[0].Hp; a.G = y.G; a.clip = y.cfg.grad_clip;
+    a.rpt = h->rpt; a.x6_split = h->x6_split; a.x6_pipe = h->x6_pipe; a.n_in = y.layer[0].n_in_p;
+    if (!sbr_rec_x6p_tail_ok(a)) return 0;
+    int nc = std::min(std::min(y.tail_keys, h->tail_chunks_max), y.T / 16);
+    if (nc < 2) return 0;
+    const int ch = (y.T + nc - 1) / nc;
+    nc = (y.T + ch - 1) / ch;
+    if (nc < 2) return 0;
+    *ch_out = ch;
+    return nc;
+}
+
 static inline void mark_on(sbr_handle* h, int i, hipStream_t st) {
     if (i == 0) h->marks_shared = 0;
     if ((h->marks_shared >> i) & 1) return;              // this step's mark i was recorded by record_shared
@@ -601,6 +637,7 @@ static inline hipEvent_t record_shared(sbr_handle* h, hipEvent_t plain, int mk) 
 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
+    h->step_open = true;                          // a training step begins: sbr_forward may start its batch-only work
     if (!h->in_train_step && h->timing) {         // phase-by-phase step (data-parallel driver): this call opens the step
         h->ring_cur = h->ring_used % sbr_handle::kRing;
         mark(h, 0);
@@ -739,6 +776,8 @@ extern "C" int sbr_forward(sbr_handle* h) {
         for (int b = 0; b < y.n_sparse; ++b)
             if (y.sparse[b].kind == 0)
                 SBR_LAUNCH(launch_sparse_catch_up_batch(s, sparse_rows(h, b), sparse_upd(h), h->bX, h->blen, y.T, y.Bp, y.F, (int)h->step_count));
+    h->tail_nc = h->step_open ? tail_plan(h, &h->tail_ch) : 0;      // overlapped tail for this step? (never for predict / top-k)
+    h->step_open = false;
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
@@ -817,7 +856,14 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             }
             SBR_HIP(hipEventRecord(h->ev_fill, sd)); h->fill_done = true;
         }
-        if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
+        if (h->tail_nc >= 2) {
+            // overlapped tail: the time-chunked sort runs on the SECOND side stream, which consumes it (scatter-add beside the
+            // chain); that stream is released by the same record as the first one
+            SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_lg_rec, 0));
+            SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
+                                           (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
+                                           h->tail_ch, h->tail_nc));
+        } else if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
             SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                            y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
                                            (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
@@ -848,7 +894,8 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
         // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
         // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
-        SBR_HIP(hipStreamWaitEvent(sd, record_shared(h, h->ev_lg, 3), 0));
+        h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
+        SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
         if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(launch_sum_cost(sd, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
@@ -875,6 +922,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
         SBR_HIP(hipEventRecord(h->ev_og, s)); h->og_recorded = true;
+        h->ev_lg_rec = h->ev_og;
         if (!fill_needed) {      // the sampled heads keep the main stream: the batch-only side work follows this record
             SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
             const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
@@ -944,6 +992,79 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                                                       // before their collective: same split of the tail
         hipStream_t sw = swap ? s : sd;      // weight-gradient GEMM
         hipStream_t sm = swap ? sd : s;      // partials + scatter
+        if (l == 0 && y.L == 1 && h->tail_nc >= 2) {
+            // ---- Overlapped tail.  The chain (64 of 256 CUs at C2) stores dxt / dhi write-through and every wave publishes the
+            // time step it has completed.  Two consumers run beside it on the idle CUs, ONE launch each, whose workgroups /
+            // waves wait inside the kernel for the time steps they read (SbrPoll, sbr_common.h):
+            //   side stream   gate (returns once every wave of the chain has published: the chain is resident, spinning
+            //                 consumers can no longer keep it off the chip) -> dW_hid GEMM into split-K slabs, short slabs for
+            //                 the time steps the chain reaches last; its workgroup 0 folds the chain's progress words into
+            //                 the one word everybody else polls -> slab reduction (-> W_hid update)
+            //   second side   gate on that word (the monitor is running) -> embedding scatter-add over the time-chunked sort
+            //   stream        with float atomics (-> W_in update)
+            //   main stream   chain -> bias / init-state partial sums (-> their update) -> joins both
+            // In a single-call step every stream applies the optimizer to what it has produced (the output layer early, on
+            // the side stream); phase-by-phase callers (data parallel) get complete gradients and update in sbr_apply_update.
+            const int tnc = h->tail_nc, CH = h->tail_ch;
+            hipStream_t s2 = h->side2;
+            const bool gru = y.cfg.cell == SBR_CELL_GRU;
+            int* words = (int*)h->A(y.a_prog);
+            const int nwaves = (y.Bp / a.rpt) * 8;
+            int* done = words + nwaves + 64;
+            h->prog_epoch = (h->prog_epoch + 1) & 0x7FFFF; if (!h->prog_epoch) h->prog_epoch = 1;
+            a.progress = words; a.prog_every = h->tail_pub_every; a.prog_epoch = h->prog_epoch;
+            const int K = y.T * y.Bp;
+            const int cap = (int)std::min<size_t>(256, y.ws2_floats / slab);
+            static const int env_small = getenv("SBR_TAIL_SMALL_SLABS") ? atoi(getenv("SBR_TAIL_SMALL_SLABS")) : 64;
+            static const int env_ksmall = getenv("SBR_TAIL_SMALL_K") ? std::max(32, atoi(getenv("SBR_TAIL_SMALL_K")) / 32 * 32) : 128;
+            SbrPoll pl{words, nwaves, done, a.prog_epoch, y.Bp, a.fault, 0, env_ksmall};
+            pl.n_small = std::max(0, std::min(std::min(env_small, cap / 2), K / pl.k_small));
+            const int rest = K - pl.n_small * pl.k_small;
+            int k_big = 512;
+            while ((rest + k_big - 1) / k_big > cap - pl.n_small) k_big += 128;
+            const int n_big = std::max(1, (rest + k_big - 1) / k_big);
+            const bool upd_here = h->in_train_step;
+            float* s1a = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+            auto upd_on = [&](hipStream_t st, size_t lo, size_t hi, size_t gap_at = (size_t)-1, size_t gap_len = 0) -> hipError_t {
+                return launch_update(st, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1a ? s1a + lo : nullptr, hi - lo - gap_len,
+                                     y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1, gap_at, gap_len);
+            };
+            SBR_LAUNCH(launch_rec_backward(s, a, false));
+            mark(h, 4);
+            // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
+            const bool out_early = upd_here && y.cfg.loss == SBR_LOSS_CCE;
+            if (out_early) SBR_LAUNCH(upd_on(sd, y.p_split, y.n_params));
+            SBR_LAUNCH(launch_tail_gate(sd, words, nwaves, a.prog_epoch, y.T, a.fault));
+            {
+                hipError_t we = hipSuccess;
+                if (!launch_gemm_slabs_x6_poll(sd, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, ly.Hp, GHp, K, ws2, n_big, k_big, GHp, slab,
+                                               gru ? a.dhi : nullptr, ly.Hp, gru ? 2 * ly.Hp : 0, &we, wg_f16 ? 2 : 3, 1.0f, wg_f16 ? 512.0f : 1.0f, pl)) {
+                    sbr_set_error("overlapped tail: the weight-gradient GEMM rejected the shape"); return SBR_EINVAL;
+                }
+                SBR_LAUNCH(we);
+            }
+            SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
+            SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                                  (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl));
+            if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
+            SBR_HIP(hipEventRecord(h->ev_tail2, s2));
+            SBR_LAUNCH(launch_splitk_reduce(sd, ws2, pl.n_small + n_big, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
+            if (upd_here) SBR_LAUNCH(upd_on(sd, ly.p_Whid, ly.p_peep));
+            SBR_HIP(hipEventRecord(h->ev_tail, sd));
+            // main stream, behind the chain
+            SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
+                                                  h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
+            mark(h, 5);
+            if (upd_here) {      // b, then (behind the gap that is W_hid) peepholes / initial states, and the output layer unless done
+                SBR_LAUNCH(upd_on(s, ly.p_b, out_early ? y.p_split : y.n_params, ly.p_Whid - ly.p_b, ly.p_peep - ly.p_Whid));
+                h->tail_updated = true;
+            }
+            SBR_HIP(hipStreamWaitEvent(s, h->ev_tail2, 0));
+            mark(h, 6);
+            SBR_HIP(hipStreamWaitEvent(s, h->ev_tail, 0));
+            h->side_pending = false;
+            continue;
+        }
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
@@ -1142,6 +1263,8 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
             }
             h->sp_exchanged[b] = 0; h->sp_ncand[b] = 0;
         }
+    } else if (h->tail_updated) {
+        // overlapped tail of a single-call step: every stream has stepped what it produced (sbr_backward_recurrent)
     } else if (h->side_pending && h->tail_swapped) {
         // side stream: everything but W_hid (W_in, b from its own scatter / partials; the output layer's gradients are its
         // own too); main stream: W_hid (its own GEMM) -- no event wait in front of it; then the main stream joins the side
@@ -1174,7 +1297,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(upd(0, y.n_params));
     }
-    h->og_recorded = false; h->tail_swapped = false;
+    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;
@@ -1397,6 +1520,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         }
         *value = w.rfind("rec_products_", 0) == 0 ? products : w.rfind("rec_rows_", 0) == 0 ? rows : wgs;
     }
+    else if (w == "tail_chunks") { int ch = 0; *value = tail_plan(h, &ch); }      // time chunks of the overlapped step tail (0: not taken)
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
     else if (w == "sparse_blocks") *value = y.n_sparse;
     else if (w == "adam_table") *value = y.n_at;

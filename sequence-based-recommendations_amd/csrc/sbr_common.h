@@ -109,6 +109,8 @@ struct Layout {
     size_t a_clx;                         // cluster handshake slots (ints)
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
+    int tail_keys;                        // time chunks the sort's key space was sized for (1: no tail overlap possible)
+    size_t a_prog;                        // [Bp / 4 * 8] progress words of the running BPTT chain (tail overlap)
 };
 
 int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err);
@@ -152,6 +154,16 @@ struct sbr_handle {
     bool grads_clean;    // the gradient section is all zero (fresh arena, or the update kernel cleared it)
     bool timing;
     unsigned timing_marks;   // which of the SBR_N_PHASES event marks a step records (sbr_enable_timing)
+    int tail_overlap;    // SBR_TAIL_OVERLAP (default 1): weight-gradient GEMM and scatter-add of finished time chunks run beside the BPTT chain
+    int tail_chunks_max; // SBR_TAIL_CHUNKS (default 8)
+    int tail_pub_every;  // SBR_TAIL_PUBLISH_EVERY: time steps between two progress words of a chain wave (default 2)
+    int tail_nc, tail_ch;   // this step: time chunks of the sort's keys / steps per chunk (0: plain keys)
+    int prog_epoch;
+    bool tail_updated;      // this step: the overlapped tail has applied the optimizer itself (single-call step)
+    hipEvent_t ev_tail, ev_tail2;
+    bool step_open;         // sbr_zero_grads has opened a training step (cleared by sbr_forward)
+    hipEvent_t ev_lg_rec;   // this step: the main-stream record that released the side stream (sbr_loss_backward_output)
+    hipStream_t side2;      // second consumer stream of the overlapped tail (scatter-add)
     bool swap_tail;      // SBR_SWAP_TAIL: after the BPTT chain the main stream keeps dW_hid, the side stream takes the scatter
     bool tail_swapped;   // ... done for this step (sbr_apply_update splits its ranges accordingly)
     unsigned marks_shared;   // marks of this step already recorded as a cross-stream event (record_shared)
@@ -175,6 +187,13 @@ void sbr_set_error(const char* fmt, ...);
 #define SBR_LAUNCH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
 
+// Consumers of a RUNNING BPTT chain (overlapped step tail): the chain's waves publish (epoch << 12) | t in words[0 .. n) once
+// all their time steps >= t are complete and written through (RecArgs.progress); ONE workgroup of the consuming GEMM
+// folds them into `done` = (epoch << 12) | max t, which every other consumer polls.  rows_per_step: K rows per time step.
+// Slabs of a polling GEMM are K-ascending with n_small slabs of k_small rows first (the time steps the chain reaches last:
+// short slabs = short tail), the rest of kchunk rows; workgroups take them from the far end.
+struct SbrPoll { const int* words; int n; int* done; int epoch; int rows_per_step; int* fault; int n_small, k_small; };
+
 // ---------------------------------------------------------------------------------------
 // Kernel launchers (each returns hipGetLastError())
 // ---------------------------------------------------------------------------------------
@@ -188,8 +207,12 @@ hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, con
 // chunk of 32 sorted entries reduces the dxt rows of equal id in registers
 // concat != 0: entry (pos, f) addresses row pos*F + f of the gradient array (embedding layer: the F embeddings of a step are
 // concatenated, not summed)
+// tch > 0: time-chunked keys (t / tch) * n_ids + id over n_tchunks chunks (cnt / offs / cur then hold n_tchunks * n_ids + 1 ints)
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos, int concat = 0);
+                               int* offs, int* cur, int* sid, int* spos, int concat = 0, int tch = 0, int n_tchunks = 1);
+int sbr_scatter_lds_ids();     // largest key space the LDS-histogram sort takes
+// overlapped step tail: wait (bounded) until every progress word of the running BPTT chain is (epoch, <= target)
+hipError_t launch_tail_gate(hipStream_t s, const int* progress, int n, int epoch, int target, int* fault);
 // emb[t][b][f*Ep + e] = W_emb[X[b][t][f]][e]          (lasagne EmbeddingLayer + flatten(outdim=3), recurrent_layers.py:48)
 hipError_t launch_gather_concat(hipStream_t s, const float* Wemb, const int* X, float* out, int T, int Bp, int F, int Ep);
 // --r_bi helpers (sbr_misc.hip).  rev(t, len) = t < len ? len-1-t : t (padding stays in place).
@@ -203,8 +226,13 @@ hipError_t launch_split_cols(hipStream_t s, const float* src, float* a, float* b
 // (out_b == NULL: W arbitrary, only the sum d is written to out_f -- the embedding case)
 hipError_t launch_uncat(hipStream_t s, const float* f, const float* r, const int* len, float* out_f, float* out_b, int T, int Bp,
                         int W, int Hp);
+// key_lo / accumulate: the entries of the keys [key_lo, key_lo + n_ids) of a time-chunked sort, ADDED to dWin
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
-                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp);
+                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo = 0, bool accumulate = false);
+// all time chunks of a time-chunked sort in ONE launch beside the running chain: every wave waits for poll.done to reach the
+// time chunk of its entries (tch steps per chunk), rows are added with float atomics (an id may occur in every chunk)
+hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll);
 
 // Tile-blocked activation layout [t][row tile of 16][column tile of 16][row 16][col 16] (floats):
 // the 16x16 tile one wave of the recurrent kernels owns is one contiguous KiB (8 full 128-B lines per
@@ -252,6 +280,10 @@ struct RecArgs {
     int* clx;               // [tiles][C] start-of-launch handshake: (epoch << 4) | XCC id of every member
     int epoch;              // unique per launch (clx is never cleared)
     int relu;               // Vanilla layers with dense input = stock lasagne RecurrentLayer: rectify instead of tanh (sbr_cell.h)
+    // overlapped step tail (rec_bwd_x6p only): dxt / dhi are stored write-through and every wave publishes
+    // (prog_epoch << 12) | t in progress[block * 8 + wave] once all its time steps >= t are complete: at launch (t = first
+    // live step + 1 ...), whenever t is a multiple of prog_every, and t_lo at the end.  NULL: plain stores, no progress
+    int* progress; int prog_every; int prog_epoch;
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
 bool sbr_rec_cluster_ok(const RecArgs& a);
@@ -260,6 +292,7 @@ hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 // sbr_rec_p.hip: pipelined bf16x6 kernels for Hp = 128 on 4-row tiles
 bool sbr_rec_x6p_ok(const RecArgs& a);
+bool sbr_rec_x6p_tail_ok(const RecArgs& a);   // ... and its backward kernel can publish progress (RecArgs.progress)
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a);
 // sbr_rec_q.hip: the same step loop for Hp = 32 / 64 (one wave per SIMD)
@@ -292,7 +325,8 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
                     const float* B2 = nullptr, long sbk2 = 0, int n_split = 0, bool small = false, int planes = 3,
-                    float sa = 1.0f, float sb = 1.0f);      // planes = 2: fp16 x3 with operand scales sa, sb (powers of two)
+                    float sa = 1.0f, float sb = 1.0f,       // planes = 2: fp16 x3 with operand scales sa, sb (powers of two)
+                    const SbrPoll* poll = nullptr);
 void sbr_gemm_set_exact_f32(bool on);
 // planes = 1: the next launch_gemm calls run on plain bf16 operands (one MFMA per block, no split-K), for any number of rows
 void sbr_gemm_set_planes(int planes);
@@ -304,6 +338,10 @@ hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, 
 bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
                           int K, float* ws, int nsplit, long ws_ld, size_t slab_stride, const float* B2, long sbk2, int n_split,
                           hipError_t* err, int planes = 3, float sa = 1.0f, float sb = 1.0f);
+// the same as a consumer of the running chain: n_small + n_big slabs (SbrPoll), K = n_small * k_small + n_big * k_big at most
+bool launch_gemm_slabs_x6_poll(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
+                               int K, float* ws, int n_big, int k_big, long ws_ld, size_t slab_stride, const float* B2, long sbk2,
+                               int n_split, hipError_t* err, int planes, float sa, float sb, const SbrPoll& poll);
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias);
 

@@ -232,6 +232,14 @@ bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, con
     return launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, nsplit, kc, slab_stride, err, B2, sbk2, n_split, false,
                           planes, sa, sb);
 }
+bool launch_gemm_slabs_x6_poll(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
+                               int K, float* ws, int n_big, int k_big, long ws_ld, size_t slab_stride, const float* B2, long sbk2,
+                               int n_split, hipError_t* err, int planes, float sa, float sb, const SbrPoll& poll) {
+    if (g_gemm_exact_f32 || M <= 0 || N <= 0 || n_big < 1 || (k_big & 31) || (poll.k_small & 31)) return false;
+    if ((long)poll.n_small * poll.k_small + (long)n_big * k_big < K) return false;
+    return launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, poll.n_small + n_big, k_big, slab_stride, err, B2, sbk2,
+                          n_split, false, planes, sa, sb, &poll);
+}
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias) {
     return splitk_reduce(s, ws, nslabs, M, N, C, ldc, bias);

@@ -20,7 +20,7 @@
 // Tried and rejected: a second stage of global prefetch (no change: latency is already covered); double-buffered
 // LDS with the split interleaved into the MFMA stream at one workgroup per CU (311 us: 376 registers push operands
 // into AGPRs and a single wave per SIMD cannot keep the pipe fed -- the same lesson as rec_fwd_x6s NT=2).
-#include "sbr_cell.h"
+#include "sbr_rec_p.h"
 #include <type_traits>
 
 
@@ -32,7 +32,55 @@ struct GemmX6Args {
     const float* bias;
     const float* B2; long sbk2; int n_split;   // columns n >= n_split of B come from B2[k*sbk2 + (n - n_split)] (GRU weight gradients)
     float sa, sb, so;                          // NP == 2 (fp16 x3): power-of-two scales of the operands on the way in, 1 / (sa sb) on the way out
+    SbrPoll poll;                              // words != NULL: consumer of a running BPTT chain (sbr_common.h)
 };
+
+// Overlapped step tail.  Workgroup (0, 0, 0) is the MONITOR of the launch: it folds the chain's per-wave progress words into
+// `done` (relaxed agent-scope loads, one write-through store when the maximum moves) until the chain has finished, and only
+// then computes its own slab -- the one the chain completes last.  Every other workgroup polls `done` from one lane until
+// its slab's first time step is complete, then takes an agent-scope acquire (the chain stored write-through; this drops
+// whatever this CU / XCD still holds of those lines from the previous training step) and runs as usual.  Spins are
+// bounded (fault bit 3).  t_need: the slab's first time step.
+__device__ __forceinline__ void x6_poll_wait(const SbrPoll& pl, bool monitor, int t_need, int tid) {
+    __shared__ int s_part[4];
+    const int tag = pl.epoch;
+    if (monitor) {
+        int last = 0x1000, spins = 0;
+        for (;;) {
+            int m = 0;
+            for (int i = tid; i < pl.n; i += 256) {
+                const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+            if ((tid & 63) == 0) s_part[tid >> 6] = m;
+            __syncthreads();
+            m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+            __syncthreads();
+            if (m != last && m != 0xfff) {
+                if (tid == 0) __hip_atomic_store(pl.done, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = m;
+            }
+            if (m <= t_need) break;
+            if (++spins > (1 << 21)) { if (tid == 0) atomicOr(pl.fault, 8); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    } else {
+        if (tid == 0) {
+            int spins = 0;
+            for (;;) {
+                const int v = __hip_atomic_load(pl.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 12) == tag && (v & 0xfff) <= t_need) break;
+                if (++spins > (1 << 21)) { atomicOr(pl.fault, 8); break; }
+                poll_sleep((v >> 12) == tag ? (v & 0xfff) - t_need : 64);
+            }
+        }
+        __syncthreads();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+}
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 x6_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) { return MFMA_BF16(a, b, c); }
 __device__ __forceinline__ f32x4 x6_mfma(const f16x8g& a, const f16x8g& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -91,7 +139,17 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int j = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    int zz = blockIdx.z, kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    if (g.poll.words) {
+        const int nz = gridDim.z;
+        zz = nz - 1 - (int)blockIdx.z;                         // the last time steps are complete first
+        const bool monitor = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0) { if (zz == nz - 1) zz = 0; else if (zz == 0) zz = nz - 1; }   // the monitor owns slab 0
+        const int ksz = zz < g.poll.n_small ? g.poll.k_small : g.kchunk;
+        kbeg = zz < g.poll.n_small ? zz * g.poll.k_small : g.poll.n_small * g.poll.k_small + (zz - g.poll.n_small) * g.kchunk;
+        kend = min(g.K, kbeg + ksz);
+        x6_poll_wait(g.poll, monitor, kbeg / g.poll.rows_per_step, threadIdx.x);
+    }
 
     // loader role: A tile (waves 0,1) or B tile (waves 2,3); rows rg*4..+3, k-chunk kc*8..+7
     const bool ldB = tid >= 128;
@@ -173,7 +231,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         __syncthreads();
     }
 
-    float* out = g.C + (size_t)blockIdx.z * g.slab_stride;
+    float* out = g.C + (size_t)zz * g.slab_stride;
 #pragma unroll
     for (int mi = 0; mi < TW; ++mi)
 #pragma unroll
@@ -200,7 +258,7 @@ static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte 
 // C + z*slab_stride, row stride ldc.
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                     int M, int N, int K, const float* bias, int nsplit, int kchunk, size_t slab_stride, hipError_t* err,
-                    const float* B2, long sbk2, int n_split, bool small, int planes, float sa, float sb) {
+                    const float* B2, long sbk2, int n_split, bool small, int planes, float sa, float sb, const SbrPoll* poll) {
     if (planes == 1) { if (M < 1 || N < 48 || K < 32) return false; }      // any number of rows: a row's scores must not depend on
     else if (M < (small ? 48 : 96) || N < (small ? 48 : 96) || K < 32) return false;   // how many rows share the call
     if (B2 && (sbn != 1 || (n_split & 3) || !x6_aligned(B2, sbk2))) return false;
@@ -208,7 +266,8 @@ bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const flo
     const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
     if (!x6_aligned(A, ra ? sak : sam) || !x6_aligned(B, rb ? sbk : sbn)) return false;
     GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split,
-                 sa, sb, 1.0f / (sa * sb)};
+                 sa, sb, 1.0f / (sa * sb), SbrPoll{nullptr, 0, nullptr, 0, 1, nullptr, 0, 0}};
+    if (poll) { if (small || nsplit < 2) return false; g.poll = *poll; }
     const int tile = small ? 64 : 128;
     const dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, nsplit);
 #define X6_GO(TW, KH, NP) do { \

@@ -2,6 +2,7 @@
 // its scatter-add gradient (K6), softmax / cross-entropy (K8), sampled heads (K10-K12),
 // optimizers (K13), test-path exclusion + top-k (K14).
 #include "sbr_common.h"
+#include "sbr_rec_p.h"
 #include <math.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -198,9 +199,14 @@ hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, 
 // LDS and issues ONE global atomic per distinct id it saw.
 #define SCAT_LDS_IDS 36864    // 144 KB of LDS counters: catalogues up to ~37 k ids (C4's 26 744) take the LDS path
 #define SCAT_BLOCK 1024
+// Time-chunked keys (tch > 0): key = (t / tch) * ids_per_chunk + id, so that the entries of one chunk of time steps are
+// contiguous in the sorted order and sorted by id inside it -- the scatter-add of a chunk can then run as soon as the BPTT
+// chain has left that chunk (sbr_backward_recurrent, "tail overlap").  n_ids is the size of the KEY space.
+__device__ __forceinline__ int scat_key(int id, int t, int tch, int ids_per_chunk) { return tch > 0 ? (t / tch) * ids_per_chunk + id : id; }
+
 __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
                                                                     int T, int Bp, int F, int n_ids, int per_block,
-                                                                    int* __restrict__ cnt) {
+                                                                    int* __restrict__ cnt, int tch, int ipc) {
     extern __shared__ int hist[];
     for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
     __syncthreads();
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* _
     const int lo = blockIdx.x * per_block, hi = min(total, lo + per_block);
     for (int i = lo + threadIdx.x; i < hi; i += SCAT_BLOCK) {
         const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
-        if (t < len[b]) atomicAdd(&hist[X[((size_t)b * T + t) * F + f]], 1);
+        if (t < len[b]) atomicAdd(&hist[scat_key(X[((size_t)b * T + t) * F + f], t, tch, ipc)], 1);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) { const int c = hist[i]; if (c) atomicAdd(&cnt[i], c); }
@@ -217,7 +223,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* _
 __global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
                                                                    int T, int Bp, int F, int n_ids, int per_block,
                                                                    int* __restrict__ cur, int* __restrict__ sid,
-                                                                   int* __restrict__ spos, int concat) {
+                                                                   int* __restrict__ spos, int concat, int tch, int ipc) {
     extern __shared__ int hist[];          // [n_ids] counts, then cursors
     for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
     __syncthreads();
@@ -225,7 +231,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __
     const int lo = blockIdx.x * per_block, hi = min(total, lo + per_block);
     for (int i = lo + threadIdx.x; i < hi; i += SCAT_BLOCK) {
         const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
-        if (t < len[b]) atomicAdd(&hist[X[((size_t)b * T + t) * F + f]], 1);
+        if (t < len[b]) atomicAdd(&hist[scat_key(X[((size_t)b * T + t) * F + f], t, tch, ipc)], 1);
     }
     __syncthreads();
     // reserve a contiguous slot range per id with one global atomic; hist[id] becomes the block's cursor
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __
     for (int i = lo + threadIdx.x; i < hi; i += SCAT_BLOCK) {
         const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
         if (t < len[b]) {
-            const int id = X[((size_t)b * T + t) * F + f];
+            const int id = scat_key(X[((size_t)b * T + t) * F + f], t, tch, ipc);
             const int slot = atomicAdd(&hist[id], 1);
             sid[slot] = id; spos[slot] = concat ? i : pos;
         }
@@ -250,32 +256,42 @@ __global__ void scat_count_kernel(const int* __restrict__ X, const int* __restri
     }
 }
 
-// exclusive scan of cnt[0..n) -> offs[0..n], offs[n] = total; cur = copy of offs (fill cursors)
+// exclusive scan of cnt[0..n) -> offs[0..n], offs[n] = total; cur = copy of offs (fill cursors).  One workgroup: the
+// counters are staged in LDS with coalesced loads (LDS = true: n <= SCAT_LDS_IDS), every thread sums a contiguous run of
+// ceil(n / 1024) of them, the 1024 run sums are scanned across the block once, every thread turns its run into prefixes in
+// place, and the result leaves with coalesced stores (the time-chunked sort scans 8 x the ids: ~30 k counters).
+template <bool LDS>
 __global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__ cnt, int n, int* __restrict__ offs,
                                                          int* __restrict__ cur) {
+    extern __shared__ int stage[];
     __shared__ int wsum[16];
-    __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? cnt[i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int carry = carry_s;
-        const int excl = carry + woff + incl - v;
-        if (i < n) { offs[i] = excl; cur[i] = excl; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    if (LDS) {
+        for (int i = threadIdx.x; i < n; i += 1024) stage[i] = cnt[i];
         __syncthreads();
     }
-    if (threadIdx.x == 0) offs[n] = carry_s;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += LDS ? stage[i] : cnt[i];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + incl - sum;                      // exclusive prefix of this thread's run
+    for (int i = lo; i < hi; ++i) {
+        const int c = LDS ? stage[i] : cnt[i];
+        if (LDS) stage[i] = run; else { offs[i] = run; cur[i] = run; }
+        run += c;
+    }
+    if (threadIdx.x == 1023) offs[n] = woff + incl;
+    if (LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) { const int v = stage[i]; offs[i] = v; cur[i] = v; }
+    }
 }
 
 __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
@@ -291,8 +307,15 @@ __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restric
     }
 }
 
+int sbr_scatter_lds_ids() { return SCAT_LDS_IDS; }
+
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos, int concat) {
+                               int* offs, int* cur, int* sid, int* spos, int concat, int tch, int n_tchunks) {
+    const int ipc = n_ids;                          // ids per time chunk
+    if (tch > 0) {
+        n_ids *= n_tchunks;                         // key space
+        if (n_ids > SCAT_LDS_IDS || (long)tch * n_tchunks < T) return hipErrorInvalidValue;
+    }
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), s);
     if (e != hipSuccess) return e;
     const int total = T * Bp * F;
@@ -302,13 +325,14 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
         const size_t lds = (size_t)n_ids * sizeof(int);
         (void)hipFuncSetAttribute((const void*)scat_count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)scat_fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt);
-        scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
-        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat);
+        scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt, tch, ipc);
+        (void)hipFuncSetAttribute((const void*)scat_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        scat_scan_kernel<true><<<1, 1024, lds, s>>>(cnt, n_ids, offs, cur);
+        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat, tch, ipc);
     } else {
         const int grid = min(1024, (total + 255) / 256);
         scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
-        scat_scan_kernel<<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+        scat_scan_kernel<false><<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
         scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos, concat);
     }
     return hipGetLastError();
@@ -318,31 +342,59 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
 // SCAT_CHUNK sorted entries per wave: 64 puts 800 waves on the chip for C2's 51 200 entries (200 workgroups, one wave per
 // SIMD: latency-bound, 1.6 TB/s of row reads); smaller chunks trade more seam atomics for memory-level parallelism
 // (SBR_SCAT_CHUNK = 16 / 32 / 64).
-template <int NV, int SCAT_CHUNK>
+// key_lo > 0 or ACC: the launch covers the sorted entries of the keys [key_lo, key_lo + n_ids) only (one time chunk of the
+// time-chunked sort, row id = key - key_lo) and ADDS to rows earlier launches of the same stream have written.
+// POLL (overlapped step tail): ONE launch over all time chunks beside the running BPTT chain.  n_ids = ids per time chunk,
+// keys = chunk * n_ids + id.  Waves take the sorted entries from the far end (late time steps are complete first); a wave
+// waits (one lane polls poll.done, bounded) until the chain has left the time chunk of its FIRST entry -- the lowest of the
+// wave, the order is ascending -- takes an agent-scope acquire, and adds its row sums with float atomics: an id may occur
+// in every chunk, and chunks finish in different waves.
+template <int NV, int SCAT_CHUNK, bool ACC = false, bool POLL = false>
 __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
-                                                          int n_ids, float* __restrict__ dWin, int R4, int Bp) {
+                                                          int n_ids, float* __restrict__ dWin, int R4, int Bp, int key_lo = 0,
+                                                          int n_tchunks = 1, int tch = 0, SbrPoll poll = SbrPoll()) {
     const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int total = offs[n_ids];
-    const int base = chunk * SCAT_CHUNK;
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const int total = offs[POLL ? n_ids * n_tchunks : key_lo + n_ids];
+    const int nch = (total + SCAT_CHUNK - 1) / SCAT_CHUNK;
+    // POLL: a bounded number of waves (the launch must leave the chip to the GEMM that runs beside it) walks the sorted
+    // entries from the far end, wave-chunk it, it + n_waves, ...
+    for (int it = wave_global; ; it += n_waves) {
+    int chunk = wave_global;
+    if (POLL) { if (it >= nch) break; chunk = nch - 1 - it; }
+    const int base = (POLL ? 0 : offs[key_lo]) + chunk * SCAT_CHUNK;
     if (base >= total) return;
     const int cnt = min(SCAT_CHUNK, total - base);
     const int e = base + (lane & (SCAT_CHUNK - 1));
     const int my_id = e < total ? sid[e] : -1;
     const int my_pos = e < total ? spos[e] : 0;
+    if (POLL) {
+        const int t_need = (__shfl(my_id, 0) / n_ids) * tch;
+        if (lane == 0) {
+            int spins = 0;
+            for (;;) {
+                const int v = __hip_atomic_load(poll.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 12) == poll.epoch && (v & 0xfff) <= t_need) break;
+                if (++spins > (1 << 21)) { atomicOr(poll.fault, 8); break; }
+                poll_sleep((v >> 12) == poll.epoch ? (v & 0xfff) - t_need : 64);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     f32x4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
     int cur_id = __shfl(my_id, 0);
-    auto flush = [&](int id) {
-        const bool owned = offs[id] >= base && offs[id + 1] <= base + cnt;    // whole segment inside this chunk
+    auto flush = [&](int key) {
+        const bool owned = !POLL && offs[key] >= base && offs[key + 1] <= base + cnt;    // whole segment inside this chunk
+        const int id = POLL ? key % n_ids : key - key_lo;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f4 = lane + 64 * v;
             if (f4 < R4) {
                 float* dst = dWin + ((size_t)id * R4 + f4) * 4;
-                if (owned) *(f32x4*)dst = acc[v];
+                if (owned) { if (ACC) *(f32x4*)dst += acc[v]; else *(f32x4*)dst = acc[v]; }
                 else { atomicAdd(dst, acc[v][0]); atomicAdd(dst + 1, acc[v][1]); atomicAdd(dst + 2, acc[v][2]); atomicAdd(dst + 3, acc[v][3]); }
             }
             acc[v] = f32x4{0, 0, 0, 0};
@@ -372,22 +424,59 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
         }
     }
     flush(cur_id);
+    if (!POLL) break;
+    }
+}
+
+hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll) {
+    const int R4 = GHp / 4, nv = (R4 + 63) / 64;
+    static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 64;
+    const int grid = std::max(1, std::min(wgs, ((max_entries + 31) / 32 + 3) / 4));
+#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, 0, n_tchunks, tch, poll)
+    if (nv <= 1) SRP(1); else if (nv <= 2) SRP(2); else if (nv <= 4) SRP(4); else return hipErrorInvalidValue;
+#undef SRP
+    return hipGetLastError();
 }
 
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
-                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp) {
+                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate) {
     const int R4 = GHp / 4;
     static const int chunk_env = getenv("SBR_SCAT_CHUNK") ? atoi(getenv("SBR_SCAT_CHUNK")) : 0;
-    const int chunk = (chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32;
+    const int chunk = (accumulate || key_lo) ? 32 : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32);
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
-#define SR(NV) do { if (chunk == 16) scat_reduce_kernel<NV, 16><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
+#define SR(NV) do { if (accumulate || key_lo) scat_reduce_kernel<NV, 32, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
+                    else if (chunk == 16) scat_reduce_kernel<NV, 16><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
                     else if (chunk == 32) scat_reduce_kernel<NV, 32><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
                     else scat_reduce_kernel<NV, 64><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); } while (0)
-    if (nv <= 1) SR(1); else if (nv <= 2) SR(2); else if (nv <= 4) SR(4); else if (nv <= 8) SR(8); else if (nv <= 16) SR(16);
+    if (accumulate || key_lo) { if (nv <= 1) SR(1); else if (nv <= 2) SR(2); else if (nv <= 4) SR(4); else return hipErrorInvalidValue; }
+    else if (nv <= 1) SR(1); else if (nv <= 2) SR(2); else if (nv <= 4) SR(4); else if (nv <= 8) SR(8); else if (nv <= 16) SR(16);
     else return hipErrorInvalidValue;
 #undef SR
+    return hipGetLastError();
+}
+
+// Gate of the overlapped step tail (sbr_backward_recurrent): returns once every wave of the running BPTT chain
+// (rec_bwd_x6p<.., WT>) has published a progress word of this launch (epoch) at or below `target`, i.e. once all time
+// steps >= target are complete AND written through to memory.  The kernels enqueued behind it on the same stream are
+// ordinary consumers of those time steps.  One workgroup; the poll is a relaxed agent-scope load with s_sleep between
+// polls; the spin is bounded (fault bit 3, reported with the cost) so that a chain that never starts cannot hang the GPU.
+__global__ void __launch_bounds__(512) tail_gate_kernel(const int* __restrict__ progress, int n, int epoch, int target, int* __restrict__ fault) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int spins = 0;
+        for (;;) {
+            const int v = __hip_atomic_load(progress + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 12) == epoch && (v & 0xfff) <= target) break;
+            if (++spins > (1 << 21)) { atomicOr(fault, 8); break; }      // ~1 s
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
+hipError_t launch_tail_gate(hipStream_t s, const int* progress, int n, int epoch, int target, int* fault) {
+    tail_gate_kernel<<<1, 512, 0, s>>>(progress, n, epoch, target, fault);
     return hipGetLastError();
 }
 

@@ -28,8 +28,55 @@ __device__ __forceinline__ void lds_inc(unsigned addr, int one) {
 __device__ __forceinline__ void st_s(const void* ubase, unsigned boff, float v) {
     asm volatile("global_store_dword %0, %1, %2" :: "v"(boff), "v"(v), "s"(ubase) : "memory");
 }
-template <int IMM>
+// WT: write-through (sc1) -- the value reaches memory that every XCD sees, for consumers that read it while this kernel
+// is still running (MI355X_MICROARCH.md, inter-workgroup visibility)
+template <int IMM, bool WT = false>
 __device__ __forceinline__ void st_si(const void* ubase, unsigned boff, float v) {
-    asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(boff), "v"(v), "s"(ubase), "n"(IMM) : "memory");
+    if constexpr (WT) asm volatile("global_store_dword %0, %1, %2 offset:%3 sc1" :: "v"(boff), "v"(v), "s"(ubase), "n"(IMM) : "memory");
+    else asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(boff), "v"(v), "s"(ubase), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void st_wt(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+// rec_bwd_x6p<.., WT>: loads with a scalar base that the compiler's vmcnt bookkeeping does not see (its own wait for the last
+// of five visible loads would be vmcnt(0) and drain the write-through stores issued behind them), and the wait that makes
+// their results valid.  Between the two the destination registers must not be read: the kernel copies nothing out of
+// them there, and tests/test_isa_lint.py checks the generated code for it.
+__device__ __forceinline__ void ld_s(float& dst, const void* ubase, unsigned boff) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(boff), "s"(ubase) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_vm5(float& a, float& b, float& c, float& d, float& e) {
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_vm1(float& a) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT) : "memory");
+}
+// a copy the compiler can neither delay nor fold (ordered with the loads above)
+__device__ __forceinline__ float copy_now(float v) {
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// one lane publishes a progress word, write-through
+__device__ __forceinline__ void publish_word(int* slot, int word) {
+    asm volatile("s_mov_b64 exec, 1\n\tglobal_store_dword %0, %1, off sc1\n\ts_mov_b64 exec, -1" :: "v"(slot), "v"(word) : "memory");
+}
+// ... once `dep` has been computed (a value that depends on the loads the publication speaks for)
+__device__ __forceinline__ void publish_word_after(int* slot, int word, float dep) {
+    asm volatile("s_mov_b64 exec, 1\n\tglobal_store_dword %0, %1, off sc1\n\ts_mov_b64 exec, -1" :: "v"(slot), "v"(word), "v"(dep) : "memory");
+}
+// ... after everything this wave has stored before is complete
+__device__ __forceinline__ void publish_progress(int* slot, int word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish_word(slot, word);
+}
+// Consumers of the running chain poll a progress word; how long to sleep between two polls when `gap` time steps (~1 us
+// each) are still missing -- thousands of pollers of one word must not load the fabric the chain's own loads go through.
+__device__ __forceinline__ void poll_sleep(int gap) {
+    if (gap < 4) { __builtin_amdgcn_s_sleep(8); return; }
+    const int n = min(gap >> 2, 16);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
 }
 }  // namespace

@@ -406,8 +406,13 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 // (sparse_lstm.py:768-772, :789-791; recurrent_layers.py:19), so dhi * 2^9 < 65504 always, and the split keeps an absolute
 // floor of 2^-36 / 2^9 = 3e-14 below that (gradients of this path are 1e-12 .. 1e-2: f32-class relative error down to
 // ~1e-9, then absolute).  The launcher takes this form only while 0 < clip <= 100.
+// WT: the overlapped step tail (sbr_backward_recurrent).  dxt / dhi leave the CU write-through and every wave publishes
+// how far it has come (RecArgs.progress), so that the weight-gradient GEMM and the embedding scatter-add of a finished
+// chunk of time steps can run on the idle CUs while the chain continues.  A wave knows its stores of step t+1 are complete
+// when the loads it issued after them have returned (the vector memory counter retires in order) -- at the top of step t,
+// where the gate math needs those loads anyway: the explicit vmcnt(0) there waits for nothing new.
 constexpr float F16_DSCALE = 512.0f;
-template <int CELL, bool EXT, bool PROF, bool F16>
+template <int CELL, bool EXT, bool PROF, bool F16, bool WT = false>
 __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;
     constexpr int NP = F16 ? 2 : 3;
@@ -470,6 +475,18 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     for (int g = 0; g < G; ++g) sdb[g] = 0.f;
 
     float sv[4] = {0.f, 0.f, 0.f, 0.f}, hprev = 0.f, hnew = 0.f, dhe = 0.f;
+    constexpr int NST = G + (CELL == CELL_GRU ? 1 : 0);           // WT: stores of a step, issued behind its loads
+    auto load_saved_wt = [&](size_t o) {                         // valid behind take_saved() only (sbr_rec_p.h)
+        ld_s(hprev, (const char*)a.hs + o, bo_h);
+        if (CELL != CELL_VANILLA) {
+            ld_s(sv[0], (const char*)a.g[0] + o, bo_g); ld_s(sv[1], (const char*)a.g[1] + o, bo_g);
+            ld_s(sv[2], (const char*)a.g[2] + o, bo_g); ld_s(sv[3], (const char*)a.g[3] + o, bo_g);
+        }
+    };
+    auto take_saved = [&](auto cnt) {
+        if (CELL != CELL_VANILLA) wait_vm5<decltype(cnt)::value>(hprev, sv[0], sv[1], sv[2], sv[3]);
+        else wait_vm1<decltype(cnt)::value>(hprev);
+    };
     auto load_saved = [&](size_t o) {                            // activations of the step at byte offset o = t * st_h
         hprev = ldf((const char*)a.hs + o, bo_h);
         if (CELL != CELL_VANILLA) {
@@ -486,11 +503,27 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     for (int t = a.t_hi - 1; t >= max(t_live, a.t_lo); --t) {     // zero rows; dh_ext still accumulates
         if (EXT) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
 #pragma unroll
-        for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = 0.f;
-        if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = 0.f;
+        for (int g = 0; g < G; ++g) {
+            float* p = a.dxt + ((size_t)t * Bp + row) * GHP + g * HP + u;
+            if (WT) st_wt(p, 0.f); else *p = 0.f;
+        }
+        if (CELL == CELL_GRU) {
+            float* p = a.dhi + ((size_t)t * Bp + row) * HP + u;
+            if (WT) st_wt(p, 0.f); else *p = 0.f;
+        }
+    }
+    int* prog_slot = nullptr; int prog_next = 0; const int prog_tag = a.prog_epoch << 12;
+    if constexpr (WT) {
+        prog_slot = a.progress + blockIdx.x * 8 + wave;
+        const int tl = max(t_live, a.t_lo);
+        publish_progress(prog_slot, prog_tag | tl);               // every step >= tl is complete (zero rows above)
+        prog_next = tl - a.prog_every;                            // publish again at or below this step
     }
     if (t_live > a.t_lo) {
-        load_saved((size_t)(t_live - 1) * st_h);
+        // (the wait names the registers: a wait without operands would let the compiler copy them first, e.g. into the
+        // registers the other role's loop keeps them in)
+        if constexpr (WT) { load_saved_wt((size_t)(t_live - 1) * st_h); take_saved(std::integral_constant<int, 0>{}); }
+        else load_saved((size_t)(t_live - 1) * st_h);
         if (CELL == CELL_VANILLA) hnew = a.hs[(size_t)t_live * Bp * HP + (size_t)row * HP + u];
     }
     // k-blocks in the order they are visited: columns of units 0-63 (all gates), then of units 64-127
@@ -502,11 +535,21 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     constexpr bool RA = decltype(role_tag)::value;
     int n = 0;                                                    // steps done
     for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
+        if constexpr (WT) take_saved(std::integral_constant<int, NST>{});      // (first iteration: already complete, see the prologue)
         // ---- N: gate math of step t (needs dh complete), publish dhi, stores, loads for step t-1
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
         cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, 0.f, 0.f, hnew, 0.f, 0.f, 0.f, dxi, dhi, dp, a.relu != 0);
+        if constexpr (WT) {
+            // The loads of step t were issued BEFORE the stores of step t + 1 (below) and after those of step t + 2: the gate
+            // math has just consumed them, so step t + 2 is complete.  Nothing waits for the write-through stores of step
+            // t + 1 themselves, whose acknowledgements take long while the consumers load the fabric.
+            if (n >= 1 && t + 2 <= prog_next) {                   // uniform
+                publish_word_after(prog_slot, prog_tag | (t + 2), dxi[0]);
+                prog_next = t + 2 - a.prog_every;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
 #pragma unroll
@@ -528,17 +571,26 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
         }
         lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
-        if (CELL == CELL_VANILLA) hnew = hprev;
-        {
+        if (CELL == CELL_VANILLA) hnew = WT ? copy_now(hprev) : hprev;
+        if constexpr (WT) {                                       // loads first: see the progress note above
+            __builtin_amdgcn_sched_barrier(0);
+            load_saved_wt(t > a.t_lo ? off_h - st_h : off_h);
+            const char* dx_t = (const char*)a.dxt + off_x;
+            st_si<0, true>(dx_t, bo_x, dxi[0]);
+            if (G > 1) st_si<HP * 4, true>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
+            if (G > 2) st_si<2 * HP * 4, true>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
+            if (CELL == CELL_GRU) st_si<0, true>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
             const char* dx_t = (const char*)a.dxt + off_x;
             st_si<0>(dx_t, bo_x, dxi[0]);
             if (G > 1) st_si<HP * 4>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
             if (G > 2) st_si<2 * HP * 4>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
             if (CELL == CELL_GRU) st_si<0>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_saved(t > a.t_lo ? off_h - st_h : off_h);            // step t-1: unconditional, clamped
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_saved(t > a.t_lo ? off_h - st_h : off_h);            // step t-1: unconditional, clamped
-        __builtin_amdgcn_sched_barrier(0);
         off_h -= st_h; off_x -= st_x;
         // ---- operands: a ring of NS k-block slots, fetched LA k-blocks ahead of their MFMAs; the pipe gate
         constexpr int NS = 2, LA = 1;          // measured: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
@@ -630,6 +682,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     }
     };
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
+    if constexpr (WT) publish_progress(prog_slot, prog_tag | a.t_lo);
     if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         const unsigned long long tot = clock64() - p_c0;
@@ -700,11 +753,21 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     const char* fe = getenv("SBR_X6_F16_BWD");                     // read per launch: the tests flip it
     // fp16 x3 products for the BPTT chain: the operand that carries gradients is bounded by the reference's own gradient clip
     const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
-    if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
+    if (a.progress && (a.prof || ext || !f16)) return hipErrorInvalidValue;     // (sbr_rec_x6p_tail_ok says when)
+    if (a.progress) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, true>)); }
+    else if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }
     else { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, false>)); }
 #undef X6P_LAUNCH
     return hipGetLastError();
+}
+
+// the write-through / progress form of the backward kernel exists for the fp16x3 products of a top (single) layer
+bool sbr_rec_x6p_tail_ok(const RecArgs& a) {
+    const char* fe = getenv("SBR_X6_F16_BWD");
+    const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
+    return sbr_rec_x6p_ok(a) && f16 && !a.prof && !a.dh_ext && a.T < 4096 &&
+           (size_t)a.T * a.Bp * a.G * HP * 4 < ((size_t)1 << 31);                    // buffer stores: 31-bit scalar offsets
 }
 
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a) {

@@ -140,6 +140,56 @@ def test_step_scheduling_switches(env, monkeypatch):
     check(PU.compare_step("GRU", [50], "BPR", N=200, B=48, T=9, S=16))
 
 
+def _tail_chunks(cell, T, N=300, B=37, flags=0, loss="CCE", S=0):
+    from sbr_amd.engine import RNNEngine
+    eng = RNNEngine(cell=cell, layers=[128], n_items=N, max_length=T, batch_size=B, loss=loss, n_samples=S, flags=flags)
+    try:
+        return eng.query("tail_chunks")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("chunks", [None, "3"])
+@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+def test_overlapped_step_tail(cell, chunks, monkeypatch):
+    # One index-input layer of 128 units and T >= 64: the BPTT chain stores dxt / dhi write-through and publishes its progress;
+    # dW_hid GEMM and scatter-add of every finished chunk of time steps run beside it (sbr_backward_recurrent).  Ragged rows
+    # (whole tiles masked for most of the time axis), Zipf ids (long runs of equal ids across the time chunks: the scatter
+    # of a chunk ADDS to rows earlier chunks wrote), T not a multiple of the chunk length.
+    if chunks:
+        monkeypatch.setenv("SBR_TAIL_CHUNKS", chunks)
+    assert _tail_chunks(cell, 70) == (3 if chunks else 4)
+    # (gap: the ranked ids are compared on the rows whose oracle logits are further apart than 1e-4 -- most of them; a tanh-only
+    # layer of 128 units is ill-conditioned over 70+ steps at larger weights, see parity_util.build_case)
+    sc = 0.1 if cell == "GRU" else 0.05
+    check(PU.compare_step(cell, [128], "CCE", N=300, B=37, T=70, scale=sc, zipf=True, gap=1e-4), tol_g=2e-4)
+    if cell == "GRU":      # (a tanh-only layer over 131 steps + Adam is chaotic with the tail switched off as well: tools/dbg_tail.py)
+        check(PU.compare_step(cell, [128], "CCE", N=300, B=64, T=131, scale=sc, full=True, gap=1e-4), tol_g=2e-4)
+    else:                  # ... and Adam's normalised steps amplify it already at 80: momentum steps for this one
+        check(PU.compare_step(cell, [128], "CCE", N=300, B=64, T=80, scale=sc, full=True, gap=1e-4, updater="nesterov"), tol_g=2e-4)
+    check(PU.compare_step(cell, [128], "CCE", N=40, B=5, T=64, scale=sc), tol_g=2e-4)          # one row tile, few ids, many duplicates
+
+
+def test_overlapped_step_tail_with_sampled_head_and_other_updaters():
+    assert _tail_chunks("GRU", 70, flags=64, loss="BPR", S=8) == 4       # SBR_FLAG_DENSE_UPDATE: no row-sparse blocks
+    check(PU.compare_step("GRU", [128], "BPR", N=300, B=37, T=70, S=8, scale=0.1, flags=64, gap=1e-4), tol_g=2e-4)
+    check(PU.compare_step("GRU", [128], "CCE", N=300, B=37, T=70, scale=0.1, updater="adagrad", gap=1e-4), tol_g=2e-4)
+    check(PU.compare_step("Vanilla", [128], "CCE", N=300, B=37, T=70, scale=0.05, updater="nesterov", gap=1e-4), tol_g=2e-4)
+
+
+def test_overlapped_step_tail_switched_off_agrees(monkeypatch):
+    monkeypatch.setenv("SBR_TAIL_OVERLAP", "0")
+    assert _tail_chunks("GRU", 70) == 0
+    check(PU.compare_step("GRU", [128], "CCE", N=300, B=37, T=70, scale=0.1, zipf=True, gap=1e-4), tol_g=2e-4)
+
+
+def test_overlapped_step_tail_is_not_taken_where_it_does_not_apply():
+    assert _tail_chunks("GRU", 40) == 0                                   # short sequences
+    assert _tail_chunks("LSTM", 70) == 0                                  # LSTM-128 keeps the barrier kernels
+    assert _tail_chunks("GRU", 70, flags=32) == 0                         # row-sparse blocks forced
+    assert _tail_chunks("GRU", 70, N=20000) == 0                          # key space beyond the LDS histogram: chunks < 2
+
+
 @pytest.mark.parametrize("H", [20, 50])
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_small_layer_barrier_kernels_agree(cell, H, monkeypatch):
