@@ -1006,7 +1006,16 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             // In a single-call step every stream applies the optimizer to what it has produced (the output layer early, on
             // the side stream); phase-by-phase callers (data parallel) get complete gradients and update in sbr_apply_update.
             const int tnc = h->tail_nc, CH = h->tail_ch;
-            hipStream_t s2 = h->side2;
+            // SBR_TAIL_OVERLAP=2: the same kernels, all on the main stream behind the chain (nothing has to run concurrently):
+            // for tools that serialise kernels (rocprofv3 --pmc) and for triage
+            const bool serial = h->tail_overlap == 2;
+            hipStream_t s2 = serial ? s : h->side2;
+            if (serial) {
+                sd = s;
+                { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
+                SBR_HIP(hipEventRecord(h->ev_tail2, h->side2));           // the sort ran there
+                SBR_HIP(hipStreamWaitEvent(s, h->ev_tail2, 0));
+            }
             const bool gru = y.cfg.cell == SBR_CELL_GRU;
             int* words = (int*)h->A(y.a_prog);
             const int nwaves = (y.Bp / a.rpt) * 8;

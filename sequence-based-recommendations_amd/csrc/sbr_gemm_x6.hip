@@ -45,7 +45,8 @@ __device__ __forceinline__ void x6_poll_wait(const SbrPoll& pl, bool monitor, in
     __shared__ int s_part[4];
     const int tag = pl.epoch;
     if (monitor) {
-        int last = 0x1000, spins = 0;
+        int last = 0x1000;
+        const unsigned long long t0 = wall_clock64();
         for (;;) {
             int m = 0;
             for (int i = tid; i < pl.n; i += 256) {
@@ -63,16 +64,16 @@ __device__ __forceinline__ void x6_poll_wait(const SbrPoll& pl, bool monitor, in
                 last = m;
             }
             if (m <= t_need) break;
-            if (++spins > (1 << 21)) { if (tid == 0) atomicOr(pl.fault, 8); break; }
+            if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
             __builtin_amdgcn_s_sleep(4);
         }
     } else {
         if (tid == 0) {
-            int spins = 0;
+            const unsigned long long t0 = wall_clock64();
             for (;;) {
                 const int v = __hip_atomic_load(pl.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((v >> 12) == tag && (v & 0xfff) <= t_need) break;
-                if (++spins > (1 << 21)) { atomicOr(pl.fault, 8); break; }
+                if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(pl.fault, 8); break; }
                 poll_sleep((v >> 12) == tag ? (v & 0xfff) - t_need : 64);
             }
         }

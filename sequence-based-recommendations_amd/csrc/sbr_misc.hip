@@ -256,24 +256,47 @@ __global__ void scat_count_kernel(const int* __restrict__ X, const int* __restri
     }
 }
 
-// exclusive scan of cnt[0..n) -> offs[0..n], offs[n] = total; cur = copy of offs (fill cursors).  One workgroup: the
-// counters are staged in LDS with coalesced loads (LDS = true: n <= SCAT_LDS_IDS), every thread sums a contiguous run of
-// ceil(n / 1024) of them, the 1024 run sums are scanned across the block once, every thread turns its run into prefixes in
-// place, and the result leaves with coalesced stores (the time-chunked sort scans 8 x the ids: ~30 k counters).
+// exclusive scan of cnt[0..n) -> offs[0..n], offs[n] = total; cur = copy of offs (fill cursors); one workgroup.
+// LDS (n <= SCAT_LDS_IDS, e.g. the ~30 k keys of the time-chunked sort): the counters are staged in LDS with coalesced loads,
+// every thread sums a contiguous run of ceil(n / 1024) of them, the 1024 run sums are scanned across the block once, every
+// thread turns its run into prefixes in place, and the result leaves with coalesced stores.  Otherwise (large catalogues):
+// one block-wide scan per 1024 counters, coalesced accesses throughout.
 template <bool LDS>
 __global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__ cnt, int n, int* __restrict__ offs,
                                                          int* __restrict__ cur) {
     extern __shared__ int stage[];
     __shared__ int wsum[16];
+    __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (LDS) {
-        for (int i = threadIdx.x; i < n; i += 1024) stage[i] = cnt[i];
+    if (!LDS) {
+        if (threadIdx.x == 0) carry_s = 0;
         __syncthreads();
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + threadIdx.x;
+            const int v = i < n ? cnt[i] : 0;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wave; ++w) woff += wsum[w];
+            const int carry = carry_s;
+            const int excl = carry + woff + incl - v;
+            if (i < n) { offs[i] = excl; cur[i] = excl; }
+            __syncthreads();
+            if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) offs[n] = carry_s;
+        return;
     }
+    for (int i = threadIdx.x; i < n; i += 1024) stage[i] = cnt[i];
+    __syncthreads();
     const int per = (n + 1023) / 1024;
     const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
     int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += LDS ? stage[i] : cnt[i];
+    for (int i = lo; i < hi; ++i) sum += stage[i];
     int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
@@ -282,16 +305,10 @@ __global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
     int run = woff + incl - sum;                      // exclusive prefix of this thread's run
-    for (int i = lo; i < hi; ++i) {
-        const int c = LDS ? stage[i] : cnt[i];
-        if (LDS) stage[i] = run; else { offs[i] = run; cur[i] = run; }
-        run += c;
-    }
+    for (int i = lo; i < hi; ++i) { const int c = stage[i]; stage[i] = run; run += c; }
     if (threadIdx.x == 1023) offs[n] = woff + incl;
-    if (LDS) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 1024) { const int v = stage[i]; offs[i] = v; cur[i] = v; }
-    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) { const int v = stage[i]; offs[i] = v; cur[i] = v; }
 }
 
 __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
@@ -372,11 +389,11 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
     if (POLL) {
         const int t_need = (__shfl(my_id, 0) / n_ids) * tch;
         if (lane == 0) {
-            int spins = 0;
+            const unsigned long long t0 = wall_clock64();
             for (;;) {
                 const int v = __hip_atomic_load(poll.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((v >> 12) == poll.epoch && (v & 0xfff) <= t_need) break;
-                if (++spins > (1 << 21)) { atomicOr(poll.fault, 8); break; }
+                if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(poll.fault, 8); break; }
                 poll_sleep((v >> 12) == poll.epoch ? (v & 0xfff) - t_need : 64);
             }
         }
@@ -465,11 +482,11 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
 // polls; the spin is bounded (fault bit 3, reported with the cost) so that a chain that never starts cannot hang the GPU.
 __global__ void __launch_bounds__(512) tail_gate_kernel(const int* __restrict__ progress, int n, int epoch, int target, int* __restrict__ fault) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int spins = 0;
+        const unsigned long long t0 = wall_clock64();
         for (;;) {
             const int v = __hip_atomic_load(progress + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((v >> 12) == epoch && (v & 0xfff) <= target) break;
-            if (++spins > (1 << 21)) { atomicOr(fault, 8); break; }      // ~1 s
+            if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(fault, 8); break; }
             __builtin_amdgcn_s_sleep(8);
         }
     }

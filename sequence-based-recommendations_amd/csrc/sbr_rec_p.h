@@ -74,6 +74,8 @@ __device__ __forceinline__ void publish_progress(int* slot, int word) {
 }
 // Consumers of the running chain poll a progress word; how long to sleep between two polls when `gap` time steps (~1 us
 // each) are still missing -- thousands of pollers of one word must not load the fabric the chain's own loads go through.
+// pollers give up after this many ticks of the 100 MHz wall clock (1.5 s) and raise the fault flag
+#define SBR_POLL_TICKS 150000000ull
 __device__ __forceinline__ void poll_sleep(int gap) {
     if (gap < 4) { __builtin_amdgcn_s_sleep(8); return; }
     const int n = min(gap >> 2, 16);

@@ -183,6 +183,12 @@ def test_overlapped_step_tail_switched_off_agrees(monkeypatch):
     check(PU.compare_step("GRU", [128], "CCE", N=300, B=37, T=70, scale=0.1, zipf=True, gap=1e-4), tol_g=2e-4)
 
 
+def test_overlapped_step_tail_kernels_on_one_stream(monkeypatch):
+    monkeypatch.setenv("SBR_TAIL_OVERLAP", "2")      # what the counter passes of tools/profile_round.sh run
+    assert _tail_chunks("GRU", 70) == 4
+    check(PU.compare_step("GRU", [128], "CCE", N=300, B=37, T=70, scale=0.1, zipf=True, gap=1e-4), tol_g=2e-4)
+
+
 def test_overlapped_step_tail_is_not_taken_where_it_does_not_apply():
     assert _tail_chunks("GRU", 40) == 0                                   # short sequences
     assert _tail_chunks("LSTM", 70) == 0                                  # LSTM-128 keeps the barrier kernels

@@ -13,8 +13,9 @@ cd $repo
 cd /tmp && export TMPDIR=/tmp
 short="python $repo/bench.py --steps 8 --warmup 3 --repeats 1 --no-cpu-baseline $@"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- $short > $out/${tag}_stats.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -o f -- $short > $out/${tag}_pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_write -o w -- $short > $out/${tag}_pmc_write.log 2>&1
+# counter passes serialise kernels: the overlapped tail's consumers cannot run beside the chain there -> SBR_TAIL_OVERLAP=2 (same kernels, one stream)
+SBR_TAIL_OVERLAP=2 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -o f -- $short > $out/${tag}_pmc_fetch.log 2>&1
+SBR_TAIL_OVERLAP=2 timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_write -o w -- $short > $out/${tag}_pmc_write.log 2>&1
 cd $repo
 python tools/pmc_summary.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_stats > $out/${tag}_pmc.json
 python bench.py --pmc-json $out/${tag}_pmc.json "$@" > $out/${tag}_bench.json 2> $out/${tag}_bench.err
