@@ -354,7 +354,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_TAIL_CHUNKS"); h->tail_chunks_max = e ? std::max(2, atoi(e)) : 8; }
     { const char* e = getenv("SBR_TAIL_PUBLISH_EVERY"); h->tail_pub_every = e ? std::max(1, atoi(e)) : 2; }
     h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr;
-    h->step_open = false;
+    h->step_open = false; h->tail_join_pending = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
@@ -818,6 +818,11 @@ static float* h_last(sbr_handle* h) {   // hid_out[-1] (sparse_lstm.py:485-486) 
 // scalar, the counting sort for the embedding scatter, the weight-gradient GEMM of finished BPTT chunks) so that
 // the main stream holds nothing but the dependent chain  logits -> softmax -> dh -> BPTT chunks -> scatter.
 static int side_join(sbr_handle* h) {
+    if (h->tail_join_pending) {      // overlapped tail of a phase-by-phase step: both consumer streams
+        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_tail2, 0));
+        SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_tail, 0));
+        h->tail_join_pending = false; h->side_pending = false;
+    }
     if (h->side_pending) {
         SBR_HIP(hipEventRecord(h->ev_join, h->side));
         SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -1068,6 +1073,13 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 SBR_LAUNCH(upd_on(s, ly.p_b, out_early ? y.p_split : y.n_params, ly.p_Whid - ly.p_b, ly.p_peep - ly.p_Whid));
                 h->tail_updated = true;
             }
+            if (h->deferred_join && !h->in_train_step && !serial) {
+                // data-parallel driver: it orders one collective behind each producing stream (W_in: second side stream,
+                // W_hid: side stream, the rest: this stream) and joins through sbr_join_side / sbr_apply_update
+                h->tail_join_pending = true;
+                mark(h, 6);
+                continue;
+            }
             SBR_HIP(hipStreamWaitEvent(s, h->ev_tail2, 0));
             mark(h, 6);
             SBR_HIP(hipStreamWaitEvent(s, h->ev_tail, 0));
@@ -1238,6 +1250,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     const Layout& y = h->lay;
     h->step_count += 1;
+    if (h->tail_join_pending) { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
     float* s1 = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
     auto upd = [&](size_t lo, size_t hi) -> hipError_t {
         if (hi <= lo) return hipSuccess;
@@ -1530,6 +1543,12 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         *value = w.rfind("rec_products_", 0) == 0 ? products : w.rfind("rec_rows_", 0) == 0 ? rows : wgs;
     }
     else if (w == "tail_chunks") { int ch = 0; *value = tail_plan(h, &ch); }      // time chunks of the overlapped step tail (0: not taken)
+    else if (w == "side_stream2") *value = (int64_t)(intptr_t)h->side2;
+    // overlapped tail, phase-by-phase step: the gradient ranges the two consumer streams produce (floats of the gradient section)
+    else if (w == "tail_win_lo") *value = (int64_t)y.layer[0].p_Win;
+    else if (w == "tail_win_hi") *value = (int64_t)y.layer[0].p_b;
+    else if (w == "tail_whid_lo") *value = (int64_t)y.layer[0].p_Whid;
+    else if (w == "tail_whid_hi") *value = (int64_t)y.layer[0].p_peep;
     else if (w == "arena_bytes") *value = (int64_t)(y.s_end * sizeof(float));
     else if (w == "sparse_blocks") *value = y.n_sparse;
     else if (w == "adam_table") *value = y.n_at;

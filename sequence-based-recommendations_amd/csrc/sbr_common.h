@@ -161,6 +161,7 @@ struct sbr_handle {
     int prog_epoch;
     bool tail_updated;      // this step: the overlapped tail has applied the optimizer itself (single-call step)
     hipEvent_t ev_tail, ev_tail2;
+    bool tail_join_pending; // overlapped tail of a phase-by-phase step: the main stream has not joined the consumer streams yet
     bool step_open;         // sbr_zero_grads has opened a training step (cleared by sbr_forward)
     hipEvent_t ev_lg_rec;   // this step: the main-stream record that released the side stream (sbr_loss_backward_output)
     hipStream_t side2;      // second consumer stream of the overlapped tail (scatter-add)

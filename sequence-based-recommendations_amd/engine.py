@@ -608,6 +608,16 @@ class RNNEngine(object):
         """torch view of the engine's internal side stream (data-parallel: collectives ordered behind it)."""
         return self.torch.cuda.ExternalStream(self.query("side_stream"), device=self.device)
 
+    def side_stream2(self):
+        """... and of the second one (overlapped step tail: the embedding scatter-add runs there)."""
+        return self.torch.cuda.ExternalStream(self.query("side_stream2"), device=self.device)
+
+    def tail_ranges(self):
+        """Overlapped step tail (query('tail_chunks') >= 2), phase-by-phase step: the float ranges of the gradient section
+        that the two consumer streams produce: ((W_in lo, hi) on side_stream2, (W_hid lo, hi) on side_stream)."""
+        q = self.query
+        return (q("tail_win_lo"), q("tail_win_hi")), (q("tail_whid_lo"), q("tail_whid_hi"))
+
     def query(self, what):
         v = ctypes.c_int64()
         self._check(self.lib.sbr_query(self.h, what.encode(), ctypes.byref(v)))

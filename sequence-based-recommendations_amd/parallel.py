@@ -27,10 +27,16 @@ class DataParallel(object):
         self.grads, self.split = engine.section("grads")
         # stream-level overlap needs the engine's side stream and device tensors (RCCL); the gloo CPU tests use a
         # stand-in engine without either
-        self.side = None
+        self.side = self.side2 = None
+        self.tail = None
         if hasattr(engine, "side_stream") and getattr(self.grads, "is_cuda", False):
             self.side = engine.side_stream()
             engine.set_deferred_join(True)
+            # overlapped step tail (engine.query("tail_chunks") >= 2): dW_in is finished by the engine's second side stream,
+            # dW_hid by the first, everything else of the recurrent part by the main stream -- one collective behind each
+            if hasattr(engine, "side_stream2") and engine.query("tail_chunks") >= 2:
+                self.side2 = engine.side_stream2()
+                self.tail = engine.tail_ranges()
 
     @staticmethod
     def shard(batch_size, world, rank):
@@ -97,11 +103,27 @@ class DataParallel(object):
             with torch.cuda.stream(self.side):       # RCCL waits for the side stream only; the main stream runs the chain
                 works = [red(lo, hi) for lo, hi in out_r]
             e.backward_recurrent()
-            e.join_side()                            # weight-gradient kernels of the recurrent part
+            if self.tail is None:
+                e.join_side()                        # weight-gradient kernels of the recurrent part
+            # (overlapped tail: no join here -- the collectives below follow the producing streams, sbr_apply_update joins)
         else:
             works = [red(lo, hi) for lo, hi in out_r]
             e.backward_recurrent()
-        works += [red(lo, hi) for lo, hi in rec_r]
+        if self.tail is not None and len(rec_r) == 1:
+            # two buckets, each behind the stream that finishes it: W_in behind the scatter-add (second side stream), and the
+            # contiguous rest -- biases and initial states (the chain's partial sums, main stream) around W_hid (slab
+            # reduction, side stream) -- behind the side stream once it has also waited for the main stream's share
+            import torch
+            (wi_lo, wi_hi), (wh_lo, wh_hi) = self.tail
+            lo, hi = rec_r[0]
+            assert lo == wi_lo and wi_hi <= wh_lo and wh_hi <= hi
+            with torch.cuda.stream(self.side2):
+                works.append(red(wi_lo, wi_hi))
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                works.append(red(wi_hi, hi))
+        else:
+            works += [red(lo, hi) for lo, hi in rec_r]
         for b in range(self._nsparse):
             self._exchange_sparse(b)
         for w in works:

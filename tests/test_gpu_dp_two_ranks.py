@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 CASES = {
     # name: (cell, layers, loss, N, B, T, S, updater)
     "gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
+    # T >= 64 on one 128-unit layer: the overlapped step tail -- one collective behind each of the engine's three streams
+    "gru128_cce_adam_overlapped_tail": ("GRU", [128], "CCE", 300, 64, 70, 0, "adam"),
     "lstm20_blackout_adagrad": ("LSTM", [20], "Blackout", 200, 32, 12, 8, "adagrad"),
     "lstm256_bpr_adam": ("LSTM", [256], "BPR", 500, 32, 10, 8, "adam"),
     # row-sparse blocks (forced on these small shapes): all-gather of (ids, rows) instead of the all-reduce of W_in / W_out
@@ -43,6 +45,7 @@ def _worker(rank, world, port, name, out):
         eng.set_all_param_values(params)
         dp = DataParallel(eng, dist)
         assert dp.side is not None                      # the stream-level path, not the stand-in one
+        assert (dp.tail is not None) == ("overlapped_tail" in name)
         if flags:
             assert len(eng.sparse_blocks()) == (1 if loss == "CCE" else 2)
         smp = batch["samples"] if loss != "CCE" else None
