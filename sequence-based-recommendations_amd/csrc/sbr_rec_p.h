@@ -38,27 +38,18 @@ __device__ __forceinline__ void st_si(const void* ubase, unsigned boff, float v)
 __device__ __forceinline__ void st_wt(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
-// rec_bwd_x6p<.., WT>: loads with a scalar base that the compiler's vmcnt bookkeeping does not see (its own wait for the last
-// of five visible loads would be vmcnt(0) and drain the write-through stores issued behind them), and the wait that makes
-// their results valid.  Between the two the destination registers must not be read: the kernel copies nothing out of
-// them there, and tests/test_isa_lint.py checks the generated code for it.
-__device__ __forceinline__ void ld_s(float& dst, const void* ubase, unsigned boff) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(boff), "s"(ubase) : "memory");
+// rec_bwd_x6p<.., WT>: one dword per lane from global memory straight into LDS (LDS-DMA): lane i's value lands at
+// lds_addr + 4 i.  Invisible to the compiler's vmcnt bookkeeping (its own waits for visible loads would also drain the
+// write-through stores issued behind them); the kernel waits by hand (wait_vm) and reads the ring with ordinary LDS loads.
+// lds_addr must be wave-uniform (it travels in M0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // M0 is "reserved": the clobber is what tells the compiler it is overwritten
+__device__ __forceinline__ void lds_dma(unsigned lds_addr, const void* ubase, unsigned boff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_addr), "v"(boff), "s"(ubase) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 template <int CNT>
-__device__ __forceinline__ void wait_vm5(float& a, float& b, float& c, float& d, float& e) {
-    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT) : "memory");
-}
-template <int CNT>
-__device__ __forceinline__ void wait_vm1(float& a) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT) : "memory");
-}
-// a copy the compiler can neither delay nor fold (ordered with the loads above)
-__device__ __forceinline__ float copy_now(float v) {
-    float r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
 // one lane publishes a progress word, write-through
 __device__ __forceinline__ void publish_word(int* slot, int word) {
     asm volatile("s_mov_b64 exec, 1\n\tglobal_store_dword %0, %1, off sc1\n\ts_mov_b64 exec, -1" :: "v"(slot), "v"(word) : "memory");

@@ -475,17 +475,31 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     for (int g = 0; g < G; ++g) sdb[g] = 0.f;
 
     float sv[4] = {0.f, 0.f, 0.f, 0.f}, hprev = 0.f, hnew = 0.f, dhe = 0.f;
-    constexpr int NST = G + (CELL == CELL_GRU ? 1 : 0);           // WT: stores of a step, issued behind its loads
-    auto load_saved_wt = [&](size_t o) {                         // valid behind take_saved() only (sbr_rec_p.h)
-        ld_s(hprev, (const char*)a.hs + o, bo_h);
+    // WT: the saved activations travel PD time steps ahead of their use through a ring in LDS (LDS-DMA, sbr_rec_p.h): beside
+    // the consumers' traffic the one step of the register prefetch below was not enough (chain 204 us against 184 alone).
+    // Per wave and stage: NL arrays x 256 bytes (lane i's dword at + 4 i).  Ordering by the in-order vector-memory counter: an
+    // iteration issues [publish] < loads of step t - PD < stores of step t.
+    constexpr int PD = 4, NL = CELL == CELL_VANILLA ? 1 : 5, NST = G + (CELL == CELL_GRU ? 1 : 0);
+    constexpr int STG = NL * 256, RING_OFF = (2 * 3 * R * DROW + 64 + 255) & ~255;
+    constexpr int VMN = NST + (PD - 1) * (NL + NST);              // younger than the loads of the step being taken
+    const unsigned ring_wave = (unsigned)(size_t)(smem_p + RING_OFF) + (unsigned)wave * (PD * STG);
+    const char* ring_lane = smem_p + RING_OFF + wave * (PD * STG) + lane * 4;
+    auto dma_saved = [&](size_t o, int slot) {                   // activations of the step at byte offset o -> ring slot
+        const unsigned m = ring_wave + (unsigned)slot * STG;
+        lds_dma(m, (const char*)a.hs + o, bo_h);
         if (CELL != CELL_VANILLA) {
-            ld_s(sv[0], (const char*)a.g[0] + o, bo_g); ld_s(sv[1], (const char*)a.g[1] + o, bo_g);
-            ld_s(sv[2], (const char*)a.g[2] + o, bo_g); ld_s(sv[3], (const char*)a.g[3] + o, bo_g);
+            lds_dma(m + 256, (const char*)a.g[0] + o, bo_g); lds_dma(m + 512, (const char*)a.g[1] + o, bo_g);
+            lds_dma(m + 768, (const char*)a.g[2] + o, bo_g); lds_dma(m + 1024, (const char*)a.g[3] + o, bo_g);
         }
     };
-    auto take_saved = [&](auto cnt) {
-        if (CELL != CELL_VANILLA) wait_vm5<decltype(cnt)::value>(hprev, sv[0], sv[1], sv[2], sv[3]);
-        else wait_vm1<decltype(cnt)::value>(hprev);
+    auto take_saved = [&](int slot) {                            // (the loop's loads were issued PD iterations ago)
+        wait_vm<VMN>();
+        const char* p = ring_lane + slot * STG;
+        hprev = *(const float*)p;
+        if (CELL != CELL_VANILLA) {
+            sv[0] = *(const float*)(p + 256); sv[1] = *(const float*)(p + 512);
+            sv[2] = *(const float*)(p + 768); sv[3] = *(const float*)(p + 1024);
+        }
     };
     auto load_saved = [&](size_t o) {                            // activations of the step at byte offset o = t * st_h
         hprev = ldf((const char*)a.hs + o, bo_h);
@@ -520,10 +534,11 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         prog_next = tl - a.prog_every;                            // publish again at or below this step
     }
     if (t_live > a.t_lo) {
-        // (the wait names the registers: a wait without operands would let the compiler copy them first, e.g. into the
-        // registers the other role's loop keeps them in)
-        if constexpr (WT) { load_saved_wt((size_t)(t_live - 1) * st_h); take_saved(std::integral_constant<int, 0>{}); }
-        else load_saved((size_t)(t_live - 1) * st_h);
+        if constexpr (WT) {      // fill the ring: steps t_live - 1 .. t_live - PD (clamped), all landed before the loop starts
+#pragma unroll
+            for (int d = 0; d < PD; ++d) dma_saved((size_t)max(t_live - 1 - d, a.t_lo) * st_h, d);
+            wait_vm<0>();
+        } else load_saved((size_t)(t_live - 1) * st_h);
         if (CELL == CELL_VANILLA) hnew = a.hs[(size_t)t_live * Bp * HP + (size_t)row * HP + u];
     }
     // k-blocks in the order they are visited: columns of units 0-63 (all gates), then of units 64-127
@@ -534,18 +549,19 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     auto steps = [&](auto role_tag) {                             // one loop per role, see rec_fwd_x6p
     constexpr bool RA = decltype(role_tag)::value;
     int n = 0;                                                    // steps done
+    int slot = 0;                                                 // WT: ring slot of step t = n % PD
     for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
-        if constexpr (WT) take_saved(std::integral_constant<int, NST>{});      // (first iteration: already complete, see the prologue)
+        if constexpr (WT) take_saved(slot);
         // ---- N: gate math of step t (needs dh complete), publish dhi, stores, loads for step t-1
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
         cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, 0.f, 0.f, hnew, 0.f, 0.f, 0.f, dxi, dhi, dp, a.relu != 0);
         if constexpr (WT) {
-            // The loads of step t were issued BEFORE the stores of step t + 1 (below) and after those of step t + 2: the gate
-            // math has just consumed them, so step t + 2 is complete.  Nothing waits for the write-through stores of step
-            // t + 1 themselves, whose acknowledgements take long while the consumers load the fabric.
+            // Progress: everything but the youngest NL + NST operations (the loads and stores the previous iteration issued) is
+            // waited for -- two iterations old by now, normally long complete -- so step t + 2 is complete and written through.
             if (n >= 1 && t + 2 <= prog_next) {                   // uniform
+                wait_vm<NL + NST>();
                 publish_word_after(prog_slot, prog_tag | (t + 2), dxi[0]);
                 prog_next = t + 2 - a.prog_every;
             }
@@ -571,10 +587,11 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
         }
         lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
-        if (CELL == CELL_VANILLA) hnew = WT ? copy_now(hprev) : hprev;
+        if (CELL == CELL_VANILLA) hnew = hprev;
         if constexpr (WT) {                                       // loads first: see the progress note above
             __builtin_amdgcn_sched_barrier(0);
-            load_saved_wt(t > a.t_lo ? off_h - st_h : off_h);
+            dma_saved(t - PD >= a.t_lo ? off_h - (size_t)PD * st_h : (size_t)a.t_lo * st_h, slot);   // step t - PD into the slot just read
+            slot = slot + 1 == PD ? 0 : slot + 1;
             const char* dx_t = (const char*)a.dxt + off_x;
             st_si<0, true>(dx_t, bo_x, dxi[0]);
             if (G > 1) st_si<HP * 4, true>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
@@ -744,7 +761,8 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
 template <int CELL>
 static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G;
-    const size_t lds = 2 * 3 * R * (size_t)(G * HP * 2 + 32) + 64;
+    size_t lds = 2 * 3 * R * (size_t)(G * HP * 2 + 32) + 64;
+    if (a.progress) lds = ((lds + 255) & ~(size_t)255) + 8 * 4 * (size_t)(G == 1 ? 1 : 5) * 256;   // + the prefetch ring (PD = 4 stages per wave)
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

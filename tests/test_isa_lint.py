@@ -1,11 +1,16 @@
 """Lint of the generated gfx950 code of rec_bwd_x6p<.., WT> (csrc/sbr_rec_p.hip), runs on CPU (hipcc cross-compiles).
 
-That kernel loads the saved activations of the next time step with hand-written `global_load_dword` instructions the
-compiler's vmcnt bookkeeping cannot see, and makes them valid with a hand-written `s_waitcnt vmcnt(n)` at the top of the next
-iteration (so that the write-through stores issued behind the loads stay in flight).  Between the two the compiler believes
-the destination registers hold their final values: any instruction it places there that READS one of them (a phi copy at the
-loop header, a spill, a hoisted use) would read a register whose load is still in flight.  The source is written so that
-this does not happen; this test checks the code the compiler actually produced."""
+That kernel brings the saved activations of later time steps into an LDS ring with hand-written LDS-DMA loads
+(`global_load_lds_dword`) that the compiler's vmcnt bookkeeping cannot see, and makes them valid with a hand-written
+`s_waitcnt vmcnt(n)` in front of the LDS reads of the step that uses them; n > 0 keeps the write-through stores issued behind
+the loads in flight.  What the source relies on, checked here on the code the compiler actually produced:
+
+  * both role loops (waves 0-3 / 4-7) of both instances (GRU, Vanilla) contain the LDS-DMA loads and a hand-written wait with
+    the count the pipeline depth implies, and NO wait for vmcnt(0) -- compiler-inserted or otherwise -- inside the loop (it
+    would drain the stores: the thing the scheme exists to avoid);
+  * inside a loop, the LDS reads of the ring come after that wait (the asm's memory clobber pins them; a read hoisted above
+    it would see a stage whose load may still be in flight);
+  * the compiler itself never touches M0 in these kernels (the DMA's LDS address travels there)."""
 import os
 import re
 import shutil
@@ -16,114 +21,52 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sequence-based-recommendations_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# PD = 4 stages; per step 5 loads + 4 stores (GRU) / 1 + 1 (Vanilla): NST + (PD - 1) * (NL + NST)
+EXPECTED_WAIT = {"1": 31, "2": 7}
 
 
-def _reads(line, regs):
-    """registers of `regs` (ints) the instruction on `line` mentions: v12, v[10:13]."""
-    hit = set()
-    for m in re.finditer(r"\bv(\d+)\b", line):
-        if int(m.group(1)) in regs:
-            hit.add(int(m.group(1)))
-    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
-        for r in range(int(m.group(1)), int(m.group(2)) + 1):
-            if r in regs:
-                hit.add(r)
-    return hit
-
-
-def lint_kernel(lines):
-    """-> list of (line number, text, registers) violations.  Checked per depth-1 loop (the two role loops of the kernel):
-    from a hand-written load to the end of the loop in text order, and from the loop's header to its hand-written wait
-    (the back edge).  Behind the loop the source waits with vmcnt(0) before anything else (publish_progress)."""
-    bad = []
-    headers = [(i, re.search(r"^\.(LBB\d+_\d+):", ln).group(1)) for i, ln in enumerate(lines)
-               if "Loop Header: Depth=1" in ln and re.search(r"^\.(LBB\d+_\d+):", ln)]
-    for h, name in headers:
-        members = [i for i, ln in enumerate(lines) if re.search(r"Header=%s\b" % name[1:], ln)]
-        last = max(members) if members else h
-        end = next((i for i in range(last + 1, len(lines)) if re.match(r"^\.LBB\d+_\d+:", lines[i])), len(lines))
-        in_asm, inflight, loaded = False, set(), set()
-        for i in range(h, end):
-            s = lines[i].strip()
-            if s.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if s.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if not s or s.startswith(";") or s.startswith("."):
-                continue
-            if in_asm:
-                m = re.match(r"global_load_dword v(\d+),", s)
-                if m:
-                    inflight.add(int(m.group(1))); loaded.add(int(m.group(1)))
-                    continue
-                if s.startswith("s_waitcnt vmcnt"):
-                    inflight.clear()
-                    continue
-            hit = _reads(s, inflight)
-            if hit:
-                bad.append((i, s, sorted(hit)))
-        in_asm = False
-        for i in range(h, end):                  # the back edge: header -> first hand-written wait
-            s = lines[i].strip()
-            if s.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if s.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if in_asm and s.startswith("s_waitcnt vmcnt"):
-                break
-            if not s or s.startswith(";") or s.startswith("."):
-                continue
-            hit = _reads(s, loaded)
-            if hit:
-                bad.append((i, s, sorted(hit)))
-    # the prologue (straight-line code in front of the first loop): first hand-written load -> the wait that follows it
-    first = headers[0][0] if headers else len(lines)
-    in_asm, inflight = False, set()
-    for i in range(0, first):
-        s = lines[i].strip()
-        if s.startswith(";;#ASMSTART"):
-            in_asm = True
+def loops_of(lines):
+    """[(first, last) line index] of the depth-1 loops (the two role loops; the prologue's fill loops carry no MFMAs)."""
+    out = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"^\.(LBB\d+_\d+):.*Loop Header: Depth=1", ln)
+        if not m:
             continue
-        if s.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        if not s or s.startswith(";") or s.startswith("."):
-            continue
-        if in_asm:
-            m = re.match(r"global_load_dword v(\d+),", s)
-            if m:
-                inflight.add(int(m.group(1)))
-                continue
-            if s.startswith("s_waitcnt vmcnt"):
-                inflight.clear()
-                continue
-        hit = _reads(s, inflight)
-        if hit:
-            bad.append((i, s, sorted(hit)))
-    return bad
+        name = m.group(1)[1:]
+        members = [j for j, l2 in enumerate(lines) if re.search(r"Header=%s\b" % name, l2)]
+        last = max(members) if members else i
+        end = next((j for j in range(last + 1, len(lines)) if re.match(r"^\.LBB\d+_\d+:", lines[j])), len(lines))
+        if any("v_mfma" in l2 for l2 in lines[i:end]):
+            out.append((i, end))
+    return out
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
-def test_no_instruction_reads_a_register_whose_hand_written_load_is_in_flight():
+def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "rec_p.s")
         subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                                "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
                                os.path.join(CSRC, "sbr_rec_p.hip")], stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
-    starts = [i for i, ln in enumerate(text) if re.match(r"^_Z11rec_bwd_x6pILi\dELb0ELb0ELb1ELb1EEv7RecArgs:", ln)]
+    starts = [(i, re.match(r"^_Z11rec_bwd_x6pILi(\d)ELb0ELb0ELb1ELb1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
+              if re.match(r"^_Z11rec_bwd_x6pILi\dELb0ELb0ELb1ELb1EEv7RecArgs:", ln)]
     assert len(starts) == 2, "expected the GRU and the Vanilla instance of rec_bwd_x6p<.., WT>"
-    for st in starts:
+    for st, cell in starts:
         end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
         body = text[st:end + 1]
-        loads = [ln for ln in body if re.match(r"\s*global_load_dword v\d+, v\d+, s\[", ln)]
-        assert len(loads) >= 2, "the hand-written loads are gone: update this lint"
-        bad = lint_kernel(body)
-        assert not bad, "\n".join("%s: line %d: %s reads in-flight %s" % (text[st].split(":")[0], i, s, r) for i, s, r in bad[:10])
-        # both role loops wait with a non-zero count: the write-through stores stay in flight
-        waits = [ln.strip() for ln in body if ln.strip().startswith("s_waitcnt vmcnt(") and "vmcnt(0)" not in ln]
-        assert len(waits) >= 2, waits
+        m0 = [ln.strip() for ln in body if re.search(r"\bm0\b", ln) and not ln.strip().startswith("s_mov_b32 m0,")
+              and not ln.strip().startswith(";")]
+        assert not m0, m0
+        loops = loops_of(body)
+        assert len(loops) == 2, "two role loops expected, found %d" % len(loops)
+        want = "s_waitcnt vmcnt(%d)" % EXPECTED_WAIT[cell]
+        for lo, hi in loops:
+            code = [ln.strip() for ln in body[lo:hi]]
+            assert any(c.startswith("global_load_lds_dword") for c in code), "no LDS-DMA load in the role loop"
+            assert want in code, (want, [c for c in code if c.startswith("s_waitcnt vmcnt")])
+            assert "s_waitcnt vmcnt(0)" not in code, "a full wait inside the role loop drains the write-through stores"
+            # ring reads: the first ds_read of the loop body is behind the wait (the ring is read at the top of an iteration,
+            # the operand planes of the MFMA phase later)
+            first_read = next(i for i, c in enumerate(code) if c.startswith("ds_read"))
+            assert code.index(want) < first_read, "an LDS read sits in front of the hand-written wait"
