@@ -287,6 +287,7 @@ struct RecArgs {
     int* progress; int prog_every; int prog_epoch;
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
+#define SBR_X6P_FUSE_MAX_T 4096      // fused gather of rec_fwd_x6p: 4 rows x T row offsets in LDS
 bool sbr_rec_cluster_ok(const RecArgs& a);
 int sbr_rec_cluster_bwd_rows(const RecArgs& a);
 hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);

@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const unsigned bo_h = (unsigned)(row * HP + u) * 4u;                                       // hs rows
     const unsigned bo_g = (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;                 // saved activations
     const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;                                      // xt rows (not fused)
-    const unsigned bo_id = (unsigned)(row * T) * 4u;                                           // ids of this row
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;                      // bytes per time step
 
     // X6P_DBG 1024 / 2048 / 512: values kept alive across the kernel only to move the operand tuples to other registers
@@ -187,20 +186,44 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (CELL == CELL_GRU && g < 2) b *= X6P_NLOG2E;
         biasv[g] = f32x4{b, b, b, b};
     }
-    auto load_id = [&](int t) -> int { return FUSE ? ldi((const char*)a.gX + (size_t)min(t, T - 1) * 4, bo_id) : 0; };
-    auto load_x = [&](int t, int id) {
-        if (FUSE) {
-            const unsigned bo = (unsigned)id * (unsigned)(GHP * 4) + (unsigned)u * 4u;   // < 2^32: checked by the launcher
+    // FUSE: the rows travel XPD time steps ahead of their use through a ring in LDS (LDS-DMA, sbr_rec_p.h: one dword per lane
+    // and gate; invisible to the compiler's vmcnt bookkeeping, waited for by hand), their byte offsets inside W_in come from
+    // a table the prologue builds in LDS from the tile's ids (R x T entries).  With the row one step ahead in registers and
+    // the id a step before that, every step of the fp16 chain (half the MFMA time of bf16x6) waited for far memory, and
+    // the address arithmetic (a 64-bit multiply-add, a 64-bit add) sat on the VALU beside the partner's MFMA stream:
+    // 177 us against 153 us for the same kernel reading a pre-gathered xt.
+    // Per iteration the wave issues: stores of step t (NSF) < DMA of step t + XPD (G).
+    constexpr int XPD = 4, NSF = CELL == CELL_VANILLA ? 1 : 5, XSTG = G * 256;
+    constexpr int XOFF_OFF = (2 * BUFB + 64 + 255) & ~255;
+    const int xring_off = (XOFF_OFF + R * T * 4 + 255) & ~255;
+    unsigned* xo_tab = (unsigned*)(smem_p + XOFF_OFF);
+    const unsigned xring_wave = (unsigned)(size_t)(smem_p + xring_off) + (unsigned)wave * (XPD * XSTG);
+    const char* xring_lane = smem_p + xring_off + wave * (XPD * XSTG) + lane * 4;
+    const unsigned* xo_row = xo_tab + q * T;                     // this lane's row of the table
+    unsigned bo_nxt = 0;                                         // byte offset of the row the NEXT DMA fetches (+ this lane's unit)
+    auto dma_x = [&](unsigned bo, int slot) {
+        const unsigned m = xring_wave + (unsigned)slot * XSTG;
 #pragma unroll
-            for (int g = 0; g < G; ++g) x[g] = ldf(a.gWin, bo, g * HP * 4);
-        } else {
-            const char* xt_t = (const char*)a.xt + (size_t)min(t, T - 1) * st_x;
-#pragma unroll
-            for (int g = 0; g < G; ++g) x[g] = ldf(xt_t, bo_x, g * HP * 4);
-        }
+        for (int g = 0; g < G; ++g) lds_dma(m + g * 256, (const char*)a.gWin + g * HP * 4, bo);
     };
-    load_x(0, load_id(0));
-    int id_next = load_id(1);
+    auto load_x = [&](int t) {                                   // not fused: a row of xt, one step ahead in registers
+        const char* xt_t = (const char*)a.xt + (size_t)min(t, T - 1) * st_x;
+#pragma unroll
+        for (int g = 0; g < G; ++g) x[g] = ldf(xt_t, bo_x, g * HP * 4);
+    };
+    if constexpr (FUSE) {
+        for (int i = threadIdx.x; i < R * T; i += 512) {
+            const int r = i / T;
+            xo_tab[i] = (unsigned)a.gX[(size_t)(blockIdx.x * R + r) * T + (i - r * T)] * (unsigned)(GHP * 4);   // < 2^32: checked by the launcher
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < XPD; ++d) dma_x(xo_row[min(d, T - 1)] + (unsigned)u * 4u, d);
+        bo_nxt = xo_row[min(XPD, T - 1)] + (unsigned)u * 4u;
+        wait_vm<0>();
+    } else {
+        load_x(0);
+    }
     __syncthreads();
     unsigned long long p_c0 = 0, p_r0 = 0, p_spin = 0, p_tok = 0, p_seg[3] = {0, 0, 0}, p_ta = 0, p_tb = 0;
     if (PROF) { p_c0 = clock64(); p_r0 = wall_clock64(); }
@@ -220,9 +243,17 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     if (X6P_DBG & 4096) asm volatile(".p2align 8");
     if (X6P_DBG & 8192) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
     if (X6P_DBG & 16384) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
+    int xslot = 0;                                                // FUSE: ring slot of step t = t % XPD
     for (int t = 0; t < tmax; ++t) {
         if (PROF) p_ta = clock64();
         if (PROF && tl && (t == 100 || t == 101)) tl[t == 100 ? 0 : 7] = p_ta;
+        if constexpr (FUSE) {
+            // the row of this step: its DMA was issued XPD iterations ago; younger than it are XPD - 1 whole iterations
+            wait_vm<(XPD - 1) * (NSF + G)>();
+            const char* xp = xring_lane + xslot * XSTG;
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = *(const float*)(xp + g * 256);
+        }
         // ---- N1
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
         OPV hp[KB][3];
@@ -372,7 +403,11 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             st_s((const char*)a.hs + off_t + st_h, bo_h, h);
         }
         off_t += st_h;
-        if (!(X6P_DBG & 2)) { load_x(t + 1, id_next); id_next = load_id(t + 2); }
+        if constexpr (FUSE) {
+            dma_x(bo_nxt, xslot);                                 // the row of step t + XPD into the slot this step has read
+            xslot = xslot + 1 == XPD ? 0 : xslot + 1;
+            bo_nxt = xo_row[min(t + XPD + 1, T - 1)] + (unsigned)u * 4u;
+        } else if (!(X6P_DBG & 2)) load_x(t + 1);
     }
     };
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
@@ -737,12 +772,17 @@ bool sbr_rec_x6p_ok(const RecArgs& a) {
     if (!a.x6_pipe || a.f32_mfma || a.Hp != HP || a.rpt != R || !a.x6_split || a.G > 3) return false;
     if ((size_t)a.Bp * a.G * HP * 4 >= ((size_t)1 << 32)) return false;          // 32-bit per-lane byte offsets
     if (a.gX && (size_t)a.n_in * a.G * HP * 4 >= ((size_t)1 << 32)) return false; // ... also into W_in (fused gather)
+    if (a.gX && a.T > SBR_X6P_FUSE_MAX_T) return false;                            // its row-offset table lives in LDS
     return true;
 }
 
 template <int CELL>
 static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
-    const size_t lds = fwd_lds_bytes();
+    size_t lds = fwd_lds_bytes();
+    if (a.gX) {      // fused gather: + the row-offset table (R x T) and the ring of rows (8 waves x XPD = 4 stages x G x 256 bytes)
+        lds = ((lds + 255) & ~(size_t)255) + (size_t)R * a.T * 4;
+        lds = ((lds + 255) & ~(size_t)255) + (size_t)8 * 4 * Gates<CELL>::G * 256;
+    }
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

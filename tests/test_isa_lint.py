@@ -21,8 +21,10 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sequence-based-recommendations_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# PD = 4 stages; per step 5 loads + 4 stores (GRU) / 1 + 1 (Vanilla): NST + (PD - 1) * (NL + NST)
+# backward, PD = 4 stages; per step 5 loads + 4 stores (GRU) / 1 + 1 (Vanilla): NST + (PD - 1) * (NL + NST)
 EXPECTED_WAIT = {"1": 31, "2": 7}
+# forward with the fused gather (rec_fwd_x6p<CELL, FUSE, .., F16>), XPD = 4: (XPD - 1) * (stores of a step + G row loads)
+EXPECTED_WAIT_FWD = {"1": 24, "2": 6}
 
 
 def loops_of(lines):
@@ -70,3 +72,33 @@ def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
             # the operand planes of the MFMA phase later)
             first_read = next(i for i, c in enumerate(code) if c.startswith("ds_read"))
             assert code.index(want) < first_read, "an LDS read sits in front of the hand-written wait"
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+def test_lds_ring_of_the_fused_gather_in_the_forward_kernel():
+    """rec_fwd_x6p<CELL, FUSE = true, PROF = false, F16 = true>: the W_in rows of later steps arrive in an LDS ring by LDS-DMA; the
+    same invariants as for the backward kernel above."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "rec_p.s")
+        subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                               "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
+                               os.path.join(CSRC, "sbr_rec_p.hip")], stderr=subprocess.DEVNULL)
+        text = open(out).read().splitlines()
+    starts = [(i, re.match(r"^_Z11rec_fwd_x6pILi(\d)ELb1ELb0ELb1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
+              if re.match(r"^_Z11rec_fwd_x6pILi\dELb1ELb0ELb1EEv7RecArgs:", ln)]
+    assert len(starts) == 2
+    for st, cell in starts:
+        end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
+        body = text[st:end + 1]
+        m0 = [ln.strip() for ln in body if re.search(r"\bm0\b", ln) and not ln.strip().startswith("s_mov_b32 m0,")
+              and not ln.strip().startswith(";")]
+        assert not m0, m0
+        loops = loops_of(body)
+        assert len(loops) == 2, "two role loops expected, found %d" % len(loops)
+        want = "s_waitcnt vmcnt(%d)" % EXPECTED_WAIT_FWD[cell]
+        for lo, hi in loops:
+            code = [ln.strip() for ln in body[lo:hi]]
+            assert any(c.startswith("global_load_lds_dword") for c in code)
+            assert want in code, (want, [c for c in code if c.startswith("s_waitcnt vmcnt")])
+            assert "s_waitcnt vmcnt(0)" not in code
+            assert not any(c.startswith("global_load_dword") for c in code), "a register-destination load is back in the step loop"
