@@ -447,8 +447,11 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 // when the loads it issued after them have returned (the vector memory counter retires in order) -- at the top of step t,
 // where the gate math needs those loads anyway: the explicit vmcnt(0) there waits for nothing new.
 constexpr float F16_DSCALE = 512.0f;
-template <int CELL, bool EXT, bool PROF, bool F16, bool WT = false>
+// WTM: 0 = the saved activations one step ahead in registers (compiler-visible loads); 1 = through the LDS ring, write-through
+// stores, progress words (the overlapped tail); 2 = through the LDS ring only (plain stores, nothing published).
+template <int CELL, bool EXT, bool PROF, bool F16, int WTM = 0>
 __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
+    constexpr bool WT = WTM == 1, RING = WTM != 0;
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;
     constexpr int NP = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate
@@ -569,7 +572,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         prog_next = tl - a.prog_every;                            // publish again at or below this step
     }
     if (t_live > a.t_lo) {
-        if constexpr (WT) {      // fill the ring: steps t_live - 1 .. t_live - PD (clamped), all landed before the loop starts
+        if constexpr (RING) {    // fill the ring: steps t_live - 1 .. t_live - PD (clamped), all landed before the loop starts
 #pragma unroll
             for (int d = 0; d < PD; ++d) dma_saved((size_t)max(t_live - 1 - d, a.t_lo) * st_h, d);
             wait_vm<0>();
@@ -586,7 +589,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     int n = 0;                                                    // steps done
     int slot = 0;                                                 // WT: ring slot of step t = n % PD
     for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
-        if constexpr (WT) take_saved(slot);
+        if constexpr (RING) take_saved(slot);
         // ---- N: gate math of step t (needs dh complete), publish dhi, stores, loads for step t-1
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
@@ -623,15 +626,15 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         }
         lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
         if (CELL == CELL_VANILLA) hnew = hprev;
-        if constexpr (WT) {                                       // loads first: see the progress note above
+        if constexpr (RING) {                                     // loads first: see the progress note above
             __builtin_amdgcn_sched_barrier(0);
             dma_saved(t - PD >= a.t_lo ? off_h - (size_t)PD * st_h : (size_t)a.t_lo * st_h, slot);   // step t - PD into the slot just read
             slot = slot + 1 == PD ? 0 : slot + 1;
             const char* dx_t = (const char*)a.dxt + off_x;
-            st_si<0, true>(dx_t, bo_x, dxi[0]);
-            if (G > 1) st_si<HP * 4, true>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
-            if (G > 2) st_si<2 * HP * 4, true>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
-            if (CELL == CELL_GRU) st_si<0, true>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
+            st_si<0, WT>(dx_t, bo_x, dxi[0]);
+            if (G > 1) st_si<HP * 4, WT>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
+            if (G > 2) st_si<2 * HP * 4, WT>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
+            if (CELL == CELL_GRU) st_si<0, WT>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
             __builtin_amdgcn_sched_barrier(0);
         } else {
             const char* dx_t = (const char*)a.dxt + off_x;
@@ -735,6 +738,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     };
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
     if constexpr (WT) publish_progress(prog_slot, prog_tag | a.t_lo);
+    else if constexpr (RING) wait_vm<0>();                       // (the last iterations' clamped loads)
     if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         const unsigned long long tot = clock64() - p_c0;
@@ -802,7 +806,7 @@ template <int CELL>
 static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G;
     size_t lds = 2 * 3 * R * (size_t)(G * HP * 2 + 32) + 64;
-    if (a.progress) lds = ((lds + 255) & ~(size_t)255) + 8 * 4 * (size_t)(G == 1 ? 1 : 5) * 256;   // + the prefetch ring (PD = 4 stages per wave)
+    lds = ((lds + 255) & ~(size_t)255) + 8 * 4 * (size_t)(G == 1 ? 1 : 5) * 256;             // + the prefetch ring (PD = 4 stages per wave)
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -812,7 +816,11 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     // fp16 x3 products for the BPTT chain: the operand that carries gradients is bounded by the reference's own gradient clip
     const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
     if (a.progress && (a.prof || ext || !f16)) return hipErrorInvalidValue;     // (sbr_rec_x6p_tail_ok says when)
-    if (a.progress) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, true>)); }
+    const char* re = getenv("SBR_X6_RING");                        // read per launch: the tests flip it
+    // (measured without consumers beside the chain: 194 us through the ring, 189 us with the register prefetch: off by default)
+    const bool ring = (re ? atoi(re) != 0 : false) && f16 && !ext && !a.prof && !a.progress;
+    if (a.progress) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 1>)); }
+    else if (ring) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 2>)); }
     else if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }
     else { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, false>)); }

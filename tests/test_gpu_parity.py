@@ -112,6 +112,15 @@ def test_backward_chain_with_bf16x6_products(cell, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12, scale=0.05))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+def test_backward_chain_with_the_lds_ring_alone(cell, monkeypatch):
+    # the overlapped tail's BPTT kernel reads its saved activations four steps ahead through an LDS ring (LDS-DMA);
+    # SBR_X6_RING=1 takes that form (plain stores, nothing published) for every step of a 128-unit GRU / Vanilla top layer
+    monkeypatch.setenv("SBR_X6_RING", "1")
+    check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
+    check(PU.compare_step(cell, [128], "CCE", N=300, B=21, T=33, scale=0.1 if cell == "GRU" else 0.05))
+
+
 def test_fp16_backward_products_at_the_clip_boundary_and_with_tiny_gradients():
     # gate gradients driven beyond +-100 (clip active: the scaled operand reaches 51200 of fp16's 65504), and a batch whose
     # gradients are ~1e-9 (popularity weights of 1e4: the absolute floor of the scaled split is 3e-14)

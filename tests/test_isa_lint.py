@@ -51,8 +51,8 @@ def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
                                "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
                                os.path.join(CSRC, "sbr_rec_p.hip")], stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
-    starts = [(i, re.match(r"^_Z11rec_bwd_x6pILi(\d)ELb0ELb0ELb1ELb1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
-              if re.match(r"^_Z11rec_bwd_x6pILi\dELb0ELb0ELb1ELb1EEv7RecArgs:", ln)]
+    starts = [(i, re.match(r"^_Z11rec_bwd_x6pILi(\d)ELb0ELb0ELb1ELi1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
+              if re.match(r"^_Z11rec_bwd_x6pILi\dELb0ELb0ELb1ELi1EEv7RecArgs:", ln)]
     assert len(starts) == 2, "expected the GRU and the Vanilla instance of rec_bwd_x6p<.., WT>"
     for st, cell in starts:
         end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
