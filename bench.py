@@ -237,6 +237,12 @@ def main():
         except Exception:
             tail_chunks = 0
         if tail_chunks >= 2:
+            try:      # effective shader clock of the BPTT chain while its consumers run beside it (in-kernel counters of the last launch)
+                cyc, ticks = eng.query("tail_chain_cycles"), eng.query("tail_chain_ticks")
+                if ticks > 0:
+                    kernels["rec_bwd"]["shader_mhz_beside_consumers"] = round(cyc / ticks * 100.0, 1)
+            except Exception:
+                pass
             # overlapped tail: the scatter phase of the step is the LAST of tail_chunks time chunks (the others ran beside the BPTT
             # chain on the side stream); its entries are 1 / tail_chunks of the batch, and it re-reads the rows it adds to
             kernels["scatter"]["alg"] /= tail_chunks

@@ -150,7 +150,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_scnt = take((size_t)lay.tail_keys * cfg.input_size + 1); lay.a_soff = take((size_t)lay.tail_keys * cfg.input_size + 1);
     lay.a_scur = take((size_t)lay.tail_keys * cfg.input_size + 1);
     lay.a_sid = take((size_t)T * Bp * lay.F); lay.a_spos = take((size_t)T * Bp * lay.F);
-    lay.a_prog = take((size_t)Bp * 2 + 192);      // per-wave words, a gap of one line, the monitor's word
+    lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, a gap of one line, the monitor's word
     // Row-sparse blocks (sbr_sparse.hip): the index-addressed rows of layer 0 (or of the embedding table) and, for the sampled
     // heads, the rows of W_out^T / b_out.  Taken when a step cannot touch every row anyway (more rows than candidates) or
     // when the flag forces it; SBR_FLAG_DENSE_UPDATE keeps the dense Lasagne-style pass over everything.
@@ -1544,6 +1544,13 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
     }
     else if (w == "tail_chunks") { int ch = 0; *value = tail_plan(h, &ch); }      // time chunks of the overlapped step tail (0: not taken)
     else if (w == "side_stream2") *value = (int64_t)(intptr_t)h->side2;
+    else if (w == "tail_chain_cycles" || w == "tail_chain_ticks") {      // last overlapped-tail BPTT launch: shader cycles / 100 MHz ticks
+        unsigned long long c[2] = {0, 0};
+        const int nwaves = (y.Bp / h->rpt) * 8;
+        SBR_HIP(hipStreamSynchronize(h->stream));
+        SBR_HIP(hipMemcpy(c, (const int*)h->A(y.a_prog) + nwaves + 128, sizeof(c), hipMemcpyDeviceToHost));
+        *value = (int64_t)c[w == "tail_chain_cycles" ? 0 : 1];
+    }
     // overlapped tail, phase-by-phase step: the gradient ranges the two consumer streams produce (floats of the gradient section)
     else if (w == "tail_win_lo") *value = (int64_t)y.layer[0].p_Win;
     else if (w == "tail_win_hi") *value = (int64_t)y.layer[0].p_b;

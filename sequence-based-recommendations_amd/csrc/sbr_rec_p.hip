@@ -549,6 +549,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     };
     unsigned long long p_c0 = 0, p_r0 = 0, p_spin = 0, p_tok = 0;
     if (PROF) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+    unsigned long long wt_c0 = 0, wt_r0 = 0;
+    if (WT) { wt_c0 = clock64(); wt_r0 = wall_clock64(); }
     __syncthreads();
 
     const int t_live = min(a.t_hi, tmax);                         // steps [t_live, t_hi) are masked for the whole tile
@@ -738,6 +740,12 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     };
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
     if constexpr (WT) publish_progress(prog_slot, prog_tag | a.t_lo);
+    if constexpr (WT) {      // shader cycles and 100 MHz wall-clock ticks of this launch (block 0, wave 0): the chain's effective clock
+        if (blockIdx.x == 0 && wave == 0 && lane == 0) {
+            unsigned long long* c = (unsigned long long*)(a.progress + gridDim.x * 8 + 128);
+            c[0] = clock64() - wt_c0; c[1] = wall_clock64() - wt_r0;
+        }
+    }
     else if constexpr (RING) wait_vm<0>();                       // (the last iterations' clamped loads)
     if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
