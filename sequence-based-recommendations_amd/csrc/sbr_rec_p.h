@@ -47,6 +47,11 @@ __device__ __forceinline__ void st_wt(float* p, float v) {
 __device__ __forceinline__ void lds_dma(unsigned lds_addr, const void* ubase, unsigned boff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_addr), "v"(boff), "s"(ubase) : "memory", "m0");
 }
+// 16 bytes per lane (lane i's four dwords at lds_addr + 16 i) for the lanes of `mask` only: one piece moves up to 1 KiB
+__device__ __forceinline__ void lds_dma_x4(unsigned lds_addr, const void* ubase, unsigned boff, unsigned long long mask) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1"
+                 :: "s"(lds_addr), "v"(boff), "s"(ubase), "s"(mask) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 template <int CNT>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }

@@ -192,19 +192,21 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     // the id a step before that, every step of the fp16 chain (half the MFMA time of bf16x6) waited for far memory, and
     // the address arithmetic (a 64-bit multiply-add, a 64-bit add) sat on the VALU beside the partner's MFMA stream:
     // 177 us against 153 us for the same kernel reading a pre-gathered xt.
-    // Per iteration the wave issues: stores of step t (NSF) < DMA of step t + XPD (G).
+    // Per iteration the wave issues: stores of step t (NSF) < the DMA piece of step t + XPD.
     constexpr int XPD = 4, NSF = CELL == CELL_VANILLA ? 1 : 5, XSTG = G * 256;
     constexpr int XOFF_OFF = (2 * BUFB + 64 + 255) & ~255;
     const int xring_off = (XOFF_OFF + R * T * 4 + 255) & ~255;
     unsigned* xo_tab = (unsigned*)(smem_p + XOFF_OFF);
     const unsigned xring_wave = (unsigned)(size_t)(smem_p + xring_off) + (unsigned)wave * (XPD * XSTG);
     const char* xring_lane = smem_p + xring_off + wave * (XPD * XSTG) + lane * 4;
-    const unsigned* xo_row = xo_tab + q * T;                     // this lane's row of the table
-    unsigned bo_nxt = 0;                                         // byte offset of the row the NEXT DMA fetches (+ this lane's unit)
+    // ONE 16-byte-per-lane piece per step: lane l < 16 G fetches the four units 4 (l % 4) .. of gate l / 16 from the W_in row of
+    // batch row (l / 4) % 4; it lands as [gate][row][unit], where lane (j, q) finds gate g at 256 g + 4 (16 q + j)
+    const unsigned* xo_row = xo_tab + ((lane >> 2) & 3) * T;     // the table row of the batch row this lane fetches for
+    const unsigned bo_lane = (unsigned)((lane >> 4) * HP + wave * 16 + (lane & 3) * 4) * 4u;
+    constexpr unsigned long long XMASK = G >= 4 ? ~0ull : ((1ull << (16 * G)) - 1ull);
+    unsigned bo_nxt = 0;                                         // byte offset the NEXT piece fetches from
     auto dma_x = [&](unsigned bo, int slot) {
-        const unsigned m = xring_wave + (unsigned)slot * XSTG;
-#pragma unroll
-        for (int g = 0; g < G; ++g) lds_dma(m + g * 256, (const char*)a.gWin + g * HP * 4, bo);
+        lds_dma_x4(xring_wave + (unsigned)slot * XSTG, a.gWin, bo, XMASK);
     };
     auto load_x = [&](int t) {                                   // not fused: a row of xt, one step ahead in registers
         const char* xt_t = (const char*)a.xt + (size_t)min(t, T - 1) * st_x;
@@ -218,8 +220,8 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int d = 0; d < XPD; ++d) dma_x(xo_row[min(d, T - 1)] + (unsigned)u * 4u, d);
-        bo_nxt = xo_row[min(XPD, T - 1)] + (unsigned)u * 4u;
+        for (int d = 0; d < XPD; ++d) dma_x(xo_row[min(d, T - 1)] + bo_lane, d);
+        bo_nxt = xo_row[min(XPD, T - 1)] + bo_lane;
         wait_vm<0>();
     } else {
         load_x(0);
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (PROF && tl && (t == 100 || t == 101)) tl[t == 100 ? 0 : 7] = p_ta;
         if constexpr (FUSE) {
             // the row of this step: its DMA was issued XPD iterations ago; younger than it are XPD - 1 whole iterations
-            wait_vm<(XPD - 1) * (NSF + G)>();
+            wait_vm<(XPD - 1) * (NSF + 1)>();
             const char* xp = xring_lane + xslot * XSTG;
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = *(const float*)(xp + g * 256);
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if constexpr (FUSE) {
             dma_x(bo_nxt, xslot);                                 // the row of step t + XPD into the slot this step has read
             xslot = xslot + 1 == XPD ? 0 : xslot + 1;
-            bo_nxt = xo_row[min(t + XPD + 1, T - 1)] + (unsigned)u * 4u;
+            bo_nxt = xo_row[min(t + XPD + 1, T - 1)] + bo_lane;
         } else if (!(X6P_DBG & 2)) load_x(t + 1);
     }
     };
@@ -518,19 +520,34 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     // Per wave and stage: NL arrays x 256 bytes (lane i's dword at + 4 i).  Ordering by the in-order vector-memory counter: an
     // iteration issues [publish] < loads of step t - PD < stores of step t.
     constexpr int PD = 4, NL = CELL == CELL_VANILLA ? 1 : 5, NST = G + (CELL == CELL_GRU ? 1 : 0);
+    constexpr int NLI = CELL == CELL_VANILLA ? 1 : 2;             // load INSTRUCTIONS of a step (16-byte pieces, below)
     constexpr int STG = NL * 256, RING_OFF = (2 * 3 * R * DROW + 64 + 255) & ~255;
-    constexpr int VMN = NST + (PD - 1) * (NL + NST);              // younger than the loads of the step being taken
+    constexpr int VMN = NST + (PD - 1) * (NLI + NST);             // younger than the loads of the step being taken
     const unsigned ring_wave = (unsigned)(size_t)(smem_p + RING_OFF) + (unsigned)wave * (PD * STG);
     const char* ring_lane = smem_p + RING_OFF + wave * (PD * STG) + lane * 4;
+    // Two 16-byte-per-lane pieces per step instead of five dword ones (a piece costs its issue slot whatever it moves): the
+    // four gate arrays are tile-blocked, so the wave's 4 rows x 16 units of each are 256 contiguous bytes -- lane l fetches
+    // chunk l % 16 of array l / 16; hs is row-major -- lanes 0-15 fetch the four 64-byte row pieces.  Both land in the
+    // ring as [array][row][unit], where lane (j, q) finds its values at 4 (16 q + j).  One scalar base per step (hs + o): the
+    // gate arrays' distance from hs rides in the lanes' offsets (same arena, same bytes per step: sbr_rec_x6p_tail_ok).
+    unsigned bo_ga = 0;
+    const unsigned bo_hs4 = (unsigned)((blockIdx.x * R + ((lane >> 2) & 3)) * HP + wave * 16 + (lane & 3) * 4) * 4u;
+    if (CELL != CELL_VANILLA) {
+        const unsigned b0 = (unsigned)sbr_blocked_index(0, blockIdx.x * R, wave * 16, Bp, HP) * 4u;     // the wave's block
+        const int k = lane >> 4;
+        const char* gk = k == 0 ? (const char*)a.g[0] : k == 1 ? (const char*)a.g[1] : k == 2 ? (const char*)a.g[2] : (const char*)a.g[3];
+        bo_ga = b0 + (unsigned)(size_t)(gk - (const char*)a.hs) + (unsigned)(lane & 15) * 16u;
+    }
     auto dma_saved = [&](size_t o, int slot) {                   // activations of the step at byte offset o -> ring slot
         const unsigned m = ring_wave + (unsigned)slot * STG;
-        lds_dma(m, (const char*)a.hs + o, bo_h);
-        if (CELL != CELL_VANILLA) {
-            lds_dma(m + 256, (const char*)a.g[0] + o, bo_g); lds_dma(m + 512, (const char*)a.g[1] + o, bo_g);
-            lds_dma(m + 768, (const char*)a.g[2] + o, bo_g); lds_dma(m + 1024, (const char*)a.g[3] + o, bo_g);
-        }
+        const char* base = (const char*)a.hs + o;
+        lds_dma_x4(m, base, bo_hs4, 0xFFFFull);
+        if (CELL != CELL_VANILLA) lds_dma_x4(m + 256, base, bo_ga, ~0ull);
     };
-    auto take_saved = [&](int slot) {                            // (the loop's loads were issued PD iterations ago)
+    // The ring is read one iteration BEFORE the values are used (at the bottom of the iteration in front, into the registers
+    // the gate math has just released), so that the LDS latency runs under the MFMA phase: read at the top of the
+    // iteration that needs them it was 115 exposed cycles per step (tools/tail_prof.py).
+    auto take_saved = [&](int slot) {                            // (these loads were issued PD - 1 iterations ago)
         wait_vm<VMN>();
         const char* p = ring_lane + slot * STG;
         hprev = *(const float*)p;
@@ -547,7 +564,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         }
         if (EXT) dhe = ldf((const char*)a.dh_ext + o, bo_h);
     };
-    unsigned long long p_c0 = 0, p_r0 = 0, p_spin = 0, p_tok = 0;
+    unsigned long long p_c0 = 0, p_r0 = 0, p_spin = 0, p_tok = 0, p_n = 0, p_m = 0, p_vm = 0;
     if (PROF) { p_c0 = clock64(); p_r0 = wall_clock64(); }
     unsigned long long wt_c0 = 0, wt_r0 = 0;
     if (WT) { wt_c0 = clock64(); wt_r0 = wall_clock64(); }
@@ -578,6 +595,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) dma_saved((size_t)max(t_live - 1 - d, a.t_lo) * st_h, d);
             wait_vm<0>();
+            take_saved(0);                                        // the first step's values
         } else load_saved((size_t)(t_live - 1) * st_h);
         if (CELL == CELL_VANILLA) hnew = a.hs[(size_t)t_live * Bp * HP + (size_t)row * HP + u];
     }
@@ -591,7 +609,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     int n = 0;                                                    // steps done
     int slot = 0;                                                 // WT: ring slot of step t = n % PD
     for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
-        if constexpr (RING) take_saved(slot);
+        unsigned long long q_top = 0;
+        if (PROF) q_top = clock64();
         // ---- N: gate math of step t (needs dh complete), publish dhi, stores, loads for step t-1
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
@@ -601,7 +620,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             // Progress: everything but the youngest NL + NST operations (the loads and stores the previous iteration issued) is
             // waited for -- two iterations old by now, normally long complete -- so step t + 2 is complete and written through.
             if (n >= 1 && t + 2 <= prog_next) {                   // uniform
-                wait_vm<NL + NST>();
+                wait_vm<NLI + NST>();
                 publish_word_after(prog_slot, prog_tag | (t + 2), dxi[0]);
                 prog_next = t + 2 - a.prog_every;
             }
@@ -638,6 +657,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             if (G > 2) st_si<2 * HP * 4, WT>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
             if (CELL == CELL_GRU) st_si<0, WT>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
             __builtin_amdgcn_sched_barrier(0);
+            { unsigned long long q0 = 0; if (PROF) q0 = clock64();
+              take_saved(slot);                                   // step t - 1 (slot has moved on to it)
+              if (PROF) p_vm += clock64() - q0; }
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             const char* dx_t = (const char*)a.dxt + off_x;
             st_si<0>(dx_t, bo_x, dxi[0]);
@@ -649,6 +672,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         off_h -= st_h; off_x -= st_x;
+        unsigned long long q_n = 0;
+        if (PROF) { q_n = clock64(); p_n += q_n - q_top; }
         // ---- operands: a ring of NS k-block slots, fetched LA k-blocks ahead of their MFMAs; the pipe gate
         constexpr int NS = 2, LA = 1;          // measured: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
         const char* db = lds + lds_rd;
@@ -734,6 +759,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         }
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
+        if (PROF) p_m += clock64() - q_n;
         if constexpr (F16) dh += fmaf(acc[1][0] + acc[2][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
         else dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
@@ -751,6 +777,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         const unsigned long long tot = clock64() - p_c0;
         o[0] = tot; o[1] = wall_clock64() - p_r0; o[2] = tot - p_spin - p_tok; o[3] = p_spin; o[4] = p_tok;
+        o[5] = p_n; o[6] = p_m; o[7] = p_vm;      // loop top -> loads / stores issued (incl. o[7]: the wait for the ring) | operands + gate + MFMAs
     }
 
     if (!last) a.state[(size_t)row * HP + u] = dh;               // hand dh to the next chunk launch
@@ -823,10 +850,14 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     const char* fe = getenv("SBR_X6_F16_BWD");                     // read per launch: the tests flip it
     // fp16 x3 products for the BPTT chain: the operand that carries gradients is bounded by the reference's own gradient clip
     const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
-    if (a.progress && (a.prof || ext || !f16)) return hipErrorInvalidValue;     // (sbr_rec_x6p_tail_ok says when)
+    if (a.progress && (ext || !f16)) return hipErrorInvalidValue;               // (sbr_rec_x6p_tail_ok says when)
+    if (a.prof && f16 && !ext) {      // in-kernel counters for the fp16x3 forms too (tools/tail_prof.py)
+        if (a.progress) X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 1>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 0>));
+        return hipGetLastError();
+    }
     const char* re = getenv("SBR_X6_RING");                        // read per launch: the tests flip it
     // (measured without consumers beside the chain: 194 us through the ring, 189 us with the register prefetch: off by default)
-    const bool ring = (re ? atoi(re) != 0 : false) && f16 && !ext && !a.prof && !a.progress;
+    const bool ring = (re ? atoi(re) != 0 : false) && f16 && !ext && !a.prof && !a.progress && sbr_rec_x6p_tail_ok(a);
     if (a.progress) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 1>)); }
     else if (ring) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 2>)); }
     else if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
@@ -840,7 +871,11 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
 bool sbr_rec_x6p_tail_ok(const RecArgs& a) {
     const char* fe = getenv("SBR_X6_F16_BWD");
     const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
-    return sbr_rec_x6p_ok(a) && f16 && !a.prof && !a.dh_ext && a.T < 4096 &&
+    for (int k = 0; k < 4 && a.cell != SBR_CELL_VANILLA; ++k) {      // one scalar base serves hs and the gate arrays (LDS-DMA loads)
+        const ptrdiff_t d = (const char*)a.g[k] - (const char*)a.hs;
+        if (d < 0 || d >= ((ptrdiff_t)1 << 31)) return false;
+    }
+    return sbr_rec_x6p_ok(a) && f16 && !a.dh_ext && a.T < 4096 &&
            (size_t)a.T * a.Bp * a.G * HP * 4 < ((size_t)1 << 31);                    // buffer stores: 31-bit scalar offsets
 }
 

@@ -21,10 +21,10 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sequence-based-recommendations_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# backward, PD = 4 stages; per step 5 loads + 4 stores (GRU) / 1 + 1 (Vanilla): NST + (PD - 1) * (NL + NST)
-EXPECTED_WAIT = {"1": 31, "2": 7}
-# forward with the fused gather (rec_fwd_x6p<CELL, FUSE, .., F16>), XPD = 4: (XPD - 1) * (stores of a step + G row loads)
-EXPECTED_WAIT_FWD = {"1": 24, "2": 6}
+# backward, PD = 4 stages; per step 2 load pieces + 4 stores (GRU) / 1 + 1 (Vanilla): NST + (PD - 1) * (NLI + NST)
+EXPECTED_WAIT = {"1": 22, "2": 7}
+# forward with the fused gather (rec_fwd_x6p<CELL, FUSE, .., F16>), XPD = 4: (XPD - 1) * (stores of a step + 1 load piece)
+EXPECTED_WAIT_FWD = {"1": 18, "2": 6}
 
 
 def loops_of(lines):
@@ -65,7 +65,7 @@ def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
         want = "s_waitcnt vmcnt(%d)" % EXPECTED_WAIT[cell]
         for lo, hi in loops:
             code = [ln.strip() for ln in body[lo:hi]]
-            assert any(c.startswith("global_load_lds_dword") for c in code), "no LDS-DMA load in the role loop"
+            assert any(c.startswith("global_load_lds_dwordx4") for c in code), "no LDS-DMA load in the role loop"
             assert want in code, (want, [c for c in code if c.startswith("s_waitcnt vmcnt")])
             assert "s_waitcnt vmcnt(0)" not in code, "a full wait inside the role loop drains the write-through stores"
             # ring reads: the first ds_read of the loop body is behind the wait (the ring is read at the top of an iteration,
