@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 3
+#define SBR_ABI_VERSION 4
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -36,7 +36,9 @@ typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_
 /* --r_t (recurrent_layers.py:9) */
 typedef enum { SBR_CELL_LSTM = 0, SBR_CELL_GRU = 1, SBR_CELL_VANILLA = 2 } sbr_cell;
 /* --loss (command_parser.py:43, :116-121) */
-typedef enum { SBR_LOSS_CCE = 0, SBR_LOSS_BLACKOUT = 1, SBR_LOSS_BPR = 2, SBR_LOSS_TOP1 = 3 } sbr_loss;
+typedef enum { SBR_LOSS_CCE = 0, SBR_LOSS_BLACKOUT = 1, SBR_LOSS_BPR = 2, SBR_LOSS_TOP1 = 3,
+               /* RNNMargin (rnn_margin.py:62-69; command_parser.py:118-119): linear output layer, multi-target losses */
+               SBR_LOSS_HINGE = 4, SBR_LOSS_LOGIT = 5, SBR_LOSS_LOGSIG = 6 } sbr_loss;
 /* --u_m (update_manager.py:4) */
 typedef enum { SBR_UPD_ADAGRAD = 0, SBR_UPD_ADADELTA = 1, SBR_UPD_RMSPROP = 2, SBR_UPD_NESTEROV = 3,
                SBR_UPD_ADAM = 4 } sbr_updater;
@@ -68,6 +70,10 @@ typedef struct sbr_config {
                                      * DENSE recurrent layers (layer 0 input = n_feat * E); 0 = index-input layer 0 */
     int32_t bidirectional;          /* --r_bi (recurrent_layers.py:70-76): every level = a forward and a backwards layer over the same
                                      * input, concatenated on the feature axis (next level / output layer see 2*H features) */
+    /* RNNMargin only (losses hinge / logit / logsig; rnn_margin.py:32-51, :112-147) */
+    float balance;                  /* --balance: weight of a false positive = balance * n_pos / (N - n_pos - n_in) */
+    int32_t n_targets;              /* --n_targets: positives per row at most (columns of `target` in sbr_set_batch, -1 = none) */
+    int32_t unique;                 /* interactions_are_unique (not --repeated_interactions): a row's input items get weight 0, target 0 */
 } sbr_config;
 
 #define SBR_FLAG_SIMPLE_REC  1   /* triage: per-step VALU recurrent kernels instead of the MFMA persistent ones */
@@ -123,6 +129,10 @@ int sbr_get_grads(sbr_handle* h, int n, float* const* host_arrays);
  * the output-layer gradients, which are complete after sbr_loss_backward_output and can be
  * all-reduced while sbr_backward_recurrent runs. */
 int sbr_section(sbr_handle* h, int which, void** dev_ptr, size_t* n_floats, size_t* split_floats);
+
+/* RNNMargin, --pb: the default target of every item (RNNMargin._default_target, rnn_margin.py:149-161: min(1 - p_i,
+ * (1 - min_access) p_i / min_access)), N floats on the host; without a call (or with NULL) it is 0 everywhere. */
+int sbr_set_default_target(sbr_handle* h, const float* default_target);
 
 /* The per-call inputs of train_function (rnn_one_hot.py:61,106; rnn_sampling.py:128,194):
  * X int32 (B,T,F) left-aligned; lengths int32 (B,) = mask.sum(1) (masks are prefix masks,

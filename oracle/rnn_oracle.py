@@ -518,6 +518,67 @@ def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, 
     return cost, a, (dh, dW, db)
 
 
+MARGIN_LOSSES = ("hinge", "logit", "logsig")
+
+
+def margin_targets(X, mask, targets, n_items, balance=1.0, unique=True, default_target=None):
+    """The dense (Y, weight) pair of RNNMargin._prepare_input (rnn_margin.py:112-147) for rows given as index arrays:
+    X (B,T,F) / mask (B,T): the input items (feature 0), targets: list of per-row lists of positive item ids
+    (SelectTargets' output, up to --n_targets of them).  weight = balance * len(target) / (N - len(target) - len(in_seq))
+    everywhere, -1 on the targets, and -- with unique interactions -- 0 on the input items (applied LAST, so an input item
+    that is also a target ends at 0); Y = the default target (zeros, or the popularity law of :149-161), 1 on the targets,
+    0 on the input items."""
+    B = len(targets)
+    Y = np.zeros((B, n_items)); W = np.zeros((B, n_items))
+    dflt = np.zeros(n_items) if default_target is None else np.asarray(default_target, dtype=np.float64)
+    for i in range(B):
+        n_in = int(np.asarray(mask[i]).sum())
+        in_seq = [int(v) for v in np.asarray(X[i])[:n_in, 0]]
+        tg = [int(t) for t in targets[i]]
+        w = balance * len(tg) / float(n_items - len(tg) - len(in_seq))
+        W[i, :] = w
+        W[i, tg] = -1
+        if unique:
+            W[i, in_seq] = 0
+        Y[i, :] = dflt
+        Y[i, tg] = 1
+        if unique:
+            Y[i, in_seq] = 0
+    return Y, W
+
+
+def margin_default_target(item_popularity, n_users, min_access=0.05):
+    """RNNMargin._default_target, popularity based (rnn_margin.py:155-159)."""
+    view_prob = np.asarray(item_popularity, dtype=np.float64) / n_users
+    return np.minimum(1 - view_prob, (1 - min_access) * view_prob / min_access)
+
+
+def margin_cost_and_grads(h, W_out, b_out, Y, Wt, loss, Bglobal=None):
+    """rnn_margin.py:62-69, :104-110: DenseLayer(N, linear) [3P]; cost = mean over rows of
+    hinge relu((p - y) w).sum() | logit (sigmoid(p - y) w).sum() | logsig -log(sigmoid((y - p) w)).sum().
+    Returns cost, p, (dh, dW_out, db_out); Bglobal as in cce_cost_and_grads."""
+    R = h.shape[0]
+    B = Bglobal or R
+    p = h @ W_out + b_out
+    if loss == "hinge":
+        z = (p - Y) * Wt
+        rows = np.maximum(z, 0.0).sum(1)
+        dp = np.where(z > 0.0, Wt, 0.0)
+    elif loss == "logit":
+        s = sigmoid(p - Y)
+        rows = (s * Wt).sum(1)
+        dp = s * (1.0 - s) * Wt
+    elif loss == "logsig":
+        z = (Y - p) * Wt
+        rows = -np.log(sigmoid(z)).sum(1)
+        dp = (1.0 - sigmoid(z)) * Wt
+    else:
+        raise ValueError("Unknown loss function")          # rnn_margin.py:49
+    cost = rows.sum() / B
+    dp = dp / B
+    return cost, p, (dp @ W_out.T, h.T @ dp, dp.sum(0))
+
+
 def cost_and_grads(params, cfg, batch):
     """cost + gradient list (Lasagne parameter order) for one batch = the symbolic part
     of RNNBase._compile_train_function (rnn_base.py:175-186) before the updates."""
@@ -527,6 +588,9 @@ def cost_and_grads(params, cfg, batch):
     if cfg["loss"] == "CCE":
         cost, act, (dh, dW, db) = cce_cost_and_grads(h, W_out, b_out, batch["target"], batch["pop"],
                                                      cfg.get("regularization", 0.0), batch.get("Bglobal"))
+    elif cfg["loss"] in MARGIN_LOSSES:      # batch["Y"], batch["weight"]: the dense pair of RNNMargin._prepare_input
+        cost, act, (dh, dW, db) = margin_cost_and_grads(h, W_out, b_out, batch["Y"], batch["weight"], cfg["loss"],
+                                                        batch.get("Bglobal"))
     else:
         cost, act, (dh, dW, db) = sampled_cost_and_grads(h, W_out, b_out, batch["target"], batch["samples"],
                                                          batch["pop"], cfg["loss"], batch.get("row_offset", 0))
@@ -592,7 +656,7 @@ def predict_scores(params, cfg, X, mask):
     _, W_out, b_out = split_params(params, cell, layers, emb, bi)
     h, _ = network_forward(params, cell, layers, X, mask, emb, bi)
     logits = h @ W_out + b_out
-    return (softmax_rows(logits) if cfg["loss"] == "CCE" else logits), logits
+    return (softmax_rows(logits) if cfg["loss"] == "CCE" else logits), logits      # (RNNMargin: linear DenseLayer, raw outputs)
 
 
 def topk_ordered(scores_row, k):
@@ -606,7 +670,9 @@ def test_function(params, cfg, X, mask, exclude_ids, k=10):
     probabilities * (1 - exclude) then ordered top-k, one row at a time."""
     cell, layers = cfg["cell"], cfg["layers"]
     _, logits = predict_scores(params, cfg, X, mask)
-    p = softmax_rows(logits)
+    # RNNMargin's output layer is linear: the generic test function (rnn_base.py:196-209) ranks its RAW outputs times
+    # (1 - exclude), so a viewed item scores 0 there and outranks every item with a negative output
+    p = logits if cfg["loss"] in MARGIN_LOSSES else softmax_rows(logits)
     out = []
     for b in range(p.shape[0]):
         row = p[b].copy()

@@ -28,7 +28,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
 #define LFAIL(...) do { snprintf(buf, sizeof(buf), __VA_ARGS__); err = buf; return SBR_EINVAL; } while (0)
     if (cfg.abi_version != SBR_ABI_VERSION) LFAIL("abi_version %d != %d", cfg.abi_version, SBR_ABI_VERSION);
     if (cfg.cell < 0 || cfg.cell > 2) LFAIL("Unknown layer type %d", cfg.cell);                  // recurrent_layers.py:90
-    if (cfg.loss < 0 || cfg.loss > 3) LFAIL("Unknown loss for the RNN model (%d)", cfg.loss);     // command_parser.py:123
+    if (cfg.loss < 0 || cfg.loss > SBR_LOSS_LOGSIG) LFAIL("Unknown loss for the RNN model (%d)", cfg.loss);     // command_parser.py:123
     if (cfg.updater < 0 || cfg.updater > 4) LFAIL("Unknown update option %d", cfg.updater);       // update_manager.py:22
     if (cfg.n_layers < 1 || cfg.n_layers > SBR_MAX_LAYERS) LFAIL("n_layers must be in [1,%d]", SBR_MAX_LAYERS);
     for (int l = 0; l < cfg.n_layers; ++l)
@@ -38,7 +38,9 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     if (cfg.max_length < 1) LFAIL("max_length must be >= 1");
     if (cfg.batch_size < 1 || cfg.local_batch < 1 || cfg.local_batch > cfg.batch_size) LFAIL("need 1 <= local_batch <= batch_size");
     if (cfg.row_offset < 0 || cfg.row_offset + cfg.local_batch > cfg.batch_size) LFAIL("row_offset/local_batch outside the global batch");
-    if (cfg.loss != SBR_LOSS_CCE && cfg.n_samples < 1) LFAIL("sampled losses need n_samples >= 1");
+    const bool margin = cfg.loss >= SBR_LOSS_HINGE;
+    if (cfg.loss != SBR_LOSS_CCE && !margin && cfg.n_samples < 1) LFAIL("sampled losses need n_samples >= 1");
+    if (margin && (cfg.n_targets < 1 || cfg.n_targets > 4096)) LFAIL("the multi-target losses need 1 <= n_targets <= 4096");
     if (cfg.learning_rate <= 0.0f) LFAIL("learning_rate must be > 0");
     if (cfg.embedding_size < 0 || cfg.embedding_size > 4096) LFAIL("embedding_size must be in [0,4096]");
 #undef LFAIL
@@ -47,8 +49,9 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.L = cfg.n_layers; lay.G = sbr_gates(cfg.cell); lay.T = cfg.max_length;
     lay.B = cfg.local_batch; lay.Bp = (cfg.local_batch + 15) / 16 * 16;
     lay.N = cfg.n_items; lay.F = cfg.n_feat; lay.Bg = cfg.batch_size;
-    lay.S = cfg.loss == SBR_LOSS_CCE ? 0 : cfg.n_samples;
+    lay.S = (cfg.loss == SBR_LOSS_CCE || margin) ? 0 : cfg.n_samples;
     lay.C = lay.Bg + lay.S;
+    lay.NT = margin ? cfg.n_targets : 1;
     const int G = lay.G, T = lay.T, Bp = lay.Bp;
 
     lay.E = cfg.embedding_size > 0 ? cfg.embedding_size : 0;
@@ -138,7 +141,8 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_ws2 = take(lay.ws2_floats);
     lay.a_X = take((size_t)Bp * T * lay.F);
     lay.a_len = take(Bp);
-    lay.a_tgt = take(std::max(lay.Bg, Bp));
+    lay.a_tgt = take((size_t)std::max(lay.Bg, Bp) * lay.NT);
+    lay.a_dflt = margin ? take(lay.N) : 0;
     lay.a_smp = take(std::max(lay.S, 1));
     lay.a_cells = take(std::max(lay.C, 1));
     lay.a_pop = take(Bp);
@@ -528,31 +532,43 @@ extern "C" int sbr_section(sbr_handle* h, int which, void** dev_ptr, size_t* n_f
 // ---------------------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------------------
+extern "C" int sbr_set_default_target(sbr_handle* h, const float* default_target) {
+    CHECK_ARG(h, "null handle");
+    const Layout& y = h->lay;
+    CHECK_ARG(y.cfg.loss >= SBR_LOSS_HINGE, "only the multi-target losses (hinge / logit / logsig) have a default target");
+    if (default_target) SBR_HIP(hipMemcpyAsync(h->A(y.a_dflt), default_target, (size_t)y.N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else SBR_HIP(hipMemsetAsync(h->A(y.a_dflt), 0, (size_t)y.N * sizeof(float), h->stream));
+    SBR_HIP(hipStreamSynchronize(h->stream));
+    return SBR_OK;
+}
+
 extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* lengths, const int32_t* target,
                              const int32_t* samples, const float* pop, int n_rows, int on_device) {
     CHECK_ARG(h && X && lengths, "null X / lengths");
     const Layout& y = h->lay;
     CHECK_ARG(n_rows >= 1 && n_rows <= y.B, "n_rows %d outside [1,%d]", n_rows, y.B);
-    const int n_tgt = y.S > 0 ? y.Bg : n_rows;
+    const bool margin = y.cfg.loss >= SBR_LOSS_HINGE;
+    const int n_tgt = y.S > 0 ? y.Bg : n_rows * y.NT;
     if (!on_device) {   // the reference would raise IndexError inside Theano for bad ids; check on host
         for (size_t i = 0; i < (size_t)n_rows * y.T * y.F; ++i)
             CHECK_ARG(X[i] >= 0 && X[i] < y.cfg.input_size, "input index %d out of range [0,%d)", X[i], y.cfg.input_size);
         for (int i = 0; i < n_rows; ++i) CHECK_ARG(lengths[i] >= 0 && lengths[i] <= y.T, "length %d outside [0,%d]", lengths[i], y.T);
-        if (target) for (int i = 0; i < n_tgt; ++i) CHECK_ARG(target[i] >= 0 && target[i] < y.N, "target %d out of range", target[i]);
+        if (target) for (int i = 0; i < n_tgt; ++i) CHECK_ARG((target[i] >= 0 || (margin && target[i] == -1)) && target[i] < y.N, "target %d out of range", target[i]);
         if (samples) for (int i = 0; i < y.S; ++i) CHECK_ARG(samples[i] >= 0 && samples[i] < y.N, "sample %d out of range", samples[i]);
     }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     hipStream_t s = h->stream;
     h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);
     h->bsmp = (const int*)h->A(y.a_smp); h->bpop = h->A(y.a_pop);
-    if (on_device && n_rows == y.Bp && pop) {
+    if (on_device && n_rows == y.Bp && (pop || margin)) {
         // device-resident inputs that cover every (padded) row: use them in place, no copies.  The caller
         // keeps them alive and unchanged until the step has run (stream order), as with any device input.
-        h->bX = X; h->blen = lengths; h->bpop = pop;
+        h->bX = X; h->blen = lengths; if (pop) h->bpop = pop;
         if (target) h->btgt = target;
         if (samples && y.S > 0) h->bsmp = samples;
     } else {
         if (n_rows < y.Bp) {   // padded rows: index 0, length 0, popularity 1
+            if (margin) SBR_HIP(hipMemsetAsync(h->A(y.a_tgt), 0xFF, (size_t)y.Bp * y.NT * sizeof(int), s));   // no positives
             SBR_HIP(hipMemsetAsync(h->A(y.a_X), 0, (size_t)y.Bp * y.T * y.F * sizeof(int), s));
             SBR_HIP(hipMemsetAsync(h->A(y.a_len), 0, (size_t)y.Bp * sizeof(int), s));
             SBR_LAUNCH(launch_fill(s, h->A(y.a_pop), 1.0f, y.Bp));
@@ -887,7 +903,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
         const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
     }
-    if (y.cfg.loss == SBR_LOSS_CCE) {
+    if (y.cfg.loss == SBR_LOSS_CCE || y.cfg.loss >= SBR_LOSS_HINGE) {      // dense heads: full softmax, or RNNMargin's linear layer
         float* lg = h->A(y.a_logits);
         const int Nl = (N + 3) & ~3;               // row stride of the logits / dlogits buffer
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
@@ -896,6 +912,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         const hipError_t ge = launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg);
         sbr_gemm_set_planes(3);
         SBR_LAUNCH(ge);
+        if (y.cfg.loss >= SBR_LOSS_HINGE)
+            SBR_LAUNCH(launch_margin_loss(s, lg, h->P(y.p_bout), tgt, y.NT, h->bX, h->blen, y.T, y.F, h->A(y.a_dflt), h->A(y.a_rowcost), R, N, Nl,
+                                          y.Bg, y.cfg.loss, y.cfg.balance, y.cfg.unique));
+        else
         SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, Nl, y.Bg));
         // critical path: dh = dlogits . W_out^T feeds the BPTT chain
         SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
@@ -1048,7 +1068,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_LAUNCH(launch_rec_backward(s, a, false));
             mark(h, 4);
             // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
-            const bool out_early = upd_here && y.cfg.loss == SBR_LOSS_CCE;
+            const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || y.cfg.loss >= SBR_LOSS_HINGE);
             if (out_early) SBR_LAUNCH(upd_on(sd, y.p_split, y.n_params));
             SBR_LAUNCH(launch_tail_gate(sd, words, nwaves, a.prog_epoch, y.T, a.fault));
             {
@@ -1449,8 +1469,12 @@ extern "C" int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_hos
     const int rc = full_scores(h, 0);
     if (rc != SBR_OK) return rc;
     float* lg = h->A(y.a_logits);
+    // exclude_seen 1: viewed items can never be ranked (top_k_recommendations, rnn_base.py:154-155); 2: the compiled test
+    // function's scores * (1 - exclude) (:201-202) -- the same ranking for probabilities, NOT for RNNMargin's raw outputs,
+    // where a viewed item then scores 0 and outranks every negative one
     if (exclude_seen)
-        SBR_LAUNCH(launch_exclude_seen(h->stream, lg, h->bX, h->blen, h->n_rows, y.T, y.F, y.N));
+        SBR_LAUNCH(launch_exclude_seen(h->stream, lg, h->bX, h->blen, h->n_rows, y.T, y.F, y.N,
+                                       (exclude_seen == 2 && y.cfg.loss >= SBR_LOSS_HINGE) ? 0.0f : -INFINITY));
     int* ids = (int*)h->A(y.a_topk);
     SBR_LAUNCH(launch_topk(h->stream, lg, h->n_rows, y.N, k, ids));
     SBR_HIP(hipMemcpyAsync(ids_host, ids, (size_t)h->n_rows * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));

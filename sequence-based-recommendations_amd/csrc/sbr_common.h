@@ -100,6 +100,8 @@ struct Layout {
                                           // bf16x6 GEMMs that read dlogits); [rows][N] in predict / top-k
     size_t a_dhlast;                      // [Bp][HLp]
     size_t a_rowcost;                     // [Bp]
+    int NT;                               // RNNMargin: target columns per row (1 for the other heads)
+    size_t a_dflt;                        // RNNMargin: [N] default target (zeros unless sbr_set_default_target)
     size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
     size_t a_ws; size_t ws_floats;        // split-K workspace (main stream)
     size_t a_ws2; size_t ws2_floats;      // split-K workspace of the side stream (output-layer + weight gradients)
@@ -355,6 +357,11 @@ bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const 
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
                               float* rowcost, int rows, int N, long ld, int Bglobal);
 hipError_t launch_softmax_rows(hipStream_t s, float* logits, const float* bout, int rows, int N, int do_softmax);
+// RNNMargin (rnn_margin.py:62-69, :112-147): logits (rows, N) raw h.W_out in, d cost / d logits out in place; target [rows][NT]
+// (-1 = none), X / len: the rows' input items (weight 0 and target 0 on them when unique)
+hipError_t launch_margin_loss(hipStream_t s, float* logits, const float* bout, const int* target, int NT, const int* X,
+                              const int* len, int T, int F, const float* dflt, float* rowcost, int rows, int N, long ld,
+                              int Bglobal, int loss, float balance, int unique);
 // db[n] = sum_rows d[r][n] + reg term ; cost += reg term
 hipError_t launch_colsum_bias(hipStream_t s, const float* d, int rows, int N, long ld, float* db, const float* b,
                               float reg, float* cost, float* ws /* >= 16*N floats */);
@@ -385,7 +392,8 @@ hipError_t launch_sparse_pack(hipStream_t s, const SbrSparseRows& r, const int* 
                               int epoch, int* ids_out, float* rows_out, int W, int* count);
 hipError_t launch_sparse_unpack_add(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int n, int W, int* cand);
 // top-k (rnn_base.py:196-211)
+// value: -inf (top_k_recommendations, rnn_base.py:154-155) or 0 (the compiled test function's scores * (1 - exclude), :201-202)
 hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F,
-                               int N);
+                               int N, float value);
 hipError_t launch_topk(hipStream_t s, float* scores, int rows, int N, int k, int* ids);
 hipError_t launch_fill(hipStream_t s, float* p, float v, size_t n);

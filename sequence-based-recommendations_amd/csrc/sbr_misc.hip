@@ -603,6 +603,81 @@ hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, c
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// RNNMargin's multi-target losses (rnn_margin.py:62-69), forward and backward fused, one workgroup per row.
+// The reference builds dense (B, N) target / weight matrices on the host (:112-147); here a row is: the default target
+// and the false-positive weight w = balance * n_pos / (N - n_pos - n_in) everywhere, then the overrides, few entries each
+// and possibly repeated: the positives (target 1, weight -1), and LAST -- with unique interactions -- the row's input
+// items (target 0, weight 0; an input item that is also a positive ends there).  The overridden logits are put aside
+// before the dense pass overwrites the row with gradients; duplicates are recognised by comparing against the earlier
+// entries (k <= T + NT entries in LDS).   loss / d loss / d p of one element:
+//   hinge   relu((p - y) w)               | w if (p - y) w > 0
+//   logit   sigmoid(p - y) w              | s (1 - s) w
+//   logsig  -log(sigmoid((y - p) w))      | w (1 - sigmoid((y - p) w))
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void margin_elem(int loss, float p, float y, float w, float& l, float& g) {
+    if (loss == SBR_LOSS_HINGE) { const float z = (p - y) * w; l = fmaxf(z, 0.0f); g = z > 0.0f ? w : 0.0f; }
+    else if (loss == SBR_LOSS_LOGIT) { const float s = 1.0f / (1.0f + expf(y - p)); l = s * w; g = s * (1.0f - s) * w; }
+    else { const float z = (y - p) * w; l = fmaxf(-z, 0.0f) + log1pf(expf(-fabsf(z))); g = w * (1.0f - 1.0f / (1.0f + expf(-z))); }
+}
+
+__global__ void __launch_bounds__(256) margin_loss_kernel(float* __restrict__ logits, const float* __restrict__ bout,
+                                                          const int* __restrict__ target, int NT, const int* __restrict__ X,
+                                                          const int* __restrict__ len, int T, int F, const float* __restrict__ dflt,
+                                                          float* __restrict__ rowcost, int N, long ld, int Bglobal, int loss,
+                                                          float balance, int unique) {
+    extern __shared__ int m_ids[];                 // [NT + T] ids of the override entries, then their logits (floats)
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    float* x = logits + (size_t)r * ld;
+    float* m_p = (float*)(m_ids + NT + T);
+    const int n_in = len[r];
+    int nt = 0;
+    for (int j = 0; j < NT; ++j) nt += target[(size_t)r * NT + j] >= 0 ? 1 : 0;
+    const int k = nt + (unique ? n_in : 0);
+    for (int e = tid; e < k; e += 256) {
+        const int id = e < nt ? target[(size_t)r * NT + e] : X[((size_t)r * T + (e - nt)) * F];
+        m_ids[e] = id;
+        m_p[e] = x[id] + bout[id];
+    }
+    __syncthreads();
+    const float w_fp = balance * (float)nt / (float)(N - nt - n_in);
+    const float inv = 1.0f / (float)Bglobal;
+    float acc = 0.0f;
+    for (int n = tid; n < N; n += 256) {
+        float l, g;
+        margin_elem(loss, x[n] + bout[n], dflt ? dflt[n] : 0.0f, w_fp, l, g);
+        x[n] = g * inv;
+        acc += l;
+    }
+    __syncthreads();
+    for (int e = tid; e < k; e += 256) {
+        const int id = m_ids[e];
+        const bool seen = e >= nt;
+        bool dup = false;
+        for (int f = seen ? nt : 0; f < e; ++f) dup = dup || m_ids[f] == id;         // an earlier entry of the same kind
+        if (!seen && unique) for (int f = nt; f < k; ++f) dup = dup || m_ids[f] == id;   // a positive that is also an input item
+        if (dup) continue;
+        float l0, g0, l1, g1;
+        margin_elem(loss, m_p[e], dflt ? dflt[id] : 0.0f, w_fp, l0, g0);
+        margin_elem(loss, m_p[e], seen ? 0.0f : 1.0f, seen ? 0.0f : -1.0f, l1, g1);
+        x[id] = g1 * inv;
+        acc += l1 - l0;
+    }
+    acc = block_sum(acc, red);
+    if (tid == 0) rowcost[r] = acc * inv;
+}
+
+hipError_t launch_margin_loss(hipStream_t s, float* logits, const float* bout, const int* target, int NT, const int* X,
+                              const int* len, int T, int F, const float* dflt, float* rowcost, int rows, int N, long ld,
+                              int Bglobal, int loss, float balance, int unique) {
+    if (rows <= 0) return hipSuccess;
+    const size_t lds = (size_t)(NT + T) * (sizeof(int) + sizeof(float));
+    (void)hipFuncSetAttribute((const void*)margin_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    margin_loss_kernel<<<rows, 256, lds, s>>>(logits, bout, target, NT, X, len, T, F, dflt, rowcost, N, ld, Bglobal, loss, balance, unique);
+    return hipGetLastError();
+}
+
 // predict path: x += b, optional softmax (rnn_base.py:188-194, rnn_sampling.py:144)
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ logits, const float* __restrict__ bout, int N,
                                                            int do_softmax) {
@@ -849,15 +924,15 @@ hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* 
 // K14 test path: exclude seen items, ordered top-k (rnn_base.py:196-211)
 // ---------------------------------------------------------------------------------------
 __global__ void exclude_seen_kernel(float* __restrict__ scores, const int* __restrict__ X, const int* __restrict__ len,
-                                    int rows, int T, int F, int N) {
+                                    int rows, int T, int F, int N, float value) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * T) return;
     const int r = i / T, t = i % T;
-    if (t < len[r]) scores[(size_t)r * N + X[((size_t)r * T + t) * F]] = -INFINITY;   // exclude[i, item ids] = 1
+    if (t < len[r]) scores[(size_t)r * N + X[((size_t)r * T + t) * F]] = value;   // exclude[i, item ids] = 1
 }
-hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F, int N) {
+hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F, int N, float value) {
     if (rows <= 0) return hipSuccess;
-    exclude_seen_kernel<<<(rows * T + 255) / 256, 256, 0, s>>>(scores, X, len, rows, T, F, N);
+    exclude_seen_kernel<<<(rows * T + 255) / 256, 256, 0, s>>>(scores, X, len, rows, T, F, N, value);
     return hipGetLastError();
 }
 

@@ -830,7 +830,8 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
     const char* fe = getenv("SBR_X6_F16");                         // read per launch: the tests flip it
     const bool f16 = (fe ? atoi(fe) != 0 : true) && !a.relu;       // forward products as fp16 x3 (see split2_f16); a rectified
                                                                    // state is unbounded, the fp16 split needs |h| < 65504
-    if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, false>)); }
+    if (a.prof && f16) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, true>)); }
+    else if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, true>)); }
     else { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, false>)); }
 #undef X6P_LAUNCH

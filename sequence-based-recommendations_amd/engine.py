@@ -21,12 +21,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 3
+SBR_ABI_VERSION = 4
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
 CELLS = {"LSTM": 0, "GRU": 1, "Vanilla": 2}                     # --r_t, recurrent_layers.py:9
-LOSSES = {"CCE": 0, "Blackout": 1, "BPR": 2, "TOP1": 3}          # --loss, command_parser.py:43
+LOSSES = {"CCE": 0, "Blackout": 1, "BPR": 2, "TOP1": 3,          # --loss, command_parser.py:43
+          "hinge": 4, "logit": 5, "logsig": 6}                   # ... RNNMargin's multi-target losses (command_parser.py:118-119)
+MARGIN_LOSSES = ("hinge", "logit", "logsig")
+SAMPLED_LOSSES = ("Blackout", "BPR", "TOP1")
 UPDATERS = {"adagrad": 0, "adadelta": 1, "rmsprop": 2, "nesterov": 3, "adam": 4}   # --u_m
 FLAG_SIMPLE_REC = 1
 FLAG_SIMPLE_GEMM = 2
@@ -46,12 +49,14 @@ class SbrConfig(ctypes.Structure):
                 ("loss", ctypes.c_int32), ("n_samples", ctypes.c_int32), ("updater", ctypes.c_int32),
                 ("learning_rate", ctypes.c_float), ("rho", ctypes.c_float), ("beta1", ctypes.c_float),
                 ("beta2", ctypes.c_float), ("regularization", ctypes.c_float), ("grad_clip", ctypes.c_float),
-                ("flags", ctypes.c_int32), ("embedding_size", ctypes.c_int32), ("bidirectional", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("embedding_size", ctypes.c_int32), ("bidirectional", ctypes.c_int32),
+                ("balance", ctypes.c_float), ("n_targets", ctypes.c_int32), ("unique", ctypes.c_int32)]
 
 
 # every symbol include/sbr_rnn.h declares (tests check the library exports all of them)
 EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create", "sbr_destroy", "sbr_num_params",
            "sbr_param_shape", "sbr_describe_param", "sbr_set_params", "sbr_get_params", "sbr_get_grads", "sbr_section", "sbr_set_batch",
+           "sbr_set_default_target",
            "sbr_train_step", "sbr_train_step_lagged", "sbr_lagged_flush", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
@@ -92,6 +97,7 @@ def load_library(path=None):
     lib.sbr_section.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t),
                                 ctypes.POINTER(ctypes.c_size_t)]
     lib.sbr_set_batch.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int]
+    lib.sbr_set_default_target.argtypes = [vp, vp]
     lib.sbr_train_step.argtypes = [vp, f32p]
     lib.sbr_train_step_lagged.argtypes = [vp, f32p, i32p]
     lib.sbr_lagged_flush.argtypes = [vp, f32p, i32p]
@@ -218,7 +224,8 @@ class DeviceDataset(object):
 
 def make_config(cell="GRU", layers=(50,), n_items=None, max_length=30, batch_size=16, loss="CCE", n_samples=0,
                 updater="adam", learning_rate=0.001, rho=0.9, beta1=0.9, beta2=0.999, regularization=0.0, grad_clip=100.0,
-                input_size=None, n_feat=1, local_batch=None, row_offset=0, flags=0, embedding_size=0, bidirectional=False):
+                input_size=None, n_feat=1, local_batch=None, row_offset=0, flags=0, embedding_size=0, bidirectional=False,
+                balance=1.0, n_targets=1, unique=True):
     """sbr_config for the options RNNBase.__init__ / prepare_model fix (include/sbr_rnn.h)."""
     if cell not in CELLS:
         raise ValueError("Unknown layer type")                      # recurrent_layers.py:90
@@ -243,7 +250,8 @@ def make_config(cell="GRU", layers=(50,), n_items=None, max_length=30, batch_siz
     cfg.local_batch = int(local_batch if local_batch is not None else batch_size)
     cfg.row_offset = int(row_offset)
     cfg.loss = LOSSES[loss]
-    cfg.n_samples = int(n_samples) if loss != "CCE" else 0
+    cfg.n_samples = int(n_samples) if loss in SAMPLED_LOSSES else 0
+    cfg.balance, cfg.n_targets, cfg.unique = float(balance), max(1, int(n_targets)) if loss in MARGIN_LOSSES else 1, 1 if unique else 0
     cfg.updater = UPDATERS[updater]
     cfg.learning_rate, cfg.rho, cfg.beta1, cfg.beta2 = learning_rate, rho, beta1, beta2
     cfg.regularization = regularization
@@ -309,7 +317,7 @@ class RNNEngine(object):
     def __init__(self, cell="GRU", layers=(50,), n_items=None, max_length=30, batch_size=16, loss="CCE",
                  n_samples=0, updater="adam", learning_rate=0.001, rho=0.9, beta1=0.9, beta2=0.999,
                  regularization=0.0, grad_clip=100.0, input_size=None, n_feat=1, local_batch=None, row_offset=0,
-                 flags=0, device=None, embedding_size=0, bidirectional=False):
+                 flags=0, device=None, embedding_size=0, bidirectional=False, balance=1.0, n_targets=1, unique=True):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("RNNEngine needs a HIP device (MI355X); there is no CPU fallback")
@@ -326,8 +334,9 @@ class RNNEngine(object):
                           n_samples=n_samples, updater=updater, learning_rate=learning_rate, rho=rho, beta1=beta1, beta2=beta2,
                           regularization=regularization, grad_clip=grad_clip, input_size=input_size, n_feat=n_feat,
                           local_batch=local_batch, row_offset=row_offset, flags=flags, embedding_size=embedding_size,
-                          bidirectional=bidirectional)
+                          bidirectional=bidirectional, balance=balance, n_targets=n_targets, unique=unique)
         self.cfg = cfg
+        self.n_targets = cfg.n_targets
         self.cell, self.layers, self.loss = cell, layers, loss
         self.n_items, self.max_length = cfg.n_items, cfg.max_length
         self.batch_size, self.local_batch, self.n_feat = cfg.batch_size, cfg.local_batch, cfg.n_feat
@@ -449,15 +458,31 @@ class RNNEngine(object):
         tgt = None if target is None else np.ascontiguousarray(np.asarray(target, dtype=np.int32))
         smp = None if samples is None else np.ascontiguousarray(np.asarray(samples, dtype=np.int32))
         pop = None if target_popularity is None else np.ascontiguousarray(np.asarray(target_popularity, dtype=np.float32))
-        if tgt is not None:
-            need = self.batch_size if self.loss != "CCE" else n_rows
+        if tgt is not None and self.loss in MARGIN_LOSSES:
+            # RNNMargin: (rows, n_targets) positives per row, -1 where a row has fewer (rnn_margin.py:112-147)
+            if tgt.ndim == 1:
+                tgt = tgt[:, None]
+            if tgt.shape[0] != n_rows or tgt.shape[1] > self.n_targets:
+                raise ValueError("targets must have shape (%d, <= %d), got %r" % (n_rows, self.n_targets, tgt.shape))
+            if tgt.shape[1] < self.n_targets:
+                tgt = np.concatenate([tgt, -np.ones((n_rows, self.n_targets - tgt.shape[1]), dtype=np.int32)], axis=1)
+            tgt = np.ascontiguousarray(tgt)
+        elif tgt is not None:
+            need = self.batch_size if self.loss in SAMPLED_LOSSES else n_rows
             if tgt.shape[0] != need:
                 raise ValueError("target must have %d entries, got %d" % (need, tgt.shape[0]))
-        if self.loss != "CCE" and smp is not None and smp.shape[0] != self.n_samples:
+        if self.loss in SAMPLED_LOSSES and smp is not None and smp.shape[0] != self.n_samples:
             raise ValueError("samples must have %d entries" % self.n_samples)
         p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
         self._check(self.lib.sbr_set_batch(self.h, p(X), p(lengths), p(tgt), p(smp), p(pop), n_rows, 0))
         return n_rows
+
+    def set_default_target(self, default_target=None):
+        """RNNMargin --pb: the default target of every item (RNNMargin._default_target, rnn_margin.py:149-161); None = zeros."""
+        a = None if default_target is None else np.ascontiguousarray(np.asarray(default_target, dtype=np.float32))
+        if a is not None and a.shape != (self.n_items,):
+            raise ValueError("default_target must have %d entries" % self.n_items)
+        self._check(self.lib.sbr_set_default_target(self.h, None if a is None else ctypes.c_void_p(a.ctypes.data)))
 
     def set_batch_device(self, X, lengths, target, samples, target_popularity, n_rows):
         """Same, inputs already resident in HBM (torch int32/float32 tensors on this device)."""
@@ -468,7 +493,9 @@ class RNNEngine(object):
     # ---------------------------------------------------------------- the reference's callables
     def train_function(self, X, mask, target, *rest):
         """cost = train_function(X, mask, target, [samples,] target_popularity, exclude)."""
-        if self.loss == "CCE":
+        if self.loss in MARGIN_LOSSES:      # RNNMargin: target = the positives (rows, n_targets); no popularity weights, no samples
+            pop = samples = None
+        elif self.loss == "CCE":
             pop = rest[0] if len(rest) > 0 else None
             samples = None
         else:
@@ -544,7 +571,9 @@ class RNNEngine(object):
         X, mask = theano_inputs[0], theano_inputs[1]
         n = self.set_batch(X, mask)
         ids = np.empty((n, k), dtype=np.int32)
-        self._check(self.lib.sbr_topk(self.h, int(k), 1 if exclude_seen else 0, ctypes.c_void_p(ids.ctypes.data)))
+        # exclude_seen: True / 1 = viewed items can never be ranked (top_k_recommendations, rnn_base.py:154-155); 2 = the compiled
+        # test function's scores * (1 - exclude) (:201-202): the same ranking except for RNNMargin's raw outputs
+        self._check(self.lib.sbr_topk(self.h, int(k), int(exclude_seen), ctypes.c_void_p(ids.ctypes.data)))
         return ids
 
     # ---------------------------------------------------------------- debug / timing

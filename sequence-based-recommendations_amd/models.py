@@ -171,9 +171,13 @@ class RNNBase(object):
     def train_function(self, *batch):
         return self.engine.train_function(*batch)
 
+    def _exclude_mode(self):
+        """how the compiled test function treats viewed items (engine.test_function): 0 not at all, 1 never ranked"""
+        return 1 if self.interactions_are_unique else 0
+
     def test_function(self, theano_inputs, k=10):
         """ordered top-k ids of the (single) row (rnn_base.py:205-209)."""
-        return self.engine.test_function(theano_inputs, k=k, exclude_seen=self.interactions_are_unique)[0]
+        return self.engine.test_function(theano_inputs, k=k, exclude_seen=self._exclude_mode())[0]
 
     def predict_function(self, X, mask):
         return self.engine.predict_function(X, mask)
@@ -288,8 +292,7 @@ class RNNBase(object):
         Xs, masks, goals = [], [], []
 
         def flush():
-            ids = self.engine.test_function((np.concatenate(Xs), np.concatenate(masks)), k=k,
-                                            exclude_seen=self.interactions_are_unique)
+            ids = self.engine.test_function((np.concatenate(Xs), np.concatenate(masks)), k=k, exclude_seen=self._exclude_mode())
             # a row with fewer than k rankable items carries -1 in the places it cannot fill (include/sbr_rnn.h): drop them
             out = (list(goals), [ids[i][ids[i] >= 0] for i in range(len(goals))])
             del Xs[:], masks[:], goals[:]
@@ -446,3 +449,71 @@ class RNNSampling(RNNBase):
         else:
             samples = np.random.choice(self.n_items, self.effective_sampling).astype(np.int32)
         return (X, mask, Y, samples, pop, None)
+
+
+class RNNMargin(RNNBase):
+    """RNN + linear output layer + multi-target losses hinge / logit / logsig, `--loss hinge|logit|logsig`
+    (rnn_margin.py:13-161).  The reference packs dense (B, N) target and weight matrices on the host every batch; here a
+    batch carries the positives of every row (up to --n_targets of them, -1 = none) and the engine's loss kernel derives
+    target / weight from them, from the row's own input items and from the default target (csrc/sbr_misc.hip)."""
+
+    def __init__(self, loss_function="hinge", balance=1., popularity_based=False, min_access=0.05, n_targets=1, **kwargs):
+        super(RNNMargin, self).__init__(**kwargs)
+        self.balance, self.popularity_based, self.min_access, self.n_targets = balance, popularity_based, min_access, n_targets
+        if loss_function is None:
+            loss_function = "hinge"
+        if loss_function not in ("hinge", "logit", "logsig"):
+            raise ValueError("Unknown loss function")                   # rnn_margin.py:49
+        self.loss_function_name = loss_function
+        self.name = "RNN multi-targets"
+
+    MAX_TARGETS = 4096      # columns of the engine's target array (include/sbr_rnn.h)
+
+    def _engine_targets(self):
+        return int(min(max(1, self.target_selection.n_targets), self.MAX_TARGETS))
+
+    def _engine_kwargs(self):
+        return dict(loss=self.loss_function_name, balance=float(self.balance), n_targets=self._engine_targets(),
+                    unique=bool(self.interactions_are_unique))
+
+    def prepare_model(self, dataset):
+        super(RNNMargin, self).prepare_model(dataset)
+        if self.popularity_based:                                       # rnn_margin.py:149-161
+            self.dataset = dataset
+            self.engine.set_default_target(self._default_target())
+
+    def _default_target(self):
+        if not self.popularity_based:
+            return np.zeros(self.n_items)
+        view_prob = np.asarray(self.dataset.item_popularity, dtype=np.float64) / self.dataset.training_set.n_users
+        return np.minimum(1 - view_prob, (1 - self.min_access) * view_prob / self.min_access)
+
+    def _get_model_filename(self, epochs):
+        filename = "rnn_multitarget_" + self.loss_function_name + "_b" + str(self.balance)
+        if self.popularity_based:
+            filename += "_pb_ma" + str(self.min_access)
+        return filename + "_" + self._common_filename(epochs)
+
+    def _prepare_input(self, sequences):
+        """(X, mask, targets, None, None) where the reference returns (X, mask, Y, weight, exclude) (rnn_margin.py:112-147):
+        targets (B, n_targets) int32, the positives of every row in SelectTargets' order, -1 behind the last one."""
+        B, T, F, NT = len(sequences), self.max_length, self._input_size(), self._engine_targets()
+        X = np.zeros((B, T, F), dtype=np.int32)
+        mask = np.zeros((B, T), dtype=np.float32)
+        targets = -np.ones((B, NT), dtype=np.int32)
+        for i, (user_id, in_seq, target) in enumerate(sequences):
+            n = len(in_seq)
+            if n:
+                X[i, :n, :] = np.array([self._get_features(x, user_id) for x in in_seq], dtype=np.int32)
+            mask[i, :n] = 1
+            if len(target) > NT:
+                raise ValueError("a row has %d targets, the engine was built for %d (--n_targets)" % (len(target), NT))
+            targets[i, :len(target)] = [t[0] for t in target]
+        return (X, mask, targets, None, None)
+
+    def _exclude_mode(self):
+        """The generic compiled test function (rnn_base.py:196-209) on RAW outputs: viewed items are multiplied by 0, not removed."""
+        return 2 if self.interactions_are_unique else 0
+
+    def _native_batch_builder(self, dataset):
+        return None      # the device batch builder produces one target per row

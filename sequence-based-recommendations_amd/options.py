@@ -246,7 +246,12 @@ def predictor_command_parser(parser):
                         default=0.0, type=float)
     parser.add_argument("-g", dest="gradient_clipping", help="Gradient clipping (parsed, never used: always 100)",
                         default=100, type=int)
-    parser.add_argument("--loss", help="Loss function: TOP1, BPR, Blackout (sampling) or CCE", default="CCE", type=str)
+    parser.add_argument("--loss", help="Loss function: TOP1, BPR, Blackout (sampling), hinge, logit, logsig (multi-targets) or CCE",
+                        default="CCE", type=str)
+    parser.add_argument("--pb", help="Popularity based (for RNNMargin).", action="store_true")
+    parser.add_argument("--balance", help="Balance between false positive and false negative error (for RNNMargin).",
+                        default=1., type=float)
+    parser.add_argument("--min_access", help="Estimation of minimum access probability (for RNNMargin).", default=0.05, type=float)
     parser.add_argument("--sampling", help="Number of sample for the computation of the loss in RNNSampling",
                         default=32.0, type=float)
     parser.add_argument("--sampling_bias", help="0. means uniform sampling, 1. means proportional to the item frequency",
@@ -297,7 +302,7 @@ def command_parser(*sub_command_parser, argv=None):    # helpers/command_parser.
 
 def get_predictor(args):
     """helpers/command_parser.py:84-125, RNN branch (:113-123)."""
-    from .models import RNNOneHot, RNNSampling
+    from .models import RNNOneHot, RNNSampling, RNNMargin
     if args.mf or args.uf:
         raise ValueError("--mf/--uf need feature tables the reference never loads (rnn_base.py:27-29): unsupported")
     common = dict(interactions_are_unique=(not args.repeated_interactions), max_length=args.max_length,
@@ -310,4 +315,6 @@ def get_predictor(args):
     if args.loss in ("BPR", "TOP1", "Blackout"):
         return RNNSampling(loss_function=args.loss, diversity_bias=args.diversity_bias, sampling=args.sampling,
                            sampling_bias=args.sampling_bias, **common)
+    if args.loss in ("hinge", "logit", "logsig"):                       # command_parser.py:118-119
+        return RNNMargin(loss_function=args.loss, balance=args.balance, popularity_based=args.pb, min_access=args.min_access, **common)
     raise ValueError("Unknown loss for the RNN model")

@@ -20,6 +20,10 @@ CASES = [
     D + ["--n_dropout", "0.1", "--n_swap", "0.2", "--n_shuf", "0.3", "--n_shuf_std", "2.0", "--n_ratings", "0.4"],
     D + ["--tshuffle", "--extended_set", "--save", "All", "--metrics", "sps,recall", "--progress", "500", "--mpi", "1000",
          "--max_iter", "2000", "--min_iter", "10", "--es_m", "StopAfterN", "--es_n", "4"],
+    # RNNMargin (command_parser.py:118-119)
+    D + ["--loss", "hinge", "--n_targets", "3", "--balance", "2.0"],
+    D + ["--loss", "logit", "--pb", "--min_access", "0.1", "--repeated_interactions", "--r_t", "GRU"],
+    D + ["--loss", "logsig", "--balance", "0.5", "--n_targets", "5", "--shuffle_targets"],
 ]
 
 # (argv, seed, number of training batches): the mini-batch streams that are recorded
@@ -33,6 +37,8 @@ BATCH_CASES = [
     (B + ["--n_dropout", "0.2", "--n_swap", "0.2", "--n_ratings", "0.3", "--rf"], 8, 4),
     (B + ["--shuffle_targets", "--target_bias", "0.5", "--rand_test_target"], 9, 4),
     (B + ["--n_shuf", "0.3", "--n_shuf_std", "2.0", "--loss", "TOP1", "--sampling", "4"], 10, 4),
+    (B + ["--loss", "hinge", "--n_targets", "3", "--balance", "2.0"], 19, 4),
+    (B + ["--loss", "logsig", "--n_targets", "2", "--repeated_interactions", "--pb", "--min_access", "0.2"], 20, 4),
 ]
 
 # training-loop runs with the fake functions: what is validated / saved / removed / returned
@@ -75,10 +81,12 @@ class FakeFunctions(object):
         return np.array(rows)
 
 
-def batch_to_json(batch):
+def batch_to_json(batch, p=None):
     """(X, mask, Y, [samples,] pop, exclude) -> plain lists.  `exclude` (B, n_items) is stored as the sorted item ids per
     row; this package hands None there (the engine derives it from X on the device): then it is derived from X / mask."""
     X, mask, Y = np.asarray(batch[0]), np.asarray(batch[1]), np.asarray(batch[2])
+    if len(batch) == 5 and (batch[3] is None or np.asarray(batch[3]).ndim == 2):
+        return margin_batch_to_json(batch, p)
     samples = np.asarray(batch[3]) if len(batch) == 6 else None
     pop, exclude = np.asarray(batch[-2]), batch[-1]
     assert mask.dtype == np.float32 and pop.dtype == np.float32 and Y.dtype == np.int32 and X.dtype == np.int32
@@ -92,6 +100,35 @@ def batch_to_json(batch):
         assert samples.dtype == np.int32
         out["samples"] = samples.tolist()
     return out
+
+
+def margin_batch_to_json(batch, p=None):
+    """RNNMargin: the reference hands (X, mask, Y (B,N), weight (B,N), exclude (B,N)); this package hands (X, mask, targets (B,NT),
+    None, None) and its engine derives the dense pair on the device.  Common form: the dense target / weight rows reduced to
+    what determines them (the non-zero targets, the ids with weight -1 and 0, the false-positive weight); for this package
+    they are rebuilt here from the positives, the row's inputs and the predictor's options, following rnn_margin.py:112-147."""
+    X, mask = np.asarray(batch[0]), np.asarray(batch[1])
+    if batch[3] is None:
+        N, tg = int(p.n_items), np.asarray(batch[2])
+        dflt = np.asarray(p._default_target(), dtype=np.float64)
+        Y, W = np.zeros((len(X), N)), np.zeros((len(X), N))
+        for i in range(len(X)):
+            in_seq = [int(v) for v in X[i, :int(mask[i].sum()), 0]]
+            t = [int(v) for v in tg[i] if v >= 0]
+            W[i, :] = p.balance * len(t) / float(N - len(t) - len(in_seq))
+            W[i, t] = -1
+            Y[i, :] = dflt
+            Y[i, t] = 1
+            if p.interactions_are_unique:
+                W[i, in_seq] = 0
+                Y[i, in_seq] = 0
+    else:
+        Y, W = np.asarray(batch[2], dtype=np.float64), np.asarray(batch[3], dtype=np.float64)
+        assert np.asarray(batch[2]).dtype == np.float32 and np.asarray(batch[3]).dtype == np.float32
+    return dict(X=X.tolist(), mask=mask.astype(int).tolist(),
+                Y=[[[int(i), round(float(v), 5)] for i, v in enumerate(row) if v != 0.0] for row in Y],
+                W=[dict(minus_one=np.flatnonzero(row == -1).tolist(), zero=np.flatnonzero(row == 0).tolist(),
+                        fp=round(float(np.max(row)), 6)) for row in W])
 
 
 # `test.py` runs: (argv after -d ROOT, epochs of the checkpoint files present in models/)

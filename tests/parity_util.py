@@ -57,16 +57,37 @@ def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=Fals
     batch = make_batch(rng, B, T, N, S=S, F=F, n_in0=N + n_opt, full=full, zipf=zipf)
     batch["pop"] = (batch["pop"] * popscale).astype(np.float32)
     cfg = dict(cell=cell, layers=list(layers), loss=loss, regularization=0.0, embedding=emb, bidirectional=bi)
+    if loss in O.MARGIN_LOSSES:      # RNNMargin: S = --n_targets; 1 .. S positives per row (-1 = none), some repeated / also in the input
+        NT = max(S, 1)
+        tg = -np.ones((B, NT), dtype=np.int32)
+        for b in range(B):
+            k = 1 + (b % NT)
+            tg[b, :k] = rng.integers(0, N, size=k)
+        if B > 1:
+            tg[1, 0] = batch["X"][1, 0, 0]
+        if B > 2 and NT > 1:
+            tg[2, :2] = tg[2, 0]
+        batch["targets"] = tg
     return params, cfg, batch
 
 
+def margin_oracle_batch(batch, N, balance=1.0, unique=True, default_target=None):
+    """the dense (Y, weight) pair the oracle's margin head takes, from the per-row positives of build_case"""
+    ob = oracle_batch(batch)
+    tg = [[int(t) for t in row if t >= 0] for row in batch["targets"]]
+    ob["Y"], ob["weight"] = O.margin_targets(batch["X"], batch["mask"], tg, N, balance=balance, unique=unique,
+                                             default_target=default_target)
+    return ob
+
+
 def engine_for(cfg, N, B, T, S=0, F=1, n_opt=0, updater="adam", lr=0.01, flags=0, reg=0.0, local_batch=None,
-               row_offset=0):
+               row_offset=0, balance=1.0, unique=True):
     from sbr_amd.engine import RNNEngine
     return RNNEngine(cell=cfg["cell"], layers=cfg["layers"], n_items=N, max_length=T, batch_size=B, loss=cfg["loss"],
                      n_samples=S, updater=updater, learning_rate=lr, rho=0.9, beta1=0.9, beta2=0.999,
                      regularization=reg, input_size=N + n_opt, n_feat=F, flags=flags, local_batch=local_batch,
-                     row_offset=row_offset, embedding_size=cfg.get("embedding", 0), bidirectional=cfg.get("bidirectional", False))
+                     row_offset=row_offset, embedding_size=cfg.get("embedding", 0), bidirectional=cfg.get("bidirectional", False),
+                     balance=balance, n_targets=max(S, 1), unique=unique)
 
 
 def oracle_batch(batch):
@@ -76,7 +97,8 @@ def oracle_batch(batch):
 
 
 def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
-                 reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False, zipf=False, k=None, gap=0.0, tweak=None):
+                 reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False, zipf=False, k=None, gap=0.0, tweak=None,
+                 balance=1.0, unique=True, default_target=None):
     """Returns dict of relative errors (engine float32 vs oracle float64).
     k: length of the ranked list compared (default min(5, N - T)); gap > 0: the ranked ids are compared on the rows
     whose oracle scores (logits) are separated by more than `gap` down to rank k + 1 -- a tie-free fixture by
@@ -87,16 +109,22 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
     if tweak is not None:
         tweak(batch)
     cfg["regularization"] = reg
-    eng = engine_for(cfg, N, B, T, S=S, F=F, n_opt=n_opt, updater=updater, flags=flags, reg=reg)
+    margin = loss in O.MARGIN_LOSSES
+    eng = engine_for(cfg, N, B, T, S=S, F=F, n_opt=n_opt, updater=updater, flags=flags, reg=reg, balance=balance, unique=unique)
+    obatch = margin_oracle_batch(batch, N, balance, unique, default_target) if margin else oracle_batch(batch)
     out = {}
     try:
         eng.set_all_param_values(params)
         back = eng.get_all_param_values()
         out["param_roundtrip"] = max(rel_err(a, b) for a, b in zip(back, params))
-        smp = batch["samples"] if loss != "CCE" else None
-        eng.set_batch(batch["X"], batch["mask"], batch["target"], smp, batch["pop"])
+        smp = batch["samples"] if (loss != "CCE" and not margin) else None
+        if margin:
+            eng.set_default_target(default_target)
+            eng.set_batch(batch["X"], batch["mask"], batch["targets"])
+        else:
+            eng.set_batch(batch["X"], batch["mask"], batch["target"], smp, batch["pop"])
         cost = eng.forward_backward()
-        ocost, ograds, aux = O.cost_and_grads(params, cfg, oracle_batch(batch))
+        ocost, ograds, aux = O.cost_and_grads(params, cfg, obatch)
         Hp = eng.debug_buffer("h_last").size // (((B + 15) // 16) * 16)
         hl = eng.debug_buffer("h_last").reshape(-1, Hp)[:B]
         if bi:      # [forward H | pad | backwards H | pad]
@@ -118,7 +146,7 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
         oparams = [p.copy() for p in params]
         costs_e, costs_o = [], []
         for _ in range(steps):
-            costs_o.append(O.train_function(oparams, cfg, upd, oracle_batch(batch)))
+            costs_o.append(O.train_function(oparams, cfg, upd, obatch))
             costs_e.append(eng.train_step(sync=True))
         new = eng.get_all_param_values()
         out["params_after_%d_steps" % steps] = max(rel_err(a, b) for a, b in zip(new, oparams))
@@ -129,19 +157,21 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
         out["predict_scores"] = rel_err(scores, oscores)
         if k is None:
             k = min(5, N - T) if N - T >= 1 else 1
-        ids = eng.test_function((batch["X"], batch["mask"]), k=k)
+        # (RNNMargin: the compiled test function's semantics, a viewed item scores 0: exclude mode 2)
+        ids = eng.test_function((batch["X"], batch["mask"]), k=k, exclude_seen=2 if margin else True)
         excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
         oids = O.test_function(oparams, cfg, batch["X"], batch["mask"], excl, k=k)
         rows = np.ones(B, dtype=bool)
         if gap > 0.0:      # rows whose k + 1 best admissible logits are pairwise further apart than `gap`
             for b in range(B):
                 row = ologits[b].copy()
-                row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
+                row[np.asarray(excl[b], dtype=np.int64)] = 0.0 if margin else -np.inf
                 top = -np.sort(-row)[:k + 1]
                 rows[b] = bool(np.all(top[:-1] - top[1:] > gap))
         oids = np.array(oids)
         for b in range(B):      # a row with fewer than k rankable items: the engine fills the places it cannot rank with -1
-            oids[b, max(0, N - len(set(excl[b]))):] = -1      # (the oracle's argpartition of zeros there is arbitrary)
+            if not margin:
+                oids[b, max(0, N - len(set(excl[b]))):] = -1      # (the oracle's argpartition of zeros there is arbitrary)
         out["topk_rows_compared"] = float(rows.sum())
         out["topk_mismatch"] = float((ids[rows] != oids[rows]).sum())
     finally:

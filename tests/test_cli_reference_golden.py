@@ -91,10 +91,10 @@ def test_mini_batch_streams(gold, root, i):
     random.seed(seed); np.random.seed(seed)
     gen = p._gen_mini_batch(p.sequence_noise(dataset.training_set()))
     for k in range(n_train):
-        assert batch_to_json(next(gen)) == g["train"][k], "training batch %d" % k
+        assert batch_to_json(next(gen), p) == g["train"][k], "training batch %d" % k
     assert float(dataset.training_set.epochs) == g["epochs"]
     random.seed(seed + 1); np.random.seed(seed + 1)
-    got = [[batch_to_json(b), [int(x) for x in goal]] for b, goal in p._gen_mini_batch(dataset.validation_set(epochs=1), test=True)]
+    got = [[batch_to_json(b, p), [int(x) for x in goal]] for b, goal in p._gen_mini_batch(dataset.validation_set(epochs=1), test=True)]
     assert got == g["test"]
 
 

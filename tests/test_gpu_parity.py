@@ -269,6 +269,26 @@ def test_sampled_heads(cell, loss):
     check(PU.compare_step(cell, [16], loss, N=40, B=6, T=5, S=7))
 
 
+@pytest.mark.parametrize("loss", ["hinge", "logit", "logsig"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_margin_heads(cell, loss):
+    # RNNMargin (rnn_margin.py): linear output layer, dense multi-target losses; S = --n_targets; rows with one to three
+    # positives, one of them repeated, one that also occurs in the row's input
+    check(PU.compare_step(cell, [20], loss, N=60, B=9, T=8, S=3, balance=1.5))
+    check(PU.compare_step(cell, [20], loss, N=60, B=9, T=8, S=2, unique=False, balance=0.5))     # --repeated_interactions
+
+
+def test_margin_head_with_popularity_based_targets_and_other_shapes():
+    from oracle import rnn_oracle as O
+    rng = np.random.default_rng(5)
+    dflt = O.margin_default_target(rng.integers(1, 80, size=300), 100, 0.1)                        # --pb --min_access 0.1
+    check(PU.compare_step("GRU", [50], "hinge", N=300, B=37, T=12, S=4, default_target=dflt))
+    check(PU.compare_step("Vanilla", [128], "logsig", N=300, B=21, T=9, S=1, scale=0.05))
+    check(PU.compare_step("LSTM", [50, 20], "logit", N=120, B=16, T=10, S=2, updater="adagrad"))
+    # the benchmark's catalogue and width, the overlapped tail's shape (T >= 64)
+    check(PU.compare_step("GRU", [128], "hinge", N=3706, B=64, T=70, S=3, scale=0.1, zipf=True, gap=1e-4), tol_g=2e-4)
+
+
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_two_layer_stack(cell):                            # recurrent_layers.py:57-68: dense layers above layer 0
     check(PU.compare_step(cell, [20, 12], "CCE", N=30, B=6, T=6))

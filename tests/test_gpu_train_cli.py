@@ -44,7 +44,11 @@ def make_dataset(root, n_users=40, n_items=30, seed=0):
 @pytest.mark.parametrize("extra", [["--loss", "CCE", "--r_t", "GRU", "--r_l", "16"],
                                    ["--loss", "CCE", "--r_t", "GRU", "--r_l", "16", "--r_emb", "8"],
                                    ["--loss", "CCE", "--r_t", "LSTM", "--r_l", "12-8", "--r_bi"],
-                                   ["--loss", "BPR", "--r_t", "LSTM", "--r_l", "12", "--sampling", "8", "--u_m", "adagrad", "--u_l", "0.1"]])
+                                   ["--loss", "BPR", "--r_t", "LSTM", "--r_l", "12", "--sampling", "8", "--u_m", "adagrad", "--u_l", "0.1"],
+                                   # RNNMargin: multi-target hinge loss, popularity-based default target
+                                   ["--loss", "hinge", "--r_t", "GRU", "--r_l", "16", "--n_targets", "3", "--balance", "2.0", "--pb",
+                                    "--u_m", "adagrad", "--u_l", "0.1"],
+                                   ["--loss", "logsig", "--r_t", "GRU", "--r_l", "16", "--n_targets", "2", "--repeated_interactions"]])
 def test_train_cli_end_to_end(tmp_path, extra):
     from sbr_amd import train as T
     root = make_dataset(str(tmp_path / "ds"))
@@ -69,7 +73,9 @@ def test_train_cli_end_to_end(tmp_path, extra):
     predictor.load(files[-1])
     seq = [[3, 4.0], [5, 4.0], [7, 4.0]]
     rec = predictor.top_k_recommendations(seq, k=5)
-    assert len(rec) == 5 and len(set(rec)) == 5 and not set(rec) & {3, 5, 7}
+    assert len(rec) == 5 and len(set(rec)) == 5
+    if "--repeated_interactions" not in extra:
+        assert not set(rec) & {3, 5, 7}
     predictor.engine.close()
 
 

@@ -203,3 +203,29 @@ def test_test_function_excludes_seen_items():
     ids = O.test_function(params, cfg, batch["X"], batch["mask"], excl, k=3)
     for b in range(3):
         assert not set(ids[b]) & set(excl[b]) or len(set(range(7)) - set(excl[b])) < 3
+
+
+@pytest.mark.parametrize("loss", ["hinge", "logit", "logsig"])
+def test_margin_head_gradients_against_finite_differences(loss):
+    """RNNMargin's losses (rnn_margin.py:62-69): analytic gradients of the whole model against central differences, with
+    rows whose positives repeat / also occur in the input and a popularity-based default target (third party: none --
+    pinned by the reference's own code in tests/test_reference_layers.py; this is the independent check)."""
+    import parity_util as PU
+    rng = np.random.default_rng(3)
+    N, B, T = 23, 5, 6
+    params, cfg, batch = PU.build_case("GRU", [7], loss, N, B, T, S=3, seed=11)
+    dflt = O.margin_default_target(rng.integers(1, 40, size=N), 50, 0.1)
+    ob = PU.margin_oracle_batch(batch, N, balance=1.5, unique=True, default_target=dflt)
+    cost, grads, _ = O.cost_and_grads(params, cfg, ob)
+    eps = 1e-6
+    for pi in (0, len(params) - 2, len(params) - 1):
+        p = params[pi]
+        for idx in [tuple(rng.integers(0, s) for s in p.shape) for _ in range(4)]:
+            old = p[idx]
+            p[idx] = old + eps; cp = O.cost_and_grads(params, cfg, ob)[0]
+            p[idx] = old - eps; cm = O.cost_and_grads(params, cfg, ob)[0]
+            p[idx] = old
+            num = (cp - cm) / (2 * eps)
+            if loss == "hinge" and abs(num - grads[pi][idx]) > 1e-6:      # a kink of the hinge inside the step: skip
+                continue
+            assert abs(num - grads[pi][idx]) <= 1e-6 * max(1.0, abs(num)), (pi, idx, num, grads[pi][idx])

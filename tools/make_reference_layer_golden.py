@@ -52,7 +52,15 @@ CASES = {
     "lstm8_cce_clip": ("LSTM", 8, "CCE", 35, 6, 8, 0, 1, 0, False, []),
     "vanilla8_cce_clip": ("Vanilla", 8, "CCE", 35, 6, 8, 0, 1, 0, False, []),
     "gru8_bpr_clip_bi": ("GRU", 8, "BPR", 35, 6, 8, 4, 1, 0, True, ["--r_bi"]),
+    # RNNMargin (rnn_margin.py): --loss hinge | logit | logsig, multi-target; S here = --n_targets.  Y / weight come from the
+    # reference's own _prepare_input
+    "gru12_hinge": ("GRU", 12, "hinge", 40, 6, 7, 3, 1, 0, False, ["--balance", "1.5"]),
+    "lstm10_logit": ("LSTM", 10, "logit", 40, 6, 7, 2, 1, 0, False, []),
+    "gru10_logsig_ri": ("GRU", 10, "logsig", 40, 6, 7, 1, 1, 0, False, ["--repeated_interactions", "--balance", "0.5"]),
+    "vanilla8_hinge_pb": ("Vanilla", 8, "hinge", 30, 5, 6, 2, 1, 0, False, ["--pb", "--min_access", "0.1"]),
+    "gru128_logsig": ("GRU", 128, "logsig", 30, 6, 8, 2, 1, 0, False, []),
 }
+MARGIN = ("hinge", "logit", "logsig")
 POPSCALE = {"gru12_cce_clip": 3e-5, "lstm8_cce_clip": 3e-5, "vanilla8_cce_clip": 3e-5, "gru8_bpr_clip_bi": 1e-5}
 
 
@@ -81,11 +89,11 @@ def main():
         seed = sum(map(ord, name))
         params, cfg, batch = PU.build_case(cell, [H], loss, N, B, T, S=S, seed=seed, F=F, n_opt=n_opt, bi=bi,
                                            popscale=POPSCALE.get(name, 1.0), scale=0.1 if H >= 128 else None)
-        if loss != "CCE":
+        if loss != "CCE" and loss not in MARGIN:
             assert len(batch["samples"]) == S
         def predictor():
             sys.argv = ["train.py", "-d", "/tmp/x/", "-b", str(B), "--max_length", str(T), "--r_t", cell, "--r_l", str(H),
-                        "--loss", loss, "--sampling", str(S or 32)] + extra
+                        "--loss", loss] + (["--n_targets", str(S)] if loss in MARGIN else ["--sampling", str(S or 32)]) + extra
             args = cp.command_parser(cp.predictor_command_parser, reftrain.training_command_parser, cp.early_stopping_command_parser)
             return args, cp.get_predictor(args)
         args, p = predictor()
@@ -95,6 +103,32 @@ def main():
             exclude[b, batch["X"][b, :int(batch["mask"][b].sum()), 0]] = 1
         feed = dict(inputs=[batch["X"], batch["mask"].astype(np.float64)], target_output=batch["target"],
                     target_popularity=batch["pop"].astype(np.float64), samples=batch["samples"], excluded_items=exclude)
+        margin = {}
+        if loss in MARGIN:
+            # (user, input sequence, targets) rows as _gen_mini_batch hands them over; 1 .. n_targets positives per row, some of
+            # them repeated, one that also occurs in the row's input
+            import types
+            rng = np.random.RandomState(seed)
+            item_pop = rng.randint(1, 50, size=N)
+            p.n_items = N
+            p.dataset = types.SimpleNamespace(training_set=types.SimpleNamespace(n_users=60), item_popularity=item_pop)
+            seqs, tg = [], -np.ones((B, S), dtype=np.int32)
+            for b in range(B):
+                n_in = int(batch["mask"][b].sum())
+                k = 1 + (b % S)
+                t_b = [int(v) for v in rng.randint(0, N, size=k)]
+                if b == 1:
+                    t_b[0] = int(batch["X"][b, 0, 0])
+                if b == 2 and k > 1:
+                    t_b[1] = t_b[0]
+                tg[b, :k] = t_b
+                seqs.append([b, [(int(i), 1.0) for i in batch["X"][b, :n_in, 0]], [(t, 1.0) for t in t_b]])
+            Xr, mr, Yr, Wr, er = p._prepare_input(seqs)                 # the reference's own packing (rnn_margin.py:112-147)
+            assert np.array_equal(Xr, batch["X"]) and np.array_equal(mr, batch["mask"]) and np.array_equal(er, exclude)
+            feed["multiple_target_output"] = Yr
+            feed["target_weight"] = Wr
+            margin = dict(targets=tg, Y=Yr, weight=Wr, balance=float(args.balance), item_popularity=item_pop, n_users=60,
+                          popularity_based=int(bool(args.pb)), min_access=float(args.min_access))
         # pass 1: the reference's own initialisers -> names and shapes in get_all_params order
         E.new_network(feed)
         p._prepare_networks(N)
@@ -125,7 +159,7 @@ def main():
             assert clip_changes > 0.05, clip_changes
         h_last = lasagne.layers.get_output(p.l_out.input_layer)
         det = lasagne.layers.get_output(p.l_out, deterministic=True)               # predict_function, rnn_base.py:192
-        test_scores = det if loss == "CCE" else theano.tensor.nnet.softmax(det)    # test function, rnn_base.py:200 / rnn_sampling.py:144
+        test_scores = det if (loss == "CCE" or loss in MARGIN) else theano.tensor.nnet.softmax(det)    # test function, rnn_base.py:200 / rnn_sampling.py:144
         if p.interactions_are_unique:
             test_scores = test_scores * (1 - theano.tensor.fmatrix("excluded_items"))   # rnn_base.py:201-202
         out = dict(cell=cell, layers=np.array([H]), loss=loss, N=N, B=B, T=T, S=S, F=F, n_opt=n_opt, bidirectional=int(bi),
@@ -134,7 +168,7 @@ def main():
                    cost=float(cost), h_last=h_last.detach().numpy(), scores=det.detach().numpy(),
                    test_scores=test_scores.detach().numpy(), n_params=len(params), clip_changes=clip_changes,
                    unique=int(p.interactions_are_unique),
-                   names=np.array([n for n, _ in layout]), model_file=p._get_model_filename(1.0))
+                   names=np.array([n for n, _ in layout]), model_file=p._get_model_filename(1.0), **margin)
         for i, (q, g) in enumerate(zip(params, grads)):
             out["p%d" % i] = q.astype(np.float32)
             out["g%d" % i] = g.detach().numpy()

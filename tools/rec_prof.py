@@ -1,7 +1,7 @@
 """In-kernel cycle counters of the recurrent kernels (SBR_FLAG_PROFILE_REC): effective shader clock
 (s_memtime vs the 100 MHz s_memrealtime) and the split work / barrier-wait per wave.
-The profiling instances of rec_fwd_x6p are the bf16x6 ones (six MFMAs per product): the fp16x3 forward that runs by default
-has no counters yet (profiles/round1_h_rec_phases_c2.txt is the bf16x6 forward)."""
+The profiling instances follow the product form the launch would take (fp16x3 by default, bf16x6 with SBR_X6_F16=0;
+profiles/round1_h_rec_phases_c2.txt is the bf16x6 forward of round 1)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -12,7 +12,7 @@ committed under tests/golden/reference_layers/.  Nothing under tests/, bench.py 
 
 What is restated here is LIBRARY behaviour, from the published Theano 0.8 / Lasagne 0.2.dev1 documentation -- not the
 reference's code:
-  theano.tensor   dot, concatenate, switch, tanh, log, sqr, ones, flatten, diag, nnet.sigmoid / softmax /
+  theano.tensor   dot, concatenate, switch, tanh, log, sqr, ones, flatten, diag, nnet.sigmoid / softmax / relu /
                   categorical_crossentropy; tensor methods dimshuffle / astype / flatten(outdim) / negative-step slices /
                   integer-array indexing; `x += y` rebinds (symbolic variables are immutable)
   theano.scan     a Python loop over the leading axis (reversed for go_backwards), outputs stacked in iteration order
@@ -410,7 +410,8 @@ def install(floatX="float64"):
              ones=lambda shape: tt(np.ones([int(s) for s in shape])),
              flatten=lambda x, outdim=1: x.flatten(outdim), diag=lambda x: torch.diagonal(x).as_subclass(TT),
              ivector=_feed_var, fvector=_feed_var, fmatrix=_feed_var, imatrix=_feed_var)
-    _mod("theano.tensor.nnet", sigmoid=sigmoid, softmax=_softmax, categorical_crossentropy=_categorical_crossentropy)
+    _mod("theano.tensor.nnet", sigmoid=sigmoid, softmax=_softmax, categorical_crossentropy=_categorical_crossentropy,
+         relu=lambda x: torch.relu(x).as_subclass(TT))
 
     class RandomStreams(object):
         def __init__(self, seed=None):
