@@ -258,6 +258,13 @@ int sbr_dataset_destroy(sbr_dataset* d);
 /* pop_db[n_items] = item_popularity ** diversity_bias (rnn_one_hot.py:103; NULL: all 1);
  * sample_cdf[n_items] = cumsum(item_popularity ** sampling_bias) (rnn_sampling.py:159-163; NULL: uniform). */
 int sbr_dataset_set_tables(sbr_dataset* d, const float* pop_db, const double* sample_cdf);
+/* Options that shape a batch beyond the defaults.  ratings[nnz] (parallel to `items`, NULL = none): with --rf a step feeds the
+ * item index and n_items + the rating's one-hot index round(rating * 2) - 1 (rnn_base.py:590-642; model built with n_feat = 2,
+ * input_size = n_items + 10).  shuffle_targets != 0: --shuffle_targets -- a row's targets are a uniform random subset of the
+ * whole remaining sequence instead of its first items (target_selection.py:45-46).  The number of targets per row is the
+ * model's (n_targets of the multi-target losses, 1 otherwise).  --target_bias and the sequence-noise options change how many
+ * rows a user yields and stay with the host generator. */
+int sbr_dataset_set_options(sbr_dataset* d, const float* ratings, int shuffle_targets);
 /* Plans one pass over the users in `order` (n_users ids, NULL = file order) for batches of batch_size rows.
  * A trailing partial batch is carried into the next planned pass, as the reference's endless generator does.
  * n_batches: complete batches now available (indices 0..n_batches-1 for sbr_build_batch). */

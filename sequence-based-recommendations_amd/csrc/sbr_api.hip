@@ -1494,7 +1494,7 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     if (nm == "dh_last") { *dev_ptr = h->A(y.a_dhlast); *n_floats = (size_t)y.Bp * y.HLt; return SBR_OK; }
     if (nm == "batch_X") { *dev_ptr = (void*)h->bX; *n_floats = (size_t)y.Bp * y.T * y.F; return SBR_OK; }
     if (nm == "batch_lengths") { *dev_ptr = (void*)h->blen; *n_floats = y.Bp; return SBR_OK; }
-    if (nm == "batch_target") { *dev_ptr = (void*)h->btgt; *n_floats = y.S > 0 ? y.Bg : y.Bp; return SBR_OK; }
+    if (nm == "batch_target") { *dev_ptr = (void*)h->btgt; *n_floats = y.S > 0 ? y.Bg : (size_t)y.Bp * y.NT; return SBR_OK; }
     if (nm == "batch_pop") { *dev_ptr = (void*)h->bpop; *n_floats = y.Bp; return SBR_OK; }
     if (nm == "batch_samples") { *dev_ptr = (void*)h->bsmp; *n_floats = y.S; return SBR_OK; }
     if (nm == "prof") { *dev_ptr = h->A(y.a_prof); *n_floats = (size_t)2 * (y.Bp / 16) * 16 * 8 * 2; return SBR_OK; }

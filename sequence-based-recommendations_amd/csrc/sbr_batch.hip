@@ -10,6 +10,8 @@ struct sbr_dataset {
     hipStream_t stream;
     int* d_items; long long* d_off;
     float* d_popdb; double* d_cdf;
+    int* d_rate;                                    // rating one-hot index (0..9) of every interaction (--rf), or NULL
+    int shuffle_targets;                            // --shuffle_targets: the targets are drawn from the whole remaining sequence
     std::vector<int64_t> len;                       // host copy of the sequence lengths
     std::vector<int> pend_user, pend_k;             // trailing partial batch carried into the next pass
     std::vector<int> seg_user, seg_k, seg_row0, seg_batch, batch_begin;   // host plan (batch_begin: n_batches+1)
@@ -138,37 +140,68 @@ __global__ void __launch_bounds__(256) bb_split_kernel(const long long* __restri
     }
 }
 
-// One wave per local row: X row, length, target, pop**db.  Blocks past the rows draw the S negatives.
-__global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ items, const long long* __restrict__ off,
+// Position (0-based, inside the remaining sequence of n_rem items) of target j of global row g.  Next-item targets
+// (SelectTargets without options, target_selection.py:41-53): j.  --shuffle_targets (random.shuffle of the remaining sequence,
+// then the first n_targets of it): the j-th element of a uniform random k-subset in random order -- Floyd's algorithm on
+// hashed draws, which every caller of the same (seed, g) reproduces (the popularity weight of a CCE row and its target are
+// written by different lanes).  k <= 16 here (the launcher falls back beyond).
+__device__ __forceinline__ int bb_target_pos(unsigned long long seed, int g, int j, int k, int n_rem, int shuffle) {
+    if (!shuffle) return j;
+    int chosen[16];
+    for (int i = 0; i < k; ++i) {
+        const int top = n_rem - k + i;                              // draw t uniformly in [0, top]
+        const unsigned long long r = mix64(seed ^ mix64(0x7A67ull + ((unsigned long long)(unsigned)g << 8) + (unsigned)i));
+        int t = (int)(r % (unsigned long long)(top + 1));
+        for (int q = 0; q < i; ++q) if (chosen[q] == t) { t = top; break; }
+        chosen[i] = t;
+    }
+    // the set is uniform; a uniform order on top of it: rotate by a hashed amount and pick (k <= 16: any fixed bijection of a
+    // uniformly random set element works for j = 0, which is all the one-target heads read)
+    const unsigned long long r2 = mix64(seed ^ mix64(0x0DDull + (unsigned long long)(unsigned)g));
+    return chosen[(j + (int)(r2 % (unsigned long long)k)) % k];
+}
+
+// One wave per local row: X row (item id, + n_items + rating index with F == 2), length, pop**db of the first target.  Blocks
+// past the rows write the targets (NT per row, -1 behind the last) and draw the S negatives.
+__global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ items, const int* __restrict__ rate,
+                                                     const long long* __restrict__ off,
                                                      const int* __restrict__ split, const int* __restrict__ rowuser,
                                                      const float* __restrict__ popdb, const double* __restrict__ cdf,
-                                                     int n_items, int T, int row_offset, int local_rows, int Bp, int tgt_rows,
-                                                     int tgt_offset, int S, unsigned long long seed, int* __restrict__ X,
+                                                     int n_items, int T, int F, int NT, int shuffle, int row_offset, int local_rows, int Bp,
+                                                     int tgt_rows, int tgt_offset, int S, unsigned long long seed, int* __restrict__ X,
                                                      int* __restrict__ lengths, int* __restrict__ target, float* __restrict__ pop,
                                                      int* __restrict__ samples) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b < Bp) {
         if (b >= local_rows) {                                     // padded rows: index 0, length 0, popularity 1
-            for (int t = lane; t < T; t += 64) X[(size_t)b * T + t] = 0;
+            for (int t = lane; t < T * F; t += 64) X[(size_t)b * T * F + t] = 0;
             if (lane == 0) { lengths[b] = 0; pop[b] = 1.0f; }
             return;
         }
         const int g = row_offset + b, l = split[g];
         const long long o = off[rowuser[g]];
         const int start = max(0, l - T), n_in = l - start;         // rnn_base.py:410: at most max_length items before l
-        for (int t = lane; t < T; t += 64) X[(size_t)b * T + t] = t < n_in ? items[o + start + t] : 0;
+        for (int t = lane; t < T; t += 64) {
+            X[((size_t)b * T + t) * F] = t < n_in ? items[o + start + t] : 0;
+            if (F == 2) X[((size_t)b * T + t) * F + 1] = t < n_in ? n_items + rate[o + start + t] : 0;   // rnn_base.py:637-642
+        }
         if (lane == 0) {
             lengths[b] = n_in;
-            pop[b] = popdb ? popdb[items[o + l]] : 1.0f;           // rnn_one_hot.py:103
+            const int n_rem = (int)(off[rowuser[g] + 1] - o) - l;
+            const int k = min(n_rem, NT);
+            pop[b] = popdb ? popdb[items[o + l + bb_target_pos(seed, g, 0, k, n_rem, shuffle)]] : 1.0f;   // rnn_one_hot.py:103
         }
         return;
     }
     const int e = (b - Bp) * 64 + lane;
-    if (e < tgt_rows) {                                            // targets: the first item after the split (:407, n_targets=1)
-        const int g = tgt_offset + e;
-        target[e] = items[off[rowuser[g]] + split[g]];
+    if (e < tgt_rows * NT) {                                       // targets (target_selection.py:41-53, rnn_base.py:407)
+        const int g = tgt_offset + e / NT, j = e % NT;
+        const long long o = off[rowuser[g]];
+        const int l = split[g], n_rem = (int)(off[rowuser[g] + 1] - o) - l;
+        const int k = min(n_rem, NT);
+        target[e] = j < k ? items[o + l + bb_target_pos(seed, g, j, k, n_rem, shuffle)] : -1;
     }
-    const int si = e - ((tgt_rows + 63) / 64) * 64;
+    const int si = e - ((tgt_rows * NT + 63) / 64) * 64;
     if (si >= 0 && si < S) {
         const unsigned long long r = mix64(seed ^ mix64(0xA5A5ull + (unsigned long long)si));
         if (!cdf) samples[si] = (int)(r % (unsigned long long)n_items);          // np.random.choice(n_items, S) (rnn_sampling.py:191)
@@ -193,7 +226,7 @@ extern "C" int sbr_dataset_create(const int32_t* items, const int64_t* offsets, 
     CHECK_ARG(offsets[0] == 0 && nnz >= 0, "offsets must start at 0");
     sbr_dataset* d = new sbr_dataset();
     d->n_users = n_users; d->nnz = nnz; d->n_items = n_items; d->stream = (hipStream_t)stream;
-    d->d_items = nullptr; d->d_off = nullptr; d->d_popdb = nullptr; d->d_cdf = nullptr;
+    d->d_items = nullptr; d->d_off = nullptr; d->d_popdb = nullptr; d->d_cdf = nullptr; d->d_rate = nullptr; d->shuffle_targets = 0;
     d->d_seg_user = d->d_seg_k = d->d_seg_row0 = d->d_batch_begin = nullptr; d->cap_su = d->cap_sk = d->cap_sr = d->cap_bb = 0;
     d->d_split = d->d_rowuser = nullptr; d->cap_rows = 0; d->n_batches = 0; d->batch_size = 0;
     d->len.resize(n_users);
@@ -216,10 +249,28 @@ extern "C" int sbr_dataset_create(const int32_t* items, const int64_t* offsets, 
 
 extern "C" int sbr_dataset_destroy(sbr_dataset* d) {
     if (!d) return SBR_OK;
-    (void)hipFree(d->d_items); (void)hipFree(d->d_off); (void)hipFree(d->d_popdb); (void)hipFree(d->d_cdf);
+    (void)hipFree(d->d_items); (void)hipFree(d->d_off); (void)hipFree(d->d_popdb); (void)hipFree(d->d_cdf); (void)hipFree(d->d_rate);
     (void)hipFree(d->d_seg_user); (void)hipFree(d->d_seg_k); (void)hipFree(d->d_seg_row0); (void)hipFree(d->d_batch_begin);
     (void)hipFree(d->d_split); (void)hipFree(d->d_rowuser);
     delete d;
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_set_options(sbr_dataset* d, const float* ratings, int shuffle_targets) {
+    CHECK_ARG(d, "null dataset");
+    d->shuffle_targets = shuffle_targets != 0;
+    (void)hipFree(d->d_rate); d->d_rate = nullptr;
+    if (ratings) {
+        // rating one-hot index: round(rating * 2) - 1 on a scale of ten (rnn_base.py:590-605), Python 2's round (half away from zero)
+        std::vector<int> idx((size_t)std::max<int64_t>(d->nnz, 1));
+        for (int64_t i = 0; i < d->nnz; ++i) {
+            const long v = (long)floor((double)ratings[i] * 2.0 + 0.5) - 1;
+            idx[i] = (int)(((v % 10) + 10) % 10);
+        }
+        SBR_HIP(hipMalloc(&d->d_rate, idx.size() * sizeof(int)));
+        SBR_HIP(hipMemcpyAsync(d->d_rate, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, d->stream));
+        SBR_HIP(hipStreamSynchronize(d->stream));
+    }
     return SBR_OK;
 }
 
@@ -294,8 +345,10 @@ extern "C" int sbr_dataset_plan_segments(sbr_dataset* d, int64_t* n_segments, co
 extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uint64_t seed) {
     CHECK_ARG(h && d, "null handle / dataset");
     const Layout& y = h->lay;
-    CHECK_ARG(y.F == 1, "the native batch builder covers one index per step (no --rf/--mf/--uf features)");
-    CHECK_ARG(d->n_items == y.N && y.cfg.input_size == y.N, "dataset has %d items, the model %d", d->n_items, y.N);
+    CHECK_ARG(y.F == 1 || (y.F == 2 && d->d_rate && y.cfg.input_size == y.N + 10),
+              "the native batch builder covers the item index and, with ratings attached (sbr_dataset_set_options), the rating index");
+    CHECK_ARG(d->n_items == y.N && (y.cfg.input_size == y.N || y.F == 2), "dataset has %d items, the model %d", d->n_items, y.N);
+    CHECK_ARG(!d->shuffle_targets || y.NT <= 16, "shuffled targets: at most 16 targets per row on the device");
     CHECK_ARG(d->batch_size == y.Bg, "the pass was planned for batches of %d rows, the model's global batch is %d", d->batch_size, y.Bg);
     CHECK_ARG(batch >= 0 && batch < d->n_batches, "batch %lld outside the planned pass [0,%lld)", (long long)batch, (long long)d->n_batches);
     CHECK_ARG(d->stream == h->stream, "dataset and engine must share one stream");
@@ -312,9 +365,9 @@ extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uin
     SBR_LAUNCH(hipGetLastError());
     const bool sampled = y.S > 0;
     const int tgt_rows = sampled ? y.Bg : y.B, tgt_offset = sampled ? 0 : y.cfg.row_offset;
-    const int extra = (tgt_rows + 63) / 64 + (y.S + 63) / 64;
-    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(d->d_items, d->d_off, d->d_split, d->d_rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
-                                                y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, (int*)h->A(y.a_X),
+    const int extra = (tgt_rows * y.NT + 63) / 64 + (y.S + 63) / 64;
+    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(d->d_items, d->d_rate, d->d_off, d->d_split, d->d_rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
+                                                y.F, y.NT, d->shuffle_targets, y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, (int*)h->A(y.a_X),
                                                 (int*)h->A(y.a_len), (int*)h->A(y.a_tgt), h->A(y.a_pop), (int*)h->A(y.a_smp));
     SBR_LAUNCH(hipGetLastError());
     h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);

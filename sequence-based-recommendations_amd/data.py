@@ -71,14 +71,17 @@ class SequenceGenerator(object):
 class NativeBatchBuilder(object):
     """Training batches built on the device (sbr_dataset_* / sbr_build_batch in include/sbr_rnn.h):
     the stand-in for `_gen_mini_batch(sequence_noise(dataset.training_set()))` + `_prepare_input`
-    (rnn_base.py:373-420, rnn_one_hot.py:83-106, rnn_sampling.py:159-194) under the default training options.
+    (rnn_base.py:373-420, rnn_one_hot.py:83-106, rnn_sampling.py:159-194, rnn_margin.py:112-147) for every option that leaves
+    the number of rows a user yields alone: --rf, --n_targets, --shuffle_targets, --db, --sampling_bias (not --target_bias and
+    the sequence noise, which stay with the host generator).
 
     The training file is parsed once (SequenceGenerator.load) and uploaded as CSR.  Per pass the users are walked in
     file order, or reshuffled like data_handling.py:139-141 with --tshuffle; the walk prints the reference's
     "Opening file (n)" line and keeps `training_set.epochs` (the fractional pass counter the training loop records,
     rnn_base.py:312) up to date per batch.  `next()` makes the next batch the engine's current batch."""
 
-    def __init__(self, engine, training_set, n_items, batch_size, pop_db=None, sample_cdf=None, seed=None):
+    def __init__(self, engine, training_set, n_items, batch_size, pop_db=None, sample_cdf=None, seed=None, ratings=False,
+                 shuffle_targets=False):
         from .engine import DeviceDataset
         if not hasattr(training_set, "users"):
             training_set.load()
@@ -88,6 +91,9 @@ class NativeBatchBuilder(object):
         items = np.concatenate(training_set.items).astype(np.int32) if len(lengths) else np.zeros(0, np.int32)
         self.ds = DeviceDataset(engine, items, offsets, n_items)
         self.ds.set_tables(pop_db, sample_cdf)
+        if ratings or shuffle_targets:      # --rf: the rating index rides beside the item index; --shuffle_targets
+            r = (np.concatenate(training_set.ratings) if len(lengths) else np.zeros(0)) if ratings else None
+            self.ds.set_options(r, shuffle_targets)
         self.n_users = len(lengths)
         self.seed = int(seed if seed is not None else random.getrandbits(63))
         self.passes, self.cursor, self.n_batches, self.built = 0, 0, 0, 0

@@ -62,7 +62,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
            "sbr_sparse_unpack_add", "sbr_dense_ranges",
-           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_plan_pass",
+           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
 _lib = None
@@ -125,6 +125,7 @@ def load_library(path=None):
     lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]
     lib.sbr_dataset_destroy.argtypes = [vp]
     lib.sbr_dataset_set_tables.argtypes = [vp, vp, vp]
+    lib.sbr_dataset_set_options.argtypes = [vp, vp, ctypes.c_int]
     lib.sbr_dataset_plan_pass.argtypes = [vp, vp, ctypes.c_int32, i64p]
     lib.sbr_dataset_plan_segments.argtypes = [vp, i64p, ctypes.POINTER(i32p), ctypes.POINTER(i32p), ctypes.POINTER(i32p),
                                               ctypes.POINTER(i32p)]
@@ -194,6 +195,12 @@ class DeviceDataset(object):
         c = None if sample_cdf is None else np.ascontiguousarray(sample_cdf, dtype=np.float64)
         self.engine._check(self.lib.sbr_dataset_set_tables(self.d, None if a is None else a.ctypes.data,
                                                            None if c is None else c.ctypes.data))
+
+    def set_options(self, ratings=None, shuffle_targets=False):
+        """ratings (nnz,) parallel to the items: --rf feeds item index + rating index (model: n_feat 2, input_size N + 10);
+        shuffle_targets: --shuffle_targets (sbr_dataset_set_options)."""
+        r = None if ratings is None else np.ascontiguousarray(ratings, dtype=np.float32)
+        self.engine._check(self.lib.sbr_dataset_set_options(self.d, None if r is None else r.ctypes.data, 1 if shuffle_targets else 0))
 
     def plan_pass(self, order, batch_size):
         o = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
@@ -398,7 +405,7 @@ class RNNEngine(object):
         X (B,T), lengths (B,), target, pop (B,), samples (S,)."""
         out = {}
         for name, rows in (("X", self.local_batch * self.max_length * self.n_feat), ("lengths", self.local_batch),
-                           ("target", self.batch_size if self.n_samples else self.local_batch), ("pop", self.local_batch),
+                           ("target", self.batch_size if self.n_samples else self.local_batch * self.n_targets), ("pop", self.local_batch),
                            ("samples", self.n_samples)):
             if rows == 0:
                 continue

@@ -305,12 +305,16 @@ class RNNBase(object):
             yield flush()
 
     def _native_batch_builder(self, dataset):
-        """Device-side batch builder when the options are the defaults it covers (one item index per step, next-item
-        target, no sequence noise); None -> the reference-style host generator.  SBR_NATIVE_BATCHES=0 disables it."""
+        """Device-side batch builder for the options it covers (item index, + rating index with --rf; next-item or shuffled
+        targets, --n_targets of them for the multi-target losses; --db, --sampling_bias); None -> the reference-style host
+        generator (sequence noise, --target_bias).  SBR_NATIVE_BATCHES=0 disables it."""
         if os.environ.get("SBR_NATIVE_BATCHES", "1") == "0":
             return None
         ts = self.target_selection
-        if self._input_size() != 1 or self.sequence_noise.name != "" or ts.n_targets != 1 or ts.shuffle or ts.bias >= 0.0:
+        multi = isinstance(self, RNNMargin)                  # only the multi-target losses look past the first target
+        if self.sequence_noise.name != "" or ts.bias >= 0.0:
+            return None      # they change how many rows a user yields: the host plan of a pass cannot know (include/sbr_rnn.h)
+        if ts.shuffle and multi and self._engine_targets() > 16:
             return None
         from .data import NativeBatchBuilder
         pop = np.asarray(dataset.item_popularity, dtype=np.float64)
@@ -318,7 +322,8 @@ class RNNBase(object):
         sb = float(getattr(self, "sampling_bias", 0.0))
         cdf = np.cumsum(np.power(pop, sb)) if (sb > 0.0 and getattr(self, "effective_sampling", 0)) else None
         return NativeBatchBuilder(self.engine, dataset.training_set, self.n_items, self.batch_size,
-                                  pop_db=np.power(pop, db).astype(np.float32), sample_cdf=cdf)
+                                  pop_db=np.power(pop, db).astype(np.float32), sample_cdf=cdf,
+                                  ratings=self.use_ratings_features, shuffle_targets=ts.shuffle)
 
     def _compute_validation_metrics(self, metrics):
         from .data import Evaluator
@@ -515,5 +520,3 @@ class RNNMargin(RNNBase):
         """The generic compiled test function (rnn_base.py:196-209) on RAW outputs: viewed items are multiplied by 0, not removed."""
         return 2 if self.interactions_are_unique else 0
 
-    def _native_batch_builder(self, dataset):
-        return None      # the device batch builder produces one target per row

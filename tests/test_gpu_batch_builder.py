@@ -184,3 +184,64 @@ def test_lagged_train_step_returns_the_same_costs_one_call_late():
     assert np.allclose(c0, c1, rtol=1e-5, atol=0)
     assert all(np.allclose(a, b, rtol=1e-4, atol=1e-6) for a, b in zip(p0, p1))
     assert c0[-1] < c0[0]
+
+
+def test_rating_feature_multiple_targets_and_shuffled_targets():
+    """The options the device builder covers beyond the defaults (sbr_dataset_set_options): --rf (second index = n_items +
+    rating one-hot index, rnn_base.py:590-642), --n_targets of the multi-target losses (the first min(k, remaining) items
+    after the split, -1 behind them; target_selection.py:53), --shuffle_targets (a uniform random subset of the whole
+    remaining sequence, :45-46)."""
+    from sbr_amd.engine import RNNEngine, DeviceDataset
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(3, 30, size=50)
+    items, offsets, n_items = encoded_dataset(lengths)
+    ratings = (0.5 + 0.5 * ((items * 7) % 10)).astype(np.float32)              # 0.5 .. 5.0 in halves: every one-hot index occurs
+    B, T, NT = 32, 8, 3
+    eng = RNNEngine(cell="GRU", layers=[16], n_items=n_items, max_length=T, batch_size=B, loss="hinge", n_targets=NT,
+                    n_feat=2, input_size=n_items + 10)
+    ds = DeviceDataset(eng, items, offsets, n_items)
+    ds.set_options(ratings, False)
+    nb = ds.plan_pass(None, B)
+    assert nb >= 3
+    for b in range(nb):
+        eng.build_batch(ds, b, seed=50 + b)
+        cur = eng.current_batch()
+        X, lens, tgt = cur["X"], cur["lengths"], cur["target"].reshape(B, NT)
+        for r in range(B):
+            u, l = (tgt[r, 0] - 1) // 64, (tgt[r, 0] - 1) % 64
+            seq, rat = items[offsets[u]:offsets[u + 1]], ratings[offsets[u]:offsets[u + 1]]
+            start = max(0, l - T)
+            assert np.array_equal(X[r, :lens[r], 0], seq[start:l])
+            want_idx = (np.floor(rat[start:l] * 2 + 0.5).astype(int) - 1) % 10
+            assert np.array_equal(X[r, :lens[r], 1], n_items + want_idx)        # python-2 round(), one-hot on a scale of ten
+            assert not X[r, lens[r]:].any()
+            k = min(NT, lengths[u] - l)
+            assert np.array_equal(tgt[r, :k], seq[l:l + k]) and np.all(tgt[r, k:] == -1)
+    # shuffled targets: every target lies in the remaining sequence, the targets of a row are distinct positions, and over
+    # many seeds the FIRST target is uniform over the remaining items
+    ds.set_options(ratings, True)
+    eng.build_batch(ds, 0, seed=1000)
+    base = eng.current_batch()["target"].reshape(B, NT).copy()
+    eng.build_batch(ds, 0, seed=1000)                                           # deterministic per seed
+    assert np.array_equal(base, eng.current_batch()["target"].reshape(B, NT))
+    hist, want = np.zeros(4), np.zeros(4)
+    n_draws = 0
+    for sd in range(400):
+        eng.build_batch(ds, 0, seed=sd)
+        cur = eng.current_batch()
+        tgt, lens, X = cur["target"].reshape(B, NT), cur["lengths"], cur["X"]
+        for r in range(B):
+            u = (X[r, 0, 0] - 1) // 64
+            l = (X[r, lens[r] - 1, 0] - 1) % 64 + 1                             # the split point: one past the last input item
+            pos = (tgt[r][tgt[r] >= 0] - 1) % 64
+            users = (tgt[r][tgt[r] >= 0] - 1) // 64
+            assert np.all(users == u) and np.all(pos >= l) and np.all(pos < lengths[u])
+            assert len(set(pos.tolist())) == len(pos) == min(NT, lengths[u] - l)
+            n_rem = lengths[u] - l
+            if n_rem >= 4:
+                hist[int((pos[0] - l) * 4 // n_rem)] += 1                       # quartile of the remaining sequence
+                want += np.bincount(np.arange(n_rem) * 4 // n_rem, minlength=4) / n_rem      # what a uniform draw gives
+                n_draws += 1
+    assert n_draws > 2000 and np.all(np.abs(hist - want) / n_draws < 0.04), (hist / n_draws, want / n_draws)
+    assert hist[3] / n_draws > 0.15                                             # next-item targets would put everything in the first quartile
+    ds.close(); eng.close()

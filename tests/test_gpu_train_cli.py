@@ -160,3 +160,29 @@ def test_raw_file_to_trained_model_through_preprocess(tmp_path):
     assert best_file is not None and 0.0 <= metrics["sps"] <= 1.0 and np.isfinite(metrics["ndcg"])
     res = Te.main(["-d", root, "-b", "8", "--max_length", "10", "--r_t", "GRU", "--r_l", "16", "--save", "--metrics", "sps,recall"])
     assert len(res) == 2 and len(glob.glob(root + "results/rnn_*")) == 1
+
+
+@pytest.mark.parametrize("extra,native", [
+    (["--rf"], True), (["--shuffle_targets"], True), (["--loss", "hinge", "--n_targets", "3"], True),
+    (["--loss", "logit", "--n_targets", "2", "--shuffle_targets", "--rf"], True),
+    (["--loss", "BPR", "--sampling", "8", "--sampling_bias", "0.5", "--db", "0.3", "--rf"], True),
+    (["--target_bias", "0.5"], False), (["--n_dropout", "0.1"], False), (["--n_swap", "0.2", "--rf"], False)])
+def test_which_options_train_on_device_built_batches(tmp_path, extra, native):
+    # every option that leaves the number of rows a user yields alone is served by the device batch builder
+    # (include/sbr_rnn.h: sbr_dataset_set_options); --target_bias and the sequence noise keep the host generator
+    from sbr_amd import options as parse, train as T
+    from sbr_amd.data import DataHandler
+    root = make_dataset(str(tmp_path / "ds"))
+    argv = ["-d", root, "-b", "8", "--max_length", "10", "--r_t", "GRU", "--r_l", "16"] + extra
+    args = parse.command_parser(parse.predictor_command_parser, parse.training_command_parser, T.early_stopping_command_parser, argv=argv)
+    predictor = parse.get_predictor(args)
+    dataset = DataHandler(dirname=root)
+    predictor.prepare_model(dataset)
+    predictor.set_dataset(dataset)
+    nb = predictor._native_batch_builder(dataset)
+    assert (nb is not None) == native
+    if nb is not None:
+        nb.close()
+    res = predictor.train(dataset, max_iter=12, progress=10 ** 9, autosave="None")
+    assert np.isfinite(res[0]["sps"][-1]) if isinstance(res, tuple) else True
+    predictor.engine.close()
