@@ -183,6 +183,5 @@ def test_which_options_train_on_device_built_batches(tmp_path, extra, native):
     assert (nb is not None) == native
     if nb is not None:
         nb.close()
-    res = predictor.train(dataset, max_iter=12, progress=10 ** 9, autosave="None")
-    assert np.isfinite(res[0]["sps"][-1]) if isinstance(res, tuple) else True
+    predictor.train(dataset, max_iter=12, progress=10 ** 9, autosave="None")      # twelve steps on those batches: finite costs or it raises
     predictor.engine.close()
