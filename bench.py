@@ -32,6 +32,7 @@ CONFIGS = {
     "c1": ("LSTM", [20], 3706, "CCE", 0),        # configs[0]: the reference's own CPU-runnable case
     "c4": ("LSTM", [256], 26744, "CCE", 0),      # configs[3] shape (per-GPU part)
     "c3": ("LSTM", [256], 100000, "Blackout", 32),
+    "l128": ("LSTM", [128], 3706, "CCE", 0),     # C2's shape with the other gated cell (the pipelined 128-unit kernels' LSTM form)
     "c5": ("LSTM", [512, 512], 1000000, "Blackout", 32),   # configs[4] shape (per-GPU part): 41 GB arena, dense Adam over 2.6 G parameters
 }
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact f32

@@ -622,7 +622,7 @@ static int tail_plan(sbr_handle* h, int* ch_out) {
     RecArgs a; memset(&a, 0, sizeof(a));
     a.cell = y.cfg.cell; a.T = y.T; a.Bp = y.Bp; a.H = y.layer[0].H; a.Hp = y.layer[0].Hp; a.G = y.G; a.clip = y.cfg.grad_clip;
     a.rpt = h->rpt; a.x6_split = h->x6_split; a.x6_pipe = h->x6_pipe; a.n_in = y.layer[0].n_in_p;
-    a.hs = h->A(y.layer[0].a_hs);
+    a.hs = h->A(y.layer[0].a_hs); a.cs = h->A(y.layer[0].a_cs);
     for (int k = 0; k < 4; ++k) a.g[k] = h->A(y.layer[0].a_g[k]);
     if (!sbr_rec_x6p_tail_ok(a)) return 0;
     int nc = std::min(std::min(y.tail_keys, h->tail_chunks_max), y.T / 16);

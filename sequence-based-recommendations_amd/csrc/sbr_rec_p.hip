@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;      // operand fragment: fp16 (two planes) or bf16 (three planes)
     constexpr int NP = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, KB = KBH, GHP = G * HP;
-    static_assert(G <= 3, "W_hid plane 3 does not fit the register file with four gates");
+    static_assert(G <= 3 || F16, "three W_hid planes of four gates do not fit the register file: an LSTM runs on the two fp16 planes only");
     constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW, BUFB = 3 * PLANEB;
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
     char* hbuf = smem_p;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, 16));
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));  // workgroup-uniform: all four rows
 
-    OPV W1[G][KB], W2[G][KB], W3[G][KB];                 // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
+    OPV W1[G][KB], W2[G][KB], W3[F16 ? 1 : G][F16 ? 1 : KB];   // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     if (!(X6P_DBG & 256)) asm("" : "+v"(w));            // see split2_f16.  NOT volatile: volatile asms keep their order and
                                                                         // serialised the 96 loads of this prologue (+20 us per launch)
                     split2_f16(w, b1, b2);
-                    W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b2;          // (W3 unused)
+                    W1[g][kb][e] = b1; W2[g][kb][e] = b2;
                 } else {
                     __bf16 b1, b2, b3;
                     split3(w, b1, b2, b3);
@@ -152,6 +152,11 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     if (X6P_DBG & 2048) { dbg_one = (float)blockIdx.x; asm volatile("" : "+v"(dbg_one)); }
     float h = a.hinit[u];
     stf(a.hs, bo_h, h);
+    float c = 0.f, pi = 0.f, pf = 0.f, po = 0.f;                 // LSTM: cell state and the peepholes of this lane's unit
+    if (CELL == CELL_LSTM) {
+        c = a.cinit[u]; pi = a.peep[u]; pf = a.peep[HP + u]; po = a.peep[2 * HP + u];
+        stf(a.cs, bo_h, c);
+    }
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
     const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16);     // A operand: tile row m = j holds batch row j >> 2
     auto publish_h = [&](int buf) {
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     // the address arithmetic (a 64-bit multiply-add, a 64-bit add) sat on the VALU beside the partner's MFMA stream:
     // 177 us against 153 us for the same kernel reading a pre-gathered xt.
     // Per iteration the wave issues: stores of step t (NSF) < the DMA piece of step t + XPD.
-    constexpr int XPD = 4, NSF = CELL == CELL_VANILLA ? 1 : 5, XSTG = G * 256;
+    constexpr int XPD = 4, NSF = CELL == CELL_VANILLA ? 1 : (CELL == CELL_LSTM ? 6 : 5), XSTG = G * 256;
     constexpr int XOFF_OFF = (2 * BUFB + 64 + 255) & ~255;
     const int xring_off = (XOFF_OFF + R * T * 4 + 255) & ~255;
     unsigned* xo_tab = (unsigned*)(smem_p + XOFF_OFF);
@@ -385,10 +390,17 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 const float cc = tanh_fast(fmaf(rg, hc, x[IC] + bias_c));
                 hn = fmaf(ug, cc - h, h);                         // (1 - u) h + u c
                 sv[0] = rg; sv[1] = ug; sv[2] = cc; sv[3] = hc;
+            } else if (CELL == CELL_LSTM) {                       // sparse_lstm.py:397-423 (peepholes, masked rows copy h and c)
+                float aa[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) aa[g] = acc[g][0];
+                hn = h;
+                cell_forward<CELL_LSTM, true>(x, aa, t < mylen, hn, c, pi, pf, po, sv);
             } else {
                 { const float pre = x[0] + acc[0][0]; hn = a.relu ? fmaxf(pre, 0.0f) : tanh_fast(pre); }
             }
-            if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; }            // uniform branch: no select while no row is masked
+            if (CELL == CELL_LSTM) { h = hn; if (F16) asm volatile("" : "+v"(h)); }   // (cell_forward has applied the mask)
+            else if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; }            // uniform branch: no select while no row is masked
             else { h = t < mylen ? hn : h; if (F16) asm volatile("" : "+v"(h)); }   // (pinned for split2_f16 either way)
         }
         if (t + 1 < tmax) {
@@ -403,6 +415,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 for (int k = 0; k < 4; ++k) st_s((const char*)a.g[k] + off_t, bo_g, sv[k]);
             }
             st_s((const char*)a.hs + off_t + st_h, bo_h, h);
+            if (CELL == CELL_LSTM) st_s((const char*)a.cs + off_t + st_h, bo_h, c);
         }
         off_t += st_h;
         if constexpr (FUSE) {
@@ -415,6 +428,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
+        if (CELL == CELL_LSTM) stf((char*)a.cs + off_t + st_h, bo_h, c);
         off_t += st_h;
     }
     if ((X6P_DBG & 512) && T < 0) a.fault[1] = (int)threadIdx.x;  // keeps the live-in v0 where it is
@@ -457,7 +471,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;
     constexpr int NP = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate
-    static_assert(G <= 3, "W_hid plane 3 does not fit the register file with four gates");
+    static_assert(G <= 3 || F16, "three W_hid planes of four gates do not fit the register file: an LSTM runs on the two fp16 planes only");
     constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW, BUFB = NP * PLANEB;
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
     char* dbuf = smem_p;                                 // [2][3 planes][R rows][DROW]
@@ -509,7 +523,15 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
     float dh = 0.f, dc = 0.f;
     if (first) { if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u]; }
-    else dh = a.state[(size_t)row * HP + u];
+    else {
+        dh = a.state[(size_t)row * HP + u];
+        if (CELL == CELL_LSTM) dc = a.state[(size_t)Bp * HP + (size_t)row * HP + u];
+    }
+    // LSTM: the row-major saved array is cs (slot t = c_{t-1}; h_{t-1} is not needed by the gate math), and "hprev" / "hnew"
+    // below carry c_{t-1} / c_t
+    const char* const sbase = CELL == CELL_LSTM ? (const char*)a.cs : (const char*)a.hs;
+    float pi = 0.f, pf = 0.f, po = 0.f, sdp[3] = {0.f, 0.f, 0.f};
+    if (CELL == CELL_LSTM) { pi = a.peep[u]; pf = a.peep[HP + u]; po = a.peep[2 * HP + u]; }
     float sdb[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) sdb[g] = 0.f;
@@ -536,11 +558,11 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         const unsigned b0 = (unsigned)sbr_blocked_index(0, blockIdx.x * R, wave * 16, Bp, HP) * 4u;     // the wave's block
         const int k = lane >> 4;
         const char* gk = k == 0 ? (const char*)a.g[0] : k == 1 ? (const char*)a.g[1] : k == 2 ? (const char*)a.g[2] : (const char*)a.g[3];
-        bo_ga = b0 + (unsigned)(size_t)(gk - (const char*)a.hs) + (unsigned)(lane & 15) * 16u;
+        bo_ga = b0 + (unsigned)(size_t)(gk - sbase) + (unsigned)(lane & 15) * 16u;
     }
     auto dma_saved = [&](size_t o, int slot) {                   // activations of the step at byte offset o -> ring slot
         const unsigned m = ring_wave + (unsigned)slot * STG;
-        const char* base = (const char*)a.hs + o;
+        const char* base = sbase + o;
         lds_dma_x4(m, base, bo_hs4, 0xFFFFull);
         if (CELL != CELL_VANILLA) lds_dma_x4(m + 256, base, bo_ga, ~0ull);
     };
@@ -557,7 +579,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         }
     };
     auto load_saved = [&](size_t o) {                            // activations of the step at byte offset o = t * st_h
-        hprev = ldf((const char*)a.hs + o, bo_h);
+        hprev = ldf(sbase + o, bo_h);
         if (CELL != CELL_VANILLA) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) sv[k] = ldf((const char*)a.g[k] + o, bo_g);
@@ -598,6 +620,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             take_saved(0);                                        // the first step's values
         } else load_saved((size_t)(t_live - 1) * st_h);
         if (CELL == CELL_VANILLA) hnew = a.hs[(size_t)t_live * Bp * HP + (size_t)row * HP + u];
+        if (CELL == CELL_LSTM) hnew = a.cs[(size_t)t_live * Bp * HP + (size_t)row * HP + u];
     }
     // k-blocks in the order they are visited: columns of units 0-63 (all gates), then of units 64-127
     constexpr int NH = KB / 2;
@@ -615,6 +638,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         if (EXT) dh += dhe;
         char* lds = dbuf + (n & 1) * BUFB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+        if (CELL == CELL_LSTM) {
+            cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, 0.f, hprev, hnew, 0.f, pi, pf, po, dxi, dhi, dp, false);
+            sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2];
+        } else
         cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, 0.f, 0.f, hnew, 0.f, 0.f, 0.f, dxi, dhi, dp, a.relu != 0);
         if constexpr (WT) {
             // Progress: everything but the youngest NL + NST operations (the loads and stores the previous iteration issued) is
@@ -646,7 +673,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
         }
         lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
-        if (CELL == CELL_VANILLA) hnew = hprev;
+        if (CELL != CELL_GRU) hnew = hprev;
         if constexpr (RING) {                                     // loads first: see the progress note above
             __builtin_amdgcn_sched_barrier(0);
             dma_saved(t - PD >= a.t_lo ? off_h - (size_t)PD * st_h : (size_t)a.t_lo * st_h, slot);   // step t - PD into the slot just read
@@ -655,6 +682,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             st_si<0, WT>(dx_t, bo_x, dxi[0]);
             if (G > 1) st_si<HP * 4, WT>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
             if (G > 2) st_si<2 * HP * 4, WT>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
+            if (G > 3) st_si<3 * HP * 4, WT>(dx_t, bo_x, dxi[G > 3 ? 3 : 0]);
             if (CELL == CELL_GRU) st_si<0, WT>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
             __builtin_amdgcn_sched_barrier(0);
             { unsigned long long q0 = 0; if (PROF) q0 = clock64();
@@ -666,6 +694,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             st_si<0>(dx_t, bo_x, dxi[0]);
             if (G > 1) st_si<HP * 4>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
             if (G > 2) st_si<2 * HP * 4>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
+            if (G > 3) st_si<3 * HP * 4>(dx_t, bo_x, dxi[G > 3 ? 3 : 0]);
             if (CELL == CELL_GRU) st_si<0>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
             __builtin_amdgcn_sched_barrier(0);
             load_saved(t > a.t_lo ? off_h - st_h : off_h);            // step t-1: unconditional, clamped
@@ -780,12 +809,16 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         o[5] = p_n; o[6] = p_m; o[7] = p_vm;      // loop top -> loads / stores issued (incl. o[7]: the wait for the ring) | operands + gate + MFMAs
     }
 
-    if (!last) a.state[(size_t)row * HP + u] = dh;               // hand dh to the next chunk launch
+    if (!last) {                                                  // hand dh (dc) to the next chunk launch
+        a.state[(size_t)row * HP + u] = dh;
+        if (CELL == CELL_LSTM) a.state[(size_t)Bp * HP + (size_t)row * HP + u] = dc;
+    }
     float* part = a.part + ((size_t)a.chunk * gridDim.x + blockIdx.x) * (GHP + 5 * HP);
     float v[G + 5];
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] = sdb[g];
-    v[G] = 0.f; v[G + 1] = 0.f; v[G + 2] = 0.f; v[G + 3] = 0.f;
+    v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2];          // peephole gradients (LSTM; zero otherwise)
+    v[G + 3] = CELL == CELL_LSTM && last ? dc : 0.f;
     v[G + 4] = last ? dh : 0.f;                                   // init-state gradient comes from the last chunk only
 #pragma unroll
     for (int k = 0; k < G + 5; ++k) {
@@ -807,8 +840,20 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
 // ---------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes() { return 2 * 3 * R * (size_t)(HP * 2 + 32) + 64; }
 
+static bool x6p_f16_fwd(const RecArgs& a) {                        // forward products as fp16 x3 (see split2_f16); a rectified
+    const char* fe = getenv("SBR_X6_F16");                         // state is unbounded, the fp16 split needs |h| < 65504
+    return (fe ? atoi(fe) != 0 : true) && !a.relu;                 // (read per launch: the tests flip it)
+}
+static bool x6p_f16_bwd(const RecArgs& a) {     // the operand that carries gradients is bounded by the reference's own gradient clip
+    const char* fe = getenv("SBR_X6_F16_BWD");
+    return (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
+}
+
 bool sbr_rec_x6p_ok(const RecArgs& a) {
-    if (!a.x6_pipe || a.f32_mfma || a.Hp != HP || a.rpt != R || !a.x6_split || a.G > 3) return false;
+    if (!a.x6_pipe || a.f32_mfma || a.Hp != HP || a.rpt != R || !a.x6_split) return false;
+    // four gates: W_hid fits the register file as two fp16 planes only, so an LSTM runs here while BOTH directions take their
+    // fp16 forms (one answer for the forward and the backward launch of a step: they share the saved activations' layout)
+    if (a.G > 3 && !(x6p_f16_fwd(a) && x6p_f16_bwd(a))) return false;
     if ((size_t)a.Bp * a.G * HP * 4 >= ((size_t)1 << 32)) return false;          // 32-bit per-lane byte offsets
     if (a.gX && (size_t)a.n_in * a.G * HP * 4 >= ((size_t)1 << 32)) return false; // ... also into W_in (fused gather)
     if (a.gX && a.T > SBR_X6P_FUSE_MAX_T) return false;                            // its row-offset table lives in LDS
@@ -827,9 +872,12 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool fuse = a.gX != nullptr;
-    const char* fe = getenv("SBR_X6_F16");                         // read per launch: the tests flip it
-    const bool f16 = (fe ? atoi(fe) != 0 : true) && !a.relu;       // forward products as fp16 x3 (see split2_f16); a rectified
-                                                                   // state is unbounded, the fp16 split needs |h| < 65504
+    const bool f16 = x6p_f16_fwd(a);
+    if constexpr (CELL == CELL_LSTM) {
+        if (!f16) return hipErrorInvalidValue;                     // (sbr_rec_x6p_ok says when)
+        if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, true>)); }
+        else { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, true>)); }
+    } else
     if (a.prof && f16) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, true>)); }
     else if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, false, true>)); }
@@ -848,10 +896,9 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool ext = a.dh_ext != nullptr;
-    const char* fe = getenv("SBR_X6_F16_BWD");                     // read per launch: the tests flip it
-    // fp16 x3 products for the BPTT chain: the operand that carries gradients is bounded by the reference's own gradient clip
-    const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
+    const bool f16 = x6p_f16_bwd(a);                               // fp16 x3 products for the BPTT chain
     if (a.progress && (ext || !f16)) return hipErrorInvalidValue;               // (sbr_rec_x6p_tail_ok says when)
+    if (CELL == CELL_LSTM && !f16) return hipErrorInvalidValue;                 // (sbr_rec_x6p_ok)
     if (a.prof && f16 && !ext) {      // in-kernel counters for the fp16x3 forms too (tools/tail_prof.py)
         if (a.progress) X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 1>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 0>));
         return hipGetLastError();
@@ -861,6 +908,7 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     const bool ring = (re ? atoi(re) != 0 : false) && f16 && !ext && !a.prof && !a.progress && sbr_rec_x6p_tail_ok(a);
     if (a.progress) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 1>)); }
     else if (ring) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 2>)); }
+    else if constexpr (CELL == CELL_LSTM) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }
     else if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }
     else { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, false>)); }
@@ -870,10 +918,10 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
 
 // the write-through / progress form of the backward kernel exists for the fp16x3 products of a top (single) layer
 bool sbr_rec_x6p_tail_ok(const RecArgs& a) {
-    const char* fe = getenv("SBR_X6_F16_BWD");
-    const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
-    for (int k = 0; k < 4 && a.cell != SBR_CELL_VANILLA; ++k) {      // one scalar base serves hs and the gate arrays (LDS-DMA loads)
-        const ptrdiff_t d = (const char*)a.g[k] - (const char*)a.hs;
+    const bool f16 = x6p_f16_bwd(a);
+    const char* sbase = a.cell == SBR_CELL_LSTM ? (const char*)a.cs : (const char*)a.hs;
+    for (int k = 0; k < 4 && a.cell != SBR_CELL_VANILLA; ++k) {      // one scalar base serves hs (cs) and the gate arrays (LDS-DMA loads)
+        const ptrdiff_t d = (const char*)a.g[k] - sbase;
         if (d < 0 || d >= ((ptrdiff_t)1 << 31)) return false;
     }
     return sbr_rec_x6p_ok(a) && f16 && !a.dh_ext && a.T < 4096 &&
@@ -881,9 +929,11 @@ bool sbr_rec_x6p_tail_ok(const RecArgs& a) {
 }
 
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a) {
-    return a.cell == SBR_CELL_GRU ? launch_bwd_p<CELL_GRU>(s, a) : launch_bwd_p<CELL_VANILLA>(s, a);
+    return a.cell == SBR_CELL_GRU ? launch_bwd_p<CELL_GRU>(s, a) : a.cell == SBR_CELL_LSTM ? launch_bwd_p<CELL_LSTM>(s, a)
+                                                                 : launch_bwd_p<CELL_VANILLA>(s, a);
 }
 
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a) {
-    return a.cell == SBR_CELL_GRU ? launch_fwd_p<CELL_GRU>(s, a) : launch_fwd_p<CELL_VANILLA>(s, a);
+    return a.cell == SBR_CELL_GRU ? launch_fwd_p<CELL_GRU>(s, a) : a.cell == SBR_CELL_LSTM ? launch_fwd_p<CELL_LSTM>(s, a)
+                                                                 : launch_fwd_p<CELL_VANILLA>(s, a);
 }

@@ -40,9 +40,9 @@ def make_batch(rng, B, T, N, S=0, F=1, n_in0=None, full=False, Bg=None, zipf=Fal
                 pop=rng.uniform(0.5, 2.0, size=B).astype(np.float32))
 
 
-def rel_err(a, b):
+def rel_err(a, b, floor=1e-12):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+    return float(np.abs(a - b).max() / (np.abs(b).max() + floor))
 
 
 def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0, emb=0, bi=False,
@@ -98,8 +98,10 @@ def oracle_batch(batch):
 
 def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
                  reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False, zipf=False, k=None, gap=0.0, tweak=None,
-                 balance=1.0, unique=True, default_target=None):
+                 balance=1.0, unique=True, default_target=None, grad_floor=1e-12):
     """Returns dict of relative errors (engine float32 vs oracle float64).
+    grad_floor: added to the largest oracle magnitude of a gradient array before dividing -- arrays far smaller than it are
+    compared absolutely (the fp16 split of the BPTT chain's gradient operand has an absolute floor, csrc/sbr_rec_p.hip).
     k: length of the ranked list compared (default min(5, N - T)); gap > 0: the ranked ids are compared on the rows
     whose oracle scores (logits) are separated by more than `gap` down to rank k + 1 -- a tie-free fixture by
     assertion, `topk_rows_compared` reports how many rows that is; tweak(batch): edits the batch in place (e.g. plants
@@ -137,7 +139,7 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
         names = [n for n, _ in O.model_param_shapes(cell, layers, N, N + n_opt, emb, F, bi)]
         worst = 0.0
         for n, g, og in zip(names, grads, ograds):
-            e = rel_err(g, og) if np.abs(og).max() > 0 else float(np.abs(g).max())
+            e = rel_err(g, og, grad_floor) if np.abs(og).max() > 0 else float(np.abs(g).max())
             out["grad:" + n] = e
             worst = max(worst, e)
         out["grad_worst"] = worst

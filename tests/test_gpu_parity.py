@@ -14,7 +14,7 @@ def check(r, steps=2, tol_h=1e-4, tol_g=1e-4):
     assert r["param_roundtrip"] == 0.0
     assert r["h_last"] <= tol_h, r
     assert r["cost"] <= 1e-5, r
-    assert r["grad_worst"] <= tol_g, {k: v for k, v in r.items() if k.startswith("grad")}
+    assert r["grad_worst"] <= tol_g, sorted(((v, k) for k, v in r.items() if k.startswith("grad:")), reverse=True)[:4]
     assert r["params_after_%d_steps" % steps] <= 1e-3, r
     assert r["predict_scores"] <= 1e-3, r
     assert r["topk_mismatch"] == 0, r
@@ -75,7 +75,7 @@ def test_benchmark_configs_take_their_fast_kernels():
     # a silent fallback to the barrier kernels would keep every parity test green and lose 20-25 % of the step
     from sbr_amd.engine import RNNEngine
     for cell, layers, n_items, want in (("GRU", [128], 3706, 2), ("LSTM", [20], 3706, 3), ("GRU", [50], 3706, 3),
-                                        ("LSTM", [256], 26744, 1), ("LSTM", [128], 3706, 4)):
+                                        ("LSTM", [256], 26744, 1), ("LSTM", [128], 3706, 2)):
         eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=200, batch_size=256, loss="CCE")
         try:
             assert eng.query("rec_kernel") == want, (cell, layers)
@@ -85,17 +85,17 @@ def test_benchmark_configs_take_their_fast_kernels():
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])
-@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_pipelined_kernel_modes(cell, mode, monkeypatch):
-    # default (2): rec_*_x6p for GRU / Vanilla at 128 units: LDS counters instead of a per-step barrier + the matrix-pipe
+    # default (2): rec_*_x6p at 128 units: LDS counters instead of a per-step barrier + the matrix-pipe
     # gate between the two waves of a SIMD (every other 128-wide test); 1 = without the gate, 0 = the barrier kernels
     monkeypatch.setenv("SBR_X6_PIPE", mode)
     check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12))
 
 
-@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
-def test_forward_chain_with_bf16x6_products(cell, monkeypatch):
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])      # (an LSTM leaves the pipelined kernels with either switch:
+def test_forward_chain_with_bf16x6_products(cell, monkeypatch):   #  four gates fit the register file as fp16 planes only)
     # default (every other 128-wide GRU / Vanilla test): the forward chain's products as a 2-way fp16 split, 3 MFMAs
     # (rec_fwd_x6p<.., F16>); SBR_X6_F16=0: the 3-way bf16 split, 6 MFMAs, as the backward chain and the GEMMs use
     monkeypatch.setenv("SBR_X6_F16", "0")
@@ -103,7 +103,7 @@ def test_forward_chain_with_bf16x6_products(cell, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12, scale=0.05))
 
 
-@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_backward_chain_with_bf16x6_products(cell, monkeypatch):
     # default (every other 128-wide GRU / Vanilla test): the BPTT chain's products as the fp16 split too, the gradient operand
     # scaled by 2^9 (it is bounded by the clip at 100); SBR_X6_F16_BWD=0: bf16x6
@@ -112,13 +112,13 @@ def test_backward_chain_with_bf16x6_products(cell, monkeypatch):
     check(PU.compare_step(cell, [128, 128], "CCE", N=61, B=9, T=12, scale=0.05))
 
 
-@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_backward_chain_with_the_lds_ring_alone(cell, monkeypatch):
     # the overlapped tail's BPTT kernel reads its saved activations four steps ahead through an LDS ring (LDS-DMA);
     # SBR_X6_RING=1 takes that form (plain stores, nothing published) for every step of a 128-unit GRU / Vanilla top layer
     monkeypatch.setenv("SBR_X6_RING", "1")
     check(PU.compare_step(cell, [128], "CCE", N=61, B=37, T=9))
-    check(PU.compare_step(cell, [128], "CCE", N=300, B=21, T=33, scale=0.1 if cell == "GRU" else 0.05))
+    check(PU.compare_step(cell, [128], "CCE", N=300, B=21, T=33, scale=0.05 if cell == "Vanilla" else 0.1))
 
 
 def test_fp16_backward_products_at_the_clip_boundary_and_with_tiny_gradients():
@@ -128,6 +128,9 @@ def test_fp16_backward_products_at_the_clip_boundary_and_with_tiny_gradients():
     check(PU.compare_step("Vanilla", [128], "CCE", N=61, B=37, T=9, popscale=1e-4))
     check(PU.compare_step("GRU", [128], "CCE", N=61, B=37, T=40, popscale=1e4, scale=0.1), tol_g=2e-4)
     check(PU.compare_step("GRU", [128, 128], "BPR", N=61, B=9, T=12, S=8, scale=0.05))      # dense lower layer: dh_ext every step
+    check(PU.compare_step("LSTM", [128], "CCE", N=61, B=37, T=9, popscale=1e-4))
+    check(PU.compare_step("LSTM", [128], "CCE", N=61, B=37, T=40, popscale=1e4, scale=0.1), tol_g=2e-4)
+    check(PU.compare_step("LSTM", [128, 128], "BPR", N=61, B=9, T=12, S=8, scale=0.05))
 
 
 def test_fp16_forward_products_keep_f32_accuracy_over_long_chains():
@@ -149,9 +152,9 @@ def test_step_scheduling_switches(env, monkeypatch):
     check(PU.compare_step("GRU", [50], "BPR", N=200, B=48, T=9, S=16))
 
 
-def _tail_chunks(cell, T, N=300, B=37, flags=0, loss="CCE", S=0):
+def _tail_chunks(cell, T, N=300, B=37, flags=0, loss="CCE", S=0, H=128):
     from sbr_amd.engine import RNNEngine
-    eng = RNNEngine(cell=cell, layers=[128], n_items=N, max_length=T, batch_size=B, loss=loss, n_samples=S, flags=flags)
+    eng = RNNEngine(cell=cell, layers=[H], n_items=N, max_length=T, batch_size=B, loss=loss, n_samples=S, flags=flags)
     try:
         return eng.query("tail_chunks")
     finally:
@@ -159,7 +162,7 @@ def _tail_chunks(cell, T, N=300, B=37, flags=0, loss="CCE", S=0):
 
 
 @pytest.mark.parametrize("chunks", [None, "3"])
-@pytest.mark.parametrize("cell", ["GRU", "Vanilla"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_overlapped_step_tail(cell, chunks, monkeypatch):
     # One index-input layer of 128 units and T >= 64: the BPTT chain stores dxt / dhi write-through and publishes its progress;
     # dW_hid GEMM and scatter-add of every finished chunk of time steps run beside it (sbr_backward_recurrent).  Ragged rows
@@ -170,10 +173,15 @@ def test_overlapped_step_tail(cell, chunks, monkeypatch):
     assert _tail_chunks(cell, 70) == (3 if chunks else 4)
     # (gap: the ranked ids are compared on the rows whose oracle logits are further apart than 1e-4 -- most of them; a tanh-only
     # layer of 128 units is ill-conditioned over 70+ steps at larger weights, see parity_util.build_case)
-    sc = 0.1 if cell == "GRU" else 0.05
+    sc = 0.05 if cell == "Vanilla" else 0.1
     check(PU.compare_step(cell, [128], "CCE", N=300, B=37, T=70, scale=sc, zipf=True, gap=1e-4), tol_g=2e-4)
-    if cell == "GRU":      # (a tanh-only layer over 131 steps + Adam is chaotic with the tail switched off as well: tools/dbg_tail.py)
-        check(PU.compare_step(cell, [128], "CCE", N=300, B=64, T=131, scale=sc, full=True, gap=1e-4), tol_g=2e-4)
+    if cell != "Vanilla":      # (a tanh-only layer over 131 steps + Adam is chaotic with the tail switched off as well: tools/dbg_tail.py)
+        # LSTM: 131 steps from the loss the initial states' gradients are 5e-10 / 8e-10 (every other array: 6e-4 .. 4e-2), sums of
+        # per-step terms of ~1e-11 -- where the fp16 split of the chain's gradient operand has reached its absolute floor of
+        # 6e-14 per element (rec_bwd_x6p).  They come out 1.4e-12 off (2e-3 of themselves, the same with the tail switched
+        # off; 1e-6 with SBR_X6_PIPE=0), so arrays that small are held to tol_g x 2e-8 = 4e-12 absolute here.
+        check(PU.compare_step(cell, [128], "CCE", N=300, B=64, T=131, scale=sc, full=True, gap=1e-4,
+                              grad_floor=2e-8 if cell == "LSTM" else 1e-12), tol_g=2e-4)
     else:                  # ... and Adam's normalised steps amplify it already at 80: momentum steps for this one
         check(PU.compare_step(cell, [128], "CCE", N=300, B=64, T=80, scale=sc, full=True, gap=1e-4, updater="nesterov"), tol_g=2e-4)
     check(PU.compare_step(cell, [128], "CCE", N=40, B=5, T=64, scale=sc), tol_g=2e-4)          # one row tile, few ids, many duplicates
@@ -200,7 +208,7 @@ def test_overlapped_step_tail_kernels_on_one_stream(monkeypatch):
 
 def test_overlapped_step_tail_is_not_taken_where_it_does_not_apply():
     assert _tail_chunks("GRU", 40) == 0                                   # short sequences
-    assert _tail_chunks("LSTM", 70) == 0                                  # LSTM-128 keeps the barrier kernels
+    assert _tail_chunks("LSTM", 70, H=50) == 0                            # the 128-unit kernels only
     assert _tail_chunks("GRU", 70, flags=32) == 0                         # row-sparse blocks forced
     assert _tail_chunks("GRU", 70, N=20000) == 0                          # key space beyond the LDS histogram: chunks < 2
 
@@ -225,6 +233,8 @@ def test_pipelined_kernels_long_ragged_rows_and_chunks(monkeypatch):
     monkeypatch.setenv("SBR_BWD_CHUNKS", "3")
     check(PU.compare_step("GRU", [128, 128], "CCE", N=61, B=7, T=70, scale=0.05))
     check(PU.compare_step("Vanilla", [128], "Blackout", N=61, B=21, T=33, S=8))
+    check(PU.compare_step("LSTM", [128, 128], "CCE", N=61, B=7, T=70, scale=0.05))
+    check(PU.compare_step("LSTM", [128], "Blackout", N=61, B=21, T=33, S=8))
 
 
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])

@@ -5,7 +5,7 @@ That kernel brings the saved activations of later time steps into an LDS ring wi
 `s_waitcnt vmcnt(n)` in front of the LDS reads of the step that uses them; n > 0 keeps the write-through stores issued behind
 the loads in flight.  What the source relies on, checked here on the code the compiler actually produced:
 
-  * both role loops (waves 0-3 / 4-7) of both instances (GRU, Vanilla) contain the LDS-DMA loads and a hand-written wait with
+  * both role loops (waves 0-3 / 4-7) of all instances (LSTM, GRU, Vanilla) contain the LDS-DMA loads and a hand-written wait with
     the count the pipeline depth implies, and NO wait for vmcnt(0) -- compiler-inserted or otherwise -- inside the loop (it
     would drain the stores: the thing the scheme exists to avoid);
   * inside a loop, the LDS reads of the ring come after that wait (the asm's memory clobber pins them; a read hoisted above
@@ -21,10 +21,12 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sequence-based-recommendations_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# backward, PD = 4 stages; per step 2 load pieces + 4 stores (GRU) / 1 + 1 (Vanilla): NST + (PD - 1) * (NLI + NST)
-EXPECTED_WAIT = {"1": 22, "2": 7}
-# forward with the fused gather (rec_fwd_x6p<CELL, FUSE, .., F16>), XPD = 4: (XPD - 1) * (stores of a step + 1 load piece)
-EXPECTED_WAIT_FWD = {"1": 18, "2": 6}
+# (template argument CELL: 0 = LSTM, 1 = GRU, 2 = Vanilla)
+# backward, PD = 4 stages; per step 2 load pieces + 4 stores (GRU, LSTM) / 1 + 1 (Vanilla): NST + (PD - 1) * (NLI + NST)
+EXPECTED_WAIT = {"0": 22, "1": 22, "2": 7}
+# forward with the fused gather (rec_fwd_x6p<CELL, FUSE, .., F16>), XPD = 4: (XPD - 1) * (stores of a step + 1 load piece);
+# stores of a step: h + four saved gate values (GRU), + c (LSTM), h alone (Vanilla)
+EXPECTED_WAIT_FWD = {"0": 21, "1": 18, "2": 6}
 
 
 def loops_of(lines):
@@ -53,7 +55,7 @@ def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
         text = open(out).read().splitlines()
     starts = [(i, re.match(r"^_Z11rec_bwd_x6pILi(\d)ELb0ELb0ELb1ELi1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
               if re.match(r"^_Z11rec_bwd_x6pILi\dELb0ELb0ELb1ELi1EEv7RecArgs:", ln)]
-    assert len(starts) == 2, "expected the GRU and the Vanilla instance of rec_bwd_x6p<.., WT>"
+    assert len(starts) == 3, "expected the LSTM, the GRU and the Vanilla instance of rec_bwd_x6p<.., WT>"
     for st, cell in starts:
         end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
         body = text[st:end + 1]
@@ -86,7 +88,7 @@ def test_lds_ring_of_the_fused_gather_in_the_forward_kernel():
         text = open(out).read().splitlines()
     starts = [(i, re.match(r"^_Z11rec_fwd_x6pILi(\d)ELb1ELb0ELb1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
               if re.match(r"^_Z11rec_fwd_x6pILi\dELb1ELb0ELb1EEv7RecArgs:", ln)]
-    assert len(starts) == 2
+    assert len(starts) == 3
     for st, cell in starts:
         end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
         body = text[st:end + 1]
