@@ -97,6 +97,9 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_xt = take(tb * G * y.Hp);
         y.a_hs = take(tb1 * y.Hp);
         y.a_cs = cfg.cell == SBR_CELL_LSTM ? take(tb1 * y.Hp) : 0;
+        const bool wide = y.Hp == 256 || y.Hp == 512;
+        y.a_xh = wide ? take(tb1 * y.Hp) : 0;
+        y.a_pring = wide ? take(sbr_rec_c16_ring_floats(Bp, y.Hp)) : 0;
         for (int k = 0; k < 4; ++k) y.a_g[k] = cfg.cell == SBR_CELL_VANILLA ? 0 : take(tb * y.Hp);
         y.a_dxt = take(tb * G * y.Hp);
         y.a_dhi = cfg.cell == SBR_CELL_GRU ? take(tb * y.Hp) : y.a_dxt;
@@ -598,6 +601,7 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     a.xt = h->A(ly.a_xt); a.Whid = h->P(ly.p_Whid); a.peep = h->P(ly.p_peep);
     a.cinit = h->P(ly.p_cinit); a.hinit = h->P(ly.p_hinit);
     a.hs = h->A(ly.a_hs); a.cs = h->A(ly.a_cs);
+    if (ly.Hp == 256 || ly.Hp == 512) { a.xh = h->A(ly.a_xh); a.pring = h->A(ly.a_pring); }
     for (int k = 0; k < 4; ++k) a.g[k] = h->A(ly.a_g[k]);
     a.dxt = h->A(ly.a_dxt); a.dhi = h->A(ly.a_dhi); a.part = h->A(ly.a_part);
     a.xt_blocked = 0;
@@ -1561,9 +1565,10 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         int products = 0, rows = 16, wgs = y.Bp / 16;
         if (!simple_rec(h) && x6) {
             const char* fe = getenv(bwd ? "SBR_X6_F16_BWD" : "SBR_X6_F16");      // the launchers' own conditions (sbr_rec_p.hip)
-            const bool f16 = xp && !cl && (fe ? atoi(fe) != 0 : true) && (bwd ? (a.clip > 0.0f && a.clip <= 100.0f) : !a.relu);
+            const bool f16 = (xp || cl) && (fe ? atoi(fe) != 0 : true) && (bwd ? (a.clip > 0.0f && a.clip <= 100.0f) : !a.relu);
             products = f16 ? 3 : 6;
-            if (cl) { rows = bwd ? sbr_rec_cluster_bwd_rows(a) : SBR_CL_ROWS; wgs = (y.Bp / rows) * (a.Hp == 256 ? 8 : 32); }
+            if (cl && sbr_rec_c16_ok(a)) { rows = 16; wgs = (y.Bp / 16) * (a.Hp / 16); }
+            else if (cl) { rows = bwd ? sbr_rec_cluster_bwd_rows(a) : SBR_CL_ROWS; wgs = (y.Bp / rows) * (a.Hp == 256 ? 8 : 32); }
             else { rows = a.rpt; wgs = y.Bp / a.rpt; }
         }
         *value = w.rfind("rec_products_", 0) == 0 ? products : w.rfind("rec_rows_", 0) == 0 ? rows : wgs;

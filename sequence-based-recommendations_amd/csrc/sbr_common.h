@@ -43,6 +43,7 @@ struct LayerLayout {
     size_t a_xt;     // [T][Bp][G*Hp]    precomputed input (gather or dense GEMM)
     size_t a_hs;     // [T+1][Bp][Hp]    slot 0 = hid_init, slot t+1 = h_t
     size_t a_cs;     // [T+1][Bp][Hp]    LSTM cell states
+    size_t a_xh, a_pring;   // wide layers (Hp = 256 / 512): exchange arrays of the 16-row cluster kernels, else 0
     size_t a_g[4];   // [T][Bp][Hp]      LSTM i,f,g,o / GRU r,u,c~,hid_c
     size_t a_dxt;    // [T][Bp][G*Hp]    grad wrt xt (= grad wrt gates for LSTM/Vanilla)
     size_t a_dhi;    // [T][Bp][Hp]      GRU only: candidate-gate slice of grad wrt hid_input (r,u slices equal dxt)
@@ -281,6 +282,8 @@ struct RecArgs {
     int* fault;             // set to 1 when a cluster exchange wait gave up (bounded spin)
     int sentinel_done;      // the backward exchange arrays were already filled with the sentinel (side stream)
     int* clx;               // [tiles][C] start-of-launch handshake: (epoch << 4) | XCC id of every member
+    void* xh;               // 16-row cluster kernels: [T+1][Bp/16][2 planes][16][Hp] fp16, the pre-split h exchange
+    float* pring;           // ... and the ring of partial-sum blocks of the backward (sbr_rec_c16_ring_floats)
     int epoch;              // unique per launch (clx is never cleared)
     int relu;               // Vanilla layers with dense input = stock lasagne RecurrentLayer: rectify instead of tanh (sbr_cell.h)
     // overlapped step tail (rec_bwd_x6p only): dxt / dhi are stored write-through and every wave publishes
@@ -304,6 +307,8 @@ bool sbr_rec_x6q_ok(const RecArgs& a);
 hipError_t launch_rec_forward_x6q(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_x6q(hipStream_t s, const RecArgs& a);
 hipError_t sbr_rec_bwd_cl_fill(hipStream_t s, const RecArgs& a);
+bool sbr_rec_c16_ok(const RecArgs& a);
+size_t sbr_rec_c16_ring_floats(int Bp, int Hp);
 hipError_t launch_rec_forward(hipStream_t s, const RecArgs& a, bool simple);
 // true when the forward launch for these args can gather its input rows itself (RecArgs.gX/gWin/gbias)
 bool sbr_rec_fwd_can_fuse_gather(const RecArgs& a, bool simple);

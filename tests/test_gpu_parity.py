@@ -40,8 +40,8 @@ def test_streamed_whid_kernels(cell):                      # Hp = 576: W_hid fra
 @pytest.mark.parametrize("linear", ["0", "1"])
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
 def test_cluster_kernels_512_wide(cell, linear, monkeypatch):
-    # Hp = 512 (config C5's width): clusters of 32 workgroups (one unit tile each, K in four parts); forward on 8-row
-    # tiles, backward on 4-row tiles; linear=1 spreads a cluster over all XCDs
+    # Hp = 512 (config C5's width): clusters of 32 workgroups (one unit tile each, K in four parts) on 8-row tiles (the
+    # backward with bf16x6 products: 4-row tiles); linear=1 spreads a cluster over all XCDs
     monkeypatch.setenv("SBR_CL_LINEAR", linear)
     check(PU.compare_step(cell, [512], "CCE", N=61, B=37, T=7, scale=0.04), tol_h=2e-4)
 
@@ -251,6 +251,42 @@ def test_cluster_kernels_wide_layers(cell, linear, monkeypatch):
     # the agent-scope exchange must stay coherent there too.
     monkeypatch.setenv("SBR_CL_LINEAR", linear)
     check(PU.compare_step(cell, [256], "CCE", N=61, B=37, T=9), tol_h=2e-4)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_cluster_kernels_on_eight_row_tiles(cell, monkeypatch):
+    # default (every other wide-layer test): rec_*_c16 -- 16-row tiles, 16 units per workgroup, h exchanged pre-split, the
+    # backward exchanging partial sums through a ring of sentinel blocks; SBR_CL16=0: the 8-row kernels with fp16 products
+    from sbr_amd.engine import RNNEngine
+    for env, rows in (("1", 16), ("0", 8)):
+        monkeypatch.setenv("SBR_CL16", env)
+        eng = RNNEngine(cell=cell, layers=[256], n_items=61, max_length=9, batch_size=37, loss="CCE")
+        try:
+            assert eng.query("rec_rows_fwd") == rows and eng.query("rec_rows_bwd") == rows
+        finally:
+            eng.close()
+    check(PU.compare_step(cell, [256], "CCE", N=61, B=37, T=9), tol_h=2e-4)
+    # (rectifying upper layer of a Vanilla stack: Adam's normalised steps amplify rounding beyond any fixed tolerance; momentum steps)
+    check(PU.compare_step(cell, [512, 300], "CCE", N=41, B=19, T=12, scale=0.04, updater="nesterov" if cell == "Vanilla" else "adam"),
+          tol_h=2e-4)
+
+
+@pytest.mark.parametrize("which", ["SBR_X6_F16", "SBR_X6_F16_BWD"])
+def test_cluster_kernels_with_bf16x6_products(which, monkeypatch):
+    # either switch off: the 8-row cluster kernels (the 16-row ones exist on fp16 planes only), that chain with three bf16
+    # planes (W_hid plane 3 in LDS; Hp = 512 backward on 4-row tiles), the other with the 2-way fp16 split (rec_*_cl<.., F16>)
+    monkeypatch.setenv(which, "0")
+    check(PU.compare_step("LSTM", [256], "CCE", N=61, B=37, T=9), tol_h=2e-4)
+    check(PU.compare_step("GRU", [512], "CCE", N=61, B=37, T=7, scale=0.04), tol_h=2e-4)
+
+
+def test_cluster_kernels_fp16_products_with_active_clip_and_tiny_gradients():
+    check(PU.compare_step("LSTM", [256], "CCE", N=61, B=21, T=9, popscale=1e-4), tol_h=2e-4)
+    check(PU.compare_step("GRU", [256], "CCE", N=61, B=21, T=30, popscale=1e4, scale=0.05), tol_h=2e-4, tol_g=2e-4)
+    # (gradients 1e4 times the usual: Adam's eps no longer damps the elements whose gradient is noise beside the largest of
+    # their array, and their sign decides a whole step -- the updated parameters are not compared here)
+    r = PU.compare_step("LSTM", [512], "CCE", N=61, B=13, T=7, popscale=1e-4, scale=0.04)
+    assert r["h_last"] <= 2e-4 and r["cost"] <= 1e-5 and r["grad_worst"] <= 1e-4 and r["topk_mismatch"] == 0, r
 
 
 def test_cluster_kernels_padded_width_and_long_ragged_rows():
