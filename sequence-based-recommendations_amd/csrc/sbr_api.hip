@@ -98,7 +98,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         y.a_hs = take(tb1 * y.Hp);
         y.a_cs = cfg.cell == SBR_CELL_LSTM ? take(tb1 * y.Hp) : 0;
         const bool wide = y.Hp == 256 || y.Hp == 512;
-        y.a_xh = wide ? take(tb1 * y.Hp) : 0;
+        y.a_xh = wide ? take((size_t)4 * Bp * y.Hp) : 0;
         y.a_pring = wide ? take(sbr_rec_c16_ring_floats(Bp, y.Hp)) : 0;
         for (int k = 0; k < 4; ++k) y.a_g[k] = cfg.cell == SBR_CELL_VANILLA ? 0 : take(tb * y.Hp);
         y.a_dxt = take(tb * G * y.Hp);

@@ -282,7 +282,7 @@ struct RecArgs {
     int* fault;             // set to 1 when a cluster exchange wait gave up (bounded spin)
     int sentinel_done;      // the backward exchange arrays were already filled with the sentinel (side stream)
     int* clx;               // [tiles][C] start-of-launch handshake: (epoch << 4) | XCC id of every member
-    void* xh;               // 16-row cluster kernels: [T+1][Bp/16][2 planes][16][Hp] fp16, the pre-split h exchange
+    void* xh;               // 16-row cluster kernels: ring [4][Bp/16][2 planes][16][Hp] fp16, the pre-split h exchange
     float* pring;           // ... and the ring of partial-sum blocks of the backward (sbr_rec_c16_ring_floats)
     int epoch;              // unique per launch (clx is never cleared)
     int relu;               // Vanilla layers with dense input = stock lasagne RecurrentLayer: rectify instead of tanh (sbr_cell.h)

@@ -311,6 +311,65 @@ __global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__
     for (int i = threadIdx.x; i < n; i += 1024) { const int v = stage[i]; offs[i] = v; cur[i] = v; }
 }
 
+// Large catalogues (the counters do not fit LDS): three small launches instead of one workgroup walking the whole array
+// (1 M counters took it 2 ms: a thousand rounds of three barriers) -- per 4096-counter block the local exclusive prefixes
+// and the block's total; the totals' exclusive scan (one workgroup; parked in `cnt`, which nobody reads any more); the add.
+constexpr int SCAN_BLK = 4096;
+__global__ void __launch_bounds__(1024) scat_scan_local_kernel(const int* __restrict__ cnt, int n, int* __restrict__ offs,
+                                                               int* __restrict__ bsum) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * SCAN_BLK + threadIdx.x * 4;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? cnt[i0 + k] : 0;
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (i0 + k < n) offs[i0 + k] = run; run += v[k]; }
+    if (threadIdx.x == 1023) bsum[blockIdx.x] = run;
+}
+__global__ void __launch_bounds__(1024) scat_scan_totals_kernel(const int* __restrict__ bsum, int nb, int* __restrict__ bpre,
+                                                                int* __restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? bsum[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        if (i < nb) bpre[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+__global__ void __launch_bounds__(1024) scat_scan_add_kernel(const int* __restrict__ bpre, int n, int* __restrict__ offs,
+                                                             int* __restrict__ cur) {
+    const int carry = bpre[blockIdx.x];
+    const int i0 = blockIdx.x * SCAN_BLK + threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) { const int v = offs[i0 + k] + carry; offs[i0 + k] = v; cur[i0 + k] = v; }
+}
+
 __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
                                  int* __restrict__ cur, int* __restrict__ sid, int* __restrict__ spos, int concat) {
     const int total = T * Bp * F;
@@ -349,7 +408,13 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
     } else {
         const int grid = min(1024, (total + 255) / 256);
         scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
-        scat_scan_kernel<false><<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+        const int nb = (n_ids + SCAN_BLK - 1) / SCAN_BLK;
+        if (nb <= 1) scat_scan_kernel<false><<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+        else {      // block totals in cur[0 .. nb) (rewritten by the add), their prefixes in cnt[0 .. nb) (not read any more)
+            scat_scan_local_kernel<<<nb, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+            scat_scan_totals_kernel<<<1, 1024, 0, s>>>(cur, nb, cnt, offs + n_ids);
+            scat_scan_add_kernel<<<nb, 1024, 0, s>>>(cnt, n_ids, offs, cur);
+        }
         scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos, concat);
     }
     return hipGetLastError();

@@ -111,11 +111,12 @@ __device__ __forceinline__ int cl_fetch(f32x4 (&v)[NP], SRC src, int W, bool fas
                 v[i] = x.f;
             }
         }
-        bool ok = true;
+        unsigned mx = 0u;                                // the sentinel is the largest 32-bit pattern: one v_max3_u32 per two words
 #pragma unroll
         for (int i = 0; i < NP; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ok = ok && __float_as_uint(v[i][e]) != CL_SENT;
+            for (int e = 0; e < 4; ++e) mx = max(mx, __float_as_uint(v[i][e]));
+        const bool ok = mx != CL_SENT;
         if (ok || dead) break;
         if (++tries > CL_SPIN_LIMIT) { dead = true; atomicOr(fault, 1); break; }   // bounded: never hang the GPU
         __builtin_amdgcn_s_sleep(1);
@@ -1190,7 +1191,7 @@ __device__ __forceinline__ unsigned cl_pair_word(float v, int j) {
     _Float16 a1, a2;
     cl_split2(v, a1, a2);
     const unsigned s1 = cl_f16_bits(a1), s2 = cl_f16_bits(a2);
-    const unsigned recv = (unsigned)__shfl_xor((int)((j & 1) ? s1 : s2), 1);
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)((j & 1) ? s1 : s2), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
     return (j & 1) ? (recv | (s2 << 16)) : (s1 | (recv << 16));
 }
 
@@ -1235,6 +1236,13 @@ __global__ void __launch_bounds__(256, 2) rec_fwd_c16(RecArgs a) {
     // this lane's word of the exchanged tile: plane j & 1, row rl, units (u & ~1, + 1)
     const int ue = (mem * 16 + (j & ~1));
     const unsigned xoff = (unsigned)((j & 1) * PLANEB + rl * ROWB + (((ue >> 3) ^ rl) << 4) + (ue & 7) * 2);
+    // The exchange array is a ring of XRING time steps (slot t % XRING holds h_{t-1}), small enough to live in the XCD's L2
+    // with every line complete: with one tile image per time step ([T + 1] slots, each written once by 4-byte stores of 16
+    // workgroups) a poll took ~2600 cycles whoever arrived first -- reading a line the L2 holds partially written first
+    // fetches the rest of it from memory.  A slot is a sentinel again before it is reused: a member resets ITS OWN words of
+    // slot t - 1 once its poll of step t has succeeded (every member has then published step t, so has finished reading
+    // t - 1), and writes them again for step t + 3 -- behind two more polls, whose waits have seen that reset acknowledged.
+    constexpr int XRING = 4;
     char* const xh = (char*)a.xh + (size_t)tile * TILEB;
     const size_t xstep = (size_t)ntiles * TILEB;
     cl_store1((unsigned*)(xh + xoff), cl_pair_word(h, j), fast);
@@ -1265,26 +1273,28 @@ __global__ void __launch_bounds__(256, 2) rec_fwd_c16(RecArgs a) {
     // the ~7 stores of a step took ~3000 cycles to be acknowledged (measured: "exchange wait" 2990 cycles at 0.05 re-polls per
     // step).  Only the exchange word is stored in front of the poll; hs / cs / the saved gates of step t - 1 wait in
     // registers and leave behind the poll of step t, a full step before the next wait.
+    // ... and they are issued behind the barrier, between the operand reads and the MFMAs, with running offsets (hs / cs
+    // and the tile-blocked gate arrays both advance Bp * Hp floats per step): nothing of it sits between poll and barrier.
     float h_pend = 0.f, c_pend = 0.f, sv_pend[4] = {0.f, 0.f, 0.f, 0.f};
-    auto store_step = [&](int t) {                       // results of step t (h_t = slot t + 1)
-        const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
-        a.hs[o] = h_pend;
-        if (CELL == CELL_LSTM) a.cs[o] = c_pend;
+    const size_t st_step = (size_t)Bp * HP;
+    size_t o_h = st_step + (size_t)row * HP + u, o_g = sbr_blocked_index(0, row, u, Bp, HP);   // of the step being stored
+    auto store_step = [&]() {                            // results of the step behind o_h / o_g (h_t = slot t + 1)
+        a.hs[o_h] = h_pend;
+        if (CELL == CELL_LSTM) a.cs[o_h] = c_pend;
         if (CELL != CELL_VANILLA) {
-            const size_t og = sbr_blocked_index(t, row, u, Bp, HP);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a.g[k][og] = sv_pend[k];
+            for (int k = 0; k < 4; ++k) a.g[k][o_g] = sv_pend[k];
         }
+        o_h += st_step; o_g += st_step;
     };
     for (int t = 0; t < tmax; ++t) {
         load_x(t + 1, id_next, xn);                      // unconditional (clamped), as in rec_fwd_cl
         id_nn = load_id(t + 2);
         {   // h_{t-1} of all Hp units, pre-split by its producers: a straight copy into LDS
             f32x4 v[NP];
-            const float* base = (const float*)(xh + (size_t)t * xstep);
+            const float* base = (const float*)(xh + (size_t)(t & (XRING - 1)) * xstep);
             p_tries += cl_fetch<NP>(v, [&](int r, int) { return base + (size_t)r * 4; }, 4, fast, dead, a.fault);
             CL_TICK(0);
-            if (t > 0) store_step(t - 1);
 #pragma unroll
             for (int i = 0; i < NP; ++i) *(f32x4*)(hpl + (threadIdx.x + i * 256) * 16) = v[i];
         }
@@ -1301,6 +1311,12 @@ __global__ void __launch_bounds__(256, 2) rec_fwd_c16(RecArgs a) {
                 hp[kb][0] = *(const f16x8c*)(hb + ch);
                 hp[kb][1] = *(const f16x8c*)(hb + ch + PLANEB);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0) {                                 // (under the operand reads' latency)
+                cl_store1((unsigned*)(xh + (size_t)((t - 1) & (XRING - 1)) * xstep + xoff), CL_SENT, fast);
+                store_step();
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kb = 0; kb < KBW; ++kb) {
 #pragma unroll
@@ -1330,14 +1346,14 @@ __global__ void __launch_bounds__(256, 2) rec_fwd_c16(RecArgs a) {
         for (int g = 0; g < G; ++g) x[g] = xn[g];        // before this step's stores are issued (vmcnt retires in order)
         id_next = id_nn;
         __builtin_amdgcn_sched_barrier(0);
-        cl_store1((unsigned*)(xh + (size_t)(t + 1) * xstep + xoff), cl_pair_word(h, j), fast);   // the cluster waits for it
+        cl_store1((unsigned*)(xh + (size_t)((t + 1) & (XRING - 1)) * xstep + xoff), cl_pair_word(h, j), fast);   // the cluster waits for it
         h_pend = h; c_pend = c;
 #pragma unroll
         for (int k = 0; k < 4; ++k) sv_pend[k] = sv[k];
         CL_TICK(4);
         if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CL_TICK(5); }      // (counters only: the exchange store's own round trip)
     }
-    if (tmax > 0) store_step(tmax - 1);
+    if (tmax > 0) store_step();
     for (int t = tmax; t < T; ++t) {                     // past the tile's longest row: the state is carried
         const size_t o = ((size_t)(t + 1) * Bp + row) * HP + u;
         a.hs[o] = h;
@@ -1446,6 +1462,7 @@ __global__ void __launch_bounds__(256, 2) rec_bwd_c16(RecArgs a) {
     }
     if (prof) p_t = clock64();
     int n = 0;                                           // steps done: ring slot n % RING
+    size_t o_x = ((size_t)(tmax - 1) * Bp + row) * GHP + u, o_d = ((size_t)(tmax - 1) * Bp + row) * HP + u;   // of step t (used for t >= 0 only)
     for (int t = tmax - 1; t >= 0; --t, ++n) {
         if (a.dh_ext) dh += a.dh_ext[((size_t)t * Bp + row) * HP + u];
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
@@ -1501,14 +1518,9 @@ __global__ void __launch_bounds__(256, 2) rec_bwd_c16(RecArgs a) {
             float* base = pmine + (size_t)(n & (RING - 1)) * slotf;
             p_tries += cl_fetch<NP>(v, [&](int r, int) { return (const float*)base + (size_t)r * 4; }, 4, fast, dead, a.fault);
             CL_TICK(2);
-            const f32x4 sent = f32x4{__uint_as_float(CL_SENT), __uint_as_float(CL_SENT), __uint_as_float(CL_SENT), __uint_as_float(CL_SENT)};
 #pragma unroll
-            for (int i = 0; i < NP; ++i) { sum += v[i]; cl_store4(base + (size_t)(threadIdx.x + i * 256) * 4, sent, fast); }
+            for (int i = 0; i < NP; ++i) sum += v[i];
         }
-        // dxt / dhi of this step: behind the poll (in front of it its wait would cover them too, see rec_fwd_c16)
-#pragma unroll
-        for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = dxi[g];
-        if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = dhi[2];
         *(f32x4*)(red + (wave * 64 + lane) * 16) = sum;
         __syncthreads();                                 // the four waves' sums visible; every wave is done reading the A planes
         CL_TICK(3);
@@ -1516,6 +1528,18 @@ __global__ void __launch_bounds__(256, 2) rec_bwd_c16(RecArgs a) {
 #pragma unroll
         for (int sw = 0; sw < 4; ++sw) add += *(const float*)(red + (sw * 64 + lane) * 16 + wave * 4);
         dh += add;
+        // Behind the poll (in front of it its wait would cover them too, see rec_fwd_c16) and behind the reduction (nobody
+        // waits for them): the blocks just read go back to the sentinel, dxt / dhi of this step leave
+        {
+            const f32x4 sent = f32x4{__uint_as_float(CL_SENT), __uint_as_float(CL_SENT), __uint_as_float(CL_SENT), __uint_as_float(CL_SENT)};
+            float* base = pmine + (size_t)(n & (RING - 1)) * slotf;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) cl_store4(base + (size_t)(threadIdx.x + i * 256) * 4, sent, fast);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) a.dxt[o_x + g * HP] = dxi[g];
+        if (CELL == CELL_GRU) a.dhi[o_d] = dhi[2];
+        o_x -= (size_t)Bp * GHP; o_d -= (size_t)Bp * HP;
         CL_TICK(4);
     }
     if (prof && lane == 0 && tile * C + mem < 32) {
@@ -1583,7 +1607,7 @@ template <int CELL, int HP>
 static hipError_t fwd_cl(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G, R = SBR_CL_ROWS;
     if (sbr_rec_c16_ok(a)) {
-        hipError_t e = hipMemsetAsync(a.xh, 0xFF, (size_t)(a.T + 1) * a.Bp * HP * sizeof(float), s);   // sentinel
+        hipError_t e = hipMemsetAsync(a.xh, 0xFF, (size_t)4 * a.Bp * HP * sizeof(float), s);   // the ring's slots: sentinel
         if (e != hipSuccess) return e;
         const size_t lds = (size_t)2 * 16 * HP * 2 + 4 * G * 1024;
         CL_LAUNCH((rec_fwd_c16<CELL, HP>), HP / 16, 16, lds);
