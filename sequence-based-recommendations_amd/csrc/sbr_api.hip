@@ -660,6 +660,7 @@ static inline hipEvent_t record_shared(sbr_handle* h, hipEvent_t plain, int mk) 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     h->step_open = true;                          // a training step begins: sbr_forward may start its batch-only work
+    h->out_early = false;
     if (!h->in_train_step && h->timing) {         // phase-by-phase step (data-parallel driver): this call opens the step
         h->ring_cur = h->ring_used % sbr_handle::kRing;
         mark(h, 0);
@@ -934,6 +935,16 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_colsum_bias(sd, lg, R, N, Nl, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
         SBR_LAUNCH(launch_gemm(sd, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws2, y.ws2_floats, sg));
         SBR_HIP(hipEventRecord(h->ev_og, sd)); h->og_recorded = true;   // output-layer gradients + cost complete
+        // Single-call step, dense updates: the output layer is stepped right here, beside the BPTT chain (nothing reads W_out
+        // any more: dh was computed in front of the record the side stream waited on); sbr_apply_update leaves the range
+        // out.  C4: 46 us off the end of the step.  (The overlapped tail does the same itself; phase-by-phase callers --
+        // data parallel -- reduce the gradients first.)
+        if (h->in_train_step && !y.n_sparse && h->tail_nc == 0 && !simple_gemm(h)) {
+            float* s1e = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+            SBR_LAUNCH(launch_update(sd, y.cfg.updater, h->P(y.p_split), h->Gd(y.p_split), h->St(0, y.p_split), s1e ? s1e + y.p_split : nullptr,
+                                     y.n_params - y.p_split, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
+            h->out_early = true;
+        }
     } else {
         const int C = y.C;
         int* cells = (int*)h->A(y.a_cells);
@@ -1125,6 +1136,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 const float* dxc = a.dxt + (size_t)a.t_lo * y.Bp * GHp;
                 const float* dhcc = gru ? a.dhi + (size_t)a.t_lo * y.Bp * ly.Hp : nullptr;
                 hipError_t we = hipSuccess;
+                // swapped tail: this GEMM's slabs share the second workspace with the split-K slabs of the side stream's dW_out
+                // GEMM -- normally long reduced by now, but nothing ordered the two (a wait on a complete event is free)
+                if (sw == s && h->og_recorded) SBR_HIP(hipStreamWaitEvent(s, h->ev_og, 0));
                 if (!wg_gemm && launch_wgrad_slabs(sw, hsc, dxc, dhcc, slabs, ly.Hp, GHp, Kc, nsl, &we)) {
                     SBR_LAUNCH(we);
                 } else if (launch_gemm_slabs_x6(sw, hsc, 1, ly.Hp, dxc, GHp, 1, ly.Hp, GHp, Kc, slabs, nsl, GHp, slab, dhcc, ly.Hp,
@@ -1283,6 +1297,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         return launch_update(h->stream, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1 ? s1 + lo : nullptr, hi - lo,
                              y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
     };
+    const size_t p_end = h->out_early ? y.p_split : y.n_params;     // the output layer was stepped beside the BPTT chain
     if (y.n_sparse) {
         // dense pass over everything outside the sparse blocks, then one row-sparse step per block over the rows this step
         // touched: the scatter's sorted ids / the sampled cells, or (data parallel) the ids gathered from every rank
@@ -1318,7 +1333,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         // own too); main stream: W_hid (its own GEMM) -- no event wait in front of it; then the main stream joins the side
         // stream, normally done by then
         const LayerLayout& l0 = y.layer[0];
-        SBR_LAUNCH(launch_update(h->side, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, l0.p_Whid + (y.n_params - l0.p_peep),
+        SBR_LAUNCH(launch_update(h->side, y.cfg.updater, h->P(0), h->Gd(0), h->St(0, 0), s1, l0.p_Whid + (p_end - l0.p_peep),
                                  y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count, l0.p_Whid,
                                  l0.p_peep - l0.p_Whid));
         SBR_LAUNCH(upd(l0.p_Whid, l0.p_peep));
@@ -1332,20 +1347,20 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
             // updated while dW_hid finishes
             SBR_LAUNCH(upd(0, y.layer[0].p_Whid));                         // W_in, b: main-stream gradients only
             { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
-            SBR_LAUNCH(upd(y.layer[0].p_Whid, y.n_params));               // W_hid, peepholes, initial states, output layer
+            SBR_LAUNCH(upd(y.layer[0].p_Whid, p_end));                    // W_hid, peepholes, initial states, output layer
         } else {
             SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
             size_t pos = 0;
             for (int l = 0; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
-            SBR_LAUNCH(upd(pos, y.n_params));
+            SBR_LAUNCH(upd(pos, p_end));
             { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
             for (int l = 0; l < y.L * y.D; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
         }
     } else {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
-        SBR_LAUNCH(upd(0, y.n_params));
+        SBR_LAUNCH(upd(0, p_end));
     }
-    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false;
+    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;

@@ -134,6 +134,7 @@ struct sbr_handle {
     bool deferred_join;  // phases called one by one do not join the side stream (sbr_set_deferred_join)
     bool og_recorded;    // ev_og marks the output-layer gradients of this step complete
     bool fill_done;      // the cluster BPTT sentinel fill of this step was issued on the side stream (ev_fill)
+    bool out_early;      // this step's output-layer parameters were stepped on the side stream beside the BPTT chain
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)

@@ -152,6 +152,8 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
             costs_e.append(eng.train_step(sync=True))
         new = eng.get_all_param_values()
         out["params_after_%d_steps" % steps] = max(rel_err(a, b) for a, b in zip(new, oparams))
+        for n, a, b in zip(names, new, oparams):      # (diagnostics: which array)
+            out["pstep:" + n] = rel_err(a, b)
         out["cost_after_steps"] = abs(costs_e[-1] - costs_o[-1]) / (abs(costs_o[-1]) + 1e-12)
         # predict / top-k on the updated model
         scores = eng.predict_function(batch["X"], batch["mask"])
