@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 4
+#define SBR_ABI_VERSION 5
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -262,9 +262,20 @@ int sbr_dataset_set_tables(sbr_dataset* d, const float* pop_db, const double* sa
  * item index and n_items + the rating's one-hot index round(rating * 2) - 1 (rnn_base.py:590-642; model built with n_feat = 2,
  * input_size = n_items + 10).  shuffle_targets != 0: --shuffle_targets -- a row's targets are a uniform random subset of the
  * whole remaining sequence instead of its first items (target_selection.py:45-46).  The number of targets per row is the
- * model's (n_targets of the multi-target losses, 1 otherwise).  --target_bias and the sequence-noise options change how many
- * rows a user yields and stay with the host generator. */
+ * model's (n_targets of the multi-target losses, 1 otherwise).  --target_bias (rows can run out of targets) stays with the host
+ * generator. */
 int sbr_dataset_set_options(sbr_dataset* d, const float* ratings, int shuffle_targets);
+/* Sequence noise for the pass planned NEXT (SequenceNoise.__call__, sequence_noise.py:52-94; call before sbr_dataset_plan_pass,
+ * once per pass): per user, in the reference's order -- dropout of items (a user left with fewer than two items yields no rows
+ * this pass), swaps of neighbours with probability n_swap (an item swaps at most once), swaps with the item int(N(0, 1) *
+ * shuf_std) places away with probability n_shuf, rating +- 0.5 clamped to [1, 5] with probability n_ratings (only with ratings
+ * attached).  The batches of the pass read the noised copy; rows carried over from the previous pass are re-drawn from it.
+ * All probabilities 0: the pass reads the sequences as they are.  A law, not the reference's random stream. */
+int sbr_dataset_noise_pass(sbr_dataset* d, float dropout, float swap, float shuf, float shuf_std, float ratings_perturb, uint64_t seed);
+/* (tests / tooling) the sequences the next planned pass reads: items[nnz] and rating_index[nnz] (may be NULL) in the CSR layout
+ * of sbr_dataset_create -- user u's items[offsets[u] .. offsets[u] + lengths[u]) -- and lengths[n_users]; the noised copy behind
+ * sbr_dataset_noise_pass, the sequences as uploaded otherwise. */
+int sbr_dataset_current_sequences(sbr_dataset* d, int32_t* items, int32_t* rating_index, int32_t* lengths);
 /* Plans one pass over the users in `order` (n_users ids, NULL = file order) for batches of batch_size rows.
  * A trailing partial batch is carried into the next planned pass, as the reference's endless generator does.
  * n_batches: complete batches now available (indices 0..n_batches-1 for sbr_build_batch). */

@@ -12,6 +12,11 @@ struct sbr_dataset {
     float* d_popdb; double* d_cdf;
     int* d_rate;                                    // rating one-hot index (0..9) of every interaction (--rf), or NULL
     int shuffle_targets;                            // --shuffle_targets: the targets are drawn from the whole remaining sequence
+    // sequence noise (sbr_dataset_noise_pass): this pass's noised copy of every user's sequence, stored at the user's own
+    // offset (dropout only shortens it) + its length; `noised` = the batches of the pass read the copy
+    int *d_items_n, *d_rate_n, *d_len_n; int noised; int64_t max_len;
+    std::vector<int> len_n32;
+    std::vector<int64_t> len_cur;                   // lengths the current plan was made for (noised or not)
     std::vector<int64_t> len;                       // host copy of the sequence lengths
     std::vector<int> pend_user, pend_k;             // trailing partial batch carried into the next pass
     std::vector<int> seg_user, seg_k, seg_row0, seg_batch, batch_begin;   // host plan (batch_begin: n_batches+1)
@@ -32,8 +37,11 @@ extern "C" int sbr_plan_pass_host(const int64_t* lengths, const int32_t* order, 
     CHECK_ARG(B >= 1 && n_users >= 0 && *n_pend >= 0 && *n_pend <= B, "bad batch size / pending count");
     int64_t ns = 0, nb = 0; int j = 0;
     for (int i = 0; i < *n_pend; ++i) {             // rows of the partial batch the previous pass left behind
-        seg_user[ns] = pend_user[i]; seg_k[ns] = pend_k[i]; seg_row0[ns] = j; seg_batch[ns] = (int)nb; ++ns;
-        j += pend_k[i];
+        // (with sequence noise the user's sequence of THIS pass may be shorter than the one the rows were counted for)
+        const int k = (int)std::min<int64_t>(pend_k[i], lengths[pend_user[i]] - 2);
+        if (k <= 0) continue;
+        seg_user[ns] = pend_user[i]; seg_k[ns] = k; seg_row0[ns] = j; seg_batch[ns] = (int)nb; ++ns;
+        j += k;
     }
     CHECK_ARG(j < B || *n_pend == 0, "pending rows fill a whole batch");
     for (int64_t i = 0; i < n_users; ++i) {
@@ -72,7 +80,8 @@ __device__ __forceinline__ unsigned key32(unsigned long long seed, unsigned a, u
 // (random.sample, rnn_base.py:402) and in ascending order (sorted(...)).  Every candidate gets a 32-bit key
 // hashed from (seed, user, index); the k smallest keys win: a 4-pass radix select in LDS finds the k-th key,
 // an ordered compaction writes the winners.  Key ties at the threshold are broken by index.
-__global__ void __launch_bounds__(256) bb_split_kernel(const long long* __restrict__ off, const int* __restrict__ seg_user,
+__global__ void __launch_bounds__(256) bb_split_kernel(const long long* __restrict__ off, const int* __restrict__ len_n,
+                                                       const int* __restrict__ seg_user,
                                                        const int* __restrict__ seg_k, const int* __restrict__ seg_row0,
                                                        int seg_begin, unsigned long long seed, int* __restrict__ split,
                                                        int* __restrict__ rowuser) {
@@ -82,7 +91,7 @@ __global__ void __launch_bounds__(256) bb_split_kernel(const long long* __restri
     __shared__ int wsum[8];
     const int s = seg_begin + blockIdx.x, tid = threadIdx.x;
     const int user = seg_user[s], k = seg_k[s], row0 = seg_row0[s];
-    const int n = (int)(off[user + 1] - off[user]) - 2;
+    const int n = (len_n ? len_n[user] : (int)(off[user + 1] - off[user])) - 2;
     // the segment's first row is part of the seed: a user who owns two segments of one batch (the carried tail of the previous
     // pass meeting the same user in the new pass) draws independent split points for each, as random.sample does
     const unsigned long long sd = seed ^ mix64(0x5EEDull + (unsigned long long)user) ^ mix64(0xB0Bull + ((unsigned long long)(unsigned)row0 << 20));
@@ -164,7 +173,7 @@ __device__ __forceinline__ int bb_target_pos(unsigned long long seed, int g, int
 // One wave per local row: X row (item id, + n_items + rating index with F == 2), length, pop**db of the first target.  Blocks
 // past the rows write the targets (NT per row, -1 behind the last) and draw the S negatives.
 __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ items, const int* __restrict__ rate,
-                                                     const long long* __restrict__ off,
+                                                     const long long* __restrict__ off, const int* __restrict__ len_n,
                                                      const int* __restrict__ split, const int* __restrict__ rowuser,
                                                      const float* __restrict__ popdb, const double* __restrict__ cdf,
                                                      int n_items, int T, int F, int NT, int shuffle, int row_offset, int local_rows, int Bp,
@@ -187,7 +196,7 @@ __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ ite
         }
         if (lane == 0) {
             lengths[b] = n_in;
-            const int n_rem = (int)(off[rowuser[g] + 1] - o) - l;
+            const int n_rem = (len_n ? len_n[rowuser[g]] : (int)(off[rowuser[g] + 1] - o)) - l;
             const int k = min(n_rem, NT);
             pop[b] = popdb ? popdb[items[o + l + bb_target_pos(seed, g, 0, k, n_rem, shuffle)]] : 1.0f;   // rnn_one_hot.py:103
         }
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ ite
     if (e < tgt_rows * NT) {                                       // targets (target_selection.py:41-53, rnn_base.py:407)
         const int g = tgt_offset + e / NT, j = e % NT;
         const long long o = off[rowuser[g]];
-        const int l = split[g], n_rem = (int)(off[rowuser[g] + 1] - o) - l;
+        const int l = split[g], n_rem = (len_n ? len_n[rowuser[g]] : (int)(off[rowuser[g] + 1] - o)) - l;
         const int k = min(n_rem, NT);
         target[e] = j < k ? items[o + l + bb_target_pos(seed, g, j, k, n_rem, shuffle)] : -1;
     }
@@ -215,6 +224,82 @@ __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ ite
 }
 
 // ---------------------------------------------------------------------------------------
+// Sequence noise (sequence_noise.py:52-94): per pass and user, in this order -- dropout of items (a user left with fewer than
+// two is skipped), swaps of neighbours (an item swaps at most once), swaps with an item a normal distance away, half-star
+// rating perturbation.  One wave per user, the sequence staged in LDS: the compaction is a ballot prefix, the two swap
+// passes are what the reference's loops are -- sequential -- run by lane 0 on LDS.  Draws are hashed from
+// (seed, user, stage, index): a law, not the reference's Mersenne stream (tests/test_gpu_batch_builder.py).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float bb_unif(unsigned long long seed, unsigned stage, unsigned user, unsigned i) {
+    return (float)(key32(seed ^ mix64(0x401Eull + stage), user, i) >> 8) * (1.0f / 16777216.0f);      // [0, 1)
+}
+__global__ void __launch_bounds__(64) bb_noise_kernel(const int* __restrict__ items, const int* __restrict__ rate,
+                                                      const long long* __restrict__ off, int* __restrict__ items_n,
+                                                      int* __restrict__ rate_n, int* __restrict__ len_n, float p_drop, float p_swap,
+                                                      float p_shuf, float shuf_std, float p_rate, unsigned long long seed) {
+    extern __shared__ int nz[];                      // [L] items | [L] rating indices
+    const unsigned u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long o = off[u];
+    const int L = (int)(off[u + 1] - o);
+    int* it = nz; int* rt = nz + L;
+    for (int i = lane; i < L; i += 64) { it[i] = items[o + i]; rt[i] = rate ? rate[o + i] : 0; }
+    __syncthreads();
+    int n = L;
+    if (p_drop > 0.0f) {                             // keep an item while random() >= dropout; order preserved
+        int w = 0;
+        for (int c0 = 0; c0 < L; c0 += 64) {
+            const int i = c0 + lane;
+            const bool keep = i < L && bb_unif(seed, 0u, u, (unsigned)i) >= p_drop;
+            const int a = i < L ? it[i] : 0, b = i < L ? rt[i] : 0;
+            const unsigned long long m = __ballot(keep);
+            __syncthreads();                         // (one wave: every lane has read its element before any lane writes)
+            if (keep) { const int pos = w + __popcll(m & ((1ull << lane) - 1)); it[pos] = a; rt[pos] = b; }
+            w += __popcll(m);
+            __syncthreads();
+        }
+        n = w;
+        if (n < 2) n = 0;                            // "if len(sequence) < 2: continue": the user yields nothing this pass
+    }
+    if (lane == 0 && n >= 2) {
+        if (p_swap > 0.0f) {
+            int i = 0;
+            while (i < n - 1) {
+                if (bb_unif(seed, 1u, u, (unsigned)i) < p_swap) {
+                    const int a = it[i], b = rt[i];
+                    it[i] = it[i + 1]; rt[i] = rt[i + 1]; it[i + 1] = a; rt[i + 1] = b;
+                    i += 1;                          // don't allow to swap twice the same item
+                }
+                i += 1;
+            }
+        }
+        if (p_shuf > 0.0f) {
+            for (int i = 0; i < n; ++i) {
+                if (bb_unif(seed, 2u, u, (unsigned)i) < p_shuf) {
+                    // int(np.random.randn() * shuf_std) + i, clamped into the sequence (Box-Muller on two hashed uniforms)
+                    const float u1 = fmaxf(bb_unif(seed, 3u, u, (unsigned)i), 5.9604645e-8f), u2 = bb_unif(seed, 4u, u, (unsigned)i);
+                    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+                    const int other = max(0, min(n - 1, (int)(z * shuf_std) + i));
+                    const int a = it[i], b = rt[i];
+                    it[i] = it[other]; rt[i] = rt[other]; it[other] = a; rt[other] = b;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        int r = rt[i];
+        if (rate && p_rate > 0.0f && bb_unif(seed, 5u, u, (unsigned)i) < p_rate) {
+            // +- half a star, clamped to [1, 5]: the one-hot index is 2 * rating - 1
+            r = bb_unif(seed, 6u, u, (unsigned)i) < 0.5f ? min(9, r + 1) : max(1, r - 1);
+        }
+        items_n[o + i] = it[i];
+        if (rate_n) rate_n[o + i] = r;
+    }
+    if (lane == 0) len_n[u] = n;
+}
+
+// ---------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------
 extern "C" int sbr_dataset_create(const int32_t* items, const int64_t* offsets, int64_t n_users, int32_t n_items, void* stream,
@@ -227,13 +312,16 @@ extern "C" int sbr_dataset_create(const int32_t* items, const int64_t* offsets, 
     sbr_dataset* d = new sbr_dataset();
     d->n_users = n_users; d->nnz = nnz; d->n_items = n_items; d->stream = (hipStream_t)stream;
     d->d_items = nullptr; d->d_off = nullptr; d->d_popdb = nullptr; d->d_cdf = nullptr; d->d_rate = nullptr; d->shuffle_targets = 0;
+    d->d_items_n = d->d_rate_n = d->d_len_n = nullptr; d->noised = 0; d->max_len = 0;
     d->d_seg_user = d->d_seg_k = d->d_seg_row0 = d->d_batch_begin = nullptr; d->cap_su = d->cap_sk = d->cap_sr = d->cap_bb = 0;
     d->d_split = d->d_rowuser = nullptr; d->cap_rows = 0; d->n_batches = 0; d->batch_size = 0;
     d->len.resize(n_users);
     for (int64_t u = 0; u < n_users; ++u) {
         d->len[u] = offsets[u + 1] - offsets[u];
         if (d->len[u] < 0) { delete d; sbr_set_error("offsets not monotone at user %lld", (long long)u); return SBR_EINVAL; }
+        d->max_len = std::max(d->max_len, d->len[u]);
     }
+    d->len_cur = d->len;
     for (int64_t i = 0; i < nnz; ++i)
         if (items[i] < 0 || items[i] >= n_items) { delete d; sbr_set_error("item id %d out of range [0,%d)", items[i], n_items); return SBR_EINVAL; }
     if (hipMalloc(&d->d_items, std::max<int64_t>(nnz, 1) * sizeof(int)) != hipSuccess ||
@@ -252,6 +340,7 @@ extern "C" int sbr_dataset_destroy(sbr_dataset* d) {
     (void)hipFree(d->d_items); (void)hipFree(d->d_off); (void)hipFree(d->d_popdb); (void)hipFree(d->d_cdf); (void)hipFree(d->d_rate);
     (void)hipFree(d->d_seg_user); (void)hipFree(d->d_seg_k); (void)hipFree(d->d_seg_row0); (void)hipFree(d->d_batch_begin);
     (void)hipFree(d->d_split); (void)hipFree(d->d_rowuser);
+    (void)hipFree(d->d_items_n); (void)hipFree(d->d_rate_n); (void)hipFree(d->d_len_n);
     delete d;
     return SBR_OK;
 }
@@ -271,6 +360,47 @@ extern "C" int sbr_dataset_set_options(sbr_dataset* d, const float* ratings, int
         SBR_HIP(hipMemcpyAsync(d->d_rate, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, d->stream));
         SBR_HIP(hipStreamSynchronize(d->stream));
     }
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_noise_pass(sbr_dataset* d, float dropout, float swap, float shuf, float shuf_std, float ratings_perturb,
+                                      uint64_t seed) {
+    CHECK_ARG(d, "null dataset");
+    CHECK_ARG(dropout >= 0.0f && dropout < 1.0f && swap >= 0.0f && swap < 1.0f && ratings_perturb >= 0.0f && ratings_perturb < 1.0f &&
+              shuf >= 0.0f && shuf <= 1.0f, "noise probabilities out of range (sequence_noise.py:46-51)");
+    if (!(dropout > 0.0f || swap > 0.0f || shuf > 0.0f || (ratings_perturb > 0.0f && d->d_rate))) {
+        d->noised = 0; d->len_cur = d->len;
+        return SBR_OK;
+    }
+    const size_t lds = (size_t)std::max<int64_t>(d->max_len, 1) * 2 * sizeof(int);
+    CHECK_ARG(lds <= 64 * 1024, "a sequence of %lld items does not fit the noise kernel's staging (8192)", (long long)d->max_len);
+    if (!d->d_items_n) {
+        SBR_HIP(hipMalloc(&d->d_items_n, std::max<int64_t>(d->nnz, 1) * sizeof(int)));
+        SBR_HIP(hipMalloc(&d->d_len_n, d->n_users * sizeof(int)));
+    }
+    if (d->d_rate && !d->d_rate_n) SBR_HIP(hipMalloc(&d->d_rate_n, std::max<int64_t>(d->nnz, 1) * sizeof(int)));
+    // batches of the previous pass may still be reading the previous copy: the stream orders the kernel behind them
+    (void)hipFuncSetAttribute((const void*)bb_noise_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    bb_noise_kernel<<<(unsigned)d->n_users, 64, lds, d->stream>>>(d->d_items, d->d_rate, d->d_off, d->d_items_n, d->d_rate ? d->d_rate_n : nullptr,
+                                                                   d->d_len_n, dropout, swap, shuf, shuf_std, ratings_perturb,
+                                                                   seed * 0x9E3779B97F4A7C15ull + 0x5EEDull);
+    SBR_LAUNCH(hipGetLastError());
+    d->len_n32.resize(d->n_users);
+    SBR_HIP(hipMemcpyAsync(d->len_n32.data(), d->d_len_n, d->n_users * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    d->len_cur.resize(d->n_users);
+    for (int64_t u = 0; u < d->n_users; ++u) d->len_cur[u] = d->len_n32[u];
+    d->noised = 1;
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_current_sequences(sbr_dataset* d, int32_t* items, int32_t* rating_index, int32_t* lengths) {
+    CHECK_ARG(d && items && lengths, "null argument");
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    SBR_HIP(hipMemcpy(items, d->noised ? d->d_items_n : d->d_items, d->nnz * sizeof(int), hipMemcpyDeviceToHost));
+    if (rating_index && d->d_rate)
+        SBR_HIP(hipMemcpy(rating_index, d->noised ? d->d_rate_n : d->d_rate, d->nnz * sizeof(int), hipMemcpyDeviceToHost));
+    for (int64_t u = 0; u < d->n_users; ++u) lengths[u] = (int32_t)d->len_cur[u];
     return SBR_OK;
 }
 
@@ -311,7 +441,7 @@ extern "C" int sbr_dataset_plan_pass(sbr_dataset* d, const int32_t* order, int32
     const size_t cap = (size_t)d->n_users + np + 1;
     d->seg_user.resize(cap); d->seg_k.resize(cap); d->seg_row0.resize(cap); d->seg_batch.resize(cap);
     int64_t ns = 0, nb = 0;
-    const int rc = sbr_plan_pass_host(d->len.data(), order, d->n_users, B, pu.data(), pk.data(), &np, d->seg_user.data(),
+    const int rc = sbr_plan_pass_host(d->len_cur.data(), order, d->n_users, B, pu.data(), pk.data(), &np, d->seg_user.data(),
                                       d->seg_k.data(), d->seg_row0.data(), d->seg_batch.data(), &ns, &nb);
     if (rc != SBR_OK) return rc;
     d->pend_user.assign(pu.begin(), pu.begin() + np); d->pend_k.assign(pk.begin(), pk.begin() + np);
@@ -361,12 +491,15 @@ extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uin
     }
     const int sb = d->batch_begin[batch], se = d->batch_begin[batch + 1];
     const unsigned long long sd = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(batch + 1));
-    bb_split_kernel<<<se - sb, 256, 0, s>>>(d->d_off, d->d_seg_user, d->d_seg_k, d->d_seg_row0, sb, sd, d->d_split, d->d_rowuser);
+    const int* len_n = d->noised ? d->d_len_n : nullptr;      // this pass's noised copy of the sequences (sbr_dataset_noise_pass)
+    const int* src_items = d->noised ? d->d_items_n : d->d_items;
+    const int* src_rate = d->noised && d->d_rate ? d->d_rate_n : d->d_rate;
+    bb_split_kernel<<<se - sb, 256, 0, s>>>(d->d_off, len_n, d->d_seg_user, d->d_seg_k, d->d_seg_row0, sb, sd, d->d_split, d->d_rowuser);
     SBR_LAUNCH(hipGetLastError());
     const bool sampled = y.S > 0;
     const int tgt_rows = sampled ? y.Bg : y.B, tgt_offset = sampled ? 0 : y.cfg.row_offset;
     const int extra = (tgt_rows * y.NT + 63) / 64 + (y.S + 63) / 64;
-    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(d->d_items, d->d_rate, d->d_off, d->d_split, d->d_rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
+    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(src_items, src_rate, d->d_off, len_n, d->d_split, d->d_rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
                                                 y.F, y.NT, d->shuffle_targets, y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, (int*)h->A(y.a_X),
                                                 (int*)h->A(y.a_len), (int*)h->A(y.a_tgt), h->A(y.a_pop), (int*)h->A(y.a_smp));
     SBR_LAUNCH(hipGetLastError());

@@ -72,8 +72,9 @@ class NativeBatchBuilder(object):
     """Training batches built on the device (sbr_dataset_* / sbr_build_batch in include/sbr_rnn.h):
     the stand-in for `_gen_mini_batch(sequence_noise(dataset.training_set()))` + `_prepare_input`
     (rnn_base.py:373-420, rnn_one_hot.py:83-106, rnn_sampling.py:159-194, rnn_margin.py:112-147) for every option that leaves
-    the number of rows a user yields alone: --rf, --n_targets, --shuffle_targets, --db, --sampling_bias (not --target_bias and
-    the sequence noise, which stay with the host generator).
+    the batch plan of a pass computable on the host: --rf, --n_targets, --shuffle_targets, --db, --sampling_bias, and the
+    sequence noise (--n_dropout, --n_swap, --n_shuf, --n_ratings: a device pass over the users before each pass is planned,
+    sequence_noise.py:52-94); not --target_bias, which stays with the host generator.
 
     The training file is parsed once (SequenceGenerator.load) and uploaded as CSR.  Per pass the users are walked in
     file order, or reshuffled like data_handling.py:139-141 with --tshuffle; the walk prints the reference's
@@ -81,7 +82,7 @@ class NativeBatchBuilder(object):
     rnn_base.py:312) up to date per batch.  `next()` makes the next batch the engine's current batch."""
 
     def __init__(self, engine, training_set, n_items, batch_size, pop_db=None, sample_cdf=None, seed=None, ratings=False,
-                 shuffle_targets=False):
+                 shuffle_targets=False, noise=None):
         from .engine import DeviceDataset
         if not hasattr(training_set, "users"):
             training_set.load()
@@ -95,6 +96,7 @@ class NativeBatchBuilder(object):
             r = (np.concatenate(training_set.ratings) if len(lengths) else np.zeros(0)) if ratings else None
             self.ds.set_options(r, shuffle_targets)
         self.n_users = len(lengths)
+        self.noise = noise if (noise is not None and getattr(noise, "name", "") != "") else None      # a SequenceNoise
         self.seed = int(seed if seed is not None else random.getrandbits(63))
         self.passes, self.cursor, self.n_batches, self.built = 0, 0, 0, 0
         self._frac = np.zeros(0)
@@ -106,6 +108,9 @@ class NativeBatchBuilder(object):
         if self.ts.shuffle:
             random.shuffle(self.ts.order)
             order = np.asarray(self.ts.order, dtype=np.int32)
+        if self.noise is not None:      # this pass's noised copy of every sequence; the plan below sees its lengths
+            nz = self.noise
+            self.ds.noise_pass(nz.dropout, nz.swap, nz.shuf, nz.shuf_std, nz.ratings_perturb, seed=self.seed + 7919 * self.passes)
         self.n_batches = self.ds.plan_pass(order, self.batch_size)
         seg = self.ds.segments()
         # fraction of the pass consumed when batch b is complete: position of its last user in the walk

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 4
+SBR_ABI_VERSION = 5
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
@@ -62,7 +62,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
            "sbr_sparse_unpack_add", "sbr_dense_ranges",
-           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_plan_pass",
+           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_noise_pass", "sbr_dataset_current_sequences", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
 _lib = None
@@ -126,6 +126,8 @@ def load_library(path=None):
     lib.sbr_dataset_destroy.argtypes = [vp]
     lib.sbr_dataset_set_tables.argtypes = [vp, vp, vp]
     lib.sbr_dataset_set_options.argtypes = [vp, vp, ctypes.c_int]
+    lib.sbr_dataset_noise_pass.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64]
+    lib.sbr_dataset_current_sequences.argtypes = [vp, vp, vp, vp]
     lib.sbr_dataset_plan_pass.argtypes = [vp, vp, ctypes.c_int32, i64p]
     lib.sbr_dataset_plan_segments.argtypes = [vp, i64p, ctypes.POINTER(i32p), ctypes.POINTER(i32p), ctypes.POINTER(i32p),
                                               ctypes.POINTER(i32p)]
@@ -201,6 +203,20 @@ class DeviceDataset(object):
         shuffle_targets: --shuffle_targets (sbr_dataset_set_options)."""
         r = None if ratings is None else np.ascontiguousarray(ratings, dtype=np.float32)
         self.engine._check(self.lib.sbr_dataset_set_options(self.d, None if r is None else r.ctypes.data, 1 if shuffle_targets else 0))
+
+    def noise_pass(self, dropout=0.0, swap=0.0, shuf=0.0, shuf_std=0.0, ratings_perturb=0.0, seed=0):
+        """Sequence noise for the pass planned next (sbr_dataset_noise_pass; SequenceNoise.__call__)."""
+        with self.engine.torch.cuda.device(self.engine.device):
+            self.engine._check(self.lib.sbr_dataset_noise_pass(self.d, float(dropout), float(swap), float(shuf), float(shuf_std),
+                                                               float(ratings_perturb), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def current_sequences(self, nnz):
+        """(items, rating_index, lengths) the next planned pass reads: the noised copy behind noise_pass (tests / tooling)."""
+        items, rate = np.zeros(max(1, int(nnz)), np.int32), np.zeros(max(1, int(nnz)), np.int32)
+        lens = np.zeros(self.n_users, np.int32)
+        with self.engine.torch.cuda.device(self.engine.device):
+            self.engine._check(self.lib.sbr_dataset_current_sequences(self.d, items.ctypes.data, rate.ctypes.data, lens.ctypes.data))
+        return items[:int(nnz)], rate[:int(nnz)], lens
 
     def plan_pass(self, order, batch_size):
         o = None if order is None else np.ascontiguousarray(order, dtype=np.int32)

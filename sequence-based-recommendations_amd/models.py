@@ -306,14 +306,19 @@ class RNNBase(object):
 
     def _native_batch_builder(self, dataset):
         """Device-side batch builder for the options it covers (item index, + rating index with --rf; next-item or shuffled
-        targets, --n_targets of them for the multi-target losses; --db, --sampling_bias); None -> the reference-style host
-        generator (sequence noise, --target_bias).  SBR_NATIVE_BATCHES=0 disables it."""
+        targets, --n_targets of them for the multi-target losses; --db, --sampling_bias; the sequence noise); None -> the
+        reference-style host generator (--target_bias).  SBR_NATIVE_BATCHES=0 disables it."""
         if os.environ.get("SBR_NATIVE_BATCHES", "1") == "0":
             return None
         ts = self.target_selection
         multi = isinstance(self, RNNMargin)                  # only the multi-target losses look past the first target
-        if self.sequence_noise.name != "" or ts.bias >= 0.0:
-            return None      # they change how many rows a user yields: the host plan of a pass cannot know (include/sbr_rnn.h)
+        if ts.bias >= 0.0:
+            return None      # a row can run out of targets: the host plan of a pass cannot know (include/sbr_rnn.h)
+        if self.sequence_noise.name != "":
+            if not hasattr(dataset.training_set, "users"):
+                dataset.training_set.load()
+            if max([len(x) for x in dataset.training_set.items] + [0]) > 8192:
+                return None  # (a sequence longer than the noise kernel's LDS staging)
         if ts.shuffle and multi and self._engine_targets() > 16:
             return None
         from .data import NativeBatchBuilder
@@ -323,7 +328,7 @@ class RNNBase(object):
         cdf = np.cumsum(np.power(pop, sb)) if (sb > 0.0 and getattr(self, "effective_sampling", 0)) else None
         return NativeBatchBuilder(self.engine, dataset.training_set, self.n_items, self.batch_size,
                                   pop_db=np.power(pop, db).astype(np.float32), sample_cdf=cdf,
-                                  ratings=self.use_ratings_features, shuffle_targets=ts.shuffle)
+                                  ratings=self.use_ratings_features, shuffle_targets=ts.shuffle, noise=self.sequence_noise)
 
     def _compute_validation_metrics(self, metrics):
         from .data import Evaluator

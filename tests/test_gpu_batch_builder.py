@@ -245,3 +245,147 @@ def test_rating_feature_multiple_targets_and_shuffled_targets():
     assert n_draws > 2000 and np.all(np.abs(hist - want) / n_draws < 0.04), (hist / n_draws, want / n_draws)
     assert hist[3] / n_draws > 0.15                                             # next-item targets would put everything in the first quartile
     ds.close(); eng.close()
+
+
+def _host_noise(seqs, **kw):
+    """The reference-style host implementation (options.SequenceNoise, sequence_noise.py:52-94) over a list of sequences of
+    [item, rating] pairs; returns the noised sequences (None where the user is skipped)."""
+    from sbr_amd.options import SequenceNoise
+    nz = SequenceNoise(**kw)
+    out = []
+    for s in seqs:
+        got = list(nz(iter([([list(p) for p in s], 0)])))      # (a skipped user yields nothing)
+        out.append(got[0][0] if got else None)
+    return out
+
+
+def test_sequence_noise_laws():
+    """sbr_dataset_noise_pass against the reference's procedure (sequence_noise.py:52-94), as laws over many passes: the device
+    draws are hashed, not the reference's Mersenne stream."""
+    from sbr_amd.engine import RNNEngine, DeviceDataset
+    rng = np.random.default_rng(11)
+    lengths = rng.integers(2, 60, size=60)
+    items, offsets, n_items = encoded_dataset(lengths)
+    nnz = len(items)
+    ratings = (0.5 + 0.5 * ((items * 7) % 10)).astype(np.float32)
+    eng = RNNEngine(cell="GRU", layers=[16], n_items=n_items, max_length=8, batch_size=32, loss="CCE", n_feat=2, input_size=n_items + 10)
+    ds = DeviceDataset(eng, items, offsets, n_items)
+    ds.set_options(ratings, False)
+    idx0 = ((np.floor(ratings * 2 + 0.5).astype(int) - 1) % 10)
+    seqs = [[[int(items[offsets[u] + i]), float(ratings[offsets[u] + i])] for i in range(lengths[u])] for u in range(len(lengths))]
+    np.random.seed(5)
+
+    def device(seed, **kw):
+        ds.noise_pass(seed=seed, **kw)
+        it, rt, ln = ds.current_sequences(nnz)
+        return [(it[offsets[u]:offsets[u] + ln[u]], rt[offsets[u]:offsets[u] + ln[u]]) for u in range(len(lengths))], ln
+
+    # ---- no noise: the sequences as uploaded
+    got, ln = device(1)
+    assert np.array_equal(ln, lengths) and all(np.array_equal(g[0], items[offsets[u]:offsets[u + 1]]) for u, g in enumerate(got))
+    # ---- dropout: an order-preserving subsequence; every item kept with probability 1 - p; fewer than two left -> skipped
+    kept = tot = skipped = short = 0
+    for sd in range(40):
+        got, ln = device(100 + sd, dropout=0.3)
+        for u, (it, rt) in enumerate(got):
+            pos = (it - 1) % 64
+            assert np.all((it - 1) // 64 == u) and np.all(np.diff(pos) > 0)
+            assert np.array_equal(rt, idx0[offsets[u] + pos])                   # the rating travels with its item
+            if ln[u] == 0:
+                skipped += 1
+            else:
+                assert ln[u] >= 2
+                kept += ln[u]; tot += lengths[u]
+    assert abs(kept / tot - 0.7) < 0.02, kept / tot                             # (skipped users are short ones: a small bias upward)
+    assert skipped > 0                                                          # users of 2 - 3 items lose one often enough
+    # ---- swap / shuffle: permutations of the user's own sequence; displacement statistics match the host procedure's
+    def displacement_hist(noised_positions):
+        h = np.zeros(5)
+        for pos in noised_positions:
+            d = np.abs(pos - np.arange(len(pos)))
+            h += np.bincount(np.digitize(d, [1, 2, 4, 8]), minlength=5)
+        return h / h.sum()
+
+    for kw in (dict(swap=0.25), dict(shuf=0.2, shuf_std=5.0), dict(swap=0.1, shuf=0.1, shuf_std=3.0)):
+        dev_pos, host_pos = [], []
+        for sd in range(30):
+            got, ln = device(200 + sd, **kw)
+            assert np.array_equal(ln, lengths)
+            for u, (it, rt) in enumerate(got):
+                pos = (it - 1) % 64
+                assert sorted(pos.tolist()) == list(range(lengths[u]))          # a permutation
+                assert np.array_equal(rt, idx0[offsets[u] + pos])
+                dev_pos.append(pos)
+            for u, s in enumerate(_host_noise(seqs, **kw)):
+                host_pos.append((np.array([p[0] for p in s]) - 1) % 64)
+        hd, hh = displacement_hist(dev_pos), displacement_hist(host_pos)
+        assert np.all(np.abs(hd - hh) < 0.012), (kw, hd, hh)
+        assert hd[0] < 0.95                                                     # something moved
+    if True:      # swap: an item moves at most one place
+        got, _ = device(999, swap=0.4)
+        assert all(np.all(np.abs((it - 1) % 64 - np.arange(len(it))) <= 1) for it, _ in got)
+    # ---- rating perturbation: +- one half-star index, clamped to ratings 1 .. 5 (index 1 .. 9); items untouched
+    up = down = same = 0
+    exp_up = exp_down = 0.0
+    for sd in range(30):
+        got, ln = device(300 + sd, ratings_perturb=0.3)
+        for u, (it, rt) in enumerate(got):
+            assert np.array_equal(it, items[offsets[u]:offsets[u + 1]])
+            d = rt - idx0[offsets[u]:offsets[u + 1]]
+            assert np.all(np.abs(d) <= 1) and np.all(rt[d != 0] >= 1) and np.all(rt <= 9)
+            up += int((d == 1).sum()); down += int((d == -1).sum()); same += int((d == 0).sum())
+            i0 = idx0[offsets[u]:offsets[u + 1]]
+            # a perturbed rating changes unless the clamp undoes it: up at index 9, down at index 1; down at index 0 (rating
+            # 0.5) is max(1, 0) = rating 1: index 1, a step UP
+            exp_up += 0.3 * (0.5 * (i0 < 9).sum() + 0.5 * (i0 == 0).sum())
+            exp_down += 0.3 * 0.5 * (i0 >= 2).sum()
+    n = up + down + same
+    assert abs(up - exp_up) / n < 0.008 and abs(down - exp_down) / n < 0.008, (up / n, exp_up / n, down / n, exp_down / n)
+    ds.close(); eng.close()
+
+
+def test_batches_of_a_noised_pass_read_the_noised_copy():
+    """With noise the pass is planned on the noised lengths and every row is cut from the noised copy; rows carried over from
+    the previous pass are cut from the NEW copy (their count clamped to what it offers)."""
+    from sbr_amd.engine import RNNEngine, DeviceDataset
+    rng = np.random.default_rng(13)
+    lengths = rng.integers(2, 40, size=70)
+    items, offsets, n_items = encoded_dataset(lengths)
+    B, T = 32, 8
+    eng = RNNEngine(cell="GRU", layers=[16], n_items=n_items, max_length=T, batch_size=B, loss="CCE")
+    ds = DeviceDataset(eng, items, offsets, n_items)
+    rows_total = 0
+    for p in range(3):
+        ds.noise_pass(dropout=0.3, swap=0.2, seed=40 + p)
+        it, _, ln = ds.current_sequences(len(items))
+        nb = ds.plan_pass(None, B)
+        seg = ds.segments()
+        assert nb >= 2
+        for u, k in zip(seg[:, 0], seg[:, 1]):
+            assert 1 <= k <= ln[u] - 2                                          # never more rows than the noised sequence offers
+        assert not np.isin(np.nonzero(ln == 0)[0], seg[:, 0]).any()             # skipped users own no rows
+        for b in range(nb):
+            eng.build_batch(ds, b, seed=70 + 10 * p + b)
+            cur = eng.current_batch()
+            X, lens, tgt = cur["X"], cur["lengths"], cur["target"]
+            for r in range(B):
+                u = (tgt[r] - 1) // 64
+                seq = it[offsets[u]:offsets[u] + ln[u]]
+                where = np.nonzero(seq == tgt[r])[0]
+                assert len(where) == 1                                          # (items of a user are distinct in this dataset)
+                l = int(where[0])
+                assert l >= 2 and np.array_equal(X[r, :lens[r], 0], seq[max(0, l - T):l]) and not X[r, lens[r]:].any()
+                rows_total += 1
+    assert rows_total >= 3 * 2 * B
+    # a training loop on noised passes runs and learns
+    from oracle import rnn_oracle as O
+    eng.set_all_param_values(O.init_params("GRU", [16], n_items, np.random.default_rng(7), dtype=np.float32))
+    costs = []
+    for p in range(6):
+        ds.noise_pass(dropout=0.1, shuf=0.1, shuf_std=2.0, seed=90 + p)
+        nb = ds.plan_pass(None, B)
+        for b in range(nb):
+            eng.build_batch(ds, b, seed=500 + 31 * p + b)
+            costs.append(eng.train_step())
+    assert np.all(np.isfinite(costs)) and np.mean(costs[-4:]) < np.mean(costs[:4])
+    ds.close(); eng.close()
