@@ -1580,7 +1580,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         int products = 0, rows = 16, wgs = y.Bp / 16;
         if (!simple_rec(h) && x6) {
             const char* fe = getenv(bwd ? "SBR_X6_F16_BWD" : "SBR_X6_F16");      // the launchers' own conditions (sbr_rec_p.hip)
-            const bool f16 = (xp || cl) && (fe ? atoi(fe) != 0 : true) && (bwd ? (a.clip > 0.0f && a.clip <= 100.0f) : !a.relu);
+            const bool f16 = (xp || cl || xq) && (fe ? atoi(fe) != 0 : true) && (bwd ? (a.clip > 0.0f && a.clip <= 100.0f) : !a.relu);
             products = f16 ? 3 : 6;
             if (cl && sbr_rec_c16_ok(a)) { rows = 16; wgs = (y.Bp / 16) * (a.Hp / 16); }
             else if (cl) { rows = bwd ? sbr_rec_cluster_bwd_rows(a) : SBR_CL_ROWS; wgs = (y.Bp / rows) * (a.Hp == 256 ? 8 : 32); }

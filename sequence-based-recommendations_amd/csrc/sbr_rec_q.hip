@@ -13,16 +13,33 @@
 // With one wave per SIMD nothing overlaps the gate math, so a step is (MFMAs) + (everything else) serially and the
 // instruction count of "everything else" is the whole game at these sizes (C1: 24 MFMAs = 384 cycles per step).
 #include "sbr_rec_p.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 constexpr int RQ = 4;
+// "f16x3" (sbr_rec_p.hip: split2_f16): an operand as a1 + a2 / 2048 in two fp16 planes, a product in three MFMAs instead of
+// bf16x6's six; the forward's operand is h in [-1, 1] (not behind a rectifier), the backward's gradient operand has passed
+// the reference's clip (<= 100) and is scaled by 2^9.  Same switches as the 128-unit kernels (SBR_X6_F16, SBR_X6_F16_BWD).
+typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
+constexpr float Q_F16_LO = 2048.0f, Q_F16_DSCALE = 512.0f;
+__device__ __forceinline__ f32x4 mfma_q(const f16x8q& a, const f16x8q& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split2_q(float v, _Float16& a1, _Float16& a2) {
+    asm("" : "+v"(v));                                   // one rounding to fp16 for both uses (see split2_f16)
+    a1 = (_Float16)v;
+    a2 = (_Float16)((v - (float)a1) * Q_F16_LO);
+}
 }
 
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int CELL, int HQ, bool FUSE>
+template <int CELL, int HQ, bool FUSE, bool F16>
 __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
+    using OPV = std::conditional_t<F16, f16x8q, bf16x8>;
+    constexpr int NPL = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, KB = HQ / 32, NW = HQ / 16, GHP = G * HQ;
     static_assert(G * KB * 12 <= 144, "W_hid planes must fit the register file");
     constexpr int HROW = HQ * 2 + 32, PLANEB = RQ * HROW, BUFB = 3 * PLANEB;
@@ -44,17 +61,24 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));  // workgroup-uniform: all four rows
     tmin = __builtin_amdgcn_readfirstlane(min(tmin, __shfl_xor(tmin, 32)));  // steps below it: no row is masked
 
-    bf16x8 W1[G][KB], W2[G][KB], W3[G][KB];              // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
+    OPV W1[G][KB], W2[G][KB], W3[F16 ? 1 : G][F16 ? 1 : KB];   // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                __bf16 b1, b2, b3;
                 const float sc = (CELL == CELL_GRU && g < 2) ? X6P_NLOG2E : 1.0f;     // sigmoid gates: see the gate math
-                split3(sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HQ + u], b1, b2, b3);
-                W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b3;
+                const float w = sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HQ + u];
+                if constexpr (F16) {
+                    _Float16 b1, b2;
+                    split2_q(w, b1, b2);
+                    W1[g][kb][e] = b1; W2[g][kb][e] = b2;
+                } else {
+                    __bf16 b1, b2, b3;
+                    split3(w, b1, b2, b3);
+                    W1[g][kb][e] = b1; W2[g][kb][e] = b2; W3[g][kb][e] = b3;
+                }
             }
 
     const unsigned bo_h = (unsigned)(row * HQ + u) * 4u;                                       // hs / cs rows
@@ -73,12 +97,19 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
     const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16);     // A operand: tile row m = j holds batch row j >> 2
     auto publish_h = [&](int buf) {
+        char* base = hbuf + buf * BUFB + lds_pub;
+        if constexpr (F16) {
+            _Float16 h1, h2;
+            split2_q(h, h1, h2);
+            *(_Float16*)(base) = h1;
+            *(_Float16*)(base + PLANEB) = h2;
+        } else {
         unsigned p1, p2, p3;
         split3_trunc(h, p1, p2, p3);
-        char* base = hbuf + buf * BUFB + lds_pub;
         *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
         *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
         *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+        }
     };
     publish_h(0);
 
@@ -114,16 +145,16 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
     size_t off_t = 0;                                              // t * st_h
     for (int t = 0; t < tmax; ++t) {
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
-        bf16x8 hp[KB][3];
+        OPV hp[KB][NPL];
         int fl;
         auto load_all = [&]() {                                   // counter first, then planes: the LDS keeps a wave's order
             fl = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                hp[kb][0] = *(const bf16x8*)(hb + kb * 64);
-                hp[kb][1] = *(const bf16x8*)(hb + kb * 64 + PLANEB);
-                hp[kb][2] = *(const bf16x8*)(hb + kb * 64 + 2 * PLANEB);
+                hp[kb][0] = *(const OPV*)(hb + kb * 64);
+                hp[kb][1] = *(const OPV*)(hb + kb * 64 + PLANEB);
+                if constexpr (!F16) hp[kb][NPL - 1] = *(const OPV*)(hb + kb * 64 + 2 * PLANEB);
             }
         };
         load_all();
@@ -137,9 +168,27 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
             } while (__builtin_amdgcn_readfirstlane(fl) < NW * t);
         }
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("" :: "v"(hp[kb][0]), "v"(hp[kb][1]), "v"(hp[kb][2]));
+        for (int kb = 0; kb < KB; ++kb) asm volatile("" :: "v"(hp[kb][0]), "v"(hp[kb][1]), "v"(hp[kb][NPL - 1]));
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[G];
+        if constexpr (F16) {      // acc: h1 w1 (+ bias as the C operand); lo: the low-order products h2 w1 + h1 w2 (/ 2048)
+            const f32x4 z4 = f32x4{0, 0, 0, 0};
+            f32x4 lo[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) lo[g] = z4;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) lo[g] = mfma_q(hp[kb][1], W1[g][kb], lo[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) lo[g] = mfma_q(hp[kb][0], W2[g][kb], lo[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = mfma_q(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][0] = fmaf(lo[g][0], 1.0f / Q_F16_LO, acc[g][0]);
+        } else {
 #define X6Q_TERM(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = MFMA_BF16(HOP, WOP, acc[g]);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -154,6 +203,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
             X6Q_TERM(hp[kb][0], W1[g][kb])
         }
 #undef X6Q_TERM
+        }
         __builtin_amdgcn_sched_barrier(0);                        // (the MFMA D -> VALU read hazard right below is padded by hipcc: same basic block)
         {
             float hn, cn = cst;
@@ -205,8 +255,10 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
 // A operand = dhi planes (LDS), B operand = the W_hid rows of the wave's 16 units (registers); every operand plane of
 // the step is fetched before its MFMAs.  Chunked BPTT protocol (t_lo / t_hi / state / part) as in rec_bwd_x6s.
 // ---------------------------------------------------------------------------------------
-template <int CELL, int HQ, bool EXT>
+template <int CELL, int HQ, bool EXT, bool F16>
 __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
+    using OPV = std::conditional_t<F16, f16x8q, bf16x8>;
+    constexpr int NPL = F16 ? 2 : 3;
     constexpr int G = Gates<CELL>::G, NW = HQ / 16, GHP = G * HQ, KB = GHP / 32;
     static_assert(KB * 24 <= 200, "weights + operand planes must fit the register file");
     constexpr int DROW = GHP * 2 + 32, PLANEB = RQ * DROW, BUFB = 3 * PLANEB;
@@ -228,16 +280,23 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, 16));
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));
 
-    bf16x8 W1[KB], W2[KB], W3[KB];                       // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
+    OPV W1[KB], W2[KB], W3[F16 ? 1 : KB];                // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const float* src = a.Whid + (size_t)u * GHP + kb * 32 + 8 * q;
         const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            __bf16 b1, b2, b3;
-            split3(e < 4 ? lo[e & 3] : hi[e & 3], b1, b2, b3);
-            W1[kb][e] = b1; W2[kb][e] = b2; W3[kb][e] = b3;
+            const float w = e < 4 ? lo[e & 3] : hi[e & 3];
+            if constexpr (F16) {
+                _Float16 b1, b2;
+                split2_q(w, b1, b2);
+                W1[kb][e] = b1; W2[kb][e] = b2;
+            } else {
+                __bf16 b1, b2, b3;
+                split3(w, b1, b2, b3);
+                W1[kb][e] = b1; W2[kb][e] = b2; W3[kb][e] = b3;
+            }
         }
     }
 
@@ -296,12 +355,19 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         if (CELL == CELL_LSTM) { sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2]; }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            char* base = lds + lds_pub + g * HQ * 2;
+            if constexpr (F16) {
+                _Float16 d1, d2;
+                split2_q(dhi[g] * Q_F16_DSCALE, d1, d2);          // |dhi| <= clip <= 100: below fp16's 65504
+                *(_Float16*)(base) = d1;
+                *(_Float16*)(base + PLANEB) = d2;
+            } else {
             unsigned p1, p2, p3;
             split3_trunc(dhi[g], p1, p2, p3);
-            char* base = lds + lds_pub + g * HQ * 2;
             *(unsigned short*)(base) = (unsigned short)(p1 >> 16);
             *(unsigned short*)(base + PLANEB) = (unsigned short)(p2 >> 16);
             *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
+            }
         }
         lds_inc(lds_cnt, one);
         if (CELL == CELL_LSTM) cnew = cprev;
@@ -319,16 +385,16 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         off_h -= st_h; off_x -= st_x;
         const char* db = lds + lds_rd;
-        bf16x8 dpl[KB][3];
+        OPV dpl[KB][NPL];
         int fl;
         auto load_all = [&]() {
             fl = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                dpl[kb][0] = *(const bf16x8*)(db + kb * 64);
-                dpl[kb][1] = *(const bf16x8*)(db + kb * 64 + PLANEB);
-                dpl[kb][2] = *(const bf16x8*)(db + kb * 64 + 2 * PLANEB);
+                dpl[kb][0] = *(const OPV*)(db + kb * 64);
+                dpl[kb][1] = *(const OPV*)(db + kb * 64 + PLANEB);
+                if constexpr (!F16) dpl[kb][NPL - 1] = *(const OPV*)(db + kb * 64 + 2 * PLANEB);
             }
         };
         load_all();
@@ -342,10 +408,20 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
             } while (__builtin_amdgcn_readfirstlane(fl) < NW * (n + 1));
         }
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("" :: "v"(dpl[kb][0]), "v"(dpl[kb][1]), "v"(dpl[kb][2]));
+        for (int kb = 0; kb < KB; ++kb) asm volatile("" :: "v"(dpl[kb][0]), "v"(dpl[kb][1]), "v"(dpl[kb][NPL - 1]));
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 z4 = f32x4{0, 0, 0, 0};
         f32x4 acc[3] = {z4, z4, z4};
+        if constexpr (F16) {      // acc[0]: d1 w1; acc[1], acc[2]: the low-order products (/ 2048); all / 2^9 (the operand's scale)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                acc[1] = mfma_q(dpl[kb][1], W1[kb], acc[1]);
+                acc[2] = mfma_q(dpl[kb][0], W2[kb], acc[2]);
+                acc[0] = mfma_q(dpl[kb][0], W1[kb], acc[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dh += fmaf(acc[1][0] + acc[2][0], 1.0f / Q_F16_LO, acc[0][0]) * (1.0f / Q_F16_DSCALE);
+        } else {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             acc[0] = MFMA_BF16(dpl[kb][0], W3[kb], acc[0]);
@@ -357,6 +433,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);                        // (MFMA D -> VALU read hazard: padded by hipcc, same basic block)
         dh += acc[0][0] + acc[1][0] + acc[2][0];
+        }
     }
 
     if (!last) {                                                  // hand dh / dc to the next chunk launch
@@ -402,14 +479,20 @@ template <int CELL, int HQ>
 static hipError_t launch_fwd_q(hipStream_t s, const RecArgs& a) {
     const size_t lds = 2 * 3 * RQ * (size_t)(HQ * 2 + 32) + 64;
     const int nb = a.Bp / RQ;
-    if (a.gX) X6Q_LAUNCH((rec_fwd_x6q<CELL, HQ, true>), HQ * 4, lds); else X6Q_LAUNCH((rec_fwd_x6q<CELL, HQ, false>), HQ * 4, lds);
+    const char* fe = getenv("SBR_X6_F16");                         // read per launch: the tests flip it
+    const bool f16 = (fe ? atoi(fe) != 0 : true) && !a.relu;       // (a rectified state is unbounded)
+    if (f16) { if (a.gX) X6Q_LAUNCH((rec_fwd_x6q<CELL, HQ, true, true>), HQ * 4, lds); else X6Q_LAUNCH((rec_fwd_x6q<CELL, HQ, false, true>), HQ * 4, lds); }
+    else { if (a.gX) X6Q_LAUNCH((rec_fwd_x6q<CELL, HQ, true, false>), HQ * 4, lds); else X6Q_LAUNCH((rec_fwd_x6q<CELL, HQ, false, false>), HQ * 4, lds); }
     return hipGetLastError();
 }
 template <int CELL, int HQ>
 static hipError_t launch_bwd_q(hipStream_t s, const RecArgs& a) {
     const size_t lds = 2 * 3 * RQ * (size_t)(Gates<CELL>::G * HQ * 2 + 32) + 64;
     const int nb = a.Bp / RQ;
-    if (a.dh_ext) X6Q_LAUNCH((rec_bwd_x6q<CELL, HQ, true>), HQ * 4, lds); else X6Q_LAUNCH((rec_bwd_x6q<CELL, HQ, false>), HQ * 4, lds);
+    const char* fe = getenv("SBR_X6_F16_BWD");                     // read per launch: the tests flip it
+    const bool f16 = (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;      // the clip bounds the gradient operand
+    if (f16) { if (a.dh_ext) X6Q_LAUNCH((rec_bwd_x6q<CELL, HQ, true, true>), HQ * 4, lds); else X6Q_LAUNCH((rec_bwd_x6q<CELL, HQ, false, true>), HQ * 4, lds); }
+    else { if (a.dh_ext) X6Q_LAUNCH((rec_bwd_x6q<CELL, HQ, true, false>), HQ * 4, lds); else X6Q_LAUNCH((rec_bwd_x6q<CELL, HQ, false, false>), HQ * 4, lds); }
     return hipGetLastError();
 }
 #undef X6Q_LAUNCH

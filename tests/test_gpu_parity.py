@@ -222,6 +222,22 @@ def test_small_layer_barrier_kernels_agree(cell, H, monkeypatch):
     check(PU.compare_step(cell, [H], "CCE", N=61, B=37, T=9))
 
 
+@pytest.mark.parametrize("which", ["SBR_X6_F16", "SBR_X6_F16_BWD"])
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "Vanilla"])
+def test_small_layer_kernels_with_bf16x6_products(cell, which, monkeypatch):
+    # default (every other small-layer test): both chains of rec_*_x6q on the 2-way fp16 split, three MFMAs per product;
+    # the switches bring back the three bf16 planes
+    monkeypatch.setenv(which, "0")
+    check(PU.compare_step(cell, [20], "CCE", N=61, B=37, T=9))
+    check(PU.compare_step(cell, [50, 20], "CCE", N=61, B=9, T=12, scale=0.1))
+
+
+def test_small_layer_fp16_products_at_the_clip_boundary_and_with_tiny_gradients():
+    check(PU.compare_step("LSTM", [20], "CCE", N=61, B=37, T=9, popscale=1e-4))
+    check(PU.compare_step("GRU", [50], "CCE", N=61, B=37, T=40, popscale=1e4, scale=0.1), tol_g=2e-4)
+    check(PU.compare_step("LSTM", [50, 20], "BPR", N=61, B=9, T=12, S=8, scale=0.1))
+
+
 def test_small_layer_kernels_two_layers_ragged_and_chunks(monkeypatch):
     monkeypatch.setenv("SBR_BWD_CHUNKS", "3")
     check(PU.compare_step("LSTM", [50, 20], "CCE", N=61, B=7, T=70, scale=0.05))
