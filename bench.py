@@ -214,9 +214,9 @@ def main():
                                "N=%d items, Zipf(1.0) ids, lengths=%s, %d rows per GPU"
                                % (args.config, cell, "-".join(map(str, layers)), T, B, loss, n_items, args.lengths, B),
                    "global_batch": Bg, "seq_len": T, "parallelism": "dp%d" % world, "last_cost": round(cost, 5),
-                   "arithmetic": "f32 tensors and accumulation; matrix products of f32 operands as exact splits on the bf16 / fp16 "
-                                 "matrix pipe (bf16x6: backward chain and GEMMs, fp16x3: forward chain of 128-unit GRU / Vanilla) "
-                                 "with f32-class error, DESIGN.md section 3"},
+                   "arithmetic": "f32 tensors and accumulation; matrix products of f32 operands as splits on the fp16 / bf16 "
+                                 "matrix pipe with f32-class error: fp16x3 (three MFMAs per product) in both recurrent chains and the "
+                                 "dW_hid GEMM, bf16x6 in the other GEMMs, DESIGN.md section 3"},
     }
 
     if rank == 0 and phases is not None:

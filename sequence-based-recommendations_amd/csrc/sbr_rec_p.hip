@@ -1,5 +1,5 @@
-// Pipelined bf16x6 recurrent kernels for GRU / Vanilla layers of 128 units on 4-row tiles ("x6p"): the kernels of
-// BASELINE config C2.  Same arithmetic and global data layout as rec_fwd_x6s / rec_bwd_x6s (sbr_rec.hip: one workgroup
+// Pipelined recurrent kernels for layers of 128 units on 4-row tiles ("x6p"; GRU, Vanilla, and LSTM on fp16 planes): the
+// kernels of BASELINE config C2.  Same arithmetic and global data layout as rec_fwd_x6s / rec_bwd_x6s (sbr_rec.hip: one workgroup
 // of eight waves, two per SIMD, per 4-row tile for all T steps; f32 operands split exactly into three bf16 planes, six
 // MFMA terms); the schedule inside the workgroup is rebuilt around three facts measured on the MI355X
 // (tools/probes/mfma_share_probe.hip, valu_beside_mfma_probe.hip, lds_mask_probe.hip):
@@ -23,7 +23,8 @@
 //      (sbr_read_cost reports it) instead of hanging the GPU.
 //   2. A gate on the matrix pipe: waves 0-3 start their MFMA phase only when their partner has issued its own (fact a:
 //      otherwise they starve the partner's last MFMAs, whose results everybody waits for).
-//   3. All three W_hid planes in registers (144 VGPRs; a fourth gate does not fit: LSTM keeps x6s); activations are the
+//   3. All three W_hid planes in registers (144 VGPRs; a fourth gate fits as two fp16 planes only: LSTM runs the F16 forms,
+//      see sbr_rec_x6p_ok); activations are the
 //      A operand with every batch row filling four tile rows, so lane (j, q) finishes (row q, unit j) from accumulator
 //      element 0 without a select; biases ride in as the MFMA C operand; sigmoid gates are pre-scaled by -log2(e).
 //   4. Everything outside the MFMA phase is written for VALU count (fact b): scalar-advanced addresses, single-

