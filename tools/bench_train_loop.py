@@ -1,6 +1,6 @@
 """End-to-end throughput of the training LOOP (batch building + step), native device builder vs the reference-style host
 generator, on an ML-1M-shaped synthetic dataset written in the reference's on-disk format.
-    python tools/bench_train_loop.py [--iters 300] [--host-iters 8]
+    python tools/bench_train_loop.py [--iters 1000] [--host-iters 8]
 Prints one JSON line."""
 import argparse
 import json
@@ -59,7 +59,7 @@ def run(root, native, iters, B, T):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--host-iters", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--max_length", type=int, default=200)
