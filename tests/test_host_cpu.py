@@ -272,6 +272,28 @@ def test_native_batch_plan_equals_the_reference_fill_order(lib, B, seed):
     assert got == want
 
 
+def test_native_batch_plan_with_lengths_that_change_between_passes(lib):
+    # sequence noise (sbr_dataset_noise_pass): every pass is planned on that pass's noised lengths; the rows a pass carries
+    # over are cut from the NEXT pass's copy of their user, so their count is clamped to what that copy offers, and a user the
+    # dropout left with fewer than two items (length 0) owns no rows at all
+    from sbr_amd.engine import plan_pass_host
+    B = 8
+    seg, nb, pending = plan_pass_host([12, 6, 4], None, B, lib=lib)          # 8 rows (user 0, truncated) | 4 + 2 rows carried
+    assert nb == 1 and pending == [(1, 4), (2, 2)]
+    new_len = np.array([12, 3, 4])                                           # user 1 keeps 3 items this pass: one row at most
+    seg2, nb2, pending2 = plan_pass_host(new_len, None, B, pending, lib=lib)
+    first = seg2[seg2[:, 3] == 0]
+    assert list(first[0, :2]) == [1, 1] and list(first[1, :2]) == [2, 2]     # carried rows first: clamped 4 -> 1, then 2 as counted
+    assert list(first[2, :2]) == [0, 5]                                      # the new pass fills the batch: user 0, min(8 - 3, 10)
+    for b in range(nb2):
+        rows = seg2[seg2[:, 3] == b]
+        assert rows[:, 1].sum() == B and list(rows[:, 2]) == list(np.cumsum(np.r_[0, rows[:-1, 1]]))
+    assert np.all(seg2[:, 1] <= new_len[seg2[:, 0]] - 2)
+    # a carried user that vanished this pass (fewer than two items left) is dropped, the batch is filled by the others
+    seg3, nb3, _ = plan_pass_host([0, 9, 7], None, B, [(0, 5)], lib=lib)
+    assert nb3 >= 1 and 0 not in seg3[:, 0]
+
+
 def test_native_batch_plan_rejects_bad_arguments(lib):
     from sbr_amd.engine import plan_pass_host
     with pytest.raises(ValueError):
