@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 5
+#define SBR_ABI_VERSION 6
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -262,8 +262,7 @@ int sbr_dataset_set_tables(sbr_dataset* d, const float* pop_db, const double* sa
  * item index and n_items + the rating's one-hot index round(rating * 2) - 1 (rnn_base.py:590-642; model built with n_feat = 2,
  * input_size = n_items + 10).  shuffle_targets != 0: --shuffle_targets -- a row's targets are a uniform random subset of the
  * whole remaining sequence instead of its first items (target_selection.py:45-46).  The number of targets per row is the
- * model's (n_targets of the multi-target losses, 1 otherwise).  --target_bias (rows can run out of targets) stays with the host
- * generator. */
+ * model's (n_targets of the multi-target losses, 1 otherwise). */
 int sbr_dataset_set_options(sbr_dataset* d, const float* ratings, int shuffle_targets);
 /* Sequence noise for the pass planned NEXT (SequenceNoise.__call__, sequence_noise.py:52-94; call before sbr_dataset_plan_pass,
  * once per pass): per user, in the reference's order -- dropout of items (a user left with fewer than two items yields no rows
@@ -272,6 +271,22 @@ int sbr_dataset_set_options(sbr_dataset* d, const float* ratings, int shuffle_ta
  * attached).  The batches of the pass read the noised copy; rows carried over from the previous pass are re-drawn from it.
  * All probabilities 0: the pass reads the sequences as they are.  A law, not the reference's random stream. */
 int sbr_dataset_noise_pass(sbr_dataset* d, float dropout, float swap, float shuf, float shuf_std, float ratings_perturb, uint64_t seed);
+/* --target_bias (SelectTargets, target_selection.py:36-53): keep_prob[n_items] = (min(pop) / pop) ** bias; a candidate target
+ * survives with that probability, a row none of whose remaining items survives is skipped and does not count towards its batch
+ * (rnn_base.py:404-409).  Which rows a pass has is then a draw, so with a table set the rows of a pass -- user, split point,
+ * target positions -- are planned on the host at sbr_dataset_plan_pass (sbr_plan_rows_host below: the reference's procedure
+ * with splitmix64 draws seeded from `seed` and the pass number) and uploaded; sbr_build_batch only packs them.  n_targets must
+ * be the model's.  With sequence noise on, the rows a pass carries over are dropped (they index the previous pass's copy).
+ * keep_prob == NULL switches back to device-drawn rows. */
+int sbr_dataset_set_target_bias(sbr_dataset* d, const float* keep_prob, int32_t n_targets, uint64_t seed);
+/* The host row planner (no device needed; used by the CPU tests).  items / offsets: the CSR of sbr_dataset_create; lengths:
+ * NULL or the current length of every user's sequence (<= its CSR extent); order: NULL or the user order of the pass;
+ * pend_*: rows carried in (n_pend < batch_size of them) and out; row_*: the rows of the complete batches, batch-major,
+ * row_tgt[n_rows][n_targets] = positions inside the remaining sequence (items[offsets[u] + split + pos]), -1 behind the last. */
+int sbr_plan_rows_host(const int32_t* items, const int64_t* offsets, const int64_t* lengths, const int32_t* order, int64_t n_users,
+                       int32_t batch_size, int32_t n_targets, int32_t shuffle, const float* keep_prob, uint64_t seed,
+                       int32_t* pend_user, int32_t* pend_split, int32_t* pend_tgt, int32_t* n_pend, int64_t cap_rows,
+                       int32_t* row_user, int32_t* row_split, int32_t* row_tgt, int64_t* n_rows, int64_t* n_batches);
 /* (tests / tooling) the sequences the next planned pass reads: items[nnz] and rating_index[nnz] (may be NULL) in the CSR layout
  * of sbr_dataset_create -- user u's items[offsets[u] .. offsets[u] + lengths[u]) -- and lengths[n_users]; the noised copy behind
  * sbr_dataset_noise_pass, the sequences as uploaded otherwise. */

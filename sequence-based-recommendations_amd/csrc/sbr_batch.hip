@@ -4,6 +4,7 @@
 // two kernels on the engine's stream.  The host only walks the user list once per pass (integer bookkeeping).
 #include "sbr_common.h"
 #include <algorithm>
+#include <unordered_map>
 
 struct sbr_dataset {
     int64_t n_users, nnz; int n_items;
@@ -17,6 +18,14 @@ struct sbr_dataset {
     int *d_items_n, *d_rate_n, *d_len_n; int noised; int64_t max_len;
     std::vector<int> len_n32;
     std::vector<int64_t> len_cur;                   // lengths the current plan was made for (noised or not)
+    // --target_bias (sbr_dataset_set_target_bias): whether a row has a target is a draw, so the rows of a pass -- user, split
+    // point, target positions -- are planned on the HOST (sbr_plan_rows_host) and uploaded; the device only packs them
+    int host_rows, hr_targets; uint64_t hr_seed, hr_pass;
+    std::vector<float> keep_prob;
+    std::vector<int> h_items, h_items_cur;          // host copy of the sequences (as uploaded / this pass's noised copy)
+    std::vector<int64_t> h_off;
+    std::vector<int> hr_user, hr_split, hr_tgt, hr_pu, hr_ps, hr_pt;      // rows of the pass (complete batches) | carried rows
+    int *d_hr_user, *d_hr_split, *d_hr_tgt; size_t cap_hru, cap_hrs, cap_hrt;
     std::vector<int64_t> len;                       // host copy of the sequence lengths
     std::vector<int> pend_user, pend_k;             // trailing partial batch carried into the next pass
     std::vector<int> seg_user, seg_k, seg_row0, seg_batch, batch_begin;   // host plan (batch_begin: n_batches+1)
@@ -62,6 +71,92 @@ extern "C" int sbr_plan_pass_host(const int64_t* lengths, const int32_t* order, 
     for (int i = 0; i < np; ++i) { pend_user[i] = seg_user[first + i]; pend_k[i] = seg_k[first + i]; }
     ns = first;
     *n_pend = np; *n_segments = ns; *n_batches = nb;
+    return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Host-planned rows: _gen_mini_batch with a target selection that can come back empty (rnn_base.py:394-415 with
+// SelectTargets.__call__, target_selection.py:41-53).  Per user: k = min(B - j, len - 2) sorted distinct split points
+// (random.sample); per split point the targets are the first n_targets items of the remaining sequence -- after
+// random.shuffle with --shuffle_targets -- that survive a draw against keep_prob[item] (--target_bias); a row without
+// a target is skipped and does not count towards the batch.  Rows come out batch-major; the rows of the unfinished last
+// batch are carried to the next pass as they are (the reference's generator keeps them too).  Draws: splitmix64 from `seed`.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct HostRng {
+    unsigned long long s;
+    unsigned long long next() { s += 0x9E3779B97F4A7C15ull; unsigned long long x = s; x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; return x ^ (x >> 31); }
+    int below(int n) { return (int)(next() % (unsigned long long)n); }                       // n <= 2^31: bias < 2^-33
+    float unif() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }                   // [0, 1)
+};
+}
+extern "C" int sbr_plan_rows_host(const int32_t* items, const int64_t* offsets, const int64_t* lengths, const int32_t* order,
+                                  int64_t n_users, int32_t B, int32_t n_targets, int32_t shuffle, const float* keep_prob, uint64_t seed,
+                                  int32_t* pend_user, int32_t* pend_split, int32_t* pend_tgt, int32_t* n_pend, int64_t cap_rows,
+                                  int32_t* row_user, int32_t* row_split, int32_t* row_tgt, int64_t* n_rows, int64_t* n_batches) {
+    CHECK_ARG(items && offsets && pend_user && pend_split && pend_tgt && n_pend && row_user && row_split && row_tgt && n_rows && n_batches,
+              "null argument");
+    CHECK_ARG(B >= 1 && n_users >= 0 && n_targets >= 1 && *n_pend >= 0 && *n_pend < B, "bad batch size / targets / pending count");
+    HostRng rng{seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull};
+    int64_t nr = 0;
+    int j = 0;
+    auto emit = [&](int u, int l, const int* tg) -> bool {
+        if (nr >= cap_rows) return false;
+        row_user[nr] = u; row_split[nr] = l;
+        for (int t = 0; t < n_targets; ++t) row_tgt[nr * n_targets + t] = tg[t];
+        ++nr; return true;
+    };
+    for (int i = 0; i < *n_pend; ++i) {
+        if (!emit(pend_user[i], pend_split[i], pend_tgt + (size_t)i * n_targets)) { sbr_set_error("row capacity too small"); return SBR_EINVAL; }
+        ++j;
+    }
+    std::vector<char> mark;
+    std::vector<int> tg(n_targets);
+    std::unordered_map<int, int> perm;
+    for (int64_t ui = 0; ui < n_users; ++ui) {
+        const int u = order ? order[ui] : (int)ui;
+        CHECK_ARG(u >= 0 && u < n_users, "user id %d out of range", u);
+        const int64_t L = lengths ? lengths[u] : offsets[u + 1] - offsets[u];
+        if (L < 2) continue;
+        const int n = (int)L - 2, k = std::min(B - j, n);
+        if (k <= 0) continue;
+        mark.assign(n, 0);
+        if (k >= n) std::fill(mark.begin(), mark.end(), 1);
+        else for (int i = n - k; i < n; ++i) { const int t = rng.below(i + 1); if (mark[t]) mark[i] = 1; else mark[t] = 1; }   // Floyd: a uniform k-subset
+        const int32_t* seq = items + offsets[u];
+        int skipped = 0;
+        for (int c = 0; c < n; ++c) {
+            if (!mark[c]) continue;
+            const int l = 2 + c, n_rem = (int)L - l;
+            int taken = 0;
+            std::fill(tg.begin(), tg.end(), -1);
+            if (!shuffle) {
+                for (int p = 0; p < n_rem && taken < n_targets; ++p)
+                    if (!keep_prob || rng.unif() <= keep_prob[seq[l + p]]) tg[taken++] = p;
+            } else {      // a lazily drawn uniform order of the remaining sequence (sparse Fisher-Yates), filtered as it comes
+                perm.clear();
+                for (int i = 0; i < n_rem && taken < n_targets; ++i) {
+                    const int r = i + rng.below(n_rem - i);
+                    auto ir = perm.find(r); const int vr = ir == perm.end() ? r : ir->second;
+                    auto ii = perm.find(i); const int vi = ii == perm.end() ? i : ii->second;
+                    perm[r] = vi;
+                    if (!keep_prob || rng.unif() <= keep_prob[seq[l + vr]]) tg[taken++] = vr;
+                }
+            }
+            if (taken == 0) { ++skipped; continue; }
+            if (!emit(u, l, tg.data())) { sbr_set_error("row capacity too small"); return SBR_EINVAL; }
+        }
+        j += k - skipped;
+        if (j == B) j = 0;
+    }
+    // the rows of the unfinished batch sit at the tail
+    const int64_t nb = nr / B;
+    const int np = (int)(nr - nb * B);
+    for (int i = 0; i < np; ++i) {
+        pend_user[i] = row_user[nb * B + i]; pend_split[i] = row_split[nb * B + i];
+        for (int t = 0; t < n_targets; ++t) pend_tgt[(size_t)i * n_targets + t] = row_tgt[(nb * B + i) * n_targets + t];
+    }
+    *n_pend = np; *n_rows = nb * B; *n_batches = nb;
     return SBR_OK;
 }
 
@@ -179,7 +274,7 @@ __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ ite
                                                      int n_items, int T, int F, int NT, int shuffle, int row_offset, int local_rows, int Bp,
                                                      int tgt_rows, int tgt_offset, int S, unsigned long long seed, int* __restrict__ X,
                                                      int* __restrict__ lengths, int* __restrict__ target, float* __restrict__ pop,
-                                                     int* __restrict__ samples) {
+                                                     int* __restrict__ samples, const int* __restrict__ tgtpos) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b < Bp) {
         if (b >= local_rows) {                                     // padded rows: index 0, length 0, popularity 1
@@ -198,7 +293,8 @@ __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ ite
             lengths[b] = n_in;
             const int n_rem = (len_n ? len_n[rowuser[g]] : (int)(off[rowuser[g] + 1] - o)) - l;
             const int k = min(n_rem, NT);
-            pop[b] = popdb ? popdb[items[o + l + bb_target_pos(seed, g, 0, k, n_rem, shuffle)]] : 1.0f;   // rnn_one_hot.py:103
+            const int p0 = tgtpos ? tgtpos[(size_t)g * NT] : bb_target_pos(seed, g, 0, k, n_rem, shuffle);   // (host-planned rows: given)
+            pop[b] = popdb ? popdb[items[o + l + p0]] : 1.0f;                                              // rnn_one_hot.py:103
         }
         return;
     }
@@ -208,7 +304,8 @@ __global__ void __launch_bounds__(64) bb_pack_kernel(const int* __restrict__ ite
         const long long o = off[rowuser[g]];
         const int l = split[g], n_rem = (len_n ? len_n[rowuser[g]] : (int)(off[rowuser[g] + 1] - o)) - l;
         const int k = min(n_rem, NT);
-        target[e] = j < k ? items[o + l + bb_target_pos(seed, g, j, k, n_rem, shuffle)] : -1;
+        if (tgtpos) { const int p = tgtpos[(size_t)g * NT + j]; target[e] = p >= 0 ? items[o + l + p] : -1; }
+        else target[e] = j < k ? items[o + l + bb_target_pos(seed, g, j, k, n_rem, shuffle)] : -1;
     }
     const int si = e - ((tgt_rows * NT + 63) / 64) * 64;
     if (si >= 0 && si < S) {
@@ -313,6 +410,9 @@ extern "C" int sbr_dataset_create(const int32_t* items, const int64_t* offsets, 
     d->n_users = n_users; d->nnz = nnz; d->n_items = n_items; d->stream = (hipStream_t)stream;
     d->d_items = nullptr; d->d_off = nullptr; d->d_popdb = nullptr; d->d_cdf = nullptr; d->d_rate = nullptr; d->shuffle_targets = 0;
     d->d_items_n = d->d_rate_n = d->d_len_n = nullptr; d->noised = 0; d->max_len = 0;
+    d->host_rows = 0; d->hr_targets = 1; d->hr_seed = 0; d->hr_pass = 0;
+    d->d_hr_user = d->d_hr_split = d->d_hr_tgt = nullptr; d->cap_hru = d->cap_hrs = d->cap_hrt = 0;
+    d->h_items.assign(items, items + nnz); d->h_off.assign(offsets, offsets + n_users + 1);
     d->d_seg_user = d->d_seg_k = d->d_seg_row0 = d->d_batch_begin = nullptr; d->cap_su = d->cap_sk = d->cap_sr = d->cap_bb = 0;
     d->d_split = d->d_rowuser = nullptr; d->cap_rows = 0; d->n_batches = 0; d->batch_size = 0;
     d->len.resize(n_users);
@@ -341,6 +441,7 @@ extern "C" int sbr_dataset_destroy(sbr_dataset* d) {
     (void)hipFree(d->d_seg_user); (void)hipFree(d->d_seg_k); (void)hipFree(d->d_seg_row0); (void)hipFree(d->d_batch_begin);
     (void)hipFree(d->d_split); (void)hipFree(d->d_rowuser);
     (void)hipFree(d->d_items_n); (void)hipFree(d->d_rate_n); (void)hipFree(d->d_len_n);
+    (void)hipFree(d->d_hr_user); (void)hipFree(d->d_hr_split); (void)hipFree(d->d_hr_tgt);
     delete d;
     return SBR_OK;
 }
@@ -391,6 +492,21 @@ extern "C" int sbr_dataset_noise_pass(sbr_dataset* d, float dropout, float swap,
     d->len_cur.resize(d->n_users);
     for (int64_t u = 0; u < d->n_users; ++u) d->len_cur[u] = d->len_n32[u];
     d->noised = 1;
+    if (d->host_rows) {      // the host plans the rows of the pass: it needs this pass's copy of the sequences
+        d->h_items_cur.resize((size_t)std::max<int64_t>(d->nnz, 1));
+        SBR_HIP(hipMemcpy(d->h_items_cur.data(), d->d_items_n, d->nnz * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return SBR_OK;
+}
+
+extern "C" int sbr_dataset_set_target_bias(sbr_dataset* d, const float* keep_prob, int32_t n_targets, uint64_t seed) {
+    CHECK_ARG(d, "null dataset");
+    d->hr_pu.clear(); d->hr_ps.clear(); d->hr_pt.clear(); d->pend_user.clear(); d->pend_k.clear();
+    if (!keep_prob) { d->host_rows = 0; d->keep_prob.clear(); return SBR_OK; }
+    CHECK_ARG(n_targets >= 1 && n_targets <= 1024, "n_targets out of range");
+    for (int i = 0; i < d->n_items; ++i) CHECK_ARG(keep_prob[i] >= 0.0f && keep_prob[i] <= 1.0f, "keep_prob[%d] outside [0, 1]", i);
+    d->keep_prob.assign(keep_prob, keep_prob + d->n_items);
+    d->host_rows = 1; d->hr_targets = n_targets; d->hr_seed = seed; d->hr_pass = 0;
     return SBR_OK;
 }
 
@@ -431,8 +547,46 @@ static int upload(int** dev, size_t* cap, const std::vector<int>& v, hipStream_t
     return SBR_OK;
 }
 
+static int plan_pass_host_rows(sbr_dataset* d, const int32_t* order, int32_t B, int64_t* n_batches) {
+    const int NT = d->hr_targets;
+    if (d->batch_size != B) { d->hr_pu.clear(); d->hr_ps.clear(); d->hr_pt.clear(); d->batch_size = B; }
+    if (d->noised) { d->hr_pu.clear(); d->hr_ps.clear(); d->hr_pt.clear(); }      // carried rows index the previous pass's noised copy: dropped
+    std::vector<int> pu(B), ps(B), pt((size_t)B * NT);
+    int np = (int)d->hr_pu.size();
+    std::copy(d->hr_pu.begin(), d->hr_pu.end(), pu.begin());
+    std::copy(d->hr_ps.begin(), d->hr_ps.end(), ps.begin());
+    std::copy(d->hr_pt.begin(), d->hr_pt.end(), pt.begin());
+    int64_t cap = B;
+    for (int64_t u = 0; u < d->n_users; ++u) cap += std::max<int64_t>(0, std::min<int64_t>(B, d->len_cur[u] - 2));
+    d->hr_user.resize(cap); d->hr_split.resize(cap); d->hr_tgt.resize((size_t)cap * NT);
+    int64_t nr = 0, nb = 0;
+    const int rc = sbr_plan_rows_host(d->noised ? d->h_items_cur.data() : d->h_items.data(), d->h_off.data(), d->len_cur.data(), order,
+                                      d->n_users, B, NT, d->shuffle_targets, d->keep_prob.data(), d->hr_seed + 0x9E37ull * (++d->hr_pass),
+                                      pu.data(), ps.data(), pt.data(), &np, cap, d->hr_user.data(), d->hr_split.data(), d->hr_tgt.data(), &nr, &nb);
+    if (rc != SBR_OK) return rc;
+    d->hr_pu.assign(pu.begin(), pu.begin() + np); d->hr_ps.assign(ps.begin(), ps.begin() + np); d->hr_pt.assign(pt.begin(), pt.begin() + (size_t)np * NT);
+    d->hr_user.resize(nr); d->hr_split.resize(nr); d->hr_tgt.resize((size_t)nr * NT);
+    // segments (runs of one user inside a batch), for the callers that follow the pass (sbr_dataset_plan_segments)
+    d->seg_user.clear(); d->seg_k.clear(); d->seg_row0.clear(); d->seg_batch.clear();
+    for (int64_t r = 0; r < nr; ++r) {
+        const int b = (int)(r / B), g = (int)(r % B);
+        if (g > 0 && d->hr_user[r] == d->hr_user[r - 1]) { d->seg_k.back() += 1; continue; }
+        d->seg_user.push_back(d->hr_user[r]); d->seg_k.push_back(1); d->seg_row0.push_back(g); d->seg_batch.push_back(b);
+    }
+    d->batch_begin.assign(nb + 1, 0);
+    SBR_HIP(hipStreamSynchronize(d->stream));      // the previous plan may still be read by batches in flight
+    int r;
+    if ((r = upload(&d->d_hr_user, &d->cap_hru, d->hr_user, d->stream)) != SBR_OK) return r;
+    if ((r = upload(&d->d_hr_split, &d->cap_hrs, d->hr_split, d->stream)) != SBR_OK) return r;
+    if ((r = upload(&d->d_hr_tgt, &d->cap_hrt, d->hr_tgt, d->stream)) != SBR_OK) return r;
+    SBR_HIP(hipStreamSynchronize(d->stream));
+    d->n_batches = nb; *n_batches = nb;
+    return SBR_OK;
+}
+
 extern "C" int sbr_dataset_plan_pass(sbr_dataset* d, const int32_t* order, int32_t B, int64_t* n_batches) {
     CHECK_ARG(d && n_batches && B >= 1, "bad plan arguments");
+    if (d->host_rows) return plan_pass_host_rows(d, order, B, n_batches);
     if (d->batch_size != B) { d->pend_user.clear(); d->pend_k.clear(); d->batch_size = B; }
     std::vector<int> pu(B), pk(B);
     int np = (int)d->pend_user.size();
@@ -478,7 +632,7 @@ extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uin
     CHECK_ARG(y.F == 1 || (y.F == 2 && d->d_rate && y.cfg.input_size == y.N + 10),
               "the native batch builder covers the item index and, with ratings attached (sbr_dataset_set_options), the rating index");
     CHECK_ARG(d->n_items == y.N && (y.cfg.input_size == y.N || y.F == 2), "dataset has %d items, the model %d", d->n_items, y.N);
-    CHECK_ARG(!d->shuffle_targets || y.NT <= 16, "shuffled targets: at most 16 targets per row on the device");
+    CHECK_ARG(!d->shuffle_targets || y.NT <= 16 || d->host_rows, "shuffled targets: at most 16 targets per row on the device");
     CHECK_ARG(d->batch_size == y.Bg, "the pass was planned for batches of %d rows, the model's global batch is %d", d->batch_size, y.Bg);
     CHECK_ARG(batch >= 0 && batch < d->n_batches, "batch %lld outside the planned pass [0,%lld)", (long long)batch, (long long)d->n_batches);
     CHECK_ARG(d->stream == h->stream, "dataset and engine must share one stream");
@@ -489,19 +643,25 @@ extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uin
         SBR_HIP(hipMalloc(&d->d_rowuser, (size_t)y.Bg * sizeof(int)));
         d->cap_rows = y.Bg;
     }
-    const int sb = d->batch_begin[batch], se = d->batch_begin[batch + 1];
     const unsigned long long sd = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(batch + 1));
     const int* len_n = d->noised ? d->d_len_n : nullptr;      // this pass's noised copy of the sequences (sbr_dataset_noise_pass)
     const int* src_items = d->noised ? d->d_items_n : d->d_items;
     const int* src_rate = d->noised && d->d_rate ? d->d_rate_n : d->d_rate;
-    bb_split_kernel<<<se - sb, 256, 0, s>>>(d->d_off, len_n, d->d_seg_user, d->d_seg_k, d->d_seg_row0, sb, sd, d->d_split, d->d_rowuser);
-    SBR_LAUNCH(hipGetLastError());
+    const int *split = d->d_split, *rowuser = d->d_rowuser, *tgtpos = nullptr;
+    if (d->host_rows) {      // rows planned on the host (target bias): user, split point and target positions are given
+        CHECK_ARG(d->hr_targets == y.NT, "the rows were planned for %d targets, the model has %d", d->hr_targets, y.NT);
+        split = d->d_hr_split + batch * y.Bg; rowuser = d->d_hr_user + batch * y.Bg; tgtpos = d->d_hr_tgt + batch * (int64_t)y.Bg * y.NT;
+    } else {
+        const int sb = d->batch_begin[batch], se = d->batch_begin[batch + 1];
+        bb_split_kernel<<<se - sb, 256, 0, s>>>(d->d_off, len_n, d->d_seg_user, d->d_seg_k, d->d_seg_row0, sb, sd, d->d_split, d->d_rowuser);
+        SBR_LAUNCH(hipGetLastError());
+    }
     const bool sampled = y.S > 0;
     const int tgt_rows = sampled ? y.Bg : y.B, tgt_offset = sampled ? 0 : y.cfg.row_offset;
     const int extra = (tgt_rows * y.NT + 63) / 64 + (y.S + 63) / 64;
-    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(src_items, src_rate, d->d_off, len_n, d->d_split, d->d_rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
+    bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(src_items, src_rate, d->d_off, len_n, split, rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
                                                 y.F, y.NT, d->shuffle_targets, y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, (int*)h->A(y.a_X),
-                                                (int*)h->A(y.a_len), (int*)h->A(y.a_tgt), h->A(y.a_pop), (int*)h->A(y.a_smp));
+                                                (int*)h->A(y.a_len), (int*)h->A(y.a_tgt), h->A(y.a_pop), (int*)h->A(y.a_smp), tgtpos);
     SBR_LAUNCH(hipGetLastError());
     h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);
     h->bsmp = (const int*)h->A(y.a_smp); h->bpop = h->A(y.a_pop);

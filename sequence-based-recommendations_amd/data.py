@@ -74,7 +74,8 @@ class NativeBatchBuilder(object):
     (rnn_base.py:373-420, rnn_one_hot.py:83-106, rnn_sampling.py:159-194, rnn_margin.py:112-147) for every option that leaves
     the batch plan of a pass computable on the host: --rf, --n_targets, --shuffle_targets, --db, --sampling_bias, and the
     sequence noise (--n_dropout, --n_swap, --n_shuf, --n_ratings: a device pass over the users before each pass is planned,
-    sequence_noise.py:52-94); not --target_bias, which stays with the host generator.
+    sequence_noise.py:52-94), and --target_bias (the rows of a pass are then planned on the host by the library, the device
+    packs them: sbr_dataset_set_target_bias).
 
     The training file is parsed once (SequenceGenerator.load) and uploaded as CSR.  Per pass the users are walked in
     file order, or reshuffled like data_handling.py:139-141 with --tshuffle; the walk prints the reference's
@@ -82,7 +83,7 @@ class NativeBatchBuilder(object):
     rnn_base.py:312) up to date per batch.  `next()` makes the next batch the engine's current batch."""
 
     def __init__(self, engine, training_set, n_items, batch_size, pop_db=None, sample_cdf=None, seed=None, ratings=False,
-                 shuffle_targets=False, noise=None):
+                 shuffle_targets=False, noise=None, keep_prob=None, n_targets=1):
         from .engine import DeviceDataset
         if not hasattr(training_set, "users"):
             training_set.load()
@@ -95,6 +96,8 @@ class NativeBatchBuilder(object):
         if ratings or shuffle_targets:      # --rf: the rating index rides beside the item index; --shuffle_targets
             r = (np.concatenate(training_set.ratings) if len(lengths) else np.zeros(0)) if ratings else None
             self.ds.set_options(r, shuffle_targets)
+        if keep_prob is not None:           # --target_bias: rows planned on the host (a row may run out of targets)
+            self.ds.set_target_bias(keep_prob, n_targets, seed=int(seed if seed is not None else random.getrandbits(62)))
         self.n_users = len(lengths)
         self.noise = noise if (noise is not None and getattr(noise, "name", "") != "") else None      # a SequenceNoise
         self.seed = int(seed if seed is not None else random.getrandbits(63))

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 5
+SBR_ABI_VERSION = 6
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
@@ -62,7 +62,8 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
            "sbr_sparse_unpack_add", "sbr_dense_ranges",
-           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_noise_pass", "sbr_dataset_current_sequences", "sbr_dataset_plan_pass",
+           "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_noise_pass", "sbr_dataset_current_sequences", "sbr_dataset_set_target_bias",
+           "sbr_plan_rows_host", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
 
 _lib = None
@@ -128,6 +129,9 @@ def load_library(path=None):
     lib.sbr_dataset_set_options.argtypes = [vp, vp, ctypes.c_int]
     lib.sbr_dataset_noise_pass.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64]
     lib.sbr_dataset_current_sequences.argtypes = [vp, vp, vp, vp]
+    lib.sbr_dataset_set_target_bias.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_uint64]
+    lib.sbr_plan_rows_host.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_uint64,
+                                       vp, vp, vp, i32p, ctypes.c_int64, vp, vp, vp, i64p, i64p]
     lib.sbr_dataset_plan_pass.argtypes = [vp, vp, ctypes.c_int32, i64p]
     lib.sbr_dataset_plan_segments.argtypes = [vp, i64p, ctypes.POINTER(i32p), ctypes.POINTER(i32p), ctypes.POINTER(i32p),
                                               ctypes.POINTER(i32p)]
@@ -178,6 +182,40 @@ def plan_pass_host(lengths, order, batch_size, pending=None, lib=None):
     return seg, nb.value, [(int(pu[i]), int(pk[i])) for i in range(npend.value)]
 
 
+def plan_rows_host(items, offsets, order, batch_size, n_targets=1, shuffle=False, keep_prob=None, seed=0, pending=None, lengths=None,
+                   lib=None):
+    """The rows of one pass planned on the host (sbr_plan_rows_host; no GPU needed): the reference's _gen_mini_batch with a
+    target selection that can come back empty (--target_bias).  Returns (rows, n_batches, pending): rows = int array
+    (n, 2 + n_targets) of (user, split, target positions...), batch-major; pending = the carried rows in the same format."""
+    lib = lib or load_library()
+    items = np.ascontiguousarray(items, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    lens = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.int64)
+    order_a = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
+    kp = None if keep_prob is None else np.ascontiguousarray(keep_prob, dtype=np.float32)
+    pend = np.zeros((0, 2 + n_targets), np.int32) if pending is None else np.asarray(pending, dtype=np.int32).reshape(-1, 2 + n_targets)
+    pu, ps, pt = np.zeros(batch_size, np.int32), np.zeros(batch_size, np.int32), np.zeros(batch_size * n_targets, np.int32)
+    pu[:len(pend)], ps[:len(pend)] = pend[:, 0], pend[:, 1]
+    pt[:len(pend) * n_targets] = pend[:, 2:].reshape(-1)
+    npend = ctypes.c_int32(len(pend))
+    L = (offsets[1:] - offsets[:-1]) if lens is None else lens
+    cap = int(batch_size + np.minimum(batch_size, np.maximum(0, L - 2)).sum())
+    ru, rs, rt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap * n_targets, np.int32)
+    nr, nb = ctypes.c_int64(), ctypes.c_int64()
+    rc = lib.sbr_plan_rows_host(items.ctypes.data, offsets.ctypes.data, None if lens is None else lens.ctypes.data,
+                                None if order_a is None else order_a.ctypes.data, n, int(batch_size), int(n_targets), 1 if shuffle else 0,
+                                None if kp is None else kp.ctypes.data, int(seed) & 0xFFFFFFFFFFFFFFFF, pu.ctypes.data, ps.ctypes.data,
+                                pt.ctypes.data, ctypes.byref(npend), cap, ru.ctypes.data, rs.ctypes.data, rt.ctypes.data,
+                                ctypes.byref(nr), ctypes.byref(nb))
+    if rc != 0:
+        raise ValueError(lib.sbr_last_error().decode("utf-8", "replace"))
+    rows = np.concatenate([ru[:nr.value, None], rs[:nr.value, None], rt[:nr.value * n_targets].reshape(-1, n_targets)], axis=1)
+    k = npend.value
+    pending = np.concatenate([pu[:k, None], ps[:k, None], pt[:k * n_targets].reshape(-1, n_targets)], axis=1)
+    return rows, nb.value, pending
+
+
 class DeviceDataset(object):
     """The training sequences in HBM (CSR) + the per-pass batch plan (sbr_dataset_* in include/sbr_rnn.h)."""
 
@@ -203,6 +241,13 @@ class DeviceDataset(object):
         shuffle_targets: --shuffle_targets (sbr_dataset_set_options)."""
         r = None if ratings is None else np.ascontiguousarray(ratings, dtype=np.float32)
         self.engine._check(self.lib.sbr_dataset_set_options(self.d, None if r is None else r.ctypes.data, 1 if shuffle_targets else 0))
+
+    def set_target_bias(self, keep_prob=None, n_targets=1, seed=0):
+        """--target_bias: keep_prob (n_items,) = (min(pop) / pop) ** bias; the rows of a pass are then planned on the host
+        (sbr_dataset_set_target_bias).  None switches back to device-drawn rows."""
+        kp = None if keep_prob is None else np.ascontiguousarray(keep_prob, dtype=np.float32)
+        self.engine._check(self.lib.sbr_dataset_set_target_bias(self.d, None if kp is None else kp.ctypes.data, int(n_targets),
+                                                                int(seed) & 0xFFFFFFFFFFFFFFFF))
 
     def noise_pass(self, dropout=0.0, swap=0.0, shuf=0.0, shuf_std=0.0, ratings_perturb=0.0, seed=0):
         """Sequence noise for the pass planned next (sbr_dataset_noise_pass; SequenceNoise.__call__)."""

@@ -305,21 +305,19 @@ class RNNBase(object):
             yield flush()
 
     def _native_batch_builder(self, dataset):
-        """Device-side batch builder for the options it covers (item index, + rating index with --rf; next-item or shuffled
-        targets, --n_targets of them for the multi-target losses; --db, --sampling_bias; the sequence noise); None -> the
-        reference-style host generator (--target_bias).  SBR_NATIVE_BATCHES=0 disables it."""
+        """Device-side batch builder: item index, + rating index with --rf; next-item or shuffled targets, --n_targets of them
+        for the multi-target losses; --db, --sampling_bias; the sequence noise; --target_bias (rows planned on the host by
+        the library).  None -> the reference-style host generator: SBR_NATIVE_BATCHES=0, or a case the builder refuses."""
         if os.environ.get("SBR_NATIVE_BATCHES", "1") == "0":
             return None
         ts = self.target_selection
         multi = isinstance(self, RNNMargin)                  # only the multi-target losses look past the first target
-        if ts.bias >= 0.0:
-            return None      # a row can run out of targets: the host plan of a pass cannot know (include/sbr_rnn.h)
         if self.sequence_noise.name != "":
             if not hasattr(dataset.training_set, "users"):
                 dataset.training_set.load()
             if max([len(x) for x in dataset.training_set.items] + [0]) > 8192:
                 return None  # (a sequence longer than the noise kernel's LDS staging)
-        if ts.shuffle and multi and self._engine_targets() > 16:
+        if ts.shuffle and multi and self._engine_targets() > 16 and ts.bias < 0.0:
             return None
         from .data import NativeBatchBuilder
         pop = np.asarray(dataset.item_popularity, dtype=np.float64)
@@ -328,7 +326,10 @@ class RNNBase(object):
         cdf = np.cumsum(np.power(pop, sb)) if (sb > 0.0 and getattr(self, "effective_sampling", 0)) else None
         return NativeBatchBuilder(self.engine, dataset.training_set, self.n_items, self.batch_size,
                                   pop_db=np.power(pop, db).astype(np.float32), sample_cdf=cdf,
-                                  ratings=self.use_ratings_features, shuffle_targets=ts.shuffle, noise=self.sequence_noise)
+                                  ratings=self.use_ratings_features, shuffle_targets=ts.shuffle, noise=self.sequence_noise,
+                                  keep_prob=(np.power(np.min(np.maximum(1, pop)) / np.maximum(1, pop), ts.bias).astype(np.float32)
+                                             if ts.bias >= 0.0 else None),
+                                  n_targets=self._engine_targets() if multi else 1)
 
     def _compute_validation_metrics(self, metrics):
         from .data import Evaluator

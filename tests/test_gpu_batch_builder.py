@@ -389,3 +389,55 @@ def test_batches_of_a_noised_pass_read_the_noised_copy():
             costs.append(eng.train_step())
     assert np.all(np.isfinite(costs)) and np.mean(costs[-4:]) < np.mean(costs[:4])
     ds.close(); eng.close()
+
+
+def test_target_bias_rows_planned_on_the_host_are_packed_as_planned():
+    """--target_bias (sbr_dataset_set_target_bias): the rows of a pass come from the host planner (its laws against the
+    reference's procedure: tests/test_host_cpu.py); the device packs exactly those rows -- inputs cut at the planned split
+    point, the planned target positions, popularity weight of the first target."""
+    from sbr_amd.engine import RNNEngine, DeviceDataset, plan_rows_host
+    rng = np.random.default_rng(17)
+    lengths = rng.integers(2, 40, size=60)
+    items, offsets, n_items = encoded_dataset(lengths)
+    pop = 1.0 + (np.arange(n_items) % 5) ** 2
+    keep = np.power(pop.min() / pop, 0.8).astype(np.float32)
+    pop_db = np.power(pop, 0.5).astype(np.float32)
+    B, T, NT = 32, 8, 2
+    eng = RNNEngine(cell="GRU", layers=[16], n_items=n_items, max_length=T, batch_size=B, loss="hinge", n_targets=NT)
+    ds = DeviceDataset(eng, items, offsets, n_items)
+    ds.set_tables(pop_db, None)
+    for shuffle in (False, True):
+        ds.set_options(None, shuffle)
+        ds.set_target_bias(keep, NT, seed=77)
+        pending = None
+        for p in range(2):
+            nb = ds.plan_pass(None, B)
+            want, nb_w, pending = plan_rows_host(items, offsets, None, B, n_targets=NT, shuffle=shuffle, keep_prob=keep,
+                                                 seed=77 + 0x9E37 * (p + 1), pending=pending)
+            assert nb == nb_w and nb >= 3
+            seg = ds.segments()
+            assert seg[:, 1].sum() == nb * B
+            for b in range(nb):
+                eng.build_batch(ds, b, seed=5)
+                cur = eng.current_batch()
+                X, lens, tgt, w = cur["X"], cur["lengths"], cur["target"].reshape(B, NT), cur["pop"]
+                for r in range(B):
+                    u, l, tp = want[b * B + r, 0], want[b * B + r, 1], want[b * B + r, 2:]
+                    seq = items[offsets[u]:offsets[u + 1]]
+                    assert np.array_equal(X[r, :lens[r], 0], seq[max(0, l - T):l]) and lens[r] == min(T, l)
+                    assert np.array_equal(tgt[r], np.where(tp >= 0, seq[np.minimum(l + np.maximum(tp, 0), len(seq) - 1)], -1))
+                    assert abs(w[r] - pop_db[seq[l + tp[0]]]) < 1e-6
+    # with the bias on, popular items are targets less often than their share of the candidates
+    ds.set_options(None, False)
+    ds.set_target_bias(keep, NT, seed=5)
+    hits = np.zeros(5); cand = np.zeros(5)
+    for p in range(6):
+        nb = ds.plan_pass(None, B)
+        for b in range(nb):
+            eng.build_batch(ds, b, seed=9)
+            t0 = eng.current_batch()["target"].reshape(B, NT)[:, 0]
+            hits += np.bincount(t0 % 5, minlength=5)
+    assert hits[0] / hits.sum() > 0.30 and hits[4] / hits.sum() < 0.16, hits / hits.sum()      # keep_prob 1 against 17 ** -0.8 = 0.10
+    ds.set_target_bias(None)
+    assert ds.plan_pass(None, B) >= 3                                           # back to device-drawn rows
+    ds.close(); eng.close()

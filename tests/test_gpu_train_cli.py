@@ -168,10 +168,11 @@ def test_raw_file_to_trained_model_through_preprocess(tmp_path):
     (["--loss", "BPR", "--sampling", "8", "--sampling_bias", "0.5", "--db", "0.3", "--rf"], True),
     (["--n_dropout", "0.1"], True), (["--n_swap", "0.2", "--rf"], True),
     (["--n_shuf", "0.2", "--n_shuf_std", "3", "--n_ratings", "0.3", "--rf", "--n_dropout", "0.2"], True),
-    (["--target_bias", "0.5"], False)])
+    (["--target_bias", "0.5"], True), (["--target_bias", "1.0", "--shuffle_targets", "--n_dropout", "0.1"], True),
+    (["--loss", "hinge", "--n_targets", "3", "--target_bias", "0.5"], True)])
 def test_which_options_train_on_device_built_batches(tmp_path, extra, native):
-    # every option whose batch plan the host can make is served by the device batch builder (include/sbr_rnn.h:
-    # sbr_dataset_set_options, sbr_dataset_noise_pass); --target_bias keeps the host generator
+    # every batch option is served by the device batch builder (include/sbr_rnn.h: sbr_dataset_set_options,
+    # sbr_dataset_noise_pass, sbr_dataset_set_target_bias)
     from sbr_amd import options as parse, train as T
     from sbr_amd.data import DataHandler
     root = make_dataset(str(tmp_path / "ds"))

@@ -294,6 +294,106 @@ def test_native_batch_plan_with_lengths_that_change_between_passes(lib):
     assert nb3 >= 1 and 0 not in seg3[:, 0]
 
 
+def _reference_rows(lengths, order, B, n_batches, n_targets=1, shuffle=False, bias=-1.0, pop=None, seed=0):
+    """Rows (user, split, [target positions]) per batch as the reference-style generator produces them (models._gen_mini_batch
+    with options.SelectTargets: rnn_base.py:394-415, target_selection.py:36-53); item ids encode (user, position)."""
+    import random
+    from sbr_amd.models import RNNOneHot
+    from sbr_amd.options import SelectTargets
+    random.seed(seed); np.random.seed(seed)
+    ts = SelectTargets(n_targets=n_targets, shuffle=shuffle, bias=bias)
+    m = _model(RNNOneHot, max_length=6, batch_size=B, target_selection=ts)
+    if bias >= 0:
+        ts.keep_prob = _KeepByUserPos(pop)      # (set_dataset derived a table from the fake dataset's popularity)
+    m.n_items = 10 ** 7
+
+    def gen():
+        while True:
+            for u in order:
+                if lengths[u] >= 2:
+                    yield [[u * 1000 + p, 3.0] for p in range(lengths[u])], str(u)
+    m._prepare_input = lambda sequences: [(int(uid), seq[-1][0] % 1000 + 1, [t[0] % 1000 for t in tgt]) for uid, seq, tgt in sequences]
+    g = m._gen_mini_batch(gen())
+    return [next(g) for _ in range(n_batches)]
+
+
+class _KeepByUserPos(object):
+    """keep_prob table indexed by the encoded item id u * 1000 + p: the popularity of the REAL item at that position."""
+    def __init__(self, table):
+        self.table = table
+    def __getitem__(self, enc):
+        return self.table[enc]
+
+
+@pytest.mark.parametrize("shuffle,bias,NT", [(False, -1.0, 1), (False, 0.7, 1), (True, 0.7, 3), (False, 1.5, 2)])
+def test_host_planned_rows_follow_the_reference_procedure(lib, shuffle, bias, NT):
+    # sbr_plan_rows_host (the rows of a pass with --target_bias): structure exactly, draws as laws against the reference-style
+    # generator run many times -- how many rows a user yields, how often a row is skipped, where the first target lies
+    from sbr_amd.engine import plan_rows_host, plan_pass_host
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(1, 30, size=40)
+    lengths[5], lengths[9] = 2, 60
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    items = np.concatenate([u * 1000 + np.arange(L) for u, L in enumerate(lengths)]).astype(np.int32)     # encoded (user, position)
+    n_items = int(items.max()) + 1
+    keep = None
+    if bias >= 0:
+        pop = np.ones(n_items); pop[items] = 1 + (items % 7) ** 2                # some positions hold "popular" items
+        keep = np.power(pop.min() / pop, bias).astype(np.float32)
+    B, order = 16, list(rng.permutation(len(lengths)))
+    # ---- structure
+    pending, all_rows = None, []
+    for p in range(3):
+        rows, nb, pending = plan_rows_host(items, offsets, order, B, n_targets=NT, shuffle=shuffle, keep_prob=keep, seed=11 + p, pending=pending, lib=lib)
+        assert len(rows) == nb * B and len(pending) < B
+        for r in rows:
+            u, l, tg = r[0], r[1], r[2:]
+            n_rem = lengths[u] - l
+            assert 2 <= l < lengths[u] and tg[0] >= 0
+            got = tg[tg >= 0]
+            assert np.all(got < n_rem) and len(set(got.tolist())) == len(got) and np.all(tg[len(got):] == -1)
+            if not shuffle:
+                assert np.all(np.diff(got) > 0)                                  # in sequence order
+                if keep is None:
+                    assert list(got) == list(range(min(NT, n_rem)))              # the next items
+        for b in range(nb):                                                      # a user's rows of a batch: contiguous, split points ascending
+            blk = rows[b * B:(b + 1) * B]
+            for u in set(blk[:, 0].tolist()):
+                idx = np.nonzero(blk[:, 0] == u)[0]
+                assert np.all(np.diff(blk[idx, 1]) > 0) or len(idx) == 1 or (np.diff(idx) > 1).any()
+        all_rows.append(rows)
+    if keep is None and not shuffle:      # nothing is skipped: the fill order is sbr_plan_pass_host's
+        seg, nb0, _ = plan_pass_host(lengths, order, B, lib=lib)
+        rows, nb, _ = plan_rows_host(items, offsets, order, B, n_targets=NT, seed=5, lib=lib)
+        assert nb == nb0
+        counts = [(int(u), int((rows[b * B:(b + 1) * B, 0] == u).sum())) for b in range(nb) for u in dict.fromkeys(rows[b * B:(b + 1) * B, 0].tolist())]
+        assert counts == [(int(u), int(k)) for u, k in seg[:, :2]]
+        return
+    # ---- laws: the same statistics from the reference-style generator and from the planner, over many passes
+    def stats(row_iter):
+        n = first_sum = ntg = 0
+        per_user = np.zeros(len(lengths))
+        for u, l, tg in row_iter:
+            n += 1; per_user[u] += 1; ntg += len(tg)
+            first_sum += (tg[0] / max(1, lengths[u] - l))                        # relative position of the first target
+        return n, per_user / max(1, n), first_sum / max(1, n), ntg / max(1, n)
+    ref_rows, dev_rows = [], []
+    nbatch, nbs = 10, []                                                         # the first ten batches of a pass, either way
+    for sd in range(150):
+        rows, nb, _ = plan_rows_host(items, offsets, order, B, n_targets=NT, shuffle=shuffle, keep_prob=keep, seed=100 + sd, lib=lib)
+        nbs.append(nb)
+        assert nb >= nbatch
+        dev_rows += [(int(r[0]), int(r[1]), [int(t) for t in r[2:] if t >= 0]) for r in rows[:nbatch * B]]
+    for sd in range(150):
+        for batch in _reference_rows(lengths, order, B, nbatch, n_targets=NT, shuffle=shuffle, bias=bias, pop=keep, seed=sd):
+            ref_rows += [(u, l, [t - l for t in tg]) for u, l, tg in batch]
+    nd, pud, fd, td = stats(dev_rows)
+    nr_, pur, fr, tr = stats(ref_rows)
+    assert nd == nr_ == 150 * nbatch * B
+    assert np.abs(pud - pur).max() < 0.015, np.abs(pud - pur).max()               # share of the rows each user owns
+    assert abs(fd - fr) < 0.02 and abs(td - tr) < 0.06, (fd, fr, td, tr)
+
+
 def test_native_batch_plan_rejects_bad_arguments(lib):
     from sbr_amd.engine import plan_pass_host
     with pytest.raises(ValueError):
