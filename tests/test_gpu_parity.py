@@ -419,6 +419,16 @@ def test_long_sequences_chunked_bptt(cell, chunks, monkeypatch):
     check(PU.compare_step(cell, [20], "CCE", N=41, B=9, T=70, seed=3), tol_h=2e-4)
 
 
+@pytest.mark.parametrize("cell,layers,B,T", [("LSTM", [256], 1, 1), ("GRU", [256], 3, 2), ("LSTM", [512], 17, 1), ("Vanilla", [256], 16, 3),
+                                             ("LSTM", [128], 1, 1), ("LSTM", [128], 5, 2), ("GRU", [256, 256], 2, 1), ("LSTM", [300], 33, 5),
+                                             ("LSTM", [20], 1, 1)])
+def test_smallest_shapes_on_the_cluster_and_pipelined_kernels(cell, layers, B, T):
+    # one row, one step, a tile with one live row, a stack whose lower layer gets dh_ext at its only step
+    r = PU.compare_step(cell, layers, "CCE", N=30, B=B, T=T, scale=0.05, k=1)
+    assert r["h_last"] <= 2e-4 and r["cost"] <= 1e-5 and r["grad_worst"] <= 2e-4 and r["params_after_2_steps"] <= 1e-3, r
+    assert r["topk_mismatch"] == 0
+
+
 def test_ragged_and_edge_lengths():
     # rows of length 1 and T, a row whose items are all id 0 (== the pad id), B not a multiple of 16
     check(PU.compare_step("GRU", [16], "CCE", N=33, B=17, T=11, seed=5))
