@@ -366,6 +366,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
+    h->out_early = false; h->dh_slabs_n = 0;
     h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
@@ -660,7 +661,7 @@ static inline hipEvent_t record_shared(sbr_handle* h, hipEvent_t plain, int mk) 
 extern "C" int sbr_zero_grads(sbr_handle* h) {
     CHECK_ARG(h, "null handle");
     h->step_open = true;                          // a training step begins: sbr_forward may start its batch-only work
-    h->out_early = false;
+    h->out_early = false; h->dh_slabs_n = 0;
     if (!h->in_train_step && h->timing) {         // phase-by-phase step (data-parallel driver): this call opens the step
         h->ring_cur = h->ring_used % sbr_handle::kRing;
         mark(h, 0);
@@ -862,6 +863,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     const int R = h->n_rows, Hp = y.HLt, N = y.N;      // Hp: the output layer's input width (both directions with --r_bi)
     const bool sg = simple_gemm(h);
     h->grads_clean = false;
+    h->dh_slabs_n = 0;
     float* hl = h_last(h);
     float* ws = h->A(y.a_ws);
     float* ws2 = h->A(y.a_ws2);
@@ -922,8 +924,18 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
                                           y.Bg, y.cfg.loss, y.cfg.balance, y.cfg.unique));
         else
         SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, Nl, y.Bg));
-        // critical path: dh = dlogits . W_out^T feeds the BPTT chain
-        SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg));
+        // critical path: dh = dlogits . W_out^T feeds the BPTT chain.  Where the chain is rec_bwd_x6p, the split-K slabs of this
+        // GEMM stay unreduced and the chain's prologue adds them: one launch (7 us + its gap) less in front of it
+        int keep = 0;
+        bool fold = false;
+        if (!sg && y.D == 1 && R == y.Bp && !simple_rec(h)) {
+            static const bool fold_on = getenv("SBR_FOLD_DH") ? atoi(getenv("SBR_FOLD_DH")) != 0 : true;
+            RecArgs ra = rec_args(h, y.L - 1);
+            fold = fold_on && sbr_rec_x6p_ok(ra) && !sbr_rec_cluster_ok(ra);
+        }
+        SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg, 0, 0,
+                               fold ? &keep : nullptr));
+        h->dh_slabs_n = keep;
         // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
         // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
         h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
@@ -1003,6 +1015,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             if (l == y.L - 1) SBR_HIP(hipStreamWaitEvent(s, h->ev_fill, 0));
         }
         a.dh_last = l == y.L - 1 ? h->A(y.a_dhlast) : nullptr;
+        if (l == y.L - 1 && h->dh_slabs_n > 0) { a.dh_slabs = ws; a.n_dh_slabs = h->dh_slabs_n; }      // (sbr_loss_backward_output)
         a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
         if (a.prof) a.prof += (size_t)(y.Bp / 16) * 16 * 8;
         const int nblk = sbr_rec_bwd_blocks(a, simple_rec(h));

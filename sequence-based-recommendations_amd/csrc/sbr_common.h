@@ -135,6 +135,7 @@ struct sbr_handle {
     bool og_recorded;    // ev_og marks the output-layer gradients of this step complete
     bool fill_done;      // the cluster BPTT sentinel fill of this step was issued on the side stream (ev_fill)
     bool out_early;      // this step's output-layer parameters were stepped on the side stream beside the BPTT chain
+    int dh_slabs_n;      // > 0: dh_last of this step sits in the main workspace as that many unreduced split-K slabs
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
     int bwd_chunks;      // BPTT launches per layer (1..SBR_BWD_CHUNKS)
@@ -259,6 +260,8 @@ struct RecArgs {
     float* hs; float* cs; float* g[4];
     // backward only
     const float* dh_last;   // [Bp][Hp] grad wrt the final hidden state (top layer) or NULL
+    const float* dh_slabs;  // rec_bwd_x6p only: dh_last as n_dh_slabs unreduced split-K slabs of [Bp][Hp] (the kernel's prologue
+    int n_dh_slabs;         // adds them: one small reduction launch less in front of the BPTT chain), or NULL / 0
     const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
     float* dxt; float* dhi; // dhi: GRU only, compact [T][Bp][Hp] = candidate-gate slice of grad wrt hid_input (r,u slices == dxt)
     // BPTT in time chunks (so the weight-gradient GEMM of finished chunks runs beside the chain): this launch
@@ -329,7 +332,9 @@ hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk
 // A: m = pos, k = col over K columns;  B: k = pos, n = col over N columns).
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                        float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
-                       bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0);
+                       bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0, int* keep_slabs = nullptr);
+// keep_slabs != NULL: where the split-K form runs, its slabs stay in ws (slab z at ws + z * M * N, row stride N), the
+// reduction is left to the consumer and *keep_slabs = their number; otherwise *keep_slabs = 0 and C holds the result
 
 // bf16x6 GEMM (sbr_gemm_x6.hip): false = shape not supported, use the f32 kernel
 bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,

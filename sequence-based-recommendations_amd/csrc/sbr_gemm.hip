@@ -247,7 +247,8 @@ hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int 
 
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                        long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple,
-                       int a_blk_Bp, int b_blk_Bp) {
+                       int a_blk_Bp, int b_blk_Bp, int* keep_slabs) {
+    if (keep_slabs) *keep_slabs = 0;
     if (M <= 0 || N <= 0) return hipSuccess;
     GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, a_blk_Bp, b_blk_Bp, K, nullptr, (long)N, (size_t)M * N};
     if (simple) {
@@ -287,7 +288,8 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
         if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ns > 1 ? ws : C, ns > 1 ? (long)N : ldc, M, N, K, bias, ns, kc,
                            (size_t)M * N, &e, nullptr, 0, 0, small)) {
             if (e == hipSuccess && ns > 1) {
-                e = splitk_reduce(s, ws, ns, M, N, C, ldc, bias);
+                if (keep_slabs && !bias) *keep_slabs = ns;                // the consumer adds the slabs
+                else e = splitk_reduce(s, ws, ns, M, N, C, ldc, bias);
             }
             return e;
         }

@@ -523,7 +523,21 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
 
     const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
     float dh = 0.f, dc = 0.f;
-    if (first) { if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u]; }
+    if (first) {
+        if (a.n_dh_slabs) {                                       // dh_last arrives as unreduced split-K slabs of the dh GEMM
+            const float* p = a.dh_slabs + (size_t)row * HP + u;
+            const size_t st = (size_t)Bp * HP;
+            int z = 0;
+            for (; z + 8 <= a.n_dh_slabs; z += 8) {               // eight loads in flight (one after the other: 6 us)
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(z + k) * st];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dh += v[k];
+            }
+            for (; z < a.n_dh_slabs; ++z) dh += p[(size_t)z * st];
+        } else if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u];
+    }
     else {
         dh = a.state[(size_t)row * HP + u];
         if (CELL == CELL_LSTM) dc = a.state[(size_t)Bp * HP + (size_t)row * HP + u];
