@@ -74,6 +74,25 @@ def initial_parameters(cfg, rng):
     return initial_values(describe_params(cfg), rng)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` started directly (no torch.distributed.run around it): start the N ranks here -- one
+    process per GPU, rendezvous on 127.0.0.1 at a free port -- with this very command line; rank 0 prints the JSON line, the
+    children's stdout / stderr pass through, the exit code is theirs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")                 # (torch.distributed.run would set 1 and say so on stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +110,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the line reports the median region and all of them")
     ap.add_argument("--pmc-json", default=None, help="HBM counter bytes per launch for roofline.traffic, from a separate rocprofv3 --pmc pass "
                     "of this same command (tools/pmc_summary.py output); without it traffic is null")
+    ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the data-parallel step: nccl = RCCL over xGMI (one rank per GPU); gloo lets several "
+                         "ranks share one device (RCCL refuses that) -- how the one-GPU test box exercises --gpus 2")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     def log(*a):
         print("[bench %6.1fs]" % (time.perf_counter() - T0), *a, file=sys.stderr, flush=True)
@@ -106,14 +130,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py measures the HIP engine: no GPU visible")
+    if world > n_dev and args.dp_backend == "nccl":
+        raise SystemExit("--gpus %d but %d visible device(s): RCCL needs one GPU per rank (--dp-backend gloo shares devices)" % (world, n_dev))
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dp_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cell, layers, n_items, loss, n_samples = CONFIGS[args.config]
     B, T = args.batch, args.max_length
@@ -215,8 +246,9 @@ def main():
                                % (args.config, cell, "-".join(map(str, layers)), T, B, loss, n_items, args.lengths, B),
                    "global_batch": Bg, "seq_len": T, "parallelism": "dp%d" % world, "last_cost": round(cost, 5),
                    "arithmetic": "f32 tensors and accumulation; matrix products of f32 operands as splits on the fp16 / bf16 "
-                                 "matrix pipe with f32-class error: fp16x3 (three MFMAs per product) in both recurrent chains and the "
-                                 "dW_hid GEMM, bf16x6 in the other GEMMs, DESIGN.md section 3"},
+                                 "matrix pipe with f32-class error: the two-plane fp16 split in both recurrent chains (planes packed into the "
+                                 "tile rows: two MFMAs per product) and the dW_hid GEMM (three), bf16x6 in the other GEMMs, "
+                                 "DESIGN.md section 3"},
     }
 
     if rank == 0 and phases is not None:

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 6
+#define SBR_ABI_VERSION 7
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -194,6 +194,16 @@ int sbr_sparse_info(sbr_handle* h, int b, int64_t* n_rows, int64_t* row_floats, 
 int sbr_sparse_pack(sbr_handle* h, int b, int32_t* ids_dev, float* rows_dev, int32_t* count_host);
 int sbr_sparse_unpack_add(sbr_handle* h, int b, const int32_t* ids_dev, const float* rows_dev, int count);
 int sbr_dense_ranges(sbr_handle* h, int cap, int64_t* lo, int64_t* hi, int* n);
+/* The same exchange without a host round trip (ABI 7): the number of packed rows stays on the device and travels IN BAND.
+ *   sbr_sparse_pack_device     ids_dev is [1 + max_local_rows] ints: ids_dev[0] = the row count, ids_dev[1 ..] the ids;
+ *                              rows_dev [max_local_rows][row_floats].  Nothing is synchronised.
+ *   (the ranks all-gather both buffers at their fixed capacity: ids_all [world][1 + max_local_rows], rows_all
+ *    [world][max_local_rows][row_floats])
+ *   sbr_sparse_unpack_add_all  adds every rank's rows in rank order (one launch per rank, its count read on the device).
+ * A fixed-capacity all-gather moves max_local_rows rows per rank whatever the step touched: the caller chooses per block
+ * between this form (small blocks: the host read is the cost) and the counted one above (large blocks: the bytes are). */
+int sbr_sparse_pack_device(sbr_handle* h, int b, int32_t* ids_dev, float* rows_dev);
+int sbr_sparse_unpack_add_all(sbr_handle* h, int b, const int32_t* ids_all, const float* rows_all, int world);
 
 /* predict_function(X, mask) (rnn_base.py:188-194) on the current batch: scores (rows,N);
  * softmax probabilities for CCE (DenseLayer softmax, rnn_one_hot.py:65), raw activations

@@ -1275,6 +1275,39 @@ extern "C" int sbr_sparse_unpack_add(sbr_handle* h, int b, const int32_t* ids_de
     return SBR_OK;
 }
 
+extern "C" int sbr_sparse_pack_device(sbr_handle* h, int b, int32_t* ids_dev, float* rows_dev) {
+    CHECK_ARG(h && ids_dev && rows_dev, "null argument");
+    CHECK_ARG(b >= 0 && b < h->lay.n_sparse, "sparse block %d outside [0,%d)", b, h->lay.n_sparse);
+    const Layout& y = h->lay; const SparseBlockLayout& sb = y.sparse[b];
+    { const int rc = side_join(h); if (rc != SBR_OK) return rc; }      // the block's gradients come from both streams
+    const int epoch = ++h->sp_epoch;
+    // the running count of the pack kernel IS the in-band word ids_dev[0]
+    if (sb.kind == 0) {
+        SBR_LAUNCH(launch_sparse_pack(h->stream, sparse_rows(h, b), (const int*)h->A(y.a_sid), (const int*)h->A(y.a_soff) + y.cfg.input_size, 0,
+                                      y.T * y.Bp * y.F, (int*)h->A(sb.a_mark), epoch, ids_dev + 1, rows_dev, sb.W, ids_dev));
+    } else {
+        SBR_LAUNCH(launch_sparse_pack(h->stream, sparse_rows(h, b), (const int*)h->A(y.a_cells), nullptr, y.C, y.C, (int*)h->A(sb.a_mark), epoch,
+                                      ids_dev + 1, rows_dev, sb.W, ids_dev));
+    }
+    h->sp_exchanged[b] = 1; h->sp_ncand[b] = 0;
+    return SBR_OK;
+}
+
+extern "C" int sbr_sparse_unpack_add_all(sbr_handle* h, int b, const int32_t* ids_all, const float* rows_all, int world) {
+    CHECK_ARG(h && ids_all && rows_all, "null argument");
+    CHECK_ARG(b >= 0 && b < h->lay.n_sparse, "sparse block %d outside [0,%d)", b, h->lay.n_sparse);
+    const SparseBlockLayout& sb = h->lay.sparse[b];
+    if (!h->sp_exchanged[b]) { sbr_set_error("sbr_sparse_unpack_add_all: call sbr_sparse_pack_device for this step first"); return SBR_ESTATE; }
+    const int cap = sb.max_local;
+    CHECK_ARG(world >= 1 && h->sp_ncand[b] == 0 && (long)world * cap <= sb.cand_cap, "%d ranks x %d rows exceed the candidate capacity %d", world, cap, sb.cand_cap);
+    for (int r = 0; r < world; ++r)      // rank order, one stream: every replica adds in the same order
+        SBR_LAUNCH(launch_sparse_unpack_add_dev(h->stream, sparse_rows(h, b), ids_all + (size_t)r * (cap + 1), rows_all + (size_t)r * cap * sb.W,
+                                                cap, sb.W, (int*)h->A(sb.a_cand) + (size_t)r * cap));
+    h->sp_ncand[b] = world * cap;          // slots beyond a rank's count hold -1 (skipped by the row-sparse step)
+    h->grads_clean = false;
+    return SBR_OK;
+}
+
 extern "C" int sbr_dense_ranges(sbr_handle* h, int cap, int64_t* lo, int64_t* hi, int* n) {
     CHECK_ARG(h && lo && hi && n, "null argument");
     const Layout& y = h->lay;
@@ -1594,7 +1627,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         if (!simple_rec(h) && x6) {
             const char* fe = getenv(bwd ? "SBR_X6_F16_BWD" : "SBR_X6_F16");      // the launchers' own conditions (sbr_rec_p.hip)
             const bool f16 = (xp || cl || xq) && (fe ? atoi(fe) != 0 : true) && (bwd ? (a.clip > 0.0f && a.clip <= 100.0f) : !a.relu);
-            products = f16 ? 3 : 6;
+            products = f16 ? (xp && !cl ? sbr_rec_x6p_f16_terms() : 3) : 6;
             if (cl && sbr_rec_c16_ok(a)) { rows = 16; wgs = (y.Bp / 16) * (a.Hp / 16); }
             else if (cl) { rows = bwd ? sbr_rec_cluster_bwd_rows(a) : SBR_CL_ROWS; wgs = (y.Bp / rows) * (a.Hp == 256 ? 8 : 32); }
             else { rows = a.rpt; wgs = y.Bp / a.rpt; }

@@ -303,6 +303,7 @@ hipError_t launch_rec_forward_cl(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_cl(hipStream_t s, const RecArgs& a);
 // sbr_rec_p.hip: pipelined bf16x6 kernels for Hp = 128 on 4-row tiles
 bool sbr_rec_x6p_ok(const RecArgs& a);
+int sbr_rec_x6p_f16_terms();              // MFMAs per f32 product of the x6p kernels' fp16 forms (2: packed planes, sbr_rec_p.hip)
 bool sbr_rec_x6p_tail_ok(const RecArgs& a);   // ... and its backward kernel can publish progress (RecArgs.progress)
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a);
@@ -402,6 +403,7 @@ hipError_t launch_sparse_step_list(hipStream_t s, const SbrSparseRows& r, const 
 hipError_t launch_sparse_pack(hipStream_t s, const SbrSparseRows& r, const int* list, const int* n_dev, int n_host, int n_max, int* mark,
                               int epoch, int* ids_out, float* rows_out, int W, int* count);
 hipError_t launch_sparse_unpack_add(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int n, int W, int* cand);
+hipError_t launch_sparse_unpack_add_dev(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int cap, int W, int* cand);
 // top-k (rnn_base.py:196-211)
 // value: -inf (top_k_recommendations, rnn_base.py:154-155) or 0 (the compiled test function's scores * (1 - exclude), :201-202)
 hipError_t launch_exclude_seen(hipStream_t s, float* scores, const int* X, const int* len, int rows, int T, int F,

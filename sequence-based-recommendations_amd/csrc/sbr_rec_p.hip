@@ -44,6 +44,15 @@
 #ifndef X6P_DBG
 #define X6P_DBG 0        // timing experiments only (tools/probes/x6p_variants.sh): wrong results by design
 #endif
+#ifndef X6P_BWD_NS
+#define X6P_BWD_NS 2     // backward: operand slots / k-blocks fetched ahead of their MFMAs
+#endif
+#ifndef X6P_BWD_LA
+#define X6P_BWD_LA 1
+#endif
+#ifndef X6P_PACK
+#define X6P_PACK 1       // 0: the fp16 forms with three MFMAs per product (round 2), for same-box A/B runs (SBR_LIB)
+#endif
 
 namespace {
 
@@ -96,6 +105,7 @@ template <int CELL, bool FUSE, bool PROF, bool F16>
 __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;      // operand fragment: fp16 (two planes) or bf16 (three planes)
     constexpr int NP = F16 ? 2 : 3;
+    constexpr bool PK = F16 && X6P_PACK;                     // packed planes: two MFMAs per product, see "Packed planes" above
     constexpr int G = Gates<CELL>::G, KB = KBH, GHP = G * HP;
     static_assert(G <= 3 || F16, "three W_hid planes of four gates do not fit the register file: an LSTM runs on the two fp16 planes only");
     constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW, BUFB = 3 * PLANEB;
@@ -159,7 +169,8 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         stf(a.cs, bo_h, c);
     }
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
-    const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16);     // A operand: tile row m = j holds batch row j >> 2
+    // A operand: tile row m = j holds batch row j >> 2; PK: plane j & 1 of it (rows 4r + 2, 4r + 3 repeat rows 4r, 4r + 1)
+    const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16 + (PK ? (j & 1) * PLANEB : 0));
     auto publish_h = [&](int buf) {
         char* base = hbuf + buf * BUFB + lds_pub;
         if constexpr (F16) {
@@ -190,7 +201,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         float b = FUSE ? a.gbias[g * HP + u] : 0.f;
         if (CELL == CELL_GRU && g == 2) { bias_c = b; b = 0.f; }
         if (CELL == CELL_GRU && g < 2) b *= X6P_NLOG2E;
-        biasv[g] = f32x4{b, b, b, b};
+        biasv[g] = PK ? f32x4{b, 0.f, 0.f, 0.f} : f32x4{b, b, b, b};      // PK: element 1 collects the low-order products
     }
     // FUSE: the rows travel XPD time steps ahead of their use through a ring in LDS (LDS-DMA, sbr_rec_p.h: one dword per lane
     // and gate; invisible to the compiler's vmcnt bookkeeping, waited for by hand), their byte offsets inside W_in come from
@@ -272,7 +283,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 #pragma unroll
             for (int kb = 2 * half; kb < 2 * half + 2; ++kb) {
                 hp[kb][0] = *(const OPV*)(hb + kb * 64);
-                hp[kb][1] = *(const OPV*)(hb + kb * 64 + PLANEB);
+                hp[kb][1] = PK ? hp[kb][0] : *(const OPV*)(hb + kb * 64 + PLANEB);
                 hp[kb][2] = NP == 3 ? *(const OPV*)(hb + kb * 64 + 2 * PLANEB) : hp[kb][1];
             }
         };
@@ -319,7 +330,32 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         f32x4 acc[G], acl[G];                                     // acl: the low-order products of the fp16 form
 #define X6P_TERM(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = mfma16(HOP, WOP, acc[g]);
 #define X6P_TERL(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acl[g] = mfma16(HOP, WOP, acl[g]);
-        if constexpr (F16) {
+        if constexpr (PK) {
+            // acc[g][0] = h1 w1 (+ bias), acc[g][1] = h2 w1, acl[g][0] = h1 w2 (acl[g][1] = h2 w2: below f32 rounding, dropped)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb == KB / 2 && RA) ensure_half(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (PROF && tl && t == 100) tl[1 + kb] = clock64();
+                if (kb == 0) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acl[g] = mfma16(hp[kb][0], W2[g][kb], f32x4{0.f, 0.f, 0.f, 0.f});
+                } else { X6P_TERL(hp[kb][0], W2[g][kb]) }
+                if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (kb == 0) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W1[g][kb], biasv[g]);
+                } else { X6P_TERM(hp[kb][0], W1[g][kb]) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acl[g][0], 1.0f / F16_LO, acc[g][0]);
+        } else if constexpr (F16) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 if (kb == KB / 2 && RA) ensure_half(1);
@@ -471,6 +507,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     constexpr bool WT = WTM == 1, RING = WTM != 0;
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;
     constexpr int NP = F16 ? 2 : 3;
+    constexpr bool PK = F16 && X6P_PACK;                 // packed planes: two MFMAs per product ("Packed planes" above)
     constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate
     static_assert(G <= 3 || F16, "three W_hid planes of four gates do not fit the register file: an LSTM runs on the two fp16 planes only");
     constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW, BUFB = NP * PLANEB;
@@ -519,7 +556,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     const unsigned bo_g = (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;
     const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;
-    const unsigned lds_pub = (unsigned)(q * DROW + u * 2), lds_rd = (unsigned)((j >> 2) * DROW + q * 16);
+    const unsigned lds_pub = (unsigned)(q * DROW + u * 2), lds_rd = (unsigned)((j >> 2) * DROW + q * 16 + (PK ? (j & 1) * PLANEB : 0));
 
     const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
     float dh = 0.f, dc = 0.f;
@@ -719,7 +756,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         unsigned long long q_n = 0;
         if (PROF) { q_n = clock64(); p_n += q_n - q_top; }
         // ---- operands: a ring of NS k-block slots, fetched LA k-blocks ahead of their MFMAs; the pipe gate
-        constexpr int NS = 2, LA = 1;          // measured: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
+        constexpr int NS = X6P_BWD_NS, LA = X6P_BWD_LA;   // round 2, three MFMAs per block: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
         const char* db = lds + lds_rd;
         OPV dpl[NS][NP];
         int fl[2];
@@ -728,7 +765,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             if ((X6P_DBG & 64) && (i & 1)) { for (int pp = 0; pp < NP; ++pp) dpl[s][pp] = dpl[s ^ 1][pp]; return; }   // half the LDS reads
             if ((X6P_DBG & 128) && (i % 4)) { for (int pp = 0; pp < NP; ++pp) dpl[s][pp] = dpl[s ^ 1][pp]; return; }  // a quarter
             dpl[s][0] = *(const OPV*)(db + kb * 64);
-            dpl[s][1] = *(const OPV*)(db + kb * 64 + PLANEB);
+            dpl[s][1] = PK ? dpl[s][0] : *(const OPV*)(db + kb * 64 + PLANEB);
             if constexpr (NP == 3) dpl[s][2] = *(const OPV*)(db + kb * 64 + 2 * PLANEB);
         };
         auto load_flag = [&](int half) {
@@ -783,7 +820,11 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 load_kb(i + LA);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
+            if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
+                acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]);
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
+                acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
+            } else if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
                 if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
                 acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
                 acc[2] = mfma16(dpl[s][0], W2[kb], acc[2]);
@@ -804,7 +845,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
         if (PROF) p_m += clock64() - q_n;
-        if constexpr (F16) dh += fmaf(acc[1][0] + acc[2][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
+        if constexpr (PK) dh += fmaf(acc[0][1] + acc[1][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
+        else if constexpr (F16) dh += fmaf(acc[1][0] + acc[2][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
         else dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
     };
@@ -863,6 +905,8 @@ static bool x6p_f16_bwd(const RecArgs& a) {     // the operand that carries grad
     const char* fe = getenv("SBR_X6_F16_BWD");
     return (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
 }
+
+int sbr_rec_x6p_f16_terms() { return X6P_PACK ? 2 : 3; }
 
 bool sbr_rec_x6p_ok(const RecArgs& a) {
     if (!a.x6_pipe || a.f32_mfma || a.Hp != HP || a.rpt != R || !a.x6_split) return false;

@@ -294,6 +294,33 @@ __global__ void __launch_bounds__(256) sp_unpack_kernel(SbrSparseRows r, const i
     }
 }
 
+// ... with the rank's row count on the device (ids[0]; the ids follow): slots j >= count of the candidate list get -1
+__global__ void __launch_bounds__(256) sp_unpack_dev_kernel(SbrSparseRows r, const int* __restrict__ ids, const float* __restrict__ rows, int cap,
+                                                            int W, int* __restrict__ cand) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int n = min(max(ids[0], 0), cap);
+    for (int j = wave; j < cap; j += nwaves) {
+        const int id = j < n ? ids[1 + j] : -1;
+        if (lane == 0) cand[j] = id;
+        if (id < 0 || id >= r.n_rows) continue;
+        const float* src = rows + (size_t)j * W;
+        int col = 0;
+        for (int pr = 0; pr < r.npairs; ++pr) {
+            float* g = r.g + r.off[pr] + (size_t)id * r.stride[pr];
+            for (int c = lane; c < r.width[pr]; c += 64) g[c] += src[col + c];
+            col += r.width[pr];
+        }
+    }
+}
+
+hipError_t launch_sparse_unpack_add_dev(hipStream_t s, const SbrSparseRows& r, const int* ids, const float* rows, int cap, int W, int* cand) {
+    if (cap <= 0) return hipSuccess;
+    sp_unpack_dev_kernel<<<std::max(1, std::min(16384, (cap + 3) / 4)), 256, 0, s>>>(r, ids, rows, cap, W, cand);
+    return hipGetLastError();
+}
+
 hipError_t launch_sparse_pack(hipStream_t s, const SbrSparseRows& r, const int* list, const int* n_dev, int n_host, int n_max, int* mark,
                               int epoch, int* ids_out, float* rows_out, int W, int* count) {
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);

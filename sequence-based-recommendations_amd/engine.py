@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 6
+SBR_ABI_VERSION = 7
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
@@ -61,7 +61,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
-           "sbr_sparse_unpack_add", "sbr_dense_ranges",
+           "sbr_sparse_unpack_add", "sbr_dense_ranges", "sbr_sparse_pack_device", "sbr_sparse_unpack_add_all",
            "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_noise_pass", "sbr_dataset_current_sequences", "sbr_dataset_set_target_bias",
            "sbr_plan_rows_host", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
@@ -688,6 +688,26 @@ class RNNEngine(object):
             assert ids.is_contiguous() and rows.is_contiguous()
         self._check(self.lib.sbr_sparse_unpack_add(self.h, b, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(rows.data_ptr()),
                                                    int(count)))
+
+    def sparse_pack_device(self, b):
+        """The touched rows of block b with their count IN BAND and nothing synchronised: (ids int32 [1 + cap] with ids[0] =
+        the count, rows float32 [cap, row_floats]) -- the engine's exchange buffers, gathered at their fixed capacity."""
+        if not hasattr(self, "_sp_dev"):
+            self._sp_dev = {}
+        if b not in self._sp_dev:
+            n_rows, w, cap = self.sparse_blocks()[b]
+            with self.torch.cuda.device(self.device):
+                self._sp_dev[b] = (self.torch.empty(cap + 1, dtype=self.torch.int32, device=self.device),
+                                   self.torch.empty((cap, w), dtype=self.torch.float32, device=self.device))
+        ids, rows = self._sp_dev[b]
+        self._check(self.lib.sbr_sparse_pack_device(self.h, b, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(rows.data_ptr())))
+        return ids, rows
+
+    def sparse_unpack_add_all(self, b, ids_all, rows_all, world):
+        """Adds every rank's gathered rows (ids_all [world, 1 + cap], rows_all [world, cap, row_floats]) in rank order."""
+        assert ids_all.is_contiguous() and rows_all.is_contiguous()
+        self._check(self.lib.sbr_sparse_unpack_add_all(self.h, b, ctypes.c_void_p(ids_all.data_ptr()),
+                                                       ctypes.c_void_p(rows_all.data_ptr()), int(world)))
 
     def dense_ranges(self):
         """[(lo, hi)] float ranges of the gradient section (trailing cost included) outside the sparse blocks."""

@@ -41,12 +41,13 @@ def test_default_config_line_without_cpu_leg():
     r = d["roofline"]
     assert r["kernel"] in ("rec_bwd", "rec_fwd")
     assert r["traffic"] is None and r["traffic_source"] is None      # only from a counter pass of the same command (--pmc-json)
-    # the matrix pipe runs fp16x3 products on 4 live rows of 16: 12x the algorithmic flops, on the 64 CUs the launch occupies
+    # the matrix pipe runs the fp16 split with its two operand planes packed into the tile rows (two MFMAs per product) on 4 live
+    # rows of 16: 8x the algorithmic flops, on the 64 CUs the launch occupies
     mp = r["matrix_pipe"]
-    assert r["active_cus"] == 64 and mp["terms_per_f32_product"] == 3 and mp["live_rows_of_16"] == 4
-    assert mp["issued_tflops"] == pytest.approx(12 * r["achieved"], rel=1e-2) and 0 < mp["frac"] < mp["frac_of_active_cus"] < 1
+    assert r["active_cus"] == 64 and mp["terms_per_f32_product"] == 2 and mp["live_rows_of_16"] == 4
+    assert mp["issued_tflops"] == pytest.approx(8 * r["achieved"], rel=1e-2) and 0 < mp["frac"] < mp["frac_of_active_cus"] < 1
     k = d["kernels"]
-    assert k["rec_fwd"]["matrix_pipe"]["terms_per_f32_product"] == 3          # fp16x3 forward chain
+    assert k["rec_fwd"]["matrix_pipe"]["terms_per_f32_product"] == 2          # the forward chain likewise
     for name in ("scatter", "gather_fused", "gather_unfused", "output_projection", "output_projection_bf16"):
         assert k[name]["us"] > 0 and 0 < k[name]["frac"] < 1, name
     assert k["gather_unfused"]["bound"] == "hbm" and k["gather_unfused"]["achieved"] > 500      # GB/s

@@ -27,7 +27,7 @@ def check(r, steps, tol_g=1e-5, tol_h=1e-5, rows=None):
     assert r["h_last"] <= tol_h, r
     assert r["cost"] <= 1e-5, r
     assert r["grad_worst"] <= tol_g, grads
-    assert r["params_after_%d_steps" % steps] <= 1e-3, r
+    PU.params_ok(r, steps, bar=1e-3, tol_g=tol_g)
     assert r["predict_scores"] <= 1e-4, r
     assert r["topk_mismatch"] == 0, r
     if rows is not None:
