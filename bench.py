@@ -74,6 +74,53 @@ def initial_parameters(cfg, rng):
     return initial_values(describe_params(cfg), rng)
 
 
+def counter_passes(argv_child, log):
+    """HBM bytes per launch and kernel from two rocprofv3 --pmc passes of THIS command (child: --quick, few steps), FETCH_SIZE and
+    WRITE_SIZE each in its own run with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3: the two do not fit one pass; on
+    gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane streams -> doubled; WRITE_SIZE as reported).  Counter passes
+    serialise kernels, so the overlapped tail's consumers cannot wait beside the chain there: SBR_TAIL_OVERLAP=2 (the same
+    kernels on one stream).  Returns {kernel name: {"fetch_kb", "write_kb", "hbm_bytes", "launches"}} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        log("counter passes skipped: no rocprofv3")
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="sbr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", SBR_TAIL_OVERLAP="2")
+    try:
+        for ctr, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "c", "--",
+                   sys.executable, os.path.abspath(__file__)] + argv_child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                log("counter pass %s failed (rc %d): %s" % (ctr, r.returncode, r.stderr[-300:]))
+                return None
+            acc = {}
+            for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(fn) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] == ctr:
+                            acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                m = sum(v[1:]) / (len(v) - 1) if len(v) > 1 else v[0]      # (the first launch of a kernel includes its code fetch)
+                out.setdefault(k, {})[key] = m
+                out[k]["launches"] = len(v)
+    except Exception as ex:
+        log("counter passes skipped:", ex)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for k, e in out.items():
+        e["hbm_bytes"] = int(2 * e.get("fetch_kb", 0.0) * 1024 + e.get("write_kb", 0.0) * 1024)
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N ...` started directly (no torch.distributed.run around it): start the N ranks here -- one
     process per GPU, rendezvous on 127.0.0.1 at a free port -- with this very command line; rank 0 prints the JSON line, the
@@ -110,6 +157,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the line reports the median region and all of them")
     ap.add_argument("--pmc-json", default=None, help="HBM counter bytes per launch for roofline.traffic, from a separate rocprofv3 --pmc pass "
                     "of this same command (tools/pmc_summary.py output); without it traffic is null")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the counter passes (two rocprofv3 --pmc child runs of this command, "
+                    "FETCH_SIZE and WRITE_SIZE, ~1 min) that fill roofline.traffic")
+    ap.add_argument("--quick", action="store_true", help="timed regions only: no survey extras, no sustained / train-loop / counter / "
+                    "CPU legs (what the counter passes run as their child)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the one long region behind the timed ones (0: skip)")
+    ap.add_argument("--loop-iters", type=int, default=1000, help="iterations of the end-to-end training-loop leg (0: skip)")
     ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the data-parallel step: nccl = RCCL over xGMI (one rank per GPU); gloo lets several "
                          "ranks share one device (RCCL refuses that) -- how the one-GPU test box exercises --gpus 2")
@@ -144,7 +197,21 @@ def main():
         if args.dp_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo announces its connections on STDOUT from C++ ("[Gloo] Rank 0 is connected to ..."): keep the one-JSON-line contract
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                try:
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:
+                    pass
+                os.dup2(saved, 1)
+                os.close(saved)
 
     cell, layers, n_items, loss, n_samples = CONFIGS[args.config]
     B, T = args.batch, args.max_length
@@ -167,7 +234,7 @@ def main():
     dp = DataParallel(eng, dist)
     log("engine ready, arena %.1f MB" % (eng.arena_bytes / 1e6))
 
-    def step(i):
+    def step(i, exposed=None):
         d = dev_batches[i % nb]
         tgt = d["target"]
         if world > 1 and loss != "CCE":      # sampled heads need every rank's targets (rnn_sampling.py:137)
@@ -176,7 +243,7 @@ def main():
         if world == 1 and not args.force_dp:
             eng.train_step(sync=False)       # one C call: zero grads, fwd, loss, BPTT, scatter, Adam
         else:
-            dp.train_step()                  # same phases with the RCCL all-reduces in between
+            dp.train_step(exposed=exposed)   # same phases with the RCCL all-reduces in between
 
     for i in range(args.warmup):
         step(i)
@@ -187,6 +254,8 @@ def main():
     # only that kernel (two records).
     survey, dom_phase = None, "rec_bwd"
     try:
+        if args.quick:
+            raise RuntimeError("--quick")
         eng.enable_timing(True)
         for i in range(min(args.steps, 20)):
             step(args.warmup + i)
@@ -196,14 +265,33 @@ def main():
         dom_phase = max(cand, key=lambda k: survey[k])
     except Exception as ex:
         log("phase survey skipped:", ex)
+    # data parallel: how long the engine's stream really stands still for each collective (events around every wait; a survey
+    # pass like the one above, outside the timed regions)
+    dp_info = None
+    if world > 1 or args.force_dp:
+        n_sv = min(args.steps, 10)
+        eng.enable_timing(False)
+        ex = {}
+        for i in range(n_sv):
+            step(args.warmup + i, exposed=ex)
+        DataParallel.exposed_us(ex)
+        dp_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                   "collectives_per_step": {"dense_buckets": len(dp._views()["out"]) + (2 if "win" in dp._views() else len(dp._views()["rec"])),
+                                            "sparse_blocks": dp._nsparse},
+                   "exposed_us_per_step": {k: round(v / n_sv, 2) for k, v in sorted(ex.items())},
+                   "note": "exposed = time the engine's stream waited for the collective (HIP events around each wait, survey pass "
+                           "of %d steps); buckets: out = output layer (issued behind the side stream, runs beside the BPTT chain), "
+                           "win / rest = W_in behind the scatter stream, the rest behind the slab-reduction stream (overlapped "
+                           "tail), rec = the recurrent part in one bucket otherwise" % n_sv}
     eng.enable_timing(True, only=dom_phase)
 
-    def timed_region(first):
+    def timed_region(first, n=None):
+        n = args.steps if n is None else n
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n):
             step(first + i)
         torch.cuda.synchronize()
         if world > 1:
@@ -222,9 +310,30 @@ def main():
     cost = eng.read_cost()
     if not np.isfinite(cost):
         raise ValueError("Cost is NaN")            # rnn_base.py:291-292
+    # one long region behind the short ones: the timed regions are ~20 ms each, which the chip runs at its boost clock; this one
+    # lasts --sustained-seconds (same steps, same barriers), with the chain's own clock read from its in-kernel counters
+    sustained = None
+    if args.sustained_seconds > 0 and not args.quick:
+        try:
+            timed_dom = eng.phase_times()              # (the dominant kernel's HIP-event time belongs to the timed regions above)
+        except Exception:
+            timed_dom = None
+        n_sus = max(args.steps, int(args.sustained_seconds / (dt / args.steps)))
+        eng.enable_timing(False)
+        sdt = timed_region(args.warmup + max(1, args.repeats) * args.steps, n_sus)
+        sustained = {"steps": n_sus, "seconds": round(sdt, 3), "ms_per_step": round(sdt / n_sus * 1e3, 4),
+                     "value": round(Bg * n_sus / sdt, 1), "unit": "user-sequences/s"}
+        try:
+            if eng.query("tail_chunks") >= 2:
+                cyc, ticks = eng.query("tail_chain_cycles"), eng.query("tail_chain_ticks")
+                if ticks > 0:
+                    sustained["rec_bwd_shader_mhz"] = round(cyc / ticks * 100.0, 1)
+        except Exception:
+            pass
+        log("sustained region: %d steps, %.4f ms/step" % (n_sus, sdt / n_sus * 1e3))
 
     try:        # HIP-event time of the dominant kernel over the timed region (data-parallel: all-reduce waits sit inside it)
-        timed = eng.phase_times()
+        timed = timed_dom if (sustained is not None and timed_dom is not None) else eng.phase_times()
         phases = dict(survey) if survey is not None else None
         if phases is not None:
             phases[dom_phase] = timed[dom_phase]
@@ -251,6 +360,10 @@ def main():
                                  "DESIGN.md section 3"},
     }
 
+    if sustained is not None:
+        result["sustained"] = sustained
+    if dp_info is not None:
+        result["data_parallel"] = dp_info
     if rank == 0 and phases is not None:
         G = {"LSTM": 4, "GRU": 3, "Vanilla": 1}[cell]
         H = layers[0]
@@ -317,6 +430,33 @@ def main():
                 traffic_src = os.path.relpath(args.pmc_json, ROOT)
             except Exception as ex:
                 log("pmc json unusable:", ex)
+        elif world == 1 and not args.quick and not args.no_pmc:
+            # ... which bench.py runs itself: two rocprofv3 --pmc child passes of this very workload (counter_passes above)
+            n_child = 6 + 2
+            child = ["--steps", "6", "--warmup", "2", "--repeats", "1", "--quick", "--config", args.config, "--lengths", args.lengths,
+                     "--batch", str(B), "--max_length", str(T)]
+            pmc = counter_passes(child, log)
+            if pmc:
+                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel", "scatter": "scat_reduce_kernel"}[dom]
+                hit = [v for k, v in pmc.items() if key in k]
+                if hit:
+                    traffic = hit[0]["hbm_bytes"]
+                    traffic_src = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command (--quick --steps 6, "
+                                   "SBR_TAIL_OVERLAP=2: counter passes serialise kernels), mean over the launches after the first; "
+                                   "2 x FETCH_SIZE (gfx950) + WRITE_SIZE")
+                # the whole step: every kernel's bytes x its launches per step, against the step's algorithmic bytes
+                per_step = sum(v["hbm_bytes"] * v["launches"] / float(n_child) for v in pmc.values())
+                n_par = float(sum(int(np.prod(p.shape)) for p in params))
+                alg = Ltot * row_bytes + Ltot * row_bytes + 2 * 4 * Ltot + 8 * 4 * n_par
+                top = sorted(pmc.items(), key=lambda kv: -kv[1]["hbm_bytes"] * kv[1]["launches"])[:6]
+                result["hbm_traffic"] = {
+                    "bytes_per_step": int(per_step), "algorithmic_bytes_per_step": int(alg), "ratio": round(per_step / alg, 3),
+                    "achieved_GBps_over_the_step": round(per_step / (ms_per_step * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                    "largest": {k.split("(")[0][-60:]: {"MB_per_launch": round(v["hbm_bytes"] / 1e6, 2),
+                                                        "launches_per_step": round(v["launches"] / float(n_child), 2)} for k, v in top},
+                    "note": "algorithmic = W_in rows gathered (L x G*H*4) + dxt rows into the scatter-add (the same) + ids + the dense "
+                            "optimizer pass (8 arrays of P floats: p, g, m, v read; p, m, v written, g cleared); counters: same child "
+                            "passes as roofline.traffic"}
         result["roofline"] = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                               "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
                               "launch_us": d["us"], "matrix_pipe": d.get("matrix_pipe"), "active_cus": d.get("active_cus"),
@@ -324,6 +464,13 @@ def main():
                                       "the timed regions, vs the f32 MFMA peak; matrix_pipe = the bf16 / fp16 MFMA flops the kernel "
                                       "really issues vs the 2.5 PF dense peak; the chain is 2*T dependent steps on active_cus CUs "
                                       "(DESIGN.md section 3)"}
+        if traffic is not None and dom in ("rec_fwd", "rec_bwd"):
+            # the chains' algorithmic bytes: forward = W_in rows in (fused gather) + hs and the saved gate values out; backward = those
+            # back in + dxt (and GRU's compact candidate slice of dhi) out
+            nsave = {"LSTM": 5, "GRU": 4, "Vanilla": 0}[cell] + 1
+            alg_k = Ltot * (row_bytes + nsave * H * 4.0) if dom == "rec_fwd" else Ltot * (nsave * H * 4.0 + row_bytes + (H * 4.0 if cell == "GRU" else 0.0))
+            result["roofline"]["traffic_over_algorithmic"] = round(traffic / alg_k, 3)
+            result["roofline"]["algorithmic_bytes"] = int(alg_k)
         result["phases_us"] = {k: round(v, 2) for k, v in phases.items() if k != "total"}
         result["phases_us"]["note"] = ("%s: HIP events over the timed region; the other phases: survey pass of %d steps with "
                                        "every phase bracketed (those event records lengthen a step, so the phases do not add "
@@ -331,7 +478,7 @@ def main():
         # the embedding gather (north_star: achieved HBM GB/s on gather AND scatter).  In the step the rows are read inside
         # rec_fwd (no xt array): its algorithmic bytes over the forward kernel's time is a LOWER bound of the rate the gather runs
         # at; the stand-alone gather_xt_kernel (the step with SBR_FUSE_GATHER=0) is timed on the same shape beside it.
-        if "gather" not in kernels:
+        if "gather" not in kernels and not args.quick:
             gb = Ltot * (row_bytes + 4)
             kernels["gather_fused"] = {"bound": "hbm", "unit": "GB/s", "us": kernels["rec_fwd"]["us"],
                                        "achieved": round(gb / (kernels["rec_fwd"]["us"] * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS,
@@ -365,6 +512,8 @@ def main():
         # the dense output projection on its own (logits = h . W_out^T, rnn_one_hot.py:65): the same kernel the step
         # runs, timed with HIP events on this shape (north_star: MFMA utilisation of the output projection)
         try:
+            if args.quick:
+                raise RuntimeError("--quick")
             import ctypes
             Hl = layers[-1]
             A, Bm = torch.randn(B, Hl, device=dev), torch.randn(n_items, Hl, device=dev)
@@ -412,7 +561,7 @@ def main():
             log("output projection timing skipped:", ex)
         result["kernels"] = kernels
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.quick:
         from oracle import rnn_oracle as O          # the oracle: only this leg of the bench touches it
         from oracle import torch_ref as R
         ncores = os.cpu_count() or 1
@@ -426,11 +575,26 @@ def main():
         tr.train_function(cb)                      # warm-up (also bounds the sample if the host is slow)
         warm = time.perf_counter() - t0
         log("cpu baseline warm-up step %.2f s on %d threads (%d host cores)" % (warm, nthr, ncores))
-        n, t0 = 0, time.perf_counter()
-        while n < args.cpu_steps and (n == 0 or time.perf_counter() - t0 + warm < args.cpu_seconds):
-            tr.train_function(cb)
-            n += 1
-        cdt = (time.perf_counter() - t0) / n
+        # best of {16, 8, 4, 1} threads (--cpu-threads pins one): one timed step each while the --cpu-seconds budget lasts, widest
+        # first; a count whose expected time (the previous one scaled by the thread ratio) no longer fits is skipped and named
+        sweep, skipped, t_all = [], [], time.perf_counter()
+        counts = [nthr] if args.cpu_threads else [c for c in (16, 8, 4, 1) if c <= nthr] or [nthr]
+        est = warm
+        for c in counts:
+            if sweep and (time.perf_counter() - t_all) + warm + est * (sweep[-1][0] / float(c)) * 0.7 > args.cpu_seconds:
+                skipped.append(c)
+                continue
+            torch.set_num_threads(c)
+            n, t0 = 0, time.perf_counter()
+            while n < args.cpu_steps and (n == 0 or (time.perf_counter() - t_all) + warm + (time.perf_counter() - t0) / n < args.cpu_seconds):
+                tr.train_function(cb)
+                n += 1
+                if c != counts[0]:
+                    break                          # one step for the narrower counts
+            est = (time.perf_counter() - t0) / n
+            sweep.append((c, est, n))
+            log("cpu baseline: %d threads %.2f s/step (%d step(s))" % (c, est, n))
+        nthr, cdt, n = min(sweep, key=lambda e: e[1])
         # the reference pays its Python batch packing every iteration (rnn_one_hot.py:83-106: B*T list appends + a (B, N)
         # exclude matrix): restated literally in oracle.prepare_input_one_hot, timed on the same batch, single-threaded as there
         seqs = [(0, [(int(i), 1.0) for i in hb["X"][b, :hb["lengths"][b], 0]], [(int(hb["target"][b]), 1.0)]) for b in range(B)]
@@ -443,8 +607,12 @@ def main():
         pack = (time.perf_counter() - t0) / npk
         result["cpu_baseline"] = {"value": round(B / cdt, 1), "unit": "user-sequences/s", "cores": nthr,
                                   "kind": "port", "sample": "%d train step(s) of the same %s workload (B=%d, T=%d): torch-CPU "
-                                  "float32 port of the reference path (Theano/Lasagne not installable), %.2f s/step, "
+                                  "float32 port of the reference path -- an EAGER autograd loop over the T steps (oracle/torch_ref.py), "
+                                  "not what Theano's compiled scan + BLAS would run (Theano/Lasagne/python2 are not installable "
+                                  "here), so a lower bound of the reference's own CPU speed; %.2f s/step at the best thread count, "
                                   "%d threads of %d host cores" % (n, args.config, B, T, cdt, nthr, ncores),
+                                  "threads_sweep": {"s_per_step": {str(c): round(t, 3) for c, t, _ in sweep},
+                                                    "not_run_within_budget": skipped, "budget_s": args.cpu_seconds},
                                   "end_to_end": {"value": round(B / (cdt + pack), 1), "unit": "user-sequences/s",
                                                  "packing_s_per_batch": round(pack, 4),
                                                  "note": "compute step + reference-style _prepare_input packing of the batch "
@@ -452,6 +620,27 @@ def main():
     eng.close()
     if world > 1 or args.force_dp:
         dist.destroy_process_group()
+    if (rank == 0 and world == 1 and not args.quick and not args.force_dp and args.loop_iters > 0 and args.config == "c2"
+            and (B, T, args.lengths) == (256, 200, "full")):
+        # the training LOOP the reference runs around the step (rnn_base.py:285-300): batches built per iteration (native device
+        # builder), every cost read back (one iteration late: sbr_train_step_lagged), on an ML-1M-shaped synthetic file in the
+        # reference's on-disk format -- through the train.py mirror, >= 1000 iterations
+        try:
+            import importlib.util
+            import tempfile
+            spec = importlib.util.spec_from_file_location("bench_train_loop", os.path.join(ROOT, "tools", "bench_train_loop.py"))
+            btl = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(btl)
+            with tempfile.TemporaryDirectory() as tmp:
+                root = btl.write_dataset(os.path.join(tmp, "ds"))
+                seqs, per_it = btl.run(root, True, args.loop_iters, B, T)
+            result["train_loop"] = {"value": round(seqs, 1), "unit": "user-sequences/s", "ms_per_iteration": round(per_it * 1e3, 4),
+                                    "iterations": args.loop_iters,
+                                    "note": "python -m sbr_amd.train mirror: device batch builder + step + cost of every iteration read "
+                                            "back one iteration late; ML-1M-shaped synthetic file (6040 users, ragged sequences)"}
+            log("train loop: %.4f ms/iteration" % (per_it * 1e3))
+        except Exception as ex:
+            log("train loop leg skipped:", ex)
     if rank == 0:
         # RCCL prints its version banner through C stdio: flush that first so the JSON line is the LAST line
         try:

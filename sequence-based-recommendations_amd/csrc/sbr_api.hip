@@ -1108,12 +1108,33 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 SBR_LAUNCH(we);
             }
             SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
+            // The time chunk the chain completes LAST (chunk 0) is not left to the polling waves: each of them walks 32 sorted
+            // entries, rounds of eight rows in flight and then its atomics -- 30 - 35 us behind the chain's end for the one chunk that
+            // cannot start earlier (profiles/round3_c_timeline.txt).  It gets a launch of its own behind the polling one (same stream:
+            // the read-modify-writes of its owned segments see the atomics of the earlier chunks complete), gated on the chain's last
+            // progress word, one wave per 16 entries on the then idle chip.  SBR_TAIL_FINAL=0: the polling waves take chunk 0 too.
+            static const int tail_final = getenv("SBR_TAIL_FINAL") ? atoi(getenv("SBR_TAIL_FINAL")) : 16;
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
-                                                  (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl));
+                                                  (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
+                                                  tail_final ? y.cfg.input_size : 0));
+            if (tail_final) {
+                SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, 0, a.fault));
+                SBR_LAUNCH(launch_scatter_reduce(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, CH * y.Bp * y.F, GHp, y.Bp, 0, true, tail_final));
+            }
             if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
-            SBR_LAUNCH(launch_splitk_reduce(sd, ws2, pl.n_small + n_big, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
-            if (upd_here) SBR_LAUNCH(upd_on(sd, ly.p_Whid, ly.p_peep));
+            // single-call step: the slab reduction IS the W_hid update (one launch, one pass less behind the chain); phase-by-phase
+            // callers (data parallel) need the reduced gradient
+            static const int fuse_slabs = getenv("SBR_TAIL_FUSE_SLABS") ? atoi(getenv("SBR_TAIL_FUSE_SLABS")) : 1;
+            if (upd_here && fuse_slabs && ly.p_peep - ly.p_Whid == slab && (slab & 3) == 0) {
+                SBR_LAUNCH(launch_update_from_slabs(sd, y.cfg.updater, ws2, pl.n_small + n_big, h->P(ly.p_Whid), h->St(0, ly.p_Whid),
+                                                    s1a ? s1a + ly.p_Whid : nullptr, slab, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
+                                                    y.cfg.beta2, (long)h->step_count + 1));
+            } else {
+                SBR_LAUNCH(launch_splitk_reduce(sd, ws2, pl.n_small + n_big, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
+                if (upd_here) SBR_LAUNCH(upd_on(sd, ly.p_Whid, ly.p_peep));
+            }
             SBR_HIP(hipEventRecord(h->ev_tail, sd));
             // main stream, behind the chain
             SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),

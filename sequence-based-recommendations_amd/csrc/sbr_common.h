@@ -234,11 +234,11 @@ hipError_t launch_uncat(hipStream_t s, const float* f, const float* r, const int
                         int W, int Hp);
 // key_lo / accumulate: the entries of the keys [key_lo, key_lo + n_ids) of a time-chunked sort, ADDED to dWin
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
-                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo = 0, bool accumulate = false);
+                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo = 0, bool accumulate = false, int acc_chunk = 32);
 // all time chunks of a time-chunked sort in ONE launch beside the running chain: every wave waits for poll.done to reach the
 // time chunk of its entries (tch steps per chunk), rows are added with float atomics (an id may occur in every chunk)
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll);
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0);
 
 // Tile-blocked activation layout [t][row tile of 16][column tile of 16][row 16][col 16] (floats):
 // the 16x16 tile one wave of the recurrent kernels owns is one contiguous KiB (8 full 128-B lines per
@@ -390,6 +390,9 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
 // n elements starting at p / g / s0 / s1, skipping gap_len elements after the first gap_at (two ranges, one launch)
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);
+// ... of a block whose gradient is still split-K slabs [nslabs][n] (16-byte aligned, n % 4 == 0): reduction + step in one launch
+hipError_t launch_update_from_slabs(hipStream_t s, int updater, const float* ws, int nslabs, float* p, float* s0, float* s1, size_t n,
+                                    float lr, float rho, float b1, float b2, long t);
 // sbr_sparse.hip: row-sparse optimizer steps (lazy catch-up) and gradient exchange for the large-catalogue blocks
 struct SbrSparseRows { int npairs; size_t off[2]; int width[2]; int stride[2]; int n_rows; float *p, *g, *s0, *s1; int* last; };
 struct SbrSparseUpd { int updater; float lr, rho, b1, b2; const float* at; int n_at; int early_exit; };

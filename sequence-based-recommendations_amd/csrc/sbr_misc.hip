@@ -439,13 +439,16 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int total = offs[POLL ? n_ids * n_tchunks : key_lo + n_ids];
-    const int nch = (total + SCAT_CHUNK - 1) / SCAT_CHUNK;
+    // POLL: key_lo = the first key this launch takes (time chunk 0 -- the one the chain completes last -- is left to a launch
+    // of its own behind the chain when key_lo = n_ids: see sbr_backward_recurrent)
+    const int e_lo = POLL ? offs[key_lo] : 0;
+    const int nch = (total - e_lo + SCAT_CHUNK - 1) / SCAT_CHUNK;
     // POLL: a bounded number of waves (the launch must leave the chip to the GEMM that runs beside it) walks the sorted
     // entries from the far end, wave-chunk it, it + n_waves, ...
     for (int it = wave_global; ; it += n_waves) {
     int chunk = wave_global;
     if (POLL) { if (it >= nch) break; chunk = nch - 1 - it; }
-    const int base = (POLL ? 0 : offs[key_lo]) + chunk * SCAT_CHUNK;
+    const int base = (POLL ? e_lo : offs[key_lo]) + chunk * SCAT_CHUNK;
     if (base >= total) return;
     const int cnt = min(SCAT_CHUNK, total - base);
     const int e = base + (lane & (SCAT_CHUNK - 1));
@@ -511,25 +514,26 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
 }
 
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll) {
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key) {
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
     static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 64;
     const int grid = std::max(1, std::min(wgs, ((max_entries + 31) / 32 + 3) / 4));
-#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, 0, n_tchunks, tch, poll)
+#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tch, poll)
     if (nv <= 1) SRP(1); else if (nv <= 2) SRP(2); else if (nv <= 4) SRP(4); else return hipErrorInvalidValue;
 #undef SRP
     return hipGetLastError();
 }
 
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
-                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate) {
+                                 const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate, int acc_chunk) {
     const int R4 = GHp / 4;
     static const int chunk_env = getenv("SBR_SCAT_CHUNK") ? atoi(getenv("SBR_SCAT_CHUNK")) : 0;
-    const int chunk = (accumulate || key_lo) ? 32 : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32);
+    const int chunk = (accumulate || key_lo) ? (acc_chunk == 16 ? 16 : 32) : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32);
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
-#define SR(NV) do { if (accumulate || key_lo) scat_reduce_kernel<NV, 32, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
+#define SR(NV) do { if ((accumulate || key_lo) && chunk == 16) scat_reduce_kernel<NV, 16, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
+                    else if (accumulate || key_lo) scat_reduce_kernel<NV, 32, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
                     else if (chunk == 16) scat_reduce_kernel<NV, 16><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
                     else if (chunk == 32) scat_reduce_kernel<NV, 32><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
                     else scat_reduce_kernel<NV, 64><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); } while (0)
@@ -941,6 +945,33 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
 // K13 optimizers: lasagne.updates.{adagrad,adadelta,rmsprop,nesterov_momentum,adam} [3P]
 // (update_manager.py:24-82), applied densely to the whole flat parameter section.
 // ---------------------------------------------------------------------------------------
+// one element's step: gi = its gradient; p, s0, s1 are read and written in place
+__device__ __forceinline__ void update_element(int updater, float gi, float* __restrict__ p, float* __restrict__ s0, float* __restrict__ s1,
+                                               size_t i, float lr, float rho, float b1, float b2, float a_t) {
+    float pi = p[i];
+    if (updater == SBR_UPD_ADAGRAD) {                 // eps 1e-6
+        const float acc = s0[i] + gi * gi;
+        s0[i] = acc; pi -= lr * gi / sqrtf(acc + 1e-6f);
+    } else if (updater == SBR_UPD_RMSPROP) {          // eps 1e-6
+        const float acc = rho * s0[i] + (1.0f - rho) * gi * gi;
+        s0[i] = acc; pi -= lr * gi / sqrtf(acc + 1e-6f);
+    } else if (updater == SBR_UPD_ADADELTA) {         // eps 1e-6
+        const float acc = rho * s0[i] + (1.0f - rho) * gi * gi;
+        const float upd = gi * sqrtf(s1[i] + 1e-6f) / sqrtf(acc + 1e-6f);
+        s0[i] = acc; pi -= lr * upd;
+        s1[i] = rho * s1[i] + (1.0f - rho) * upd * upd;
+    } else if (updater == SBR_UPD_NESTEROV) {         // sgd + apply_nesterov_momentum
+        const float v = rho * s0[i] - lr * gi;
+        s0[i] = v; pi += rho * v - lr * gi;
+    } else {                                          // adam, eps 1e-8
+        const float m = b1 * s0[i] + (1.0f - b1) * gi;
+        const float v = b2 * s1[i] + (1.0f - b2) * gi * gi;
+        s0[i] = m; s1[i] = v;
+        pi -= a_t * m / (sqrtf(v) + 1e-8f);
+    }
+    p[i] = pi;
+}
+
 __global__ void update_kernel(int updater, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
                               float* __restrict__ s1, size_t n, float lr, float rho, float b1, float b2, float a_t,
                               size_t gap_at, size_t gap_len) {
@@ -949,29 +980,51 @@ __global__ void update_kernel(int updater, float* __restrict__ p, float* __restr
         const size_t i = k < gap_at ? k : k + gap_len;
         const float gi = g[i];
         g[i] = 0.0f;                                      // the gradient section is clean for the next step (no memset)
-        float pi = p[i];
-        if (updater == SBR_UPD_ADAGRAD) {                 // eps 1e-6
-            const float acc = s0[i] + gi * gi;
-            s0[i] = acc; pi -= lr * gi / sqrtf(acc + 1e-6f);
-        } else if (updater == SBR_UPD_RMSPROP) {          // eps 1e-6
-            const float acc = rho * s0[i] + (1.0f - rho) * gi * gi;
-            s0[i] = acc; pi -= lr * gi / sqrtf(acc + 1e-6f);
-        } else if (updater == SBR_UPD_ADADELTA) {         // eps 1e-6
-            const float acc = rho * s0[i] + (1.0f - rho) * gi * gi;
-            const float upd = gi * sqrtf(s1[i] + 1e-6f) / sqrtf(acc + 1e-6f);
-            s0[i] = acc; pi -= lr * upd;
-            s1[i] = rho * s1[i] + (1.0f - rho) * upd * upd;
-        } else if (updater == SBR_UPD_NESTEROV) {         // sgd + apply_nesterov_momentum
-            const float v = rho * s0[i] - lr * gi;
-            s0[i] = v; pi += rho * v - lr * gi;
-        } else {                                          // adam, eps 1e-8
-            const float m = b1 * s0[i] + (1.0f - b1) * gi;
-            const float v = b2 * s1[i] + (1.0f - b2) * gi * gi;
-            s0[i] = m; s1[i] = v;
-            pi -= a_t * m / (sqrtf(v) + 1e-8f);
-        }
-        p[i] = pi;
+        update_element(updater, gi, p, s0, s1, i, lr, rho, b1, b2, a_t);
     }
+}
+
+// The optimizer step of a parameter block whose gradient still lies in split-K slabs (dW_hid of the overlapped step tail): the
+// slab reduction of gemm_splitk_reduce_v4 -- same grouping, same summation order, so the same gradient bits -- with the step
+// applied by the thread that holds the finished sum.  One launch and one pass over the block less at the end of the step; the
+// gradient array itself is not written (it stays as the last update left it: zero).
+__global__ void __launch_bounds__(256) update_from_slabs_kernel(int updater, const f32x4* __restrict__ ws, int nsplit, size_t n,
+                                                                float* __restrict__ p, float* __restrict__ s0, float* __restrict__ s1,
+                                                                float lr, float rho, float b1, float b2, float a_t) {
+    __shared__ f32x4 red[16][16];
+    const size_t n4 = n / 4;
+    const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i4 = (size_t)blockIdx.x * 16 + j;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    if (i4 < n4) {
+        int z = grp;
+        for (; z + 48 < nsplit; z += 64) {
+            a0 += ws[(size_t)z * n4 + i4]; a1 += ws[(size_t)(z + 16) * n4 + i4];
+            a2 += ws[(size_t)(z + 32) * n4 + i4]; a3 += ws[(size_t)(z + 48) * n4 + i4];
+        }
+        for (; z < nsplit; z += 16) a0 += ws[(size_t)z * n4 + i4];
+    }
+    red[grp][j] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int jj = threadIdx.x >> 2, e = threadIdx.x & 3;             // one element per thread
+    const size_t i = ((size_t)blockIdx.x * 16 + jj) * 4 + e;
+    if (i >= n) return;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][jj][e];
+    update_element(updater, t, p, s0, s1, i, lr, rho, b1, b2, a_t);
+}
+
+hipError_t launch_update_from_slabs(hipStream_t s, int updater, const float* ws, int nslabs, float* p, float* s0, float* s1, size_t n,
+                                    float lr, float rho, float b1, float b2, long t) {
+    if (n == 0) return hipSuccess;
+    if ((n & 3) || ((uintptr_t)ws & 15)) return hipErrorInvalidValue;
+    float a_t = 0.0f;
+    if (updater == SBR_UPD_ADAM)
+        a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    update_from_slabs_kernel<<<(unsigned)((n / 4 + 15) / 16), 256, 0, s>>>(updater, (const f32x4*)ws, nslabs, n, p, s0, s1, lr, rho, b1, b2, a_t);
+    return hipGetLastError();
 }
 
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n, float lr,

@@ -50,6 +50,23 @@
 #ifndef X6P_BWD_LA
 #define X6P_BWD_LA 1
 #endif
+#ifndef X6P_MFMA_NOP
+#define X6P_MFMA_NOP -1  // >= 0: s_nop N behind every MFMA of the packed forms (experiment: does the partner's gate math get the issue port?)
+#endif
+#if X6P_MFMA_NOP >= 0
+#define X6P_GAP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" :: "n"(X6P_MFMA_NOP)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define X6P_GAP() do { } while (0)
+#endif
+#ifndef X6P_FWD_V2
+#define X6P_FWD_V2 2     // forward, packed form: 1 = the input row (+ bias) rides in as the MFMA C operand, 2 = the stores of step
+#endif                   // t - 1 are issued inside the MFMA phase of step t, 4 = the next row offset is read before the MFMAs
+#ifndef X6P_BWD_DEFER
+#define X6P_BWD_DEFER 0  // backward, ring forms: the stores of step t leave from inside its own MFMA phase (behind the first k-block)
+#endif
+#ifndef X6P_FWD_TOK
+#define X6P_FWD_TOK 1    // forward, packed form: waves 4-7 open the pipe gate this many MFMA groups (of G) before their last MFMA
+#endif
 #ifndef X6P_PACK
 #define X6P_PACK 1       // 0: the fp16 forms with three MFMAs per product (round 2), for same-box A/B runs (SBR_LIB)
 #endif
@@ -195,12 +212,14 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     // part is multiplied by r before the input part (with its bias) is added (sparse_lstm.py:786-792).
     float x[G];
     f32x4 biasv[G];
-    float bias_c = 0.f;
+    float bias_c = 0.f, bsc[G], xc_pre = 0.f;
+    unsigned bo_nxt2 = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float b = FUSE ? a.gbias[g * HP + u] : 0.f;
         if (CELL == CELL_GRU && g == 2) { bias_c = b; b = 0.f; }
         if (CELL == CELL_GRU && g < 2) b *= X6P_NLOG2E;
+        bsc[g] = b;
         biasv[g] = PK ? f32x4{b, 0.f, 0.f, 0.f} : f32x4{b, b, b, b};      // PK: element 1 collects the low-order products
     }
     // FUSE: the rows travel XPD time steps ahead of their use through a ring in LDS (LDS-DMA, sbr_rec_p.h: one dword per lane
@@ -249,6 +268,21 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     unsigned long long* tl = PROF && blockIdx.x == 0 && lane == 0 ? a.prof + (8 + wave) * 8 : nullptr;   // step-100 timeline
 
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    // X6P_FWD_V2 & 2: the NSF stores of step t - 1 leave from inside the MFMA phase of step t -- behind its first k-block, where
+    // the issue slots are free -- instead of between the publication and the next step's operand reads.  (Fused gather: the
+    // wait at the top of the loop counts NSF stores + one DMA piece per iteration; the rows of steps < XPD have landed before
+    // the loop, so the first iteration's missing stores change nothing.)
+    constexpr bool DEFER = PK && (X6P_FWD_V2 & 2);
+    float sv_st[4] = {0.f, 0.f, 0.f, 0.f}, h_st = 0.f, c_st = 0.f;
+    auto store_step = [&](size_t off, const float* svv, float hv, float cv) {
+        if (X6P_DBG & 4) return;
+        if (CELL != CELL_VANILLA) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) st_s((const char*)a.g[k] + off, bo_g, svv[k]);
+        }
+        st_s((const char*)a.hs + off + st_h, bo_h, hv);
+        if (CELL == CELL_LSTM) st_s((const char*)a.cs + off + st_h, bo_h, cv);
+    };
     size_t off_t = 0;                                              // t * st_h
     int tmin = mylen;                                              // steps below it: no row of the tile is masked
     tmin = min(tmin, __shfl_xor(tmin, 16));
@@ -272,6 +306,17 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             const char* xp = xring_lane + xslot * XSTG;
 #pragma unroll
             for (int g = 0; g < G; ++g) x[g] = *(const float*)(xp + g * 256);
+        }
+        if constexpr (PK && (X6P_FWD_V2 & 1)) {                    // x (+ bias) into element 0 of the C operands: two ops less behind the MFMAs
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (CELL == CELL_GRU && g == 2) xc_pre = x[2] + bias_c;
+                else if (CELL == CELL_GRU) biasv[g][0] = fmaf(x[g], X6P_NLOG2E, bsc[g]);
+                else biasv[g][0] = x[g] + bsc[g];
+            }
+        }
+        if constexpr (FUSE && PK && (X6P_FWD_V2 & 4)) {            // (LDS latency under the MFMA phase instead of in front of the next step)
+            bo_nxt2 = xo_row[min(t + XPD + 1, T - 1)];
         }
         // ---- N1
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
@@ -337,21 +382,20 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (kb == KB / 2 && RA) ensure_half(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-                if (kb == 0) {
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                    for (int g = 0; g < G; ++g) acl[g] = mfma16(hp[kb][0], W2[g][kb], f32x4{0.f, 0.f, 0.f, 0.f});
-                } else { X6P_TERL(hp[kb][0], W2[g][kb]) }
+                for (int g = 0; g < G; ++g) { acl[g] = mfma16(hp[kb][0], W2[g][kb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acl[g]); X6P_GAP(); }
                 if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
                     __builtin_amdgcn_sched_barrier(0);
                     load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
-                if (kb == 0) {
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                    for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W1[g][kb], biasv[g]);
-                } else { X6P_TERM(hp[kb][0], W1[g][kb]) }
+                for (int g = 0; g < G; ++g) { acc[g] = mfma16(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]); X6P_GAP(); }
                 __builtin_amdgcn_sched_barrier(0);
+                if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acl[g][0], 1.0f / F16_LO, acc[g][0]);
@@ -419,12 +463,13 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         // bias were scaled by -log2(e) when the planes were built, so a sigmoid is fma, exp2, add, rcp.
         {
             float hn;
+            constexpr bool XC = PK && (X6P_FWD_V2 & 1);                // x already sits in the accumulators
             if (CELL == CELL_GRU) {
                 constexpr int IU = G > 1 ? 1 : 0, IC = G > 2 ? 2 : 0;
-                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(x[0], X6P_NLOG2E, acc[0][0])));
-                const float ug = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(x[IU], X6P_NLOG2E, acc[IU][0])));
+                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(XC ? acc[0][0] : fmaf(x[0], X6P_NLOG2E, acc[0][0])));
+                const float ug = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(XC ? acc[IU][0] : fmaf(x[IU], X6P_NLOG2E, acc[IU][0])));
                 const float hc = acc[IC][0];
-                const float cc = tanh_fast(fmaf(rg, hc, x[IC] + bias_c));
+                const float cc = tanh_fast(fmaf(rg, hc, XC ? xc_pre : x[IC] + bias_c));
                 hn = fmaf(ug, cc - h, h);                         // (1 - u) h + u c
                 sv[0] = rg; sv[1] = ug; sv[2] = cc; sv[3] = hc;
             } else if (CELL == CELL_LSTM) {                       // sparse_lstm.py:397-423 (peepholes, masked rows copy h and c)
@@ -432,9 +477,10 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) aa[g] = acc[g][0];
                 hn = h;
-                cell_forward<CELL_LSTM, true>(x, aa, t < mylen, hn, c, pi, pf, po, sv);
+                const float xz[4] = {0.f, 0.f, 0.f, 0.f};
+                cell_forward<CELL_LSTM, true>(XC ? xz : x, aa, t < mylen, hn, c, pi, pf, po, sv);
             } else {
-                { const float pre = x[0] + acc[0][0]; hn = a.relu ? fmaxf(pre, 0.0f) : tanh_fast(pre); }
+                { const float pre = XC ? acc[0][0] : x[0] + acc[0][0]; hn = a.relu ? fmaxf(pre, 0.0f) : tanh_fast(pre); }
             }
             if (CELL == CELL_LSTM) { h = hn; if (F16) asm volatile("" : "+v"(h)); }   // (cell_forward has applied the mask)
             else if (t < tmin) { asm volatile("" : "+v"(hn)); h = hn; }            // uniform branch: no select while no row is masked
@@ -446,23 +492,22 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             if (PROF) p_seg[2] += clock64() - p_tb;
             if (PROF && tl && t == 100) tl[6] = clock64();
         }
-        if (!(X6P_DBG & 4)) {                                     // what BPTT needs of step t
-            if (CELL != CELL_VANILLA) {
+        if constexpr (DEFER) {                                    // stored from inside the next step's MFMA phase (or behind the loop)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) st_s((const char*)a.g[k] + off_t, bo_g, sv[k]);
-            }
-            st_s((const char*)a.hs + off_t + st_h, bo_h, h);
-            if (CELL == CELL_LSTM) st_s((const char*)a.cs + off_t + st_h, bo_h, c);
-        }
+            for (int k = 0; k < 4; ++k) sv_st[k] = sv[k];
+            h_st = h; c_st = c;
+        } else store_step(off_t, sv, h, c);                       // what BPTT needs of step t
         off_t += st_h;
         if constexpr (FUSE) {
             dma_x(bo_nxt, xslot);                                 // the row of step t + XPD into the slot this step has read
             xslot = xslot + 1 == XPD ? 0 : xslot + 1;
-            bo_nxt = xo_row[min(t + XPD + 1, T - 1)] + bo_lane;
+            if constexpr (PK && (X6P_FWD_V2 & 4)) bo_nxt = bo_nxt2 + bo_lane;
+            else bo_nxt = xo_row[min(t + XPD + 1, T - 1)] + bo_lane;
         } else if (!(X6P_DBG & 2)) load_x(t + 1);
     }
     };
     if (roleA) steps(std::true_type{}); else steps(std::false_type{});
+    if (DEFER && tmax > 0) store_step(off_t - st_h, sv_st, h_st, c_st);      // the last step's
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
         if (CELL == CELL_LSTM) stf((char*)a.cs + off_t + st_h, bo_h, c);
@@ -596,7 +641,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     constexpr int PD = 4, NL = CELL == CELL_VANILLA ? 1 : 5, NST = G + (CELL == CELL_GRU ? 1 : 0);
     constexpr int NLI = CELL == CELL_VANILLA ? 1 : 2;             // load INSTRUCTIONS of a step (16-byte pieces, below)
     constexpr int STG = NL * 256, RING_OFF = (2 * 3 * R * DROW + 64 + 255) & ~255;
-    constexpr int VMN = NST + (PD - 1) * (NLI + NST);             // younger than the loads of the step being taken
+    // BDEF: the NST stores of a step are issued inside its MFMA phase, i.e. BEHIND take_saved: the iteration's own stores are
+    // not in flight yet when the ring is read
+    constexpr bool BDEF = RING && PK && X6P_BWD_DEFER;
+    constexpr int VMN = (BDEF ? 0 : NST) + (PD - 1) * (NLI + NST);   // younger than the loads of the step being taken
     const unsigned ring_wave = (unsigned)(size_t)(smem_p + RING_OFF) + (unsigned)wave * (PD * STG);
     const char* ring_lane = smem_p + RING_OFF + wave * (PD * STG) + lane * 4;
     // Two 16-byte-per-lane pieces per step instead of five dword ones (a piece costs its issue slot whatever it moves): the
@@ -679,6 +727,9 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     auto korder = [](int i) { return (i % NH) / 2 * KU + (i % NH) % 2 + (i / NH) * 2; };
     size_t off_h = (size_t)(t_live - 1) * st_h, off_x = (size_t)(t_live - 1) * st_x;   // of step t
     const unsigned lds_cnt0 = (unsigned)(size_t)cnt;
+    float dxi_st[G], dhc_st = 0.f; size_t offx_st = 0, offh_st = 0;      // BDEF: what the MFMA phase stores
+#pragma unroll
+    for (int g = 0; g < G; ++g) dxi_st[g] = 0.f;
     auto steps = [&](auto role_tag) {                             // one loop per role, see rec_fwd_x6p
     constexpr bool RA = decltype(role_tag)::value;
     int n = 0;                                                    // steps done
@@ -730,12 +781,18 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             dma_saved(t - PD >= a.t_lo ? off_h - (size_t)PD * st_h : (size_t)a.t_lo * st_h, slot);   // step t - PD into the slot just read
             slot = slot + 1 == PD ? 0 : slot + 1;
+            if constexpr (BDEF) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) dxi_st[g] = dxi[g];
+                dhc_st = dhi[G - 1]; offx_st = off_x; offh_st = off_h;
+            } else {
             const char* dx_t = (const char*)a.dxt + off_x;
             st_si<0, WT>(dx_t, bo_x, dxi[0]);
             if (G > 1) st_si<HP * 4, WT>(dx_t, bo_x, dxi[G > 1 ? 1 : 0]);
             if (G > 2) st_si<2 * HP * 4, WT>(dx_t, bo_x, dxi[G > 2 ? 2 : 0]);
             if (G > 3) st_si<3 * HP * 4, WT>(dx_t, bo_x, dxi[G > 3 ? 3 : 0]);
             if (CELL == CELL_GRU) st_si<0, WT>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             { unsigned long long q0 = 0; if (PROF) q0 = clock64();
               take_saved(slot);                                   // step t - 1 (slot has moved on to it)
@@ -821,9 +878,19 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
-                acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]);
+                acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]); X6P_GAP();
                 if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
-                acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
+                acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]); X6P_GAP();
+                if (BDEF && i == 1) {                               // this step's dxt / dhi, from where the issue slots are free
+                    __builtin_amdgcn_sched_barrier(0);
+                    const char* dx_t = (const char*)a.dxt + offx_st;
+                    st_si<0, WT>(dx_t, bo_x, dxi_st[0]);
+                    if (G > 1) st_si<HP * 4, WT>(dx_t, bo_x, dxi_st[G > 1 ? 1 : 0]);
+                    if (G > 2) st_si<2 * HP * 4, WT>(dx_t, bo_x, dxi_st[G > 2 ? 2 : 0]);
+                    if (G > 3) st_si<3 * HP * 4, WT>(dx_t, bo_x, dxi_st[G > 3 ? 3 : 0]);
+                    if (CELL == CELL_GRU) st_si<0, WT>((const char*)a.dhi + offh_st, bo_h, dhc_st);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
                 if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
                 acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);

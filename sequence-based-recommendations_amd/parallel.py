@@ -64,17 +64,37 @@ class DataParallel(object):
             self._nsparse = len(e.sparse_blocks()) if hasattr(e, "sparse_blocks") else 0
         return self._rng
 
+    # Row-sparse blocks whose fixed-capacity exchange buffers stay below this many bytes per rank travel with their row count
+    # IN BAND (no host read, nothing synchronised: engine.sparse_pack_device / sparse_unpack_add_all); larger ones keep the
+    # counted form -- one 4-byte read-back per block and step against an all-gather of only the rows the step touched (at a
+    # 1 M-item catalogue the capacity is T*B_local rows of 8 KB each: there the bytes are the cost, not the read).
+    INBAND_BYTES = 32 << 20
+
     def _exchange_sparse(self, b):
         """Row-sparse block b: all-gather of (row ids, gradient rows) instead of an all-reduce of the whole block
         (8.2 GB of W_in at 1 M items against <= T*B_local rows of it per rank).  Every rank then adds all ranks'
         rows in rank order, so the replicas stay bit-identical."""
         import torch
         e, dist = self.engine, self.dist
+        if not hasattr(self, "_sp_info"):
+            self._sp_info, self._sp_all = e.sparse_blocks(), {}
+        n_rows, width, cap = self._sp_info[b]
+        if hasattr(e, "sparse_pack_device") and cap * width * 4 <= self.INBAND_BYTES:
+            ids, rows = e.sparse_pack_device(b)          # ids[0] = the count; enqueued, not waited for
+            if b not in self._sp_all:                     # persistent gather targets: [world][1 + cap], [world][cap][width]
+                self._sp_all[b] = (torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device),
+                                   torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device))
+            ids_all, rows_all = self._sp_all[b]
+            w1 = dist.all_gather(list(ids_all.unbind(0)), ids, group=self.group, async_op=True)
+            w2 = dist.all_gather(list(rows_all.unbind(0)), rows, group=self.group, async_op=True)
+            w1.wait(); w2.wait()
+            e.sparse_unpack_add_all(b, ids_all, rows_all, self.world)      # one call: rank order, counts read on the device
+            return
         ids, rows, n = e.sparse_pack(b)
         cnt = torch.tensor([n], dtype=torch.int32, device=ids.device)
         cnts = [torch.empty_like(cnt) for _ in range(self.world)]
         dist.all_gather(cnts, cnt, group=self.group)
-        counts = [int(c.item()) for c in cnts]
+        counts = [int(c) for c in torch.cat(cnts).tolist()]      # (one read-back for all ranks' counts)
         m = max(counts)
         if m == 0:
             return
@@ -87,45 +107,82 @@ class DataParallel(object):
         for r in range(self.world):
             e.sparse_unpack_add(b, gids[r], grows[r], counts[r])
 
-    def train_step(self):
-        """One step on the batch already set on the engine; returns nothing (cost: read_cost())."""
+    def _views(self):
+        """the slices of the flat gradient section that travel, made once (a slice per step costs ~2 us of host time each)"""
+        if not hasattr(self, "_vw"):
+            out_r, rec_r = self._ranges()
+            g = self.grads
+            self._vw = dict(out=[g[lo:hi] for lo, hi in out_r], rec=[g[lo:hi] for lo, hi in rec_r])
+            if self.tail is not None and len(rec_r) == 1:
+                (wi_lo, wi_hi), (wh_lo, wh_hi) = self.tail
+                lo, hi = rec_r[0]
+                assert lo == wi_lo and wi_hi <= wh_lo and wh_hi <= hi
+                self._vw["win"], self._vw["rest"] = g[wi_lo:wi_hi], g[wi_hi:hi]
+        return self._vw
+
+    def train_step(self, exposed=None):
+        """One step on the batch already set on the engine; returns nothing (cost: read_cost()).
+        exposed: a dict -- the step then brackets the wait for every collective with events on the engine's stream and adds
+        the microseconds the stream really stood still for each bucket ("out", "rec", "win", "rest", "sparse"); a survey mode
+        (events cost the stream a few microseconds each: bench.py uses it outside its timed regions)."""
         e = self.engine
         if self.world == 1 and not self.dist.is_initialized():
             e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()   # joins inside
             return
-        out_r, rec_r = self._ranges()
+        vw = self._views()
+        red = lambda t: self.dist.all_reduce(t, group=self.group, async_op=True)
         e.zero_grads()
         e.forward()
         e.loss_backward_output()
-        red = lambda lo, hi: self.dist.all_reduce(self.grads[lo:hi], group=self.group, async_op=True)
+        works = []                                       # (bucket name, work)
         if self.side is not None:
             import torch
             with torch.cuda.stream(self.side):       # RCCL waits for the side stream only; the main stream runs the chain
-                works = [red(lo, hi) for lo, hi in out_r]
+                works += [("out", red(t)) for t in vw["out"]]
             e.backward_recurrent()
             if self.tail is None:
                 e.join_side()                        # weight-gradient kernels of the recurrent part
             # (overlapped tail: no join here -- the collectives below follow the producing streams, sbr_apply_update joins)
         else:
-            works = [red(lo, hi) for lo, hi in out_r]
+            works += [("out", red(t)) for t in vw["out"]]
             e.backward_recurrent()
-        if self.tail is not None and len(rec_r) == 1:
+        if "win" in vw:
             # two buckets, each behind the stream that finishes it: W_in behind the scatter-add (second side stream), and the
             # contiguous rest -- biases and initial states (the chain's partial sums, main stream) around W_hid (slab
             # reduction, side stream) -- behind the side stream once it has also waited for the main stream's share
             import torch
-            (wi_lo, wi_hi), (wh_lo, wh_hi) = self.tail
-            lo, hi = rec_r[0]
-            assert lo == wi_lo and wi_hi <= wh_lo and wh_hi <= hi
             with torch.cuda.stream(self.side2):
-                works.append(red(wi_lo, wi_hi))
+                works.append(("win", red(vw["win"])))
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                works.append(red(wi_hi, hi))
+                works.append(("rest", red(vw["rest"])))
         else:
-            works += [red(lo, hi) for lo, hi in rec_r]
-        for b in range(self._nsparse):
-            self._exchange_sparse(b)
-        for w in works:
-            w.wait()
+            works += [("rec", red(t)) for t in vw["rec"]]      # one bucket unless sparse blocks split the section
+        if exposed is None:
+            for b in range(self._nsparse):
+                self._exchange_sparse(b)
+            for _, w in works:
+                w.wait()
+        else:
+            import torch
+            def timed(name, fn):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                exposed.setdefault("_ev", []).append((name, e0, e1))
+            for b in range(self._nsparse):
+                timed("sparse", lambda b=b: self._exchange_sparse(b))
+            for name, w in works:
+                timed(name, w.wait)
         e.apply_update()
+
+    @staticmethod
+    def exposed_us(exposed):
+        """folds the event pairs train_step(exposed=...) recorded into {bucket: total microseconds}; synchronises"""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in exposed.pop("_ev", []):
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1) * 1e3
+        for k, v in out.items():
+            exposed[k] = exposed.get(k, 0.0) + v
+        return exposed

@@ -115,6 +115,20 @@ class SparseOracleEngine(OracleEngine):
         return out
 
 
+class InbandSparseOracleEngine(SparseOracleEngine):
+    """... and with the ABI-7 form of the exchange: the row count travels in band (ids[0]), buffers at fixed capacity, one
+    unpack call for all ranks -- the path DataParallel takes for blocks below its INBAND_BYTES."""
+
+    def sparse_pack_device(self, b):
+        ids, rows, n = self.sparse_pack(b)
+        return torch.cat([torch.tensor([n], dtype=torch.int32), ids]), rows
+
+    def sparse_unpack_add_all(self, b, ids_all, rows_all, world):
+        assert ids_all.shape == (world, self.cap + 1) and rows_all.shape[:2] == (world, self.cap)
+        for r in range(world):
+            self.sparse_unpack_add(b, ids_all[r, 1:], rows_all[r], int(ids_all[r, 0]))
+
+
 def _worker(rank, world, port, loss, out, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -124,7 +138,9 @@ def _worker(rank, world, port, loss, out, sparse=False):
     params, cfg, batch = PU.build_case("GRU", [6], loss, N, B, T, S=S, seed=11)
     cfg["regularization"] = 0.03 if loss == "CCE" else 0.0
     lo, hi = DataParallel.shard(B, world, rank)
-    if sparse:
+    if sparse == "inband":
+        eng = InbandSparseOracleEngine([p.copy() for p in params], cfg, "adam", B, lo, cap=N)
+    elif sparse:
         eng = SparseOracleEngine([p.copy() for p in params], cfg, "adam", B, lo, cap=N)
     else:
         eng = OracleEngine([p.copy() for p in params], cfg, "adam", B, lo)
@@ -141,7 +157,7 @@ def _worker(rank, world, port, loss, out, sparse=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sparse", [False, True], ids=["allreduce", "sparse_exchange"])
+@pytest.mark.parametrize("sparse", [False, True, "inband"], ids=["allreduce", "sparse_exchange", "sparse_exchange_inband_counts"])
 @pytest.mark.parametrize("loss", ["CCE", "Blackout", "BPR"])
 def test_two_rank_step_equals_single_process(tmp_path, loss, sparse):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

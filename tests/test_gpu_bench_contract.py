@@ -70,3 +70,26 @@ def test_cpu_baseline_leg_is_bounded_and_reported():
     assert d["value"] > 100 * c["value"]
     e = c["end_to_end"]        # the same step + reference-style batch packing
     assert 0 < e["value"] < c["value"] and e["packing_s_per_batch"] > 0
+
+
+def test_gpus_2_starts_its_own_ranks():
+    # the driver's command form `python bench.py --gpus N ...` (no launcher around it): bench.py starts the N ranks itself.
+    # On the one-GPU test box the two ranks share the device, which RCCL refuses: gloo carries the collectives there
+    # (--dp-backend gloo); everything else -- rendezvous, row shards, barrier + max-over-ranks timing, rank 0's one line -- is
+    # the path the 8-GPU run takes.
+    d = run("--gpus", "2", "--dp-backend", "gloo", "--no-cpu-baseline", "--repeats", "2")
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (2, 6, 2) and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(512 / (d["ms_per_step"] * 1e-3), rel=2e-3)
+    p = d["data_parallel"]
+    assert p["ranks"] == 2 and p["backend"] == "gloo" and p["collectives_per_step"]["dense_buckets"] == 3
+    assert set(p["exposed_us_per_step"]) == {"out", "win", "rest"} and all(v >= 0 for v in p["exposed_us_per_step"].values())
+    assert d["roofline"]["kernel"] in ("rec_bwd", "rec_fwd") and d["roofline"]["launch_us"] > 0
+
+
+def test_one_rank_through_the_data_parallel_step():
+    # --force-dp: the phase-by-phase step with its collectives (RCCL, one rank) instead of the single-call step
+    d = run("--force-dp", "--no-cpu-baseline", "--repeats", "2")
+    check_common(d)
+    p = d["data_parallel"]
+    assert p["ranks"] == 1 and p["backend"] == "nccl"

@@ -82,3 +82,120 @@ def test_c5_shape_two_layers_512_sampled():
     r = PU.compare_step("LSTM", [512, 512], "Blackout", N=100000, B=64, T=12, S=32, zipf=True, steps=1, k=10, gap=GAP,
                         scale=0.02, seed=26, updater="adagrad", tweak=_plant_duplicate_cells)
     check(r, 1, rows=64)
+
+
+def test_c3_c4_full_length_chains_under_full_load():
+    # the cluster kernels' cross-workgroup exchange (256 resident workgroups, sbr_rec_cl.hip) over T = 200 dependent steps at
+    # B = 256 -- the configurations as benched, against the dense float64 oracle (the shorter cases above cover the heads)
+    r = PU.compare_step("LSTM", [256], "CCE", N=26744, B=256, T=200, full=True, zipf=True, steps=1, k=10, gap=GAP, scale=0.03, seed=27)
+    check(r, 1, rows=256)
+    r = PU.compare_step("LSTM", [256], "Blackout", N=100000, B=256, T=200, S=32, full=True, zipf=True, steps=1, k=10, gap=GAP,
+                        scale=0.03, seed=28, updater="adagrad", tweak=_plant_duplicate_cells)
+    check(r, 1, rows=256)
+
+
+def test_c5_million_item_catalogue_against_the_id_compacted_oracle():
+    """BASELINE configs[4] at its own catalogue: 2 x LSTM-512, N = 1 000 000 items, sampled softmax.  W_in is 2.05e9 floats
+    (8.2 GB: row byte offsets pass 2^31 at id 262 144 and 2^32 at id 524 288), far beyond what the dense float64 oracle holds.
+    Only the rows a step gathers (sparse_lstm.py:368) and the sampled cells (sparse_lstm.py:50-54, rnn_sampling.py:188-191)
+    take part in it, so the oracle runs on the COMPACTED catalogue: the n ids the batch touches (inputs, targets, samples, a few
+    bystanders), renumbered 0 .. n-1 in id order; the engine runs the real catalogue with those rows planted at their real ids
+    (0, 999 999 and both sides of the 2^31 / 2^32 byte boundaries among them) and every other W_out row unrankable.
+    Compared: cost, hidden state, every gradient on the touched rows, exact zeros everywhere else, parameters after two
+    row-sparse Adam steps (touched rows against the oracle, every other row bit-identical to what was set), ordered top-10."""
+    import numpy as np
+    from oracle import rnn_oracle as O
+    NBIG, B, T, S, n = 1000000, 64, 12, 32, 1200
+    cell, layers, loss = "LSTM", [512, 512], "Blackout"
+    params, cfg, batch = PU.build_case(cell, layers, loss, n, B, T, S=S, seed=29, zipf=True, scale=0.02)
+    _plant_duplicate_cells(batch)
+    rng = np.random.default_rng(7)
+    planted = np.array([0, 262143, 262144, 524287, 524288, NBIG - 1])
+    pool = np.setdiff1d(rng.choice(NBIG, size=n + 64, replace=False), planted)[:n - len(planted)]
+    big = np.sort(np.concatenate([planted, pool])).astype(np.int64)              # compact id c  <->  catalogue id big[c]
+    assert len(big) == n and len(np.unique(big)) == n
+    cp = np.searchsorted(big, planted)                        # the planted ids are gathered (first step of rows 0-5), sampled, targeted
+    for b in range(6):
+        batch["X"][b, 0, 0] = cp[b]
+    batch["samples"][5], batch["samples"][6], batch["target"][7], batch["target"][8] = cp[4], cp[0], cp[5], cp[2]
+    names = [nm for nm, _ in O.model_param_shapes(cell, layers, n, n, 0, 1, False)]
+    H0 = layers[0]
+
+    def widen(nm, p, fill=0.0):
+        """the compact array planted into the catalogue-sized one (rows of index-input W_in, columns of out.W, out.b)"""
+        p32 = p.astype(np.float32)
+        if nm.startswith("l0.W_in"):
+            a = np.zeros((NBIG, H0), dtype=np.float32); a[big] = p32; return a
+        if nm == "out.W":
+            a = np.zeros((p.shape[0], NBIG), dtype=np.float32); a[:, big] = p32; return a
+        if nm == "out.b":
+            a = np.full(NBIG, fill, dtype=np.float32); a[big] = p32; return a
+        return p32
+
+    eng = PU.engine_for(cfg, NBIG, B, T, S=S, updater="adam")
+    try:
+        assert len(eng.sparse_blocks()) == 2                                   # W_in rows and the W_out / b_out cells step row-sparse
+        start = [widen(nm, p, fill=-60.0) for nm, p in zip(names, params)]      # untouched items: logit -60, never ranked
+        eng.set_all_param_values(start)
+        Xb = big[batch["X"]].astype(np.int32)
+        eng.set_batch(Xb, batch["mask"], big[batch["target"]].astype(np.int32), big[batch["samples"]].astype(np.int32), batch["pop"])
+        cost = eng.forward_backward()
+        ob = PU.oracle_batch(batch)
+        ocost, ograds, aux = O.cost_and_grads(params, cfg, ob)
+        assert abs(cost - ocost) <= 1e-5 * abs(ocost)
+        Hp = eng.debug_buffer("h_last").size // (((B + 15) // 16) * 16)
+        assert PU.rel_err(eng.debug_buffer("h_last").reshape(-1, Hp)[:B, :layers[-1]], aux["h"]) <= 1e-5
+        grads = eng.get_all_grad_values()
+        for nm, g, og in zip(names, grads, ograds):
+            rest = None
+            if nm.startswith("l0.W_in") or nm == "out.b":
+                sub = g[big].copy(); g[big] = 0.0; rest = g
+            elif nm == "out.W":
+                sub = g[:, big].copy(); g[:, big] = 0.0; rest = g
+            else:
+                sub = g
+            assert PU.rel_err(sub, og) <= 1e-5, nm
+            assert rest is None or not rest.any(), nm                           # rows no id of the batch names: exactly zero
+        del grads
+        upd = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+        oparams = [p.copy() for p in params]
+        for _ in range(2):
+            O.train_function(oparams, cfg, upd, ob)
+            eng.train_step(sync=True)
+        new = eng.get_all_param_values()
+        touched = {"l0.W_in": np.unique(batch["X"][batch["mask"] > 0]),
+                   "out": np.unique(np.concatenate([batch["target"].ravel(), batch["samples"].ravel()]))}
+        for nm, a, o, s0 in zip(names, new, oparams, start):
+            if nm.startswith("l0.W_in"):
+                rows = touched["l0.W_in"]
+                assert PU.rel_err(a[big[rows]], o[rows]) <= 1e-3, nm
+                a[big[rows]] = s0[big[rows]]
+                assert np.array_equal(a, s0), nm                                # every other row: bit-identical to what was set
+            elif nm == "out.W":
+                cols = touched["out"]
+                assert PU.rel_err(a[:, big[cols]], o[:, cols]) <= 1e-3, nm
+                a[:, big[cols]] = s0[:, big[cols]]
+                assert np.array_equal(a, s0), nm
+            elif nm == "out.b":
+                cols = touched["out"]
+                assert PU.rel_err(a[big[cols]], o[cols]) <= 1e-3, nm
+                a[big[cols]] = s0[big[cols]]
+                assert np.array_equal(a, s0), nm
+            else:
+                assert PU.rel_err(a, o) <= 1e-3, nm
+        del new, start
+        # ordered top-10 over the million items = the oracle's top-10 over the compact catalogue, renamed
+        k = 10
+        ids = eng.test_function((Xb, batch["mask"]), k=k, exclude_seen=True)
+        excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
+        oids = np.array(O.test_function(oparams, cfg, batch["X"], batch["mask"], excl, k=k))
+        _, ologits = O.predict_scores(oparams, cfg, batch["X"], batch["mask"])
+        rows = np.ones(B, dtype=bool)
+        for b in range(B):
+            row = ologits[b].copy(); row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
+            top = -np.sort(-row)[:k + 1]
+            rows[b] = bool(np.all(top[:-1] - top[1:] > GAP))
+        assert rows.sum() >= 0.8 * B
+        assert np.array_equal(ids[rows], big[oids[rows]])
+    finally:
+        eng.close()

@@ -24,6 +24,9 @@ CASES = {
     "sparse_gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
     "sparse_lstm20_blackout_adagrad": ("LSTM", [20], "Blackout", 200, 32, 12, 8, "adagrad"),
     "sparse_lstm256_bpr_nesterov": ("LSTM", [256], "BPR", 500, 32, 10, 8, "nesterov"),
+    # ... the counted form of the exchange (one read-back per block; what blocks above DataParallel.INBAND_BYTES take): the
+    # other sparse cases travel with their row counts in band, nothing synchronised
+    "sparse_counted_gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
 }
 SPARSE_FLAG = 32
 
@@ -44,6 +47,8 @@ def _worker(rank, world, port, name, out):
     try:
         eng.set_all_param_values(params)
         dp = DataParallel(eng, dist)
+        if "counted" in name:
+            dp.INBAND_BYTES = 0
         assert dp.side is not None                      # the stream-level path, not the stand-in one
         assert (dp.tail is not None) == ("overlapped_tail" in name)
         if flags:
@@ -59,6 +64,8 @@ def _worker(rank, world, port, name, out):
             eng.set_batch(batch["X"][lo:hi], batch["mask"][lo:hi], tgt, smp, batch["pop"][lo:hi])
             dp.train_step()
             costs.append(eng.read_cost())
+        if flags:      # which form of the sparse exchange ran
+            assert len(getattr(dp, "_sp_all", {})) == (0 if "counted" in name else len(eng.sparse_blocks()))
         np.savez(out % rank, costs=np.array(costs), **{"p%d" % i: p for i, p in enumerate(eng.get_all_param_values())})
     finally:
         eng.close()
