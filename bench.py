@@ -170,6 +170,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    # stdout carries ONE line, the JSON: whatever the libraries underneath print there (RCCL's version banner, gloo's connection
+    # notes, the data handler's "Opening file") goes to stderr -- file descriptor 1 points at stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     def log(*a):
         print("[bench %6.1fs]" % (time.perf_counter() - T0), *a, file=sys.stderr, flush=True)
     T0 = time.perf_counter()
@@ -197,21 +203,7 @@ def main():
         if args.dp_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
-            # gloo announces its connections on STDOUT from C++ ("[Gloo] Rank 0 is connected to ..."): keep the one-JSON-line contract
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-                dist.barrier()
-            finally:
-                try:
-                    import ctypes
-                    ctypes.CDLL(None).fflush(None)
-                except Exception:
-                    pass
-                os.dup2(saved, 1)
-                os.close(saved)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cell, layers, n_items, loss, n_samples = CONFIGS[args.config]
     B, T = args.batch, args.max_length
@@ -391,10 +383,16 @@ def main():
                 pass
             # overlapped tail: the scatter phase of the step is the LAST of tail_chunks time chunks (the others ran beside the BPTT
             # chain on the side stream); its entries are 1 / tail_chunks of the batch, and it re-reads the rows it adds to
-            kernels["scatter"]["alg"] /= tail_chunks
+            try:
+                last = eng.query("tail_last_steps")
+            except Exception:
+                last = 0
+            frac = (last / float(T)) if last > 0 else 1.0 / tail_chunks
+            kernels["scatter"]["alg"] *= frac
             kernels["scatter"]["chunks"] = tail_chunks
-            kernels["scatter"]["note"] = ("overlapped tail: time chunk 0 of %d only (the others run beside rec_bwd); "
-                                          "bytes = that chunk's dxt rows + the rows it adds to" % tail_chunks)
+            kernels["scatter"]["note"] = ("overlapped tail: the phase is what is left of the scatter-add at the chain's end -- time chunk 0 "
+                                          "of %d (%s of %d time steps; the others run beside rec_bwd); bytes = that chunk's dxt rows + "
+                                          "the rows it adds to" % (tail_chunks, last if last > 0 else "1 / %d" % tail_chunks, T))
         for k, v in kernels.items():
             us = phases[k]
             peak = HBM_PEAK_GBS if v["bound"] == "hbm" else F32_MFMA_PEAK_TFLOPS
@@ -641,14 +639,15 @@ def main():
             log("train loop: %.4f ms/iteration" % (per_it * 1e3))
         except Exception as ex:
             log("train loop leg skipped:", ex)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # (C stdio buffers of the libraries: out through the redirected descriptor)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if rank == 0:
-        # RCCL prints its version banner through C stdio: flush that first so the JSON line is the LAST line
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
         print(json.dumps(result), flush=True)
 
 

@@ -38,7 +38,11 @@ typedef enum { SBR_CELL_LSTM = 0, SBR_CELL_GRU = 1, SBR_CELL_VANILLA = 2 } sbr_c
 /* --loss (command_parser.py:43, :116-121) */
 typedef enum { SBR_LOSS_CCE = 0, SBR_LOSS_BLACKOUT = 1, SBR_LOSS_BPR = 2, SBR_LOSS_TOP1 = 3,
                /* RNNMargin (rnn_margin.py:62-69; command_parser.py:118-119): linear output layer, multi-target losses */
-               SBR_LOSS_HINGE = 4, SBR_LOSS_LOGIT = 5, SBR_LOSS_LOGSIG = 6 } sbr_loss;
+               SBR_LOSS_HINGE = 4, SBR_LOSS_LOGIT = 5, SBR_LOSS_LOGSIG = 6,
+               /* RNNCluster's further sampled losses (rnn_cluster.py:158-175; `--clusters C` with --loss CCE | BPRelu | lin):
+                * cross-entropy over the sampled columns, leaky hinge on the score differences, plain differences */
+               SBR_LOSS_SCCE = 7, SBR_LOSS_BPRELU = 8, SBR_LOSS_LIN = 9 } sbr_loss;
+#define SBR_LOSS_IS_MARGIN(l) ((l) >= SBR_LOSS_HINGE && (l) <= SBR_LOSS_LOGSIG)
 /* --u_m (update_manager.py:4) */
 typedef enum { SBR_UPD_ADAGRAD = 0, SBR_UPD_ADADELTA = 1, SBR_UPD_RMSPROP = 2, SBR_UPD_NESTEROV = 3,
                SBR_UPD_ADAM = 4 } sbr_updater;
@@ -204,6 +208,49 @@ int sbr_dense_ranges(sbr_handle* h, int cap, int64_t* lo, int64_t* hi, int* n);
  * between this form (small blocks: the host read is the cost) and the counted one above (large blocks: the bytes are). */
 int sbr_sparse_pack_device(sbr_handle* h, int b, int32_t* ids_dev, float* rows_dev);
 int sbr_sparse_unpack_add_all(sbr_handle* h, int b, const int32_t* ids_all, const float* rows_all, int world);
+
+/* ------------------------------------------------------------------------------------------------
+ * The cluster head of RNNCluster (`--clusters C`; rnn_cluster.py:237-256 the cluster loss, :275-300 its training and the hard
+ * clusters, :327-352 the test function).  A second object beside the engine: it owns the cluster-selection weights Wc (H, C)
+ * and the item / cluster repartition R (N, C), reads the user representation (the engine's final hidden state: device pointer,
+ * row stride and the offset of the backwards half from sbr_debug_buffer("h_last")) and trains only its own two arrays, with its
+ * own updater state and step count, as the reference's second `self.updater(...)` call does.  The recurrent network's sampled
+ * head and loss are the engine's (losses SBR_LOSS_BLACKOUT .. SBR_LOSS_LIN).  Single rank (the head is not sharded). */
+typedef enum { SBR_CLUSTER_MIX = 0, SBR_CLUSTER_SOFTMAX = 1, SBR_CLUSTER_SIGMOID = 2 } sbr_cluster_type;   /* --cluster_type */
+typedef struct sbr_cluster_config {
+    int32_t abi_version;            /* SBR_ABI_VERSION */
+    int32_t n_items;                /* N */
+    int32_t n_hidden;               /* H: features of the user representation (2 x the top layer's width with --r_bi) */
+    int32_t hidden_split;           /* features [0, hidden_split) sit at columns [0, ..) of a row, the rest at off2 + (k - hidden_split) */
+    int32_t n_clusters;             /* --clusters */
+    int32_t cluster_type;           /* sbr_cluster_type */
+    int32_t loss;                   /* sbr_loss: Blackout / BPR / TOP1 / SCCE (--loss CCE) / BPRelu / lin (rnn_cluster.py:88-101) */
+    int32_t batch_size;             /* B rows per step: row b's positive is column b of the score matrix */
+    int32_t max_samples;            /* most cluster samples per step (--c_sampling, or --sampling when unset) */
+    int32_t updater;                /* sbr_updater */
+    float learning_rate, rho, beta1, beta2;
+    float scale;                    /* --init_scale (sbr_cluster_set_scale follows --scale_growing_rate) */
+    float noise_std;                /* --csn: std of the gaussian noise on the selection activations in training (a counter-based
+                                     * generator here, MRG_RandomStreams there: equal in law, not in stream) */
+    uint64_t seed;
+} sbr_cluster_config;
+typedef struct sbr_cluster sbr_cluster;
+sbr_cluster* sbr_cluster_create(const sbr_cluster_config* cfg, void* hip_stream);
+void sbr_cluster_destroy(sbr_cluster* c);
+int sbr_cluster_set_params(sbr_cluster* c, const float* R_host, const float* Wc_host);          /* [N][C], [H][C] */
+int sbr_cluster_get_params(sbr_cluster* c, float* R_host, float* Wc_host);
+int sbr_cluster_get_grads(sbr_cluster* c, float* dR_host, float* dWc_host);                      /* of the last forward_backward */
+int sbr_cluster_set_scale(sbr_cluster* c, float scale);                                          /* T_scale.set_value, rnn_cluster.py:400 */
+/* cost_clusters and its gradients for the B rows of h_dev (row stride ld_h floats) with targets_dev [B] and samples_dev
+ * [n_samples]; cost_host may be NULL (nothing is synchronised then) */
+int sbr_cluster_forward_backward(sbr_cluster* c, const float* h_dev, int ld_h, int off2, const int32_t* targets_dev,
+                                 const int32_t* samples_dev, int n_samples, float* cost_host);
+int sbr_cluster_apply_update(sbr_cluster* c);
+/* test path: csel_dev[r] = argmax of the selection activations of row r (z_dev [rows][C] receives them when not NULL) */
+int sbr_cluster_select(sbr_cluster* c, const float* h_dev, int ld_h, int off2, int rows, int32_t* csel_dev, float* z_dev);
+/* scores_dev[r][n] *= hard[n][csel[r]] (NULL: skip), n_used_dev[r] = sum_n hard[n][csel[r]] (NULL: skip) */
+int sbr_cluster_mask_scores(sbr_cluster* c, float* scores_dev, int ld, int rows, const int32_t* csel_dev, float* n_used_dev);
+int sbr_cluster_hard(sbr_cluster* c, float* hard_host);                                          /* [N][C] = _get_hard_clusters() */
 
 /* predict_function(X, mask) (rnn_base.py:188-194) on the current batch: scores (rows,N);
  * softmax probabilities for CCE (DenseLayer softmax, rnn_one_hot.py:65), raw activations

@@ -496,9 +496,106 @@ def sampled_loss_rows(a, B, loss, row_offset=0):
         da = np.zeros_like(a)
         da[:, B:] = d1 + s2 * (1 - s2) * 2 * neg / S
         da[rows, cols] -= d1.sum(axis=1)
+    elif loss == "SCCE":                                   # RNNCluster._cce_loss (rnn_cluster.py:158-162): CCE over the sampled columns
+        p = softmax_rows(a)
+        L = -np.log(p[rows, cols])
+        da = p.copy()
+        da[rows, cols] -= 1.0
+    elif loss == "lin":                                    # rnn_cluster.py:164-167
+        L = a[:, B:].sum(axis=1) - a[rows, cols]
+        da = np.zeros_like(a)
+        da[:, B:] = 1.0
+        da[rows, cols] -= 1.0
+    elif loss == "BPRelu":                                 # rnn_cluster.py:173-175: leaky_rectify(diff + 0.5), leakiness 0.01 [3P]
+        diff = a[:, B:] - a[rows, cols][:, None]
+        S = diff.shape[1]
+        y = diff + 0.5
+        L = np.where(y > 0, y, 0.01 * y).mean(axis=1)
+        dd = np.where(y > 0, 1.0, 0.01) / S
+        da = np.zeros_like(a)
+        da[:, B:] = dd
+        da[rows, cols] -= dd.sum(axis=1)
     else:
         raise ValueError("Unknown loss function")         # rnn_sampling.py:54
     return L, da
+
+
+# --------------------------------------------------------------------------------------
+# RNNCluster (rnn_cluster.py): the sampled head above (its own loss set, no popularity division) + a cluster head that reads the
+# user representation h and trains ONLY its own two arrays -- the cluster-selection weights Wc (H, C) and the item / cluster
+# repartition R (N, C) (rnn_cluster.py:283-285: updater(cost_clusters, params_clusters); nothing of it reaches the recurrent net)
+# --------------------------------------------------------------------------------------
+CLUSTER_LOSSES = {"CCE": "SCCE", "Blackout": "Blackout", "BPR": "BPR", "TOP1": "TOP1", "BPRelu": "BPRelu", "lin": "lin"}
+
+
+def cluster_membership(r, scale, cluster_type):
+    """target_and_samples_clusters (rnn_cluster.py:246-253) for rows r of R; also the pieces the backward needs"""
+    sm = softmax_rows(scale * r)
+    sg = sigmoid(scale * r)
+    if cluster_type == "softmax":
+        return sm, sm, None
+    if cluster_type == "mix":
+        return sm + sg, sm, sg
+    return sg, None, sg
+
+
+def cluster_cost_and_grads(h, Wc, R, target, cluster_samples, loss, scale, cluster_type, noise=None):
+    """cost_clusters (rnn_cluster.py:237-256) and its gradients wrt (Wc, R).  noise: the (B, C) draw of cluster_selection_noise
+    added to the selection activations in training (:241-242), None = off."""
+    B = target.shape[0]
+    z = h @ Wc
+    if noise is not None:
+        z = z + noise
+    p = softmax_rows(scale * z)
+    ids = np.concatenate([target, cluster_samples])
+    M, sm, sg = cluster_membership(R[ids], scale, cluster_type)
+    score = p @ M.T
+    L, ds = sampled_loss_rows(score, B, CLUSTER_LOSSES[loss])
+    cost = L.sum() / B
+    ds = ds / B
+    dp = ds @ M
+    dM = ds.T @ p
+    dz = scale * p * (dp - (dp * p).sum(axis=1, keepdims=True))
+    dr = np.zeros_like(dM)
+    if sm is not None:
+        dr += scale * sm * (dM - (dM * sm).sum(axis=1, keepdims=True))
+    if sg is not None:
+        dr += scale * sg * (1.0 - sg) * dM
+    dR = np.zeros_like(R)
+    np.add.at(dR, ids, dr)
+    return cost, score, (h.T @ dz, dR)
+
+
+def cluster_hard(R, cluster_type):
+    """_get_hard_clusters (rnn_cluster.py:293-300)"""
+    if cluster_type == "softmax":
+        return softmax_rows(100.0 * R)
+    if cluster_type == "mix":
+        return np.clip(softmax_rows(100.0 * R) + sigmoid(100.0 * R), 0.0, 1.0)
+    return sigmoid(100.0 * R)
+
+
+def cluster_test_rows(params, cfg, X, mask, exclude_ids, k=10):
+    """RNNCluster's test function (rnn_cluster.py:327-352) for every row: (ids without clusters, ids inside the selected
+    cluster, selected cluster, items in that cluster).  Scores = softmax over the full catalogue; the cluster version multiplies
+    them by the hard membership column of the row's cluster (argmax of the selection activations); seen items score 0."""
+    cell, layers, emb, bi = cfg["cell"], cfg["layers"], cfg.get("embedding", 0), cfg.get("bidirectional", False)
+    cl = cfg["clusters"]
+    R, Wc = params[-2], params[-1]
+    _, W_out, b_out = split_params(params[:-2], cell, layers, emb, bi)
+    h, _ = network_forward(params[:-2], cell, layers, X, mask, emb, bi)
+    s1 = softmax_rows(h @ W_out + b_out)
+    csel = np.argmax(h @ Wc, axis=1)
+    used = cluster_hard(R, cl["type"])[:, csel].T            # (B, N)
+    s2 = s1 * used
+    out1, out2 = [], []
+    for b in range(h.shape[0]):
+        a1, a2 = s1[b].copy(), s2[b].copy()
+        if exclude_ids is not None:
+            a1[np.asarray(exclude_ids[b], dtype=np.int64)] = 0.0
+            a2[np.asarray(exclude_ids[b], dtype=np.int64)] = 0.0
+        out1.append(topk_ordered(a1, k)); out2.append(topk_ordered(a2, k))
+    return np.array(out1), np.array(out2), csel, used.sum(axis=1), (s1, s2)
 
 
 def sampled_cost_and_grads(h, W_out, b_out, target, samples, target_popularity, loss, row_offset=0):
@@ -583,6 +680,21 @@ def cost_and_grads(params, cfg, batch):
     """cost + gradient list (Lasagne parameter order) for one batch = the symbolic part
     of RNNBase._compile_train_function (rnn_base.py:175-186) before the updates."""
     cell, layers, emb, bi = cfg["cell"], cfg["layers"], cfg.get("embedding", 0), cfg.get("bidirectional", False)
+    if cfg.get("clusters"):
+        # RNNCluster: parameter list = RNNSampling's + [R, Wc] (the order RNNCluster.save appends them, rnn_cluster.py:517-521);
+        # the train function returns `cost` only, `aux["cost_clusters"]` is the second one
+        cl = cfg["clusters"]
+        net, R, Wc = params[:-2], params[-2], params[-1]
+        per, W_out, b_out = split_params(net, cell, layers, emb, bi)
+        h, caches = network_forward(net, cell, layers, batch["X"], batch["mask"], emb, bi)
+        B = batch["target"].shape[0]
+        cost, act, (dh, dW, db) = sampled_cost_and_grads(h, W_out, b_out, batch["target"], batch["samples"], np.ones(B),
+                                                         CLUSTER_LOSSES[cfg["loss"]])
+        csm = batch["cluster_samples"] if batch.get("cluster_samples") is not None else batch["samples"]
+        ccost, cscore, (dWc, dR) = cluster_cost_and_grads(h, Wc, R, batch["target"], csm, cfg["loss"], cl["scale"], cl["type"],
+                                                          batch.get("cluster_noise"))
+        grads = network_backward(net, cell, layers, caches, dh, emb, batch["X"], bi) + [dW, db, dR, dWc]
+        return cost, grads, {"h": h, "act": act, "cost_clusters": ccost, "cluster_score": cscore}
     per, W_out, b_out = split_params(params, cell, layers, emb, bi)
     h, caches = network_forward(params, cell, layers, batch["X"], batch["mask"], emb, bi)
     if cfg["loss"] == "CCE":

@@ -28,7 +28,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
 #define LFAIL(...) do { snprintf(buf, sizeof(buf), __VA_ARGS__); err = buf; return SBR_EINVAL; } while (0)
     if (cfg.abi_version != SBR_ABI_VERSION) LFAIL("abi_version %d != %d", cfg.abi_version, SBR_ABI_VERSION);
     if (cfg.cell < 0 || cfg.cell > 2) LFAIL("Unknown layer type %d", cfg.cell);                  // recurrent_layers.py:90
-    if (cfg.loss < 0 || cfg.loss > SBR_LOSS_LOGSIG) LFAIL("Unknown loss for the RNN model (%d)", cfg.loss);     // command_parser.py:123
+    if (cfg.loss < 0 || cfg.loss > SBR_LOSS_LIN) LFAIL("Unknown loss for the RNN model (%d)", cfg.loss);     // command_parser.py:123
     if (cfg.updater < 0 || cfg.updater > 4) LFAIL("Unknown update option %d", cfg.updater);       // update_manager.py:22
     if (cfg.n_layers < 1 || cfg.n_layers > SBR_MAX_LAYERS) LFAIL("n_layers must be in [1,%d]", SBR_MAX_LAYERS);
     for (int l = 0; l < cfg.n_layers; ++l)
@@ -38,7 +38,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     if (cfg.max_length < 1) LFAIL("max_length must be >= 1");
     if (cfg.batch_size < 1 || cfg.local_batch < 1 || cfg.local_batch > cfg.batch_size) LFAIL("need 1 <= local_batch <= batch_size");
     if (cfg.row_offset < 0 || cfg.row_offset + cfg.local_batch > cfg.batch_size) LFAIL("row_offset/local_batch outside the global batch");
-    const bool margin = cfg.loss >= SBR_LOSS_HINGE;
+    const bool margin = SBR_LOSS_IS_MARGIN(cfg.loss);
     if (cfg.loss != SBR_LOSS_CCE && !margin && cfg.n_samples < 1) LFAIL("sampled losses need n_samples >= 1");
     if (margin && (cfg.n_targets < 1 || cfg.n_targets > 4096)) LFAIL("the multi-target losses need 1 <= n_targets <= 4096");
     if (cfg.learning_rate <= 0.0f) LFAIL("learning_rate must be > 0");
@@ -539,7 +539,7 @@ extern "C" int sbr_section(sbr_handle* h, int which, void** dev_ptr, size_t* n_f
 extern "C" int sbr_set_default_target(sbr_handle* h, const float* default_target) {
     CHECK_ARG(h, "null handle");
     const Layout& y = h->lay;
-    CHECK_ARG(y.cfg.loss >= SBR_LOSS_HINGE, "only the multi-target losses (hinge / logit / logsig) have a default target");
+    CHECK_ARG(SBR_LOSS_IS_MARGIN(y.cfg.loss), "only the multi-target losses (hinge / logit / logsig) have a default target");
     if (default_target) SBR_HIP(hipMemcpyAsync(h->A(y.a_dflt), default_target, (size_t)y.N * sizeof(float), hipMemcpyHostToDevice, h->stream));
     else SBR_HIP(hipMemsetAsync(h->A(y.a_dflt), 0, (size_t)y.N * sizeof(float), h->stream));
     SBR_HIP(hipStreamSynchronize(h->stream));
@@ -551,7 +551,7 @@ extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* len
     CHECK_ARG(h && X && lengths, "null X / lengths");
     const Layout& y = h->lay;
     CHECK_ARG(n_rows >= 1 && n_rows <= y.B, "n_rows %d outside [1,%d]", n_rows, y.B);
-    const bool margin = y.cfg.loss >= SBR_LOSS_HINGE;
+    const bool margin = SBR_LOSS_IS_MARGIN(y.cfg.loss);
     const int n_tgt = y.S > 0 ? y.Bg : n_rows * y.NT;
     if (!on_device) {   // the reference would raise IndexError inside Theano for bad ids; check on host
         for (size_t i = 0; i < (size_t)n_rows * y.T * y.F; ++i)
@@ -636,6 +636,28 @@ static int tail_plan(sbr_handle* h, int* ch_out) {
     nc = (y.T + ch - 1) / ch;
     if (nc < 2) return 0;
     *ch_out = ch;
+    // Chunk bounds.  The scatter-add of a time chunk can start when the chain has left it, and the chain leaves chunk 0 last:
+    // with equal chunks an eighth of the step's entries waits for the chain's end (30 - 45 us of polling waves behind it,
+    // profiles/round3_c_timeline.txt).  So the chunks near t = 0 are small -- 1, 3, 7, 18 ... steps (powers of SBR_TAIL_GEOM,
+    // default 2.6; <= 1: equal chunks) -- until a power exceeds the equal share of what is left, which the remaining chunks then
+    // take: at T = 200 and eight chunks 1, 3, 7, 18, 42, 43, 43, 43 steps (the consumers still start after a fifth of the chain).
+    // At most half of the chunks are small ones.
+    static const double geom = getenv("SBR_TAIL_GEOM") ? atof(getenv("SBR_TAIL_GEOM")) : 2.6;
+    SbrTChunks& tc = h->tail_bounds;
+    tc.n = nc;
+    tc.lo[0] = 0;
+    double pw = 1.0;
+    for (int c = 0; c < nc; ++c) {
+        const int rem = y.T - tc.lo[c], left = nc - c;
+        const int share = (rem + left - 1) / left;
+        const int n_small = nc >= 4 ? nc / 2 : (nc - 1) / 2;
+        int sz = (geom > 1.0 && c < n_small) ? std::min(share, std::max(1, (int)(pw + 0.5))) : (geom > 1.0 ? share : std::min(rem, ch));
+        if (c == nc - 1) sz = rem;
+        sz = std::max(1, std::min(sz, rem - (left - 1)));            // every later chunk keeps at least one step
+        tc.lo[c + 1] = tc.lo[c] + sz;
+        pw *= geom > 1.0 ? geom : 1.0;
+    }
+    for (int c = nc; c <= SBR_TCHUNKS_MAX; ++c) tc.lo[c] = y.T;
     return nc;
 }
 
@@ -802,6 +824,23 @@ extern "C" int sbr_forward(sbr_handle* h) {
                 SBR_LAUNCH(launch_sparse_catch_up_batch(s, sparse_rows(h, b), sparse_upd(h), h->bX, h->blen, y.T, y.Bp, y.F, (int)h->step_count));
     h->tail_nc = h->step_open ? tail_plan(h, &h->tail_ch) : 0;      // overlapped tail for this step? (never for predict / top-k)
     h->step_open = false;
+    h->tail_sorted = false;
+    if (h->tail_nc >= 2 && h->tail_overlap == 1) {
+        // Overlapped tail: the time-chunked sort of the batch's ids needs nothing but the batch, and the scatter-add consumer that
+        // waits behind it on the second side stream should be polling when the BPTT chain starts -- 45 us of sort behind the
+        // output phase left it a third of the chain behind, which it never made up (profiles/round3_e_timeline.txt: 37 us of
+        // scatter-add after the chain's end although the last time chunk is a single step).  So the sort runs now, beside the
+        // forward chain (192 idle CUs), for one event record in front of it.  SBR_TAIL_EARLY_SORT=0: behind the output phase.
+        static const int early = getenv("SBR_TAIL_EARLY_SORT") ? atoi(getenv("SBR_TAIL_EARLY_SORT")) : 1;
+        if (early) {
+            SBR_HIP(hipEventRecord(h->ev_fork, s));
+            SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
+            SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
+                                           (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
+                                           h->tail_ch, h->tail_nc, &h->tail_bounds));
+            h->tail_sorted = true;
+        }
+    }
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
@@ -890,9 +929,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             // overlapped tail: the time-chunked sort runs on the SECOND side stream, which consumes it (scatter-add beside the
             // chain); that stream is released by the same record as the first one
             SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_lg_rec, 0));
-            SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
-                                           (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
-                                           h->tail_ch, h->tail_nc));
+            if (!h->tail_sorted)
+                SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
+                                               (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
+                                               h->tail_ch, h->tail_nc, &h->tail_bounds));
         } else if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
             SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                            y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
@@ -910,7 +950,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
         const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
     }
-    if (y.cfg.loss == SBR_LOSS_CCE || y.cfg.loss >= SBR_LOSS_HINGE) {      // dense heads: full softmax, or RNNMargin's linear layer
+    if (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss)) {      // dense heads: full softmax, or RNNMargin's linear layer
         float* lg = h->A(y.a_logits);
         const int Nl = (N + 3) & ~3;               // row stride of the logits / dlogits buffer
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
@@ -919,7 +959,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         const hipError_t ge = launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg);
         sbr_gemm_set_planes(3);
         SBR_LAUNCH(ge);
-        if (y.cfg.loss >= SBR_LOSS_HINGE)
+        if (SBR_LOSS_IS_MARGIN(y.cfg.loss))
             SBR_LAUNCH(launch_margin_loss(s, lg, h->P(y.p_bout), tgt, y.NT, h->bX, h->blen, y.T, y.F, h->A(y.a_dflt), h->A(y.a_rowcost), R, N, Nl,
                                           y.Bg, y.cfg.loss, y.cfg.balance, y.cfg.unique));
         else
@@ -1096,7 +1136,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_LAUNCH(launch_rec_backward(s, a, false));
             mark(h, 4);
             // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
-            const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || y.cfg.loss >= SBR_LOSS_HINGE);
+            const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss));
             if (out_early) SBR_LAUNCH(upd_on(sd, y.p_split, y.n_params));
             SBR_LAUNCH(launch_tail_gate(sd, words, nwaves, a.prog_epoch, y.T, a.fault));
             {
@@ -1107,20 +1147,24 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 }
                 SBR_LAUNCH(we);
             }
-            SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
+            // (the scatter-add launch brings its own monitor of the chain's progress: its gate is the chain being resident, not the
+            // GEMM's monitor having started behind the output layer's gradient kernels on the other stream)
+            static const int scat_mon = getenv("SBR_TAIL_SCATTER_MONITOR") ? atoi(getenv("SBR_TAIL_SCATTER_MONITOR")) : 1;
+            if (scat_mon) SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, y.T, a.fault));
+            else SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
             // The time chunk the chain completes LAST (chunk 0) is not left to the polling waves: each of them walks 32 sorted
             // entries, rounds of eight rows in flight and then its atomics -- 30 - 35 us behind the chain's end for the one chunk that
             // cannot start earlier (profiles/round3_c_timeline.txt).  It gets a launch of its own behind the polling one (same stream:
             // the read-modify-writes of its owned segments see the atomics of the earlier chunks complete), gated on the chain's last
             // progress word, one wave per 16 entries on the then idle chip.  SBR_TAIL_FINAL=0: the polling waves take chunk 0 too.
-            static const int tail_final = getenv("SBR_TAIL_FINAL") ? atoi(getenv("SBR_TAIL_FINAL")) : 16;
+            static const int tail_final = getenv("SBR_TAIL_FINAL") ? atoi(getenv("SBR_TAIL_FINAL")) : 0;
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
-                                                  tail_final ? y.cfg.input_size : 0));
+                                                  tail_final ? y.cfg.input_size : 0, &h->tail_bounds));
             if (tail_final) {
                 SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, 0, a.fault));
                 SBR_LAUNCH(launch_scatter_reduce(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
-                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, CH * y.Bp * y.F, GHp, y.Bp, 0, true, tail_final));
+                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, (h->tail_bounds.lo[1] - h->tail_bounds.lo[0]) * y.Bp * y.F, GHp, y.Bp, 0, true, tail_final));
             }
             if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
@@ -1560,7 +1604,7 @@ extern "C" int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_hos
     // where a viewed item then scores 0 and outranks every negative one
     if (exclude_seen)
         SBR_LAUNCH(launch_exclude_seen(h->stream, lg, h->bX, h->blen, h->n_rows, y.T, y.F, y.N,
-                                       (exclude_seen == 2 && y.cfg.loss >= SBR_LOSS_HINGE) ? 0.0f : -INFINITY));
+                                       (exclude_seen == 2 && SBR_LOSS_IS_MARGIN(y.cfg.loss)) ? 0.0f : -INFINITY));
     int* ids = (int*)h->A(y.a_topk);
     SBR_LAUNCH(launch_topk(h->stream, lg, h->n_rows, y.N, k, ids));
     SBR_HIP(hipMemcpyAsync(ids_host, ids, (size_t)h->n_rows * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1656,6 +1700,7 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         *value = w.rfind("rec_products_", 0) == 0 ? products : w.rfind("rec_rows_", 0) == 0 ? rows : wgs;
     }
     else if (w == "tail_chunks") { int ch = 0; *value = tail_plan(h, &ch); }      // time chunks of the overlapped step tail (0: not taken)
+    else if (w == "tail_last_steps") { int ch = 0; *value = tail_plan(h, &ch) >= 2 ? h->tail_bounds.lo[1] : 0; }   // time steps of chunk 0 (behind the chain)
     else if (w == "side_stream2") *value = (int64_t)(intptr_t)h->side2;
     else if (w == "tail_chain_cycles" || w == "tail_chain_ticks") {      // last overlapped-tail BPTT launch: shader cycles / 100 MHz ticks
         unsigned long long c[2] = {0, 0};

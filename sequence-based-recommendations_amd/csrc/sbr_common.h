@@ -122,6 +122,16 @@ struct ParamDesc { std::string name; int layer; int kind; int gate; int64_t d0, 
 // kind: 0 W_in, 1 W_hid, 2 b, 3 peephole(i,f,o by gate 0..2), 4 cell_init, 5 hid_init, 6 out.W, 7 out.b
 void sbr_param_descs(const Layout& lay, std::vector<ParamDesc>& out);
 
+// Time chunks of the time-chunked sort (overlapped step tail): chunk c holds the time steps [lo[c], lo[c + 1]), n chunks;
+// n <= 1: plain keys.  The chunks need not be equal: the BPTT chain completes chunk 0 last, and whatever of the scatter-add
+// belongs to it can only start at the chain's end -- so the chunks shrink geometrically towards t = 0.
+#define SBR_TCHUNKS_MAX 9
+struct SbrTChunks { int n; int lo[SBR_TCHUNKS_MAX + 1]; };
+static inline SbrTChunks sbr_uniform_tchunks(int tch, int n) {
+    SbrTChunks tc; tc.n = tch > 0 ? n : 0;
+    for (int c = 0; c <= SBR_TCHUNKS_MAX; ++c) tc.lo[c] = tch * (c < n ? c : n);
+    return tc;
+}
 struct sbr_handle {
     Layout lay;
     float* arena; bool own_arena;
@@ -163,6 +173,8 @@ struct sbr_handle {
     int tail_chunks_max; // SBR_TAIL_CHUNKS (default 8)
     int tail_pub_every;  // SBR_TAIL_PUBLISH_EVERY: time steps between two progress words of a chain wave (default 2)
     int tail_nc, tail_ch;   // this step: time chunks of the sort's keys / steps per chunk (0: plain keys)
+    SbrTChunks tail_bounds; // ... and their bounds (tail_plan)
+    bool tail_sorted;       // ... the sort already runs beside the forward chain (sbr_forward)
     int prog_epoch;
     bool tail_updated;      // this step: the overlapped tail has applied the optimizer itself (single-call step)
     hipEvent_t ev_tail, ev_tail2;
@@ -215,7 +227,7 @@ hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, con
 // concatenated, not summed)
 // tch > 0: time-chunked keys (t / tch) * n_ids + id over n_tchunks chunks (cnt / offs / cur then hold n_tchunks * n_ids + 1 ints)
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos, int concat = 0, int tch = 0, int n_tchunks = 1);
+                               int* offs, int* cur, int* sid, int* spos, int concat = 0, int tch = 0, int n_tchunks = 1, const SbrTChunks* bounds = nullptr);
 int sbr_scatter_lds_ids();     // largest key space the LDS-histogram sort takes
 // overlapped step tail: wait (bounded) until every progress word of the running BPTT chain is (epoch, <= target)
 hipError_t launch_tail_gate(hipStream_t s, const int* progress, int n, int epoch, int target, int* fault);
@@ -238,7 +250,7 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
 // all time chunks of a time-chunked sort in ONE launch beside the running chain: every wave waits for poll.done to reach the
 // time chunk of its entries (tch steps per chunk), rows are added with float atomics (an id may occur in every chunk)
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0);
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0, const SbrTChunks* bounds = nullptr);
 
 // Tile-blocked activation layout [t][row tile of 16][column tile of 16][row 16][col 16] (floats):
 // the 16x16 tile one wave of the recurrent kernels owns is one contiguous KiB (8 full 128-B lines per

@@ -202,11 +202,17 @@ hipError_t launch_gather_xt(hipStream_t s, const float* Win, const float* bias, 
 // Time-chunked keys (tch > 0): key = (t / tch) * ids_per_chunk + id, so that the entries of one chunk of time steps are
 // contiguous in the sorted order and sorted by id inside it -- the scatter-add of a chunk can then run as soon as the BPTT
 // chain has left that chunk (sbr_backward_recurrent, "tail overlap").  n_ids is the size of the KEY space.
-__device__ __forceinline__ int scat_key(int id, int t, int tch, int ids_per_chunk) { return tch > 0 ? (t / tch) * ids_per_chunk + id : id; }
+__device__ __forceinline__ int scat_key(int id, int t, const SbrTChunks& tc, int ids_per_chunk) {
+    if (tc.n <= 1) return id;
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < SBR_TCHUNKS_MAX; ++k) c += (k < tc.n && t >= tc.lo[k]) ? 1 : 0;
+    return c * ids_per_chunk + id;
+}
 
 __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
                                                                     int T, int Bp, int F, int n_ids, int per_block,
-                                                                    int* __restrict__ cnt, int tch, int ipc) {
+                                                                    int* __restrict__ cnt, SbrTChunks tch, int ipc) {
     extern __shared__ int hist[];
     for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
     __syncthreads();
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(SCAT_BLOCK) scat_count_lds_kernel(const int* _
 __global__ void __launch_bounds__(SCAT_BLOCK) scat_fill_lds_kernel(const int* __restrict__ X, const int* __restrict__ len,
                                                                    int T, int Bp, int F, int n_ids, int per_block,
                                                                    int* __restrict__ cur, int* __restrict__ sid,
-                                                                   int* __restrict__ spos, int concat, int tch, int ipc) {
+                                                                   int* __restrict__ spos, int concat, SbrTChunks tch, int ipc) {
     extern __shared__ int hist[];          // [n_ids] counts, then cursors
     for (int i = threadIdx.x; i < n_ids; i += SCAT_BLOCK) hist[i] = 0;
     __syncthreads();
@@ -386,11 +392,12 @@ __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restric
 int sbr_scatter_lds_ids() { return SCAT_LDS_IDS; }
 
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos, int concat, int tch, int n_tchunks) {
+                               int* offs, int* cur, int* sid, int* spos, int concat, int tch, int n_tchunks, const SbrTChunks* bounds) {
     const int ipc = n_ids;                          // ids per time chunk
+    SbrTChunks tc = bounds ? *bounds : sbr_uniform_tchunks(tch, n_tchunks);
     if (tch > 0) {
         n_ids *= n_tchunks;                         // key space
-        if (n_ids > SCAT_LDS_IDS || (long)tch * n_tchunks < T) return hipErrorInvalidValue;
+        if (n_ids > SCAT_LDS_IDS || tc.n != n_tchunks || tc.n > SBR_TCHUNKS_MAX || tc.lo[0] != 0 || tc.lo[tc.n] < T) return hipErrorInvalidValue;
     }
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), s);
     if (e != hipSuccess) return e;
@@ -401,10 +408,10 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
         const size_t lds = (size_t)n_ids * sizeof(int);
         (void)hipFuncSetAttribute((const void*)scat_count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)scat_fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt, tch, ipc);
+        scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt, tc, ipc);
         (void)hipFuncSetAttribute((const void*)scat_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         scat_scan_kernel<true><<<1, 1024, lds, s>>>(cnt, n_ids, offs, cur);
-        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat, tch, ipc);
+        scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat, tc, ipc);
     } else {
         const int grid = min(1024, (total + 255) / 256);
         scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
@@ -431,13 +438,46 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
 // waits (one lane polls poll.done, bounded) until the chain has left the time chunk of its FIRST entry -- the lowest of the
 // wave, the order is ascending -- takes an agent-scope acquire, and adds its row sums with float atomics: an id may occur
 // in every chunk, and chunks finish in different waves.
+// The MONITOR of a polling launch (its last workgroup): folds the chain's per-wave progress words into `done` until the chain
+// has finished -- the same fold the weight-gradient GEMM's workgroup 0 runs (sbr_gemm_x6.hip); two monitors write the same
+// values, so the scatter-add does not have to wait for that launch to start (it sits behind the output layer's gradient work on
+// its stream, a third of the chain late).
+__device__ __forceinline__ void scat_monitor(const SbrPoll& pl) {
+    __shared__ int s_part[4];
+    const int tid = threadIdx.x, tag = pl.epoch;
+    int last = 0x1000;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        int m = 0;
+        for (int i = tid; i < pl.n; i += 256) {
+            const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) s_part[tid >> 6] = m;
+        __syncthreads();
+        m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+        __syncthreads();
+        if (m != last && m != 0xfff) {
+            if (tid == 0) __hip_atomic_store(pl.done, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = m;
+        }
+        if (m <= 0) break;
+        if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
 template <int NV, int SCAT_CHUNK, bool ACC = false, bool POLL = false>
 __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
                                                           int n_ids, float* __restrict__ dWin, int R4, int Bp, int key_lo = 0,
-                                                          int n_tchunks = 1, int tch = 0, SbrPoll poll = SbrPoll()) {
+                                                          int n_tchunks = 1, SbrTChunks tch = SbrTChunks(), SbrPoll poll = SbrPoll()) {
     const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    if (POLL && poll.k_small < 0 && blockIdx.x == gridDim.x - 1) { scat_monitor(poll); return; }       // (k_small < 0: this launch has a monitor)
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n_waves = (gridDim.x - ((POLL && poll.k_small < 0) ? 1 : 0)) * (blockDim.x >> 6);
     const int total = offs[POLL ? n_ids * n_tchunks : key_lo + n_ids];
     // POLL: key_lo = the first key this launch takes (time chunk 0 -- the one the chain completes last -- is left to a launch
     // of its own behind the chain when key_lo = n_ids: see sbr_backward_recurrent)
@@ -455,7 +495,7 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
     const int my_id = e < total ? sid[e] : -1;
     const int my_pos = e < total ? spos[e] : 0;
     if (POLL) {
-        const int t_need = (__shfl(my_id, 0) / n_ids) * tch;
+        const int t_need = tch.lo[min(__shfl(my_id, 0) / n_ids, SBR_TCHUNKS_MAX)];
         if (lane == 0) {
             const unsigned long long t0 = wall_clock64();
             for (;;) {
@@ -514,11 +554,16 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
 }
 
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key) {
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key,
+                                      const SbrTChunks* bounds) {
+    const SbrTChunks tc = bounds ? *bounds : sbr_uniform_tchunks(tch, n_tchunks);
+    SbrPoll pm = poll;
+    static const int own_monitor = getenv("SBR_TAIL_SCATTER_MONITOR") ? atoi(getenv("SBR_TAIL_SCATTER_MONITOR")) : 1;
+    if (own_monitor) pm.k_small = -1;      // (the field is the GEMM's; here it only says: the last workgroup is a monitor)
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
     static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 64;
-    const int grid = std::max(1, std::min(wgs, ((max_entries + 31) / 32 + 3) / 4));
-#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tch, poll)
+    const int grid = std::max(1, std::min(wgs, ((max_entries + 31) / 32 + 3) / 4)) + (own_monitor ? 1 : 0);
+#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tc, pm)
     if (nv <= 1) SRP(1); else if (nv <= 2) SRP(2); else if (nv <= 4) SRP(4); else return hipErrorInvalidValue;
 #undef SRP
     return hipGetLastError();
@@ -860,11 +905,12 @@ __global__ void __launch_bounds__(256) sampled_loss_kernel(float* __restrict__ a
     const int r = blockIdx.x, C = Bg + S, pos = row_offset + r;
     float* a = act + (size_t)r * C;
     const float scale = 1.0f / (pop[r] * (float)Bglobal);
-    for (int c = threadIdx.x; c < C; c += 256) a[c] += bc[c];       // + b[output_cells] :54
+    if (bc) { for (int c = threadIdx.x; c < C; c += 256) a[c] += bc[c]; }      // + b[output_cells] :54 (the cluster head's scores have none)
     __syncthreads();
     const float apos = a[pos];
     float L;
-    if (loss == SBR_LOSS_BLACKOUT) {                                  // rnn_sampling.py:68-72
+    if (loss == SBR_LOSS_BLACKOUT || loss == SBR_LOSS_SCCE) {         // rnn_sampling.py:68-72; SCCE: rnn_cluster.py:158-162
+        const bool blackout = loss == SBR_LOSS_BLACKOUT;
         float mx = -INFINITY;
         for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, a[c]);
         mx = block_max(mx, red);
@@ -877,7 +923,7 @@ __global__ void __launch_bounds__(256) sampled_loss_kernel(float* __restrict__ a
         float dot = 0.0f, lneg = 0.0f;
         for (int c = threadIdx.x; c < C; c += 256) {
             const float p = expf(a[c] - mx) * inv;
-            if (c >= Bg) { dot += p / (1.0f - p); lneg -= logf(1.0f - p); }
+            if (c >= Bg && blackout) { dot += p / (1.0f - p); lneg -= logf(1.0f - p); }
         }
         dot = block_sum(dot, red) - 1.0f;                             // positive: (-1/p_pos) * p_pos
         lneg = block_sum(lneg, red);
@@ -886,7 +932,7 @@ __global__ void __launch_bounds__(256) sampled_loss_kernel(float* __restrict__ a
         for (int c = threadIdx.x; c < C; c += 256) {
             const float p = expf(a[c] - mx) * inv;
             float dldp = 0.0f;
-            if (c >= Bg) dldp = 1.0f / (1.0f - p);
+            if (c >= Bg && blackout) dldp = 1.0f / (1.0f - p);
             if (c == pos) dldp += -1.0f / p;
             a[c] = p * (dldp - dot) * scale;
         }
@@ -902,6 +948,14 @@ __global__ void __launch_bounds__(256) sampled_loss_kernel(float* __restrict__ a
                     lsum += fmaxf(diff, 0.0f) + log1pf(expf(-fabsf(diff)));
                     const float dd = sigmf(diff) / (float)S;
                     da = dd; dpos += dd;
+                } else if (loss == SBR_LOSS_BPRELU) {                 // rnn_cluster.py:173-175: leaky_rectify(diff + 0.5), leakiness 0.01 [3P]
+                    const float yv = diff + 0.5f;
+                    lsum += yv > 0.0f ? yv : 0.01f * yv;
+                    const float dd = (yv > 0.0f ? 1.0f : 0.01f) / (float)S;
+                    da = dd; dpos += dd;
+                } else if (loss == SBR_LOSS_LIN) {                    // rnn_cluster.py:164-167: SUM of the negatives - the positive
+                    lsum += v;
+                    da = 1.0f;
                 } else {                                              // TOP1 :86-91
                     const float s1 = sigmf(diff), s2 = sigmf(v * v);
                     lsum += s1 + s2;
@@ -914,6 +968,7 @@ __global__ void __launch_bounds__(256) sampled_loss_kernel(float* __restrict__ a
         lsum = block_sum(lsum, red);
         dpos = block_sum(dpos, red);
         L = lsum / (float)S;
+        if (loss == SBR_LOSS_LIN) { L = lsum - apos; dpos = 1.0f; }
         if (threadIdx.x == 0) a[pos] = -dpos * scale;
     }
     if (threadIdx.x == 0) rowcost[r] = L * scale;

@@ -27,9 +27,10 @@ PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "up
 
 CELLS = {"LSTM": 0, "GRU": 1, "Vanilla": 2}                     # --r_t, recurrent_layers.py:9
 LOSSES = {"CCE": 0, "Blackout": 1, "BPR": 2, "TOP1": 3,          # --loss, command_parser.py:43
-          "hinge": 4, "logit": 5, "logsig": 6}                   # ... RNNMargin's multi-target losses (command_parser.py:118-119)
+          "hinge": 4, "logit": 5, "logsig": 6,                   # ... RNNMargin's multi-target losses (command_parser.py:118-119)
+          "SCCE": 7, "BPRelu": 8, "lin": 9}                      # ... RNNCluster's further sampled losses (its "CCE" is SCCE here)
 MARGIN_LOSSES = ("hinge", "logit", "logsig")
-SAMPLED_LOSSES = ("Blackout", "BPR", "TOP1")
+SAMPLED_LOSSES = ("Blackout", "BPR", "TOP1", "SCCE", "BPRelu", "lin")      # the last three: RNNCluster's (rnn_cluster.py:158-175)
 UPDATERS = {"adagrad": 0, "adadelta": 1, "rmsprop": 2, "nesterov": 3, "adam": 4}   # --u_m
 FLAG_SIMPLE_REC = 1
 FLAG_SIMPLE_GEMM = 2
@@ -62,6 +63,9 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
            "sbr_sparse_unpack_add", "sbr_dense_ranges", "sbr_sparse_pack_device", "sbr_sparse_unpack_add_all",
+           "sbr_cluster_create", "sbr_cluster_destroy", "sbr_cluster_set_params", "sbr_cluster_get_params", "sbr_cluster_get_grads",
+           "sbr_cluster_set_scale", "sbr_cluster_forward_backward", "sbr_cluster_apply_update", "sbr_cluster_select",
+           "sbr_cluster_mask_scores", "sbr_cluster_hard",
            "sbr_dataset_create", "sbr_dataset_destroy", "sbr_dataset_set_tables", "sbr_dataset_set_options", "sbr_dataset_noise_pass", "sbr_dataset_current_sequences", "sbr_dataset_set_target_bias",
            "sbr_plan_rows_host", "sbr_dataset_plan_pass",
            "sbr_dataset_plan_segments", "sbr_plan_pass_host", "sbr_build_batch"]
@@ -123,6 +127,18 @@ def load_library(path=None):
     lib.sbr_dense_ranges.argtypes = [vp, ctypes.c_int, i64p, i64p, ctypes.POINTER(ctypes.c_int)]
     lib.sbr_set_deferred_join.argtypes = [vp, ctypes.c_int]
     lib.sbr_join_side.argtypes = [vp]
+    lib.sbr_cluster_create.restype = vp
+    lib.sbr_cluster_create.argtypes = [vp, vp]
+    lib.sbr_cluster_destroy.restype = None
+    lib.sbr_cluster_destroy.argtypes = [vp]
+    for fn in (lib.sbr_cluster_set_params, lib.sbr_cluster_get_params, lib.sbr_cluster_get_grads):
+        fn.argtypes = [vp, vp, vp]
+    lib.sbr_cluster_set_scale.argtypes = [vp, ctypes.c_float]
+    lib.sbr_cluster_forward_backward.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, f32p]
+    lib.sbr_cluster_apply_update.argtypes = [vp]
+    lib.sbr_cluster_select.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.sbr_cluster_mask_scores.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.sbr_cluster_hard.argtypes = [vp, vp]
     lib.sbr_dataset_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.POINTER(vp)]
     lib.sbr_dataset_destroy.argtypes = [vp]
     lib.sbr_dataset_set_tables.argtypes = [vp, vp, vp]
@@ -753,3 +769,129 @@ class RNNEngine(object):
         us = (ctypes.c_float * SBR_N_PHASES)()
         self._check(self.lib.sbr_phase_times(self.h, us))
         return dict(zip(PHASE_NAMES, [float(v) for v in us]))
+
+
+# ------------------------------------------------------------------------------------------------ RNNCluster's cluster head
+CLUSTER_TYPES = {"mix": 0, "softmax": 1, "sigmoid": 2}            # --cluster_type (command_parser.py:77)
+
+
+class SbrClusterConfig(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("n_items", ctypes.c_int32), ("n_hidden", ctypes.c_int32),
+                ("hidden_split", ctypes.c_int32), ("n_clusters", ctypes.c_int32), ("cluster_type", ctypes.c_int32),
+                ("loss", ctypes.c_int32), ("batch_size", ctypes.c_int32), ("max_samples", ctypes.c_int32), ("updater", ctypes.c_int32),
+                ("learning_rate", ctypes.c_float), ("rho", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+                ("scale", ctypes.c_float), ("noise_std", ctypes.c_float), ("seed", ctypes.c_uint64)]
+
+
+class ClusterHead(object):
+    """The cluster head of RNNCluster beside an RNNEngine (include/sbr_rnn.h, csrc/sbr_cluster.hip): owns the repartition R (N, C)
+    and the selection weights Wc (H, C), reads the engine's user representation on the device, trains with its own updater state
+    (rnn_cluster.py:237-256, :282-285).  `loss` uses the engine's names (RNNCluster's "CCE" is "SCCE")."""
+
+    def __init__(self, engine, n_clusters, cluster_type="mix", loss="SCCE", max_samples=32, updater="adam", learning_rate=0.01,
+                 rho=0.9, beta1=0.9, beta2=0.999, scale=1.0, noise_std=0.0, seed=0):
+        if cluster_type not in CLUSTER_TYPES:
+            raise ValueError("Unknown cluster type")
+        if loss not in SAMPLED_LOSSES:
+            raise ValueError("Unknown cluster loss")                     # rnn_cluster.py:101
+        self.engine, self.lib, self.torch = engine, engine.lib, engine.torch
+        H = int(engine.cfg.layers[engine.cfg.n_layers - 1])
+        self.bi = bool(engine.cfg.bidirectional)
+        self.n_items, self.n_clusters, self.n_hidden = engine.n_items, int(n_clusters), H * (2 if self.bi else 1)
+        self.batch_size, self.max_samples = engine.batch_size, int(max_samples)
+        c = SbrClusterConfig()
+        c.abi_version, c.n_items, c.n_hidden, c.hidden_split = SBR_ABI_VERSION, self.n_items, self.n_hidden, H
+        c.n_clusters, c.cluster_type, c.loss = self.n_clusters, CLUSTER_TYPES[cluster_type], LOSSES[loss]
+        c.batch_size, c.max_samples, c.updater = self.batch_size, self.max_samples, UPDATERS[updater]
+        c.learning_rate, c.rho, c.beta1, c.beta2 = float(learning_rate), float(rho), float(beta1), float(beta2)
+        c.scale, c.noise_std, c.seed = float(scale), float(noise_std), int(seed)
+        self.h = self.lib.sbr_cluster_create(ctypes.byref(c), ctypes.c_void_p(engine.stream.cuda_stream))
+        if not self.h:
+            raise SbrError("sbr_cluster_create: %s" % self.lib.sbr_last_error().decode())
+        dev = engine.device
+        self._tgt = self.torch.empty(self.batch_size, dtype=self.torch.int32, device=dev)
+        self._smp = self.torch.empty(self.max_samples, dtype=self.torch.int32, device=dev)
+        self._csel = self.torch.empty(max(self.batch_size, 16), dtype=self.torch.int32, device=dev)
+        self._hard = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SbrError("libsbr_rnn error %d: %s" % (rc, self.lib.sbr_last_error().decode()))
+
+    def _h_last(self):
+        """(device pointer, row stride, offset of the backwards half) of the engine's user representation"""
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self.engine._check(self.lib.sbr_debug_buffer(self.engine.h, b"h_last", ctypes.byref(ptr), ctypes.byref(n)))
+        Bp = (self.engine.batch_size + 15) // 16 * 16
+        ld = n.value // Bp
+        return ptr, ld, (ld // 2 if self.bi else 0)
+
+    def close(self):
+        if self.h:
+            self.lib.sbr_cluster_destroy(self.h)
+            self.h = None
+
+    def set_params(self, R, Wc):
+        R = np.ascontiguousarray(R, dtype=np.float32); Wc = np.ascontiguousarray(Wc, dtype=np.float32)
+        if R.shape != (self.n_items, self.n_clusters) or Wc.shape != (self.n_hidden, self.n_clusters):
+            raise ValueError("mismatch: cluster arrays have shapes %r, %r" % (R.shape, Wc.shape))
+        self._check(self.lib.sbr_cluster_set_params(self.h, ctypes.c_void_p(R.ctypes.data), ctypes.c_void_p(Wc.ctypes.data)))
+        self._hard = None
+
+    def _get(self, fn):
+        R = np.empty((self.n_items, self.n_clusters), dtype=np.float32); Wc = np.empty((self.n_hidden, self.n_clusters), dtype=np.float32)
+        self._check(fn(self.h, ctypes.c_void_p(R.ctypes.data), ctypes.c_void_p(Wc.ctypes.data)))
+        return R, Wc
+
+    def get_params(self):
+        return self._get(self.lib.sbr_cluster_get_params)
+
+    def get_grads(self):
+        return self._get(self.lib.sbr_cluster_get_grads)
+
+    def set_scale(self, scale):
+        self._check(self.lib.sbr_cluster_set_scale(self.h, float(scale)))
+
+    def forward_backward(self, targets, cluster_samples, read_cost=True):
+        """cost_clusters and its gradients on the engine's CURRENT user representations (call after engine.forward / a step)."""
+        t = np.ascontiguousarray(targets, dtype=np.int32); sm = np.ascontiguousarray(cluster_samples, dtype=np.int32)
+        if t.shape[0] != self.batch_size or not 1 <= sm.shape[0] <= self.max_samples:
+            raise ValueError("cluster head: %d targets, %d samples (batch %d, at most %d samples)" % (t.shape[0], sm.shape[0], self.batch_size, self.max_samples))
+        self._tgt.copy_(self.torch.from_numpy(t)); self._smp[:sm.shape[0]].copy_(self.torch.from_numpy(sm))
+        ptr, ld, off2 = self._h_last()
+        cost = ctypes.c_float()
+        self._check(self.lib.sbr_cluster_forward_backward(self.h, ptr, ld, off2, ctypes.c_void_p(self._tgt.data_ptr()),
+                                                          ctypes.c_void_p(self._smp.data_ptr()), int(sm.shape[0]),
+                                                          ctypes.byref(cost) if read_cost else None))
+        return float(cost.value) if read_cost else None
+
+    def apply_update(self):
+        self._check(self.lib.sbr_cluster_apply_update(self.h))
+        self._hard = None
+
+    def select(self, rows, with_activations=False):
+        """argmax cluster of the first `rows` user representations (rnn_cluster.py:334) [, the selection activations]"""
+        ptr, ld, off2 = self._h_last()
+        z = self.torch.empty((rows, self.n_clusters), dtype=self.torch.float32, device=self.engine.device) if with_activations else None
+        self._check(self.lib.sbr_cluster_select(self.h, ptr, ld, off2, int(rows), ctypes.c_void_p(self._csel.data_ptr()),
+                                                ctypes.c_void_p(z.data_ptr()) if z is not None else None))
+        csel = self._csel[:rows].cpu().numpy().astype(np.int64)
+        return (csel, z.cpu().numpy()) if with_activations else csel
+
+    def hard_clusters(self):
+        """_get_hard_clusters() (rnn_cluster.py:293-300) as a host array (N, C); cached until the arrays change"""
+        if self._hard is None:
+            out = np.empty((self.n_items, self.n_clusters), dtype=np.float32)
+            self._check(self.lib.sbr_cluster_hard(self.h, ctypes.c_void_p(out.ctypes.data)))
+            self._hard = out
+        return self._hard
+
+    def mask_scores(self, scores_dev, csel, want_used=True):
+        """device form: scores_dev (rows, >= N) float32 tensor *= hard[:, csel[row]]; returns the items per selected cluster"""
+        rows = int(scores_dev.shape[0])
+        self._csel[:rows].copy_(self.torch.from_numpy(np.ascontiguousarray(csel, dtype=np.int32)))
+        used = self.torch.empty(rows, dtype=self.torch.float32, device=self.engine.device) if want_used else None
+        self._check(self.lib.sbr_cluster_mask_scores(self.h, ctypes.c_void_p(scores_dev.data_ptr()), int(scores_dev.stride(0)), rows,
+                                                     ctypes.c_void_p(self._csel.data_ptr()),
+                                                     ctypes.c_void_p(used.data_ptr()) if used is not None else None))
+        return used.cpu().numpy() if used is not None else None

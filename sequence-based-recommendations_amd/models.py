@@ -526,3 +526,258 @@ class RNNMargin(RNNBase):
         """The generic compiled test function (rnn_base.py:196-209) on RAW outputs: viewed items are multiplied by 0, not removed."""
         return 2 if self.interactions_are_unique else 0
 
+
+
+class RNNCluster(RNNBase):
+    """RNN + sampled output loss + item clustering, `--clusters C` (rnn_cluster.py:19-539; command_parser.py:71-77, :114-115).
+    Two models trained side by side from one forward pass: the recurrent network with its sampled head on `cost` (the engine:
+    losses Blackout / CCE over the sampled columns / BPR / TOP1 / BPRelu / lin, rnn_cluster.py:151-180), and the cluster head
+    -- selection weights and the item / cluster repartition -- on `cost_clusters` (engine.ClusterHead, csrc/sbr_cluster.hip),
+    each with its own updater state (:277-285).  Host logic as in the reference: filename grammar, batch packing with the cluster
+    samples and the growing scale, the per-user test function and its nine metrics, hard clusters for top_k_recommendations,
+    checkpoints with the two cluster arrays appended."""
+
+    ENGINE_LOSS = {"CCE": "SCCE", "Blackout": "Blackout", "BPR": "BPR", "TOP1": "TOP1", "BPRelu": "BPRelu", "lin": "lin"}
+
+    def __init__(self, n_clusters=10, loss="Blackout", cluster_type="mix", sampling=100, cluster_sampling=-1, sampling_bias=0.0,
+                 predict_with_clusters=True, cluster_selection_noise=0.0, init_scale=1.0, scale_growing_rate=1.0, max_scale=50, **kwargs):
+        super(RNNCluster, self).__init__(**kwargs)
+        self.n_clusters = n_clusters
+        self.init_scale = np.float64(init_scale)                       # np.cast[floatX]: the filename prints them as floats
+        self.effective_scale = np.float64(init_scale)
+        self.scale_growing_rate = np.float64(scale_growing_rate)
+        self.max_scale = np.float64(max_scale)
+        self.cluster_type, self.sampling_bias, self.loss = cluster_type, sampling_bias, loss
+        self.cluster_selection_noise = cluster_selection_noise
+        self.predict_with_clusters = predict_with_clusters
+        if loss not in self.ENGINE_LOSS:
+            raise ValueError("Unknown cluster loss")                   # rnn_cluster.py:101
+        self.n_samples, self.n_cluster_samples = int(sampling), int(cluster_sampling)
+        self.diversity_bias = 0.0
+        self.name = "RNN Cluster with categorical cross entropy"
+        self.metrics = {"recall": {"direction": 1}, "cluster_recall": {"direction": 1}, "sps": {"direction": 1},
+                        "cluster_sps": {"direction": 1}, "ignored_items": {"direction": -1}, "assr": {"direction": 1},
+                        "cluster_use": {"direction": 1}, "cluster_use_std": {"direction": -1}, "cluster_size": {"direction": 1}}
+        self.head = None
+
+    # ------------------------------------------------------------------ construction
+    def _engine_kwargs(self):
+        return dict(loss=self.ENGINE_LOSS[self.loss], n_samples=self.n_samples)
+
+    def prepare_model(self, dataset):
+        from .engine import ClusterHead
+        super(RNNCluster, self).prepare_model(dataset)
+        kw = self.updater.engine_kwargs()
+        self.head = ClusterHead(self.engine, self.n_clusters, self.cluster_type, loss=self.ENGINE_LOSS[self.loss],
+                                max_samples=max(self.n_samples, self.n_cluster_samples, 1), scale=float(self.effective_scale),
+                                noise_std=float(self.cluster_selection_noise), seed=np.random.randint(1, 2147462579), **kw)
+        H = self.head.n_hidden
+        # cluster_selection_layer: DenseLayer(b=None), W GlorotUniform [3P]; cluster_repartition: 0.1 * randn (rnn_cluster.py:182, :239)
+        lim = np.sqrt(6.0 / (H + self.n_clusters))
+        self.head.set_params(self._create_ini_clusters(), np.random.uniform(-lim, lim, size=(H, self.n_clusters)).astype(np.float32))
+
+    def _create_ini_clusters(self):
+        return (0.1 * np.random.randn(self.n_items, self.n_clusters)).astype(np.float32)
+
+    def _get_model_filename(self, epochs):
+        filename = "rnn_clusters" + str(self.n_clusters) + "_sc" + str(self.init_scale)
+        if self.scale_growing_rate != 1.0:
+            filename += "-" + str(self.scale_growing_rate) + "-" + str(self.max_scale)
+        filename += "_"
+        if self.sampling_bias > 0.0:
+            filename += "p" + str(self.sampling_bias)
+        filename += "s" + str(self.n_samples)
+        if self.n_cluster_samples > 0:
+            filename += "_"
+            if self.sampling_bias > 0.0:
+                filename += "p" + str(self.sampling_bias)
+            filename += "cs" + str(self.n_cluster_samples)
+        if self.cluster_type == "softmax":
+            filename += "_softmax"
+        elif self.cluster_type == "mix":
+            filename += "_mix"
+        if self.cluster_selection_noise > 0.0:
+            filename += "_n" + str(self.cluster_selection_noise)
+        filename += "_c" + self.loss
+        return filename + "_" + self._common_filename(epochs)
+
+    # ------------------------------------------------------------------ batches (rnn_cluster.py:354-407)
+    def _popularity_sample(self):
+        if not hasattr(self, "_cumsum"):
+            self._cumsum = np.cumsum(np.power(self.dataset.item_popularity, self.sampling_bias))
+        return bisect(self._cumsum, random.uniform(0, self._cumsum[-1]))
+
+    def _prepare_input(self, sequences):
+        """(X, mask, Y, samples, cluster_samples, exclude); `exclude` (B, N) -- unused by the train function, derived from X
+        on the device for the test path -- is None.  The scale of the softmax / sigmoid grows with the epochs (:395-400)."""
+        X, mask, Y, _ = self._pack(sequences)
+        if self.sampling_bias > 0.0:
+            samples = np.array([self._popularity_sample() for _ in range(self.n_samples)], dtype=np.int32)
+            if self.n_cluster_samples > 0:
+                cluster_samples = np.array([self._popularity_sample() for _ in range(self.n_cluster_samples)], dtype=np.int32)
+            else:
+                cluster_samples = samples
+        else:
+            samples = np.random.choice(self.n_items, self.n_samples).astype(np.int32)
+            if self.n_cluster_samples > 0:
+                cluster_samples = np.random.choice(self.n_items, self.n_cluster_samples).astype(np.int32)
+            else:
+                cluster_samples = samples
+        if not hasattr(self, "_last_epoch"):
+            self._last_epoch = self.dataset.training_set.epochs
+        elif self.dataset.training_set.epochs > self._last_epoch + 1 and self.scale_growing_rate != 1.0:
+            self.effective_scale *= self.scale_growing_rate ** int(self.dataset.training_set.epochs - self._last_epoch)
+            self._last_epoch += int(self.dataset.training_set.epochs - self._last_epoch)
+            print("New scale: ", self.effective_scale)
+            self.head.set_scale(float(self.effective_scale))
+        return (X, mask, Y, samples, cluster_samples, None)
+
+    def _native_batch_builder(self, dataset):
+        return None          # the cluster samples and the growing scale are host state: the reference-style generator feeds this model
+
+    # ------------------------------------------------------------------ the compiled-function seam
+    def train_function(self, X, mask, target, samples, cluster_samples, exclude=None):
+        """cost = train_function(X, mask, target, samples, cluster_samples, exclude) (rnn_cluster.py:287): both models step, the
+        recurrent network's cost comes back"""
+        self.engine.set_batch(X, mask, target, samples, np.ones(len(target), dtype=np.float32))
+        cost = self.engine.train_step(sync=True)
+        self.head.forward_backward(target, cluster_samples, read_cost=False)      # on the user representations of that step's forward
+        self.head.apply_update()
+        return cost
+
+    def _ranked(self, scores, k):
+        return np.argpartition(-scores, range(k), axis=-1)[..., :k]
+
+    def test_function(self, theano_inputs, k=10):
+        """(ids without clusters, ids inside the selected cluster, the cluster, items in it) for the single row
+        (rnn_cluster.py:327-352): softmax scores, times the hard membership of the row's cluster, viewed items zeroed"""
+        X, mask = theano_inputs[0], theano_inputs[1]
+        s1 = self.engine.test_probabilities(X, mask)
+        rows = s1.shape[0]
+        csel = self.head.select(rows)
+        used = self.head.hard_clusters()[:, csel].T
+        s2 = s1 * used
+        if self.interactions_are_unique:
+            for b in range(rows):
+                seen = X[b, :int(mask[b].sum()), 0]
+                s1[b, seen] = 0.0; s2[b, seen] = 0.0
+        return self._ranked(s1, k)[0], self._ranked(s2, k)[0], int(csel[0]), float(used[0].sum())
+
+    def _compute_validation_metrics(self, metrics):
+        from .data import Evaluator
+        clusters = np.zeros(self.n_clusters, dtype="int")
+        used_items = []
+        ev, ev_clusters = Evaluator(self.dataset, k=10), Evaluator(self.dataset, k=10)
+        for batch, goal in self._gen_mini_batch(self.dataset.validation_set(epochs=1), test=True):
+            pred1, pred2, cl, n_used = self.test_function(batch)
+            ev.add_instance(goal, pred1)
+            ev_clusters.add_instance(goal, pred2)
+            clusters[cl] += 1
+            used_items.append(n_used)
+        R = self.head.get_params()[0]
+        if self.cluster_type == "softmax":
+            ignored_items = 0
+            cluster_size = np.histogram(R.argmax(axis=1), bins=range(self.n_clusters + 1))[0].tolist()
+        elif self.cluster_type == "mix":
+            ignored_items = 0
+            sig_clusters = R > 0.0
+            sig_clusters[np.arange(self.n_items), R.argmax(axis=1)] = True
+            cluster_size = sig_clusters.sum(axis=0)
+        else:
+            ignored_items = (R.max(axis=1) < 0.0).sum()
+            cluster_size = (R > 0.0).sum(axis=0)
+        metrics["recall"].append(ev.average_recall())
+        metrics["cluster_recall"].append(ev_clusters.average_recall())
+        metrics["sps"].append(ev.sps())
+        metrics["cluster_sps"].append(ev_clusters.sps())
+        metrics["assr"].append(self.n_items / np.mean(used_items))
+        metrics["ignored_items"].append(ignored_items)
+        metrics["cluster_use"].append(clusters)
+        metrics["cluster_use_std"].append(np.std(clusters))
+        metrics["cluster_size"].append(cluster_size)
+        return metrics
+
+    def _print_progress(self, iterations, epochs, start_time, train_costs, metrics, validation_metrics):
+        print(self.name, iterations, "batchs, ", epochs, " epochs in", time() - start_time, "s")
+        print("Last train cost : ", train_costs[-1])
+        for m in self.metrics.keys():
+            print(m, ": ", metrics[m][-1])
+            if m in validation_metrics:
+                print("Best ", m, ": ", max(np.array(metrics[m]) * self.metrics[m]["direction"]) * self.metrics[m]["direction"])
+        print("-----------------")
+        print(iterations, epochs, time() - start_time, train_costs[-1], metrics["sps"][-1], metrics["cluster_sps"][-1],
+              metrics["recall"][-1], metrics["cluster_recall"][-1], metrics["assr"][-1], metrics["ignored_items"][-1],
+              metrics["cluster_use_std"][-1], file=sys.stderr)
+
+    # ------------------------------------------------------------------ recommendations (rnn_cluster.py:440-497)
+    def prepare_tests(self):
+        """Take the soft clustering and make actual clusters (rnn_cluster.py:440-466)."""
+        membership = self.head.get_params()[0]
+        params = self.engine.get_all_param_values()
+        item_embeddings, item_bias = params[-2], params[-1]
+        pos = membership > 0
+        best = np.argmax(np.where(np.arange(self.n_clusters)[None, :] == 0, membership, np.where(pos, -np.inf, membership)), axis=1)
+        # (:447-458: an item joins every cluster whose membership is positive; one with none joins the cluster of its largest
+        # non-positive membership -- the scan starts from cluster 0's value and only a strictly larger one replaces it)
+        self.clusters = []
+        none = ~pos.any(axis=1)
+        for j in range(self.n_clusters):
+            self.clusters.append(np.where(pos[:, j] | (none & (best == j)))[0])
+        self.clusters_reverse_index = [{c[j]: j for j in range(len(c))} for c in self.clusters]
+        self.clusters_embeddings = [item_embeddings[:, c] for c in self.clusters]
+        self.clusters_bias = [item_bias[c] for c in self.clusters]
+
+    def predict_function(self, sequence, mask, k, exclude):
+        """(top-k ids, number of items scored): inside the user's cluster, or over the whole catalogue with --ignore_clusters
+        (rnn_cluster.py:302-325)"""
+        self.engine.set_batch(sequence, mask)
+        self.engine.forward()
+        Bp = (self.engine.batch_size + 15) // 16 * 16
+        hl = self.engine.debug_buffer("h_last").reshape(Bp, -1)
+        H = self.recurrent_layer.layers[-1]
+        u = np.concatenate([hl[0, :H], hl[0, hl.shape[1] // 2:hl.shape[1] // 2 + H]]) if self.recurrent_layer.bidirectional else hl[0, :H]
+        if self.predict_with_clusters:
+            if not hasattr(self, "clusters"):
+                self.prepare_tests()
+            c = int(self.head.select(1)[0])
+            scores = u.dot(self.clusters_embeddings[c]) + self.clusters_bias[c]
+            idx = [self.clusters_reverse_index[c][i] for i in exclude if i in self.clusters_reverse_index[c]]
+            scores[idx] = -np.inf
+            effective_k = min(k, len(self.clusters[c]))
+            return list(self.clusters[c][np.argpartition(-scores, range(effective_k))[:effective_k]]), len(self.clusters[c])
+        params = self.engine.get_all_param_values()
+        scores = u.dot(params[-2]) + params[-1]
+        scores[exclude] = -np.inf
+        return list(np.argpartition(-scores, range(k))[:k]), self.n_items
+
+    def top_k_recommendations(self, sequence, user_id=None, k=10, exclude=None):
+        if exclude is None:
+            exclude = []
+        seq = sequence[-min(self.max_length, len(sequence)):]
+        X = np.zeros((1, self.max_length, self._input_size()), dtype=np.int32)
+        X[0, :len(seq), :] = np.array([self._get_features(x, user_id) for x in seq], dtype=np.int32)
+        mask = np.zeros((1, self.max_length), dtype=np.float32)
+        mask[0, :len(seq)] = 1
+        should_exclude = [i[0] for i in sequence] if self.interactions_are_unique else []
+        should_exclude.extend(exclude)
+        return self.predict_function(X, mask, k, should_exclude)
+
+    # ------------------------------------------------------------------ checkpoints (rnn_cluster.py:510-537)
+    def save(self, filename):
+        print("Save model in " + filename)
+        d = os.path.dirname(filename)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        R, Wc = self.head.get_params()
+        param = self.engine.get_all_param_values()
+        param.append(R)
+        param.append([Wc])
+        with open(filename, "wb") as f:
+            pickle.dump(param, f, protocol=2)
+
+    def load(self, filename):
+        with open(filename, "rb") as f:
+            param = pickle.load(f, encoding="latin1")
+        self.engine.set_all_param_values([np.asarray(i, dtype=np.float32) for i in param[:-2]])
+        self.head.set_params(np.asarray(param[-2], dtype=np.float32), np.asarray(param[-1][0], dtype=np.float32))
+        self.prepare_tests()

@@ -263,6 +263,20 @@ def predictor_command_parser(parser):
     parser.add_argument("--max_length", help="Maximum length of sequences during training (for RNNs)", default=30, type=int)
     parser.add_argument("--repeated_interactions", help="The model can recommend items with which the user already "
                         "interacted", action="store_true")
+    # RNNCluster (command_parser.py:70-77)
+    parser.add_argument("--c_sampling", help="Number of sample for the clustering loss. If unset, the same samples are used for the "
+                        "recommendation loss and for the clustering loss.", default=-1, type=int)
+    parser.add_argument("--ignore_clusters", help="Don't use clusters during test. Useful to observe the influence of clustering",
+                        action="store_true")
+    parser.add_argument("--clusters", help="Number of clusters. If unset, no clustering is used", default=-1, type=int)
+    parser.add_argument("--init_scale", help="Initial scale of the softmax and sigmoid in the clustering method.", default=1., type=float)
+    parser.add_argument("--scale_growing_rate", help="Rate of the geometric growth of the sigmoid/softmax scale in the clustering method.",
+                        default=1., type=float)
+    parser.add_argument("--max_scale", help="Max scale of the softmax and sigmoid in the clustering method.", default=50, type=float)
+    parser.add_argument("--csn", help="Cluster selection noise", default=0., type=float)
+    parser.add_argument("--cluster_type", choices=["softmax", "mix", "sigmoid"], help="Type of clusters. Softmax puts every item in 1 "
+                        "and only 1 cluster. Sigmoid allow puts items in 0 to n clusters. Mix puts items in 1 to n clusters.",
+                        default="mix", type=str)
     update_manager_command_parser(parser)
     recurrent_layers_command_parser(parser)
     sequence_noise_command_parser(parser)
@@ -302,7 +316,7 @@ def command_parser(*sub_command_parser, argv=None):    # helpers/command_parser.
 
 def get_predictor(args):
     """helpers/command_parser.py:84-125, RNN branch (:113-123)."""
-    from .models import RNNOneHot, RNNSampling, RNNMargin
+    from .models import RNNOneHot, RNNSampling, RNNMargin, RNNCluster
     if args.mf or args.uf:
         raise ValueError("--mf/--uf need feature tables the reference never loads (rnn_base.py:27-29): unsupported")
     common = dict(interactions_are_unique=(not args.repeated_interactions), max_length=args.max_length,
@@ -310,6 +324,11 @@ def get_predictor(args):
                   sequence_noise=get_sequence_noise(args), recurrent_layer=get_recurrent_layers(args),
                   use_ratings_features=args.rf, use_movies_features=args.mf, use_users_features=args.uf,
                   batch_size=args.batch_size)
+    if args.clusters > 0:                                               # command_parser.py:114-115
+        return RNNCluster(cluster_selection_noise=args.csn, loss=args.loss, predict_with_clusters=(not args.ignore_clusters),
+                          sampling_bias=args.sampling_bias, sampling=args.sampling, cluster_sampling=args.c_sampling,
+                          init_scale=args.init_scale, scale_growing_rate=args.scale_growing_rate, max_scale=args.max_scale,
+                          n_clusters=args.clusters, cluster_type=args.cluster_type, **common)
     if args.loss == "CCE":
         return RNNOneHot(diversity_bias=args.diversity_bias, regularization=args.regularization, **common)
     if args.loss in ("BPR", "TOP1", "Blackout"):

@@ -46,7 +46,9 @@ def rel_err(a, b, floor=1e-12):
 
 
 def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=False, scale=None, popscale=1.0, emb=0, bi=False,
-               zipf=False):
+               zipf=False, clusters=None):
+    """clusters: dict(n=, type="mix" | "softmax" | "sigmoid", scale=, c_sampling=0) -> an RNNCluster case (rnn_cluster.py): the
+    parameter list gains the repartition R (N, n) and the selection weights Wc (H_top, n), the batch its cluster samples"""
     if scale is None:      # a tanh-only cell with wide layers is chaotic at large weights: keep it well conditioned
         scale = 0.3 if (cell != "Vanilla" or max(layers) <= 64) else 0.05
     rng = np.random.default_rng(seed)
@@ -57,6 +59,16 @@ def build_case(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, full=Fals
     batch = make_batch(rng, B, T, N, S=S, F=F, n_in0=N + n_opt, full=full, zipf=zipf)
     batch["pop"] = (batch["pop"] * popscale).astype(np.float32)
     cfg = dict(cell=cell, layers=list(layers), loss=loss, regularization=0.0, embedding=emb, bidirectional=bi)
+    if clusters:
+        C = int(clusters["n"])
+        Htop = layers[-1] * (2 if bi else 1)
+        R = (0.1 * rng.standard_normal((N, C)) + rng.normal(0, 0.3, size=(N, C))).astype(np.float32).astype(np.float64)
+        Wc = rng.normal(0, 0.4, size=(Htop, C)).astype(np.float32).astype(np.float64)
+        params = params + [R, Wc]
+        ncs = int(clusters.get("c_sampling", 0) or 0)
+        batch["cluster_samples"] = rng.integers(0, N, size=ncs).astype(np.int32) if ncs > 0 else None
+        batch["pop"] = np.ones(B, dtype=np.float32)                 # RNNCluster's cost has no popularity division
+        cfg["clusters"] = dict(n=C, type=clusters.get("type", "mix"), scale=float(clusters.get("scale", 1.0)), c_sampling=ncs)
     if loss in O.MARGIN_LOSSES:      # RNNMargin: S = --n_targets; 1 .. S positives per row (-1 = none), some repeated / also in the input
         NT = max(S, 1)
         tg = -np.ones((B, NT), dtype=np.int32)

@@ -35,7 +35,7 @@ def check_common(d, steps=6, warmup=2):
 
 
 def test_default_config_line_without_cpu_leg():
-    d = run("--no-cpu-baseline")
+    d = run("--no-cpu-baseline", "--no-pmc", "--sustained-seconds", "0.2", "--loop-iters", "0")
     check_common(d)
     assert "cpu_baseline" not in d and d["config"]["workload"].startswith("c2:")
     r = d["roofline"]
@@ -58,12 +58,12 @@ def test_default_config_line_without_cpu_leg():
 def test_traffic_comes_only_from_a_counter_file(tmp_path):
     f = tmp_path / "pmc.json"
     f.write_text(json.dumps({"kernels": {"void rec_bwd_x6p<1>(RecArgs)": {"hbm_bytes_per_launch": 123456}}}))
-    d = run("--no-cpu-baseline", "--repeats", "1", "--pmc-json", str(f))
+    d = run("--no-cpu-baseline", "--repeats", "1", "--pmc-json", str(f), "--sustained-seconds", "0", "--loop-iters", "0")
     assert d["roofline"]["traffic"] == 123456 and d["roofline"]["traffic_source"] and d["repeats"]["n"] == 1
 
 
 def test_cpu_baseline_leg_is_bounded_and_reported():
-    d = run("--config", "c1", "--cpu-steps", "1", "--cpu-seconds", "5")
+    d = run("--config", "c1", "--cpu-steps", "1", "--cpu-seconds", "5", "--no-pmc", "--sustained-seconds", "0")
     check_common(d)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "user-sequences/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
@@ -77,7 +77,7 @@ def test_gpus_2_starts_its_own_ranks():
     # On the one-GPU test box the two ranks share the device, which RCCL refuses: gloo carries the collectives there
     # (--dp-backend gloo); everything else -- rendezvous, row shards, barrier + max-over-ranks timing, rank 0's one line -- is
     # the path the 8-GPU run takes.
-    d = run("--gpus", "2", "--dp-backend", "gloo", "--no-cpu-baseline", "--repeats", "2")
+    d = run("--gpus", "2", "--dp-backend", "gloo", "--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0")
     assert (d["n_gpus"], d["steps"], d["warmup"]) == (2, 6, 2) and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
     assert d["value"] == pytest.approx(512 / (d["ms_per_step"] * 1e-3), rel=2e-3)
@@ -89,7 +89,23 @@ def test_gpus_2_starts_its_own_ranks():
 
 def test_one_rank_through_the_data_parallel_step():
     # --force-dp: the phase-by-phase step with its collectives (RCCL, one rank) instead of the single-call step
-    d = run("--force-dp", "--no-cpu-baseline", "--repeats", "2")
+    d = run("--force-dp", "--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0")
     check_common(d)
     p = d["data_parallel"]
     assert p["ranks"] == 1 and p["backend"] == "nccl"
+
+
+def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_line():
+    # what the driver's plain `python bench.py` carries besides the timed regions: HBM bytes of the dominant kernel from the
+    # command's own two rocprofv3 --pmc child passes (never a stored number), the whole step's traffic against its algorithmic
+    # bytes, one region of >= 2 s, and the end-to-end training loop (device batch builder + lagged cost read-back)
+    d = run("--no-cpu-baseline")
+    check_common(d)
+    r = d["roofline"]
+    assert r["traffic"] > 1e8 and "rocprofv3 --pmc" in r["traffic_source"] and 0.8 < r["traffic_over_algorithmic"] < 1.5
+    t = d["hbm_traffic"]
+    assert t["bytes_per_step"] > t["algorithmic_bytes_per_step"] > 1e8 and t["ratio"] == pytest.approx(t["bytes_per_step"] / t["algorithmic_bytes_per_step"], rel=1e-2)
+    s_ = d["sustained"]
+    assert s_["seconds"] >= 1.5 and s_["steps"] >= 1000 and s_["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=0.1)
+    tl = d["train_loop"]
+    assert tl["iterations"] == 1000 and tl["ms_per_iteration"] < 2 * d["ms_per_step"] and tl["value"] > 2e5

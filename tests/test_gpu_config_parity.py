@@ -26,7 +26,7 @@ def check(r, steps, tol_g=1e-5, tol_h=1e-5, rows=None):
     assert r["param_roundtrip"] == 0.0
     assert r["h_last"] <= tol_h, r
     assert r["cost"] <= 1e-5, r
-    assert r["grad_worst"] <= tol_g, grads
+    assert r["grad_worst"] <= tol_g, {k: v for k, v in grads.items() if v > tol_g}
     PU.params_ok(r, steps, bar=1e-3, tol_g=tol_g)
     assert r["predict_scores"] <= 1e-4, r
     assert r["topk_mismatch"] == 0, r
@@ -87,10 +87,15 @@ def test_c5_shape_two_layers_512_sampled():
 def test_c3_c4_full_length_chains_under_full_load():
     # the cluster kernels' cross-workgroup exchange (256 resident workgroups, sbr_rec_cl.hip) over T = 200 dependent steps at
     # B = 256 -- the configurations as benched, against the dense float64 oracle (the shorter cases above cover the heads)
-    r = PU.compare_step("LSTM", [256], "CCE", N=26744, B=256, T=200, full=True, zipf=True, steps=1, k=10, gap=GAP, scale=0.03, seed=27)
+    # grad_floor: 200 steps from the loss the initial states' gradients of these LSTMs have decayed to ~2e-11 -- sums over the 256
+    # rows of per-row terms of ~1e-13, where the fp16 split of the chains' gradient operand has reached its absolute floor of
+    # 6e-14 per element.  They come out 2e-12 off (measured); arrays that small are held to
+    # tol_g x 4e-7 = 4e-12 absolute, the bound test_overlapped_step_tail[LSTM] uses for the same effect
+    r = PU.compare_step("LSTM", [256], "CCE", N=26744, B=256, T=200, full=True, zipf=True, steps=1, k=10, gap=GAP, scale=0.03, seed=27,
+                        grad_floor=4e-7)
     check(r, 1, rows=256)
     r = PU.compare_step("LSTM", [256], "Blackout", N=100000, B=256, T=200, S=32, full=True, zipf=True, steps=1, k=10, gap=GAP,
-                        scale=0.03, seed=28, updater="adagrad", tweak=_plant_duplicate_cells)
+                        scale=0.03, seed=28, updater="adagrad", tweak=_plant_duplicate_cells, grad_floor=4e-7)
     check(r, 1, rows=256)
 
 

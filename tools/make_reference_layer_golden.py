@@ -60,6 +60,17 @@ CASES = {
     "vanilla8_hinge_pb": ("Vanilla", 8, "hinge", 30, 5, 6, 2, 1, 0, False, ["--pb", "--min_access", "0.1"]),
     "gru128_logsig": ("GRU", 128, "logsig", 30, 6, 8, 2, 1, 0, False, []),
 }
+# RNNCluster (rnn_cluster.py: --clusters C): name: (cell, hidden, loss, N, B, T, S, cluster dict, extra argv).  Recorded: both
+# costs, d cost / d every net parameter, d cost_clusters / d (Wc, R), the selection activations, the hard clusters, both test scores
+CLUSTER_CASES = {
+    "cl_gru12_cce_mix": ("GRU", 12, "CCE", 40, 6, 7, 5, dict(n=4, type="mix", scale=1.0), []),
+    "cl_lstm10_blackout_softmax": ("LSTM", 10, "Blackout", 40, 6, 7, 5, dict(n=3, type="softmax", scale=2.5), []),
+    "cl_gru10_bpr_sigmoid_cs": ("GRU", 10, "BPR", 40, 6, 7, 5, dict(n=5, type="sigmoid", scale=1.5, c_sampling=7), []),
+    "cl_vanilla8_top1_mix": ("Vanilla", 8, "TOP1", 30, 5, 6, 4, dict(n=3, type="mix", scale=0.7), ["--repeated_interactions"]),
+    "cl_gru8_bprelu_softmax": ("GRU", 8, "BPRelu", 30, 5, 6, 4, dict(n=4, type="softmax", scale=1.0), []),
+    "cl_lstm8_lin_mix_cs": ("LSTM", 8, "lin", 30, 5, 6, 4, dict(n=2, type="mix", scale=1.2, c_sampling=3), []),
+    "cl_gru128_cce_mix": ("GRU", 128, "CCE", 30, 6, 8, 4, dict(n=6, type="mix", scale=1.0), []),
+}
 MARGIN = ("hinge", "logit", "logsig")
 POPSCALE = {"gru12_cce_clip": 3e-5, "lstm8_cce_clip": 3e-5, "vanilla8_cce_clip": 3e-5, "gru8_bpr_clip_bi": 1e-5}
 
@@ -175,6 +186,55 @@ def main():
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
         print("%-20s cost %.6f  |g|max %.3e  %d params  clip changes grads by %.2f" % (
             name, float(cost), max(float(g.abs().max()) for g in grads), len(params), clip_changes))
+
+    for name, (cell, H, loss, N, B, T, S, cl, extra) in CLUSTER_CASES.items():
+        seed = sum(map(ord, name))
+        params, cfg, batch = PU.build_case(cell, [H], loss, N, B, T, S=S, seed=seed, clusters=cl, scale=0.1 if H >= 128 else None)
+        ncs = cfg["clusters"]["c_sampling"]
+        sys.argv = ["train.py", "-d", "/tmp/x/", "-b", str(B), "--max_length", str(T), "--r_t", cell, "--r_l", str(H), "--loss", loss,
+                    "--sampling", str(S), "--clusters", str(cl["n"]), "--cluster_type", cl["type"], "--init_scale", str(cl["scale"])] + \
+                   (["--c_sampling", str(ncs)] if ncs else []) + extra
+        args = cp.command_parser(cp.predictor_command_parser, reftrain.training_command_parser, cp.early_stopping_command_parser)
+        p = cp.get_predictor(args)
+        assert type(p).__name__ == "RNNCluster"
+        exclude = np.zeros((B, N))
+        for b in range(B):
+            exclude[b, batch["X"][b, :int(batch["mask"][b].sum()), 0]] = 1
+        csm = batch["cluster_samples"] if ncs else batch["samples"]
+        feed = dict(inputs=[batch["X"], batch["mask"].astype(np.float64)], target_output=batch["target"], samples=batch["samples"],
+                    cluster_samples=csm, excluded_items=exclude)
+        net, R0, Wc0 = params[:-2], params[-2], params[-1]
+        E.new_network(feed, net + [Wc0])                 # creation order: the net, out.W, out.b, then the selection layer's W
+        p._create_ini_clusters = lambda: R0               # (the reference draws 0.1 * randn here, rnn_cluster.py:182)
+        p._prepare_networks(N)
+        assert E.leftovers() == 0
+        all_params = lasagne.layers.get_all_params(p.l_out, trainable=True)        # rnn_cluster.py:278
+        sel = p.cluster_selection_layer.get_params(trainable=True)                 # :282-283
+        assert len(sel) == 1 and tuple(sel[0].shape) == Wc0.shape                   # b=None: a selection layer without bias
+        assert [tuple(q.shape) for q in all_params] == [q.shape for q in net]
+        grads = theano.grad(p.cost, all_params)
+        gWc, gR = theano.grad(p.cost_clusters, sel + [p.cluster_repartition])
+        h_last = lasagne.layers.get_output(p.user_representation_layer, deterministic=True)
+        z = lasagne.layers.get_output(p.cluster_selection_layer, deterministic=True)
+        hard = p._get_hard_clusters()
+        s1 = theano.tensor.nnet.softmax(lasagne.layers.get_output(p.l_out, deterministic=True))      # :332
+        used = hard[:, z.argmax(dim=1)].T                                                           # :334-336, for every row
+        s2 = s1 * used
+        if p.interactions_are_unique:
+            s1 = s1 * (1 - theano.tensor.fmatrix("excluded_items")); s2 = s2 * (1 - theano.tensor.fmatrix("excluded_items"))
+        out = dict(cell=cell, layers=np.array([H]), loss=loss, N=N, B=B, T=T, S=S, n_clusters=cl["n"], cluster_type=cl["type"],
+                   scale=float(cl["scale"]), c_sampling=ncs, X=batch["X"], mask=batch["mask"], target=batch["target"],
+                   samples=batch["samples"], cluster_samples=csm, cost=float(p.cost), cost_clusters=float(p.cost_clusters),
+                   h_last=h_last.detach().numpy(), selection=z.detach().numpy(), hard=hard.detach().numpy(),
+                   test_scores=s1.detach().numpy(), test_scores_clusters=s2.detach().numpy(), unique=int(p.interactions_are_unique),
+                   n_params=len(params), names=np.array([q.pname for q in all_params] + ["cluster_repartition", "cluster_selection.W"]),
+                   model_file=p._get_model_filename(1.0))
+        for i, (q, g) in enumerate(zip(params, list(grads) + [gR, gWc])):
+            out["p%d" % i] = q.astype(np.float32)
+            out["g%d" % i] = g.detach().numpy()
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+        print("%-28s cost %.6f  cost_clusters %.6f  |g|max %.3e  %d params" % (
+            name, float(p.cost), float(p.cost_clusters), max(float(g.abs().max()) for g in grads), len(params)))
 
 
 if __name__ == "__main__":

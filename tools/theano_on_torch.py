@@ -73,6 +73,9 @@ class TT(torch.Tensor):
                 items[d] = torch.as_tensor(np.asarray(it), dtype=torch.int64)
         return torch.Tensor.__getitem__(t, tuple(items))
 
+    def dot(self, other):                            # Theano's x.dot(y) is a matrix product for 2-D operands
+        return torch.matmul(self, other).as_subclass(TT)
+
     def __iadd__(self, other):
         return self + other
 
@@ -251,14 +254,18 @@ def _identity(x):
     return x
 
 
+_DEFAULT = object()
+
+
 class DenseLayer(Layer):
-    def __init__(self, incoming, num_units, W=None, b=None, nonlinearity=Inert, **kwargs):
+    def __init__(self, incoming, num_units, W=None, b=_DEFAULT, nonlinearity=Inert, **kwargs):
         super(DenseLayer, self).__init__(incoming, **kwargs)
         self.nonlinearity = _identity if nonlinearity is None else nonlinearity
         self.num_units = num_units
         num_inputs = int(np.prod(self.input_shape[1:]))
         self.W = self.add_param(W if W is not None else GlorotUniform(), (num_inputs, num_units), name="W")
-        self.b = self.add_param(b if b is not None else Constant(0.0), (num_units,), name="b", regularizable=False)
+        # Lasagne: b omitted = Constant(0.), b=None = a layer without bias (rnn_cluster.py:239)
+        self.b = None if b is None else self.add_param(Constant(0.0) if b is _DEFAULT else b, (num_units,), name="b", regularizable=False)
 
     def get_output_shape_for(self, input_shape):
         return (input_shape[0], self.num_units)
@@ -399,8 +406,15 @@ def install(floatX="float64"):
             pass
     sys.meta_path.insert(0, Finder())
 
-    theano = _mod("theano", config=types.SimpleNamespace(floatX=floatX), scan=scan, grad=grad,
-                  shared=lambda value, **k: tt(value))
+    def shared(value, **k):                          # a shared variable: a leaf that theano.grad can differentiate with respect to
+        a = np.asarray(value)
+        if a.dtype.kind != "f":
+            return tt(a)
+        leaf = torch.tensor(a.astype(np.float64), dtype=torch.float64, requires_grad=True)
+        v = leaf.as_subclass(TT)
+        v.leaf, v.pname = leaf, k.get("name")
+        return v
+    theano = _mod("theano", config=types.SimpleNamespace(floatX=floatX), scan=scan, grad=grad, shared=shared)
     _mod("theano.gradient", grad_clip=lambda x, lo, hi: _GradClip.apply(x, lo, hi).as_subclass(TT), grad=grad)
     T = _mod("theano.tensor",
              dot=lambda a, b: torch.matmul(a, b).as_subclass(TT),
@@ -419,7 +433,8 @@ def install(floatX="float64"):
     _mod("theano.tensor.shared_randomstreams", RandomStreams=RandomStreams)
 
     _mod("lasagne")
-    _mod("lasagne.nonlinearities", sigmoid=sigmoid, tanh=tanh, identity=_identity, softmax=_softmax, linear=_identity)
+    _mod("lasagne.nonlinearities", sigmoid=sigmoid, tanh=tanh, identity=_identity, softmax=_softmax, linear=_identity,
+         leaky_rectify=lambda x: torch.where(x > 0, x, 0.01 * x).as_subclass(TT))      # LeakyRectify(leakiness=0.01) [3P]
     _mod("lasagne.init", Normal=Normal, Constant=Constant, GlorotUniform=GlorotUniform)
     _mod("lasagne.random", get_rng=lambda: np.random.RandomState(1))
     _mod("lasagne.utils", unroll_scan=Inert)
