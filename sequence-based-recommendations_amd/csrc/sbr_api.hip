@@ -30,6 +30,8 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     if (cfg.cell < 0 || cfg.cell > 2) LFAIL("Unknown layer type %d", cfg.cell);                  // recurrent_layers.py:90
     if (cfg.loss < 0 || cfg.loss > SBR_LOSS_LIN) LFAIL("Unknown loss for the RNN model (%d)", cfg.loss);     // command_parser.py:123
     if (cfg.updater < 0 || cfg.updater > 4) LFAIL("Unknown update option %d", cfg.updater);       // update_manager.py:22
+    if ((cfg.flags & SBR_FLAG_BF16_PROJECTION) && (cfg.flags & SBR_FLAG_F32_MFMA))
+        LFAIL("SBR_FLAG_BF16_PROJECTION and SBR_FLAG_F32_MFMA contradict each other (bf16 inputs / exact f32 products for the output projection)");
     if (cfg.n_layers < 1 || cfg.n_layers > SBR_MAX_LAYERS) LFAIL("n_layers must be in [1,%d]", SBR_MAX_LAYERS);
     for (int l = 0; l < cfg.n_layers; ++l)
         if (cfg.layers[l] < 1 || cfg.layers[l] > 1024) LFAIL("layer %d size %d out of range [1,1024]", l, cfg.layers[l]);
@@ -162,7 +164,17 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     // heads, the rows of W_out^T / b_out.  Taken when a step cannot touch every row anyway (more rows than candidates) or
     // when the flag forces it; SBR_FLAG_DENSE_UPDATE keeps the dense Lasagne-style pass over everything.
     lay.n_sparse = 0; lay.a_at = 0; lay.n_at = 0; lay.adam_early_exit = 0;
-    if (!(cfg.flags & SBR_FLAG_DENSE_UPDATE)) {
+    // Adam's lazy replay walks a row's missed steps one by one and stops when the momentum term can no longer move the row -- at
+    // most SBR_ADAM_REPLAY_CAP steps (sbr_sparse.hip).  With beta1 so close to 1 that the momentum is still alive there
+    // (beta1^cap > 1e-9: beta1 > 0.9975) rows untouched for longer would lose the rest of their updates: such configurations keep
+    // the dense Lasagne-style pass (exact, only slower); forcing the sparse form for them is refused.
+    const bool adam_replay_unbounded = cfg.updater == SBR_UPD_ADAM && pow((double)cfg.beta1, 8190.0) > 1e-9;
+    if (adam_replay_unbounded && (cfg.flags & SBR_FLAG_SPARSE_UPDATE)) {
+        snprintf(buf, sizeof(buf), "row-sparse Adam steps need beta1 <= 0.9975 (beta1 = %g keeps a row's momentum alive beyond the replay cap)",
+                 (double)cfg.beta1);
+        err = buf; return SBR_EINVAL;
+    }
+    if (!(cfg.flags & SBR_FLAG_DENSE_UPDATE) && !adam_replay_unbounded) {
         const bool force = cfg.flags & SBR_FLAG_SPARSE_UPDATE;
         const int world = (lay.Bg + lay.B - 1) / lay.B;
         const long cand0 = (long)T * Bp * lay.F;
@@ -360,6 +372,16 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_TAIL_OVERLAP"); h->tail_overlap = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_TAIL_CHUNKS"); h->tail_chunks_max = e ? std::max(2, atoi(e)) : 8; }
     { const char* e = getenv("SBR_TAIL_PUBLISH_EVERY"); h->tail_pub_every = e ? std::max(1, atoi(e)) : 2; }
+    { const char* e = getenv("SBR_TAIL_SHORT_CHUNKS"); h->tail_short_chunks = e ? std::max(0, atoi(e)) : 3; }
+    // (every switch is read here, once per handle: a test that flips one between two engines of a process gets what it asked for)
+    { const char* e = getenv("SBR_TAIL_GEOM"); h->tail_geom = e ? atof(e) : 2.6; }
+    { const char* e = getenv("SBR_TAIL_FINAL"); h->tail_final = e ? atoi(e) : 0; }
+    { const char* e = getenv("SBR_TAIL_FUSE_SLABS"); h->tail_fuse_slabs = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_TAIL_SMALL_SLABS"); h->tail_small_slabs = e ? atoi(e) : 64; }
+    { const char* e = getenv("SBR_TAIL_SMALL_K"); h->tail_small_k = e ? std::max(32, atoi(e) / 32 * 32) : 128; }
+    { const char* e = getenv("SBR_FOLD_DH"); h->fold_dh = e ? atoi(e) != 0 : true; }
+    { const char* e = getenv("SBR_WGRAD_F16"); h->wgrad_f16 = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_WGRAD_X6_WGS"); h->wgrad_x6_wgs = e ? atoi(e) : 512; }
     h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr;
     h->step_open = false; h->tail_join_pending = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -642,7 +664,7 @@ static int tail_plan(sbr_handle* h, int* ch_out) {
     // default 2.6; <= 1: equal chunks) -- until a power exceeds the equal share of what is left, which the remaining chunks then
     // take: at T = 200 and eight chunks 1, 3, 7, 18, 42, 43, 43, 43 steps (the consumers still start after a fifth of the chain).
     // At most half of the chunks are small ones.
-    static const double geom = getenv("SBR_TAIL_GEOM") ? atof(getenv("SBR_TAIL_GEOM")) : 2.6;
+    const double geom = h->tail_geom;
     SbrTChunks& tc = h->tail_bounds;
     tc.n = nc;
     tc.lo[0] = 0;
@@ -824,23 +846,6 @@ extern "C" int sbr_forward(sbr_handle* h) {
                 SBR_LAUNCH(launch_sparse_catch_up_batch(s, sparse_rows(h, b), sparse_upd(h), h->bX, h->blen, y.T, y.Bp, y.F, (int)h->step_count));
     h->tail_nc = h->step_open ? tail_plan(h, &h->tail_ch) : 0;      // overlapped tail for this step? (never for predict / top-k)
     h->step_open = false;
-    h->tail_sorted = false;
-    if (h->tail_nc >= 2 && h->tail_overlap == 1) {
-        // Overlapped tail: the time-chunked sort of the batch's ids needs nothing but the batch, and the scatter-add consumer that
-        // waits behind it on the second side stream should be polling when the BPTT chain starts -- 45 us of sort behind the
-        // output phase left it a third of the chain behind, which it never made up (profiles/round3_e_timeline.txt: 37 us of
-        // scatter-add after the chain's end although the last time chunk is a single step).  So the sort runs now, beside the
-        // forward chain (192 idle CUs), for one event record in front of it.  SBR_TAIL_EARLY_SORT=0: behind the output phase.
-        static const int early = getenv("SBR_TAIL_EARLY_SORT") ? atoi(getenv("SBR_TAIL_EARLY_SORT")) : 1;
-        if (early) {
-            SBR_HIP(hipEventRecord(h->ev_fork, s));
-            SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
-            SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
-                                           (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
-                                           h->tail_ch, h->tail_nc, &h->tail_bounds));
-            h->tail_sorted = true;
-        }
-    }
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
@@ -929,10 +934,9 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             // overlapped tail: the time-chunked sort runs on the SECOND side stream, which consumes it (scatter-add beside the
             // chain); that stream is released by the same record as the first one
             SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_lg_rec, 0));
-            if (!h->tail_sorted)
-                SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
-                                               (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
-                                               h->tail_ch, h->tail_nc, &h->tail_bounds));
+            SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
+                                           (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
+                                           h->tail_ch, h->tail_nc, &h->tail_bounds));
         } else if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
             SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                            y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
@@ -969,7 +973,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         int keep = 0;
         bool fold = false;
         if (!sg && y.D == 1 && R == y.Bp && !simple_rec(h)) {
-            static const bool fold_on = getenv("SBR_FOLD_DH") ? atoi(getenv("SBR_FOLD_DH")) != 0 : true;
+            const bool fold_on = h->fold_dh;
             RecArgs ra = rec_args(h, y.L - 1);
             fold = fold_on && sbr_rec_x6p_ok(ra) && !sbr_rec_cluster_ok(ra);
         }
@@ -1071,10 +1075,10 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         const bool wg_gemm = (h->wgrad_x6 && !(y.cfg.flags & SBR_FLAG_F32_MFMA) && ly.Hp >= 96) || !(ly.Hp == 32 || ly.Hp == 64 || ly.Hp == 128);
         // fp16 x3 products for that GEMM: its operands are hidden states (|h| <= 1 behind tanh / sigmoid gates) and gradients
         // that have passed the clip at +-100 (scaled by 2^9 into fp16's range), see gemm_x6_kernel NP = 2
-        static const int wgf = getenv("SBR_WGRAD_F16") ? atoi(getenv("SBR_WGRAD_F16")) : 1;
+        const int wgf = h->wgrad_f16;
         const bool wg_f16 = wgf && !a.relu && y.cfg.grad_clip > 0.0f && y.cfg.grad_clip <= 100.0f;
         if (wg_gemm && nsl > 1) {
-            static const int wgs = getenv("SBR_WGRAD_X6_WGS") ? atoi(getenv("SBR_WGRAD_X6_WGS")) : 512;
+            const int wgs = h->wgrad_x6_wgs;
             nsl = std::max(1, std::min(nsl, wgs / (((ly.Hp + 127) / 128) * ((GHp + 127) / 128)) / nc));
         }
         // Tail of a single-layer step with one BPTT launch: the main stream keeps the longer branch (dW_hid GEMM + slab
@@ -1119,8 +1123,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             a.progress = words; a.prog_every = h->tail_pub_every; a.prog_epoch = h->prog_epoch;
             const int K = y.T * y.Bp;
             const int cap = (int)std::min<size_t>(256, y.ws2_floats / slab);
-            static const int env_small = getenv("SBR_TAIL_SMALL_SLABS") ? atoi(getenv("SBR_TAIL_SMALL_SLABS")) : 64;
-            static const int env_ksmall = getenv("SBR_TAIL_SMALL_K") ? std::max(32, atoi(getenv("SBR_TAIL_SMALL_K")) / 32 * 32) : 128;
+            const int env_small = h->tail_small_slabs, env_ksmall = h->tail_small_k;
             SbrPoll pl{words, nwaves, done, a.prog_epoch, y.Bp, a.fault, 0, env_ksmall};
             pl.n_small = std::max(0, std::min(std::min(env_small, cap / 2), K / pl.k_small));
             const int rest = K - pl.n_small * pl.k_small;
@@ -1147,20 +1150,16 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 }
                 SBR_LAUNCH(we);
             }
-            // (the scatter-add launch brings its own monitor of the chain's progress: its gate is the chain being resident, not the
-            // GEMM's monitor having started behind the output layer's gradient kernels on the other stream)
-            static const int scat_mon = getenv("SBR_TAIL_SCATTER_MONITOR") ? atoi(getenv("SBR_TAIL_SCATTER_MONITOR")) : 1;
-            if (scat_mon) SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, y.T, a.fault));
-            else SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
+            SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
             // The time chunk the chain completes LAST (chunk 0) is not left to the polling waves: each of them walks 32 sorted
             // entries, rounds of eight rows in flight and then its atomics -- 30 - 35 us behind the chain's end for the one chunk that
             // cannot start earlier (profiles/round3_c_timeline.txt).  It gets a launch of its own behind the polling one (same stream:
             // the read-modify-writes of its owned segments see the atomics of the earlier chunks complete), gated on the chain's last
             // progress word, one wave per 16 entries on the then idle chip.  SBR_TAIL_FINAL=0: the polling waves take chunk 0 too.
-            static const int tail_final = getenv("SBR_TAIL_FINAL") ? atoi(getenv("SBR_TAIL_FINAL")) : 0;
+            const int tail_final = h->tail_final;
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
-                                                  tail_final ? y.cfg.input_size : 0, &h->tail_bounds));
+                                                  tail_final ? y.cfg.input_size : 0, &h->tail_bounds, h->tail_short_chunks));
             if (tail_final) {
                 SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, 0, a.fault));
                 SBR_LAUNCH(launch_scatter_reduce(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
@@ -1170,7 +1169,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
             // single-call step: the slab reduction IS the W_hid update (one launch, one pass less behind the chain); phase-by-phase
             // callers (data parallel) need the reduced gradient
-            static const int fuse_slabs = getenv("SBR_TAIL_FUSE_SLABS") ? atoi(getenv("SBR_TAIL_FUSE_SLABS")) : 1;
+            const int fuse_slabs = h->tail_fuse_slabs;
             if (upd_here && fuse_slabs && ly.p_peep - ly.p_Whid == slab && (slab & 3) == 0) {
                 SBR_LAUNCH(launch_update_from_slabs(sd, y.cfg.updater, ws2, pl.n_small + n_big, h->P(ly.p_Whid), h->St(0, ly.p_Whid),
                                                     s1a ? s1a + ly.p_Whid : nullptr, slab, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
@@ -1700,6 +1699,9 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         *value = w.rfind("rec_products_", 0) == 0 ? products : w.rfind("rec_rows_", 0) == 0 ? rows : wgs;
     }
     else if (w == "tail_chunks") { int ch = 0; *value = tail_plan(h, &ch); }      // time chunks of the overlapped step tail (0: not taken)
+    // ... whose consumers really run on the side streams (SBR_TAIL_OVERLAP=2 keeps them on the main stream: a data-parallel driver
+    // must then not order a collective behind a side stream that produces nothing)
+    else if (w == "tail_streams") { int ch = 0; *value = (tail_plan(h, &ch) >= 2 && h->tail_overlap == 1) ? 1 : 0; }
     else if (w == "tail_last_steps") { int ch = 0; *value = tail_plan(h, &ch) >= 2 ? h->tail_bounds.lo[1] : 0; }   // time steps of chunk 0 (behind the chain)
     else if (w == "side_stream2") *value = (int64_t)(intptr_t)h->side2;
     else if (w == "tail_chain_cycles" || w == "tail_chain_ticks") {      // last overlapped-tail BPTT launch: shader cycles / 100 MHz ticks

@@ -174,7 +174,11 @@ struct sbr_handle {
     int tail_pub_every;  // SBR_TAIL_PUBLISH_EVERY: time steps between two progress words of a chain wave (default 2)
     int tail_nc, tail_ch;   // this step: time chunks of the sort's keys / steps per chunk (0: plain keys)
     SbrTChunks tail_bounds; // ... and their bounds (tail_plan)
-    bool tail_sorted;       // ... the sort already runs beside the forward chain (sbr_forward)
+    int tail_short_chunks;  // time chunks (from t = 0) whose scatter-add entries are cut into short pieces (SBR_TAIL_SHORT_CHUNKS)
+    double tail_geom;       // SBR_TAIL_GEOM: growth of the small time chunks near t = 0 (<= 1: equal chunks)
+    int tail_final, tail_fuse_slabs, tail_small_slabs, tail_small_k;      // SBR_TAIL_FINAL / _FUSE_SLABS / _SMALL_SLABS / _SMALL_K
+    bool fold_dh;           // SBR_FOLD_DH
+    int wgrad_f16, wgrad_x6_wgs;                                          // SBR_WGRAD_F16, SBR_WGRAD_X6_WGS
     int prog_epoch;
     bool tail_updated;      // this step: the overlapped tail has applied the optimizer itself (single-call step)
     hipEvent_t ev_tail, ev_tail2;
@@ -250,7 +254,7 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
 // all time chunks of a time-chunked sort in ONE launch beside the running chain: every wave waits for poll.done to reach the
 // time chunk of its entries (tch steps per chunk), rows are added with float atomics (an id may occur in every chunk)
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0, const SbrTChunks* bounds = nullptr);
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0, const SbrTChunks* bounds = nullptr, int short_chunks = 0);
 
 // Tile-blocked activation layout [t][row tile of 16][column tile of 16][row 16][col 16] (floats):
 // the 16x16 tile one wave of the recurrent kernels owns is one contiguous KiB (8 full 128-B lines per
@@ -318,6 +322,11 @@ bool sbr_rec_x6p_ok(const RecArgs& a);
 int sbr_rec_x6p_f16_terms();              // MFMAs per f32 product of the x6p kernels' fp16 forms (2: packed planes, sbr_rec_p.hip)
 bool sbr_rec_x6p_tail_ok(const RecArgs& a);   // ... and its backward kernel can publish progress (RecArgs.progress)
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
+// sbr_rec_r.hip: the same step with one wave per SIMD owning two unit tiles (fp16 packed planes only; same data layout)
+bool sbr_rec_x6r_fwd_ok(const RecArgs& a);
+hipError_t launch_rec_forward_x6r(hipStream_t s, const RecArgs& a);
+bool sbr_rec_x6r_bwd_ok(const RecArgs& a);
+hipError_t launch_rec_backward_x6r(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a);
 // sbr_rec_q.hip: the same step loop for Hp = 32 / 64 (one wave per SIMD)
 bool sbr_rec_x6q_ok(const RecArgs& a);

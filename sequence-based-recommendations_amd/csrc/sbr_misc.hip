@@ -438,62 +438,41 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
 // waits (one lane polls poll.done, bounded) until the chain has left the time chunk of its FIRST entry -- the lowest of the
 // wave, the order is ascending -- takes an agent-scope acquire, and adds its row sums with float atomics: an id may occur
 // in every chunk, and chunks finish in different waves.
-// The MONITOR of a polling launch (its last workgroup): folds the chain's per-wave progress words into `done` until the chain
-// has finished -- the same fold the weight-gradient GEMM's workgroup 0 runs (sbr_gemm_x6.hip); two monitors write the same
-// values, so the scatter-add does not have to wait for that launch to start (it sits behind the output layer's gradient work on
-// its stream, a third of the chain late).
-__device__ __forceinline__ void scat_monitor(const SbrPoll& pl) {
-    __shared__ int s_part[4];
-    const int tid = threadIdx.x, tag = pl.epoch;
-    int last = 0x1000;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        int m = 0;
-        for (int i = tid; i < pl.n; i += 256) {
-            const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
-        if ((tid & 63) == 0) s_part[tid >> 6] = m;
-        __syncthreads();
-        m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
-        __syncthreads();
-        if (m != last && m != 0xfff) {
-            if (tid == 0) __hip_atomic_store(pl.done, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = m;
-        }
-        if (m <= 0) break;
-        if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-
 template <int NV, int SCAT_CHUNK, bool ACC = false, bool POLL = false>
 __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
                                                           int n_ids, float* __restrict__ dWin, int R4, int Bp, int key_lo = 0,
                                                           int n_tchunks = 1, SbrTChunks tch = SbrTChunks(), SbrPoll poll = SbrPoll()) {
     const int lane = threadIdx.x & 63;
-    if (POLL && poll.k_small < 0 && blockIdx.x == gridDim.x - 1) { scat_monitor(poll); return; }       // (k_small < 0: this launch has a monitor)
-    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int n_waves = (gridDim.x - ((POLL && poll.k_small < 0) ? 1 : 0)) * (blockDim.x >> 6);
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int total = offs[POLL ? n_ids * n_tchunks : key_lo + n_ids];
     // POLL: key_lo = the first key this launch takes (time chunk 0 -- the one the chain completes last -- is left to a launch
     // of its own behind the chain when key_lo = n_ids: see sbr_backward_recurrent)
     const int e_lo = POLL ? offs[key_lo] : 0;
-    const int nch = (total - e_lo + SCAT_CHUNK - 1) / SCAT_CHUNK;
+    // POLL: the entries of the time chunks the chain completes LAST (chunks < poll.n_small: the last ~10 time steps with the
+    // geometric bounds) are cut into SHORT pieces of SCAT_SHORT entries: what is left at the chain's end is then one round of
+    // eight rows per wave instead of a 32-entry walk (four rounds and up to 32 flushes: 30 - 35 us behind the chain,
+    // profiles/round3_f_timeline.txt)
+    constexpr int SCAT_SHORT = 8;
+    const int e_mid = POLL ? max(e_lo, min(total, offs[min(poll.n_small, n_tchunks) * n_ids])) : 0;
+    const int nchA = POLL ? (total - e_mid + SCAT_CHUNK - 1) / SCAT_CHUNK : 0, nchB = POLL ? (e_mid - e_lo + SCAT_SHORT - 1) / SCAT_SHORT : 0;
     // POLL: a bounded number of waves (the launch must leave the chip to the GEMM that runs beside it) walks the sorted
     // entries from the far end, wave-chunk it, it + n_waves, ...
     for (int it = wave_global; ; it += n_waves) {
-    int chunk = wave_global;
-    if (POLL) { if (it >= nch) break; chunk = nch - 1 - it; }
-    const int base = (POLL ? e_lo : offs[key_lo]) + chunk * SCAT_CHUNK;
-    if (base >= total) return;
-    const int cnt = min(SCAT_CHUNK, total - base);
+    int base, cnt;
+    if (POLL) {
+        if (it >= nchA + nchB) break;
+        if (it < nchA) { base = e_mid + (nchA - 1 - it) * SCAT_CHUNK; cnt = min(SCAT_CHUNK, total - base); }
+        else { base = e_lo + (nchB - 1 - (it - nchA)) * SCAT_SHORT; cnt = min(SCAT_SHORT, e_mid - base); }
+    } else {
+        base = offs[key_lo] + wave_global * SCAT_CHUNK;
+        if (base >= total) return;
+        cnt = min(SCAT_CHUNK, total - base);
+    }
+    const int lim = base + cnt;
     const int e = base + (lane & (SCAT_CHUNK - 1));
-    const int my_id = e < total ? sid[e] : -1;
-    const int my_pos = e < total ? spos[e] : 0;
+    const int my_id = e < lim ? sid[e] : -1;
+    const int my_pos = e < lim ? spos[e] : 0;
     if (POLL) {
         const int t_need = tch.lo[min(__shfl(my_id, 0) / n_ids, SBR_TCHUNKS_MAX)];
         if (lane == 0) {
@@ -554,16 +533,16 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
 }
 
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key,
-                                      const SbrTChunks* bounds) {
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll_in, int first_key,
+                                      const SbrTChunks* bounds, int short_chunks) {
     const SbrTChunks tc = bounds ? *bounds : sbr_uniform_tchunks(tch, n_tchunks);
-    SbrPoll pm = poll;
-    static const int own_monitor = getenv("SBR_TAIL_SCATTER_MONITOR") ? atoi(getenv("SBR_TAIL_SCATTER_MONITOR")) : 1;
-    if (own_monitor) pm.k_small = -1;      // (the field is the GEMM's; here it only says: the last workgroup is a monitor)
+    SbrPoll poll = poll_in;
+    poll.n_small = std::max(0, std::min(short_chunks, n_tchunks));      // (the field counts the GEMM's short slabs there; here: time chunks cut short)
+
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
     static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 64;
-    const int grid = std::max(1, std::min(wgs, ((max_entries + 31) / 32 + 3) / 4)) + (own_monitor ? 1 : 0);
-#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tc, pm)
+    const int grid = std::max(1, std::min(wgs, ((max_entries + 7) / 8 + 3) / 4));
+#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tc, poll)
     if (nv <= 1) SRP(1); else if (nv <= 2) SRP(2); else if (nv <= 4) SRP(4); else return hipErrorInvalidValue;
 #undef SRP
     return hipGetLastError();

@@ -319,6 +319,8 @@ class RNNBase(object):
                 return None  # (a sequence longer than the noise kernel's LDS staging)
         if ts.shuffle and multi and self._engine_targets() > 16 and ts.bias < 0.0:
             return None
+        if ts.bias >= 0.0 and multi and self._engine_targets() > 1024:
+            return None      # (the host row planner of --target_bias holds at most 1024 targets per row: sbr_dataset_set_target_bias)
         from .data import NativeBatchBuilder
         pop = np.asarray(dataset.item_popularity, dtype=np.float64)
         db = float(getattr(self, "diversity_bias", 0.0))

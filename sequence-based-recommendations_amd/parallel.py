@@ -12,6 +12,11 @@ part follows.  With the HIP engine the first collective is ordered behind the en
 of waiting for them (`sbr_set_deferred_join`, include/sbr_rnn.h).  The sampled heads need the targets of ALL rows on every rank (Blackout's softmax
 spans every target column, rnn_sampling.py:68-72,137): `gather_targets` all-gathers B int32.
 
+Row-sparse blocks with the lazy-exact updaters (rmsprop / adadelta / nesterov / adam): a row's missed zero-gradient steps are
+replayed when the row is next read, and WHERE that happens splits the replay (a short loop below 32 steps, closed forms above):
+calls that bring rows up to date on one rank only -- get_params / save, predict / top-k, flush_lazy -- must therefore be made by
+every rank at the same step if the replicas are to stay bit-identical (they stay equal to float32 rounding either way).
+
 `engine` is anything with the RNNEngine phase methods -- the CPU tests pass an oracle-backed
 stand-in, production passes engine.RNNEngine.
 """
@@ -34,7 +39,8 @@ class DataParallel(object):
             engine.set_deferred_join(True)
             # overlapped step tail (engine.query("tail_chunks") >= 2): dW_in is finished by the engine's second side stream,
             # dW_hid by the first, everything else of the recurrent part by the main stream -- one collective behind each
-            if hasattr(engine, "side_stream2") and engine.query("tail_chunks") >= 2:
+            # (query "tail_streams": with SBR_TAIL_OVERLAP=2 the same kernels run on the MAIN stream -- nothing to order behind)
+            if hasattr(engine, "side_stream2") and engine.query("tail_streams") == 1:
                 self.side2 = engine.side_stream2()
                 self.tail = engine.tail_ranges()
 

@@ -24,6 +24,11 @@ CASES = [
     D + ["--loss", "hinge", "--n_targets", "3", "--balance", "2.0"],
     D + ["--loss", "logit", "--pb", "--min_access", "0.1", "--repeated_interactions", "--r_t", "GRU"],
     D + ["--loss", "logsig", "--balance", "0.5", "--n_targets", "5", "--shuffle_targets"],
+    # RNNCluster (command_parser.py:70-77, :114-115)
+    D + ["--clusters", "10"],
+    D + ["--clusters", "5", "--loss", "BPR", "--sampling", "20", "--c_sampling", "11", "--cluster_type", "softmax", "--init_scale", "2.0",
+         "--scale_growing_rate", "1.1", "--max_scale", "20", "--csn", "0.1", "--sampling_bias", "0.5"],
+    D + ["--clusters", "3", "--loss", "Blackout", "--cluster_type", "sigmoid", "--ignore_clusters", "--repeated_interactions"],
 ]
 
 # (argv, seed, number of training batches): the mini-batch streams that are recorded
@@ -39,6 +44,8 @@ BATCH_CASES = [
     (B + ["--n_shuf", "0.3", "--n_shuf_std", "2.0", "--loss", "TOP1", "--sampling", "4"], 10, 4),
     (B + ["--loss", "hinge", "--n_targets", "3", "--balance", "2.0"], 19, 4),
     (B + ["--loss", "logsig", "--n_targets", "2", "--repeated_interactions", "--pb", "--min_access", "0.2"], 20, 4),
+    (B + ["--clusters", "4", "--sampling", "5"], 21, 4),
+    (B + ["--clusters", "4", "--loss", "TOP1", "--sampling", "6", "--c_sampling", "3", "--sampling_bias", "0.75"], 22, 4),
 ]
 
 # training-loop runs with the fake functions: what is validated / saved / removed / returned
@@ -87,6 +94,14 @@ def batch_to_json(batch, p=None):
     X, mask, Y = np.asarray(batch[0]), np.asarray(batch[1]), np.asarray(batch[2])
     if len(batch) == 5 and (batch[3] is None or np.asarray(batch[3]).ndim == 2):
         return margin_batch_to_json(batch, p)
+    if len(batch) == 6 and np.asarray(batch[4]).dtype.kind == "i":      # RNNCluster: (X, mask, Y, samples, cluster_samples, exclude)
+        samples, csm, exclude = np.asarray(batch[3]), np.asarray(batch[4]), batch[5]
+        assert mask.dtype == np.float32 and Y.dtype == np.int32 and X.dtype == np.int32 and samples.dtype == np.int32 and csm.dtype == np.int32
+        if exclude is None:
+            ex = [sorted(set(int(i) for i in X[b, :int(mask[b].sum()), 0])) for b in range(len(X))]
+        else:
+            ex = [np.flatnonzero(np.asarray(exclude)[b]).tolist() for b in range(len(X))]
+        return dict(X=X.tolist(), mask=mask.astype(int).tolist(), Y=Y.tolist(), samples=samples.tolist(), cluster_samples=csm.tolist(), exclude=ex)
     samples = np.asarray(batch[3]) if len(batch) == 6 else None
     pop, exclude = np.asarray(batch[-2]), batch[-1]
     assert mask.dtype == np.float32 and pop.dtype == np.float32 and Y.dtype == np.int32 and X.dtype == np.int32
