@@ -375,7 +375,6 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_TAIL_SHORT_CHUNKS"); h->tail_short_chunks = e ? std::max(0, atoi(e)) : 3; }
     // (every switch is read here, once per handle: a test that flips one between two engines of a process gets what it asked for)
     { const char* e = getenv("SBR_TAIL_GEOM"); h->tail_geom = e ? atof(e) : 2.6; }
-    { const char* e = getenv("SBR_TAIL_FINAL"); h->tail_final = e ? atoi(e) : 0; }
     { const char* e = getenv("SBR_TAIL_FUSE_SLABS"); h->tail_fuse_slabs = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_TAIL_SMALL_SLABS"); h->tail_small_slabs = e ? atoi(e) : 64; }
     { const char* e = getenv("SBR_TAIL_SMALL_K"); h->tail_small_k = e ? std::max(32, atoi(e) / 32 * 32) : 128; }
@@ -1151,20 +1150,11 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 SBR_LAUNCH(we);
             }
             SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
-            // The time chunk the chain completes LAST (chunk 0) is not left to the polling waves: each of them walks 32 sorted
-            // entries, rounds of eight rows in flight and then its atomics -- 30 - 35 us behind the chain's end for the one chunk that
-            // cannot start earlier (profiles/round3_c_timeline.txt).  It gets a launch of its own behind the polling one (same stream:
-            // the read-modify-writes of its owned segments see the atomics of the earlier chunks complete), gated on the chain's last
-            // progress word, one wave per 16 entries on the then idle chip.  SBR_TAIL_FINAL=0: the polling waves take chunk 0 too.
-            const int tail_final = h->tail_final;
+            // (tried and dropped: the last time chunk as a launch of its own behind the polling one, one wave per 16 entries on the
+            // then idle chip -- the hot rows' atomics serialise there: 23 us for 6400 entries, profiles/round3_variants.txt call d)
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
-                                                  tail_final ? y.cfg.input_size : 0, &h->tail_bounds, h->tail_short_chunks));
-            if (tail_final) {
-                SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, 0, a.fault));
-                SBR_LAUNCH(launch_scatter_reduce(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
-                                                 (const int*)h->A(y.a_soff), y.cfg.input_size, (h->tail_bounds.lo[1] - h->tail_bounds.lo[0]) * y.Bp * y.F, GHp, y.Bp, 0, true, tail_final));
-            }
+                                                  0, &h->tail_bounds, h->tail_short_chunks));
             if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
             // single-call step: the slab reduction IS the W_hid update (one launch, one pass less behind the chain); phase-by-phase

@@ -176,7 +176,7 @@ struct sbr_handle {
     SbrTChunks tail_bounds; // ... and their bounds (tail_plan)
     int tail_short_chunks;  // time chunks (from t = 0) whose scatter-add entries are cut into short pieces (SBR_TAIL_SHORT_CHUNKS)
     double tail_geom;       // SBR_TAIL_GEOM: growth of the small time chunks near t = 0 (<= 1: equal chunks)
-    int tail_final, tail_fuse_slabs, tail_small_slabs, tail_small_k;      // SBR_TAIL_FINAL / _FUSE_SLABS / _SMALL_SLABS / _SMALL_K
+    int tail_fuse_slabs, tail_small_slabs, tail_small_k;                  // SBR_TAIL_FUSE_SLABS / _SMALL_SLABS / _SMALL_K
     bool fold_dh;           // SBR_FOLD_DH
     int wgrad_f16, wgrad_x6_wgs;                                          // SBR_WGRAD_F16, SBR_WGRAD_X6_WGS
     int prog_epoch;
@@ -322,11 +322,6 @@ bool sbr_rec_x6p_ok(const RecArgs& a);
 int sbr_rec_x6p_f16_terms();              // MFMAs per f32 product of the x6p kernels' fp16 forms (2: packed planes, sbr_rec_p.hip)
 bool sbr_rec_x6p_tail_ok(const RecArgs& a);   // ... and its backward kernel can publish progress (RecArgs.progress)
 hipError_t launch_rec_forward_x6p(hipStream_t s, const RecArgs& a);
-// sbr_rec_r.hip: the same step with one wave per SIMD owning two unit tiles (fp16 packed planes only; same data layout)
-bool sbr_rec_x6r_fwd_ok(const RecArgs& a);
-hipError_t launch_rec_forward_x6r(hipStream_t s, const RecArgs& a);
-bool sbr_rec_x6r_bwd_ok(const RecArgs& a);
-hipError_t launch_rec_backward_x6r(hipStream_t s, const RecArgs& a);
 hipError_t launch_rec_backward_x6p(hipStream_t s, const RecArgs& a);
 // sbr_rec_q.hip: the same step loop for Hp = 32 / 64 (one wave per SIMD)
 bool sbr_rec_x6q_ok(const RecArgs& a);

@@ -999,7 +999,6 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool fuse = a.gX != nullptr;
     const bool f16 = x6p_f16_fwd(a);
-    if (f16 && X6P_PACK && sbr_rec_x6r_fwd_ok(a)) return launch_rec_forward_x6r(s, a);      // one wave per SIMD, two tiles each (sbr_rec_r.hip)
     if constexpr (CELL == CELL_LSTM) {
         if (!f16) return hipErrorInvalidValue;                     // (sbr_rec_x6p_ok says when)
         if (a.prof) { if (fuse) X6P_LAUNCH((rec_fwd_x6p<CELL, true, true, true>)); else X6P_LAUNCH((rec_fwd_x6p<CELL, false, true, true>)); }
@@ -1026,8 +1025,6 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     const bool f16 = x6p_f16_bwd(a);                               // fp16 x3 products for the BPTT chain
     if (a.progress && (ext || !f16)) return hipErrorInvalidValue;               // (sbr_rec_x6p_tail_ok says when)
     if (CELL == CELL_LSTM && !f16) return hipErrorInvalidValue;                 // (sbr_rec_x6p_ok)
-    if (f16 && X6P_PACK && sbr_rec_x6r_bwd_ok(a) && (!a.progress || sbr_rec_x6p_tail_ok(a)))      // one wave per SIMD, two tiles each
-        return launch_rec_backward_x6r(s, a);
     if (a.prof && f16 && !ext) {      // in-kernel counters for the fp16x3 forms too (tools/tail_prof.py)
         if (a.progress) X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 1>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 0>));
         return hipGetLastError();
