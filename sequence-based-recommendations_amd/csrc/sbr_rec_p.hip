@@ -67,6 +67,9 @@
 #ifndef X6P_FWD_TOK
 #define X6P_FWD_TOK 1    // forward, packed form: waves 4-7 open the pipe gate this many MFMA groups (of G) before their last MFMA
 #endif
+#ifndef X6P_SYNC
+#define X6P_SYNC 0       // 1: one workgroup barrier per step instead of the counters / the pipe gate / the role split (experiment:
+#endif                   // with two MFMAs per product the matrix phase is short enough for the synchronous schedule to compete)
 #ifndef X6P_PACK
 #define X6P_PACK 1       // 0: the fp16 forms with three MFMAs per product (round 2), for same-box A/B runs (SBR_LIB)
 #endif
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             }
         };
         auto ensure_half = [&](int half) {                        // the four producers of this half have published h_t
-            if (!(X6P_DBG & 32) && __builtin_amdgcn_readfirstlane(fl[half]) < 4 * t) {
+            if (!(X6P_DBG & 32) && !X6P_SYNC && __builtin_amdgcn_readfirstlane(fl[half]) < 4 * t) {
                 unsigned long long w0 = 0;
                 if (PROF) w0 = clock64();
                 int spins = 0;
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (kb == KB / 2 && RA) ensure_half(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) { acl[g] = mfma16(hp[kb][0], W2[g][kb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acl[g]); X6P_GAP(); }
                 if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
@@ -390,12 +393,12 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) { acc[g] = mfma16(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]); X6P_GAP(); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acl[g][0], 1.0f / F16_LO, acc[g][0]);
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 X6P_TERL(hp[kb][0], W2[g][kb])
-                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
                 if (kb == 0) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W1[g][kb], biasv[g]);
@@ -447,7 +450,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             // cycles at GRU) before the last one is issued, so that less of that reaction time is idle matrix pipe.  Not
             // earlier: an older wave that starts while this one still has MFMAs to issue stalls them for its whole first
             // half (measured: 2 G MFMAs early gains nothing in the forward, 3 terms early loses 5 us).
-            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             X6P_TERM(hp[kb][0], W1[g][kb])
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -488,6 +491,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         }
         if (t + 1 < tmax) {
             publish_h((t + 1) & 1);
+            if (X6P_SYNC) __syncthreads(); else
             lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
             if (PROF) p_seg[2] += clock64() - p_tb;
             if (PROF && tl && t == 100) tl[6] = clock64();
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         } else if (!(X6P_DBG & 2)) load_x(t + 1);
     }
     };
-    if (roleA) steps(std::true_type{}); else steps(std::false_type{});
+    if (roleA && !X6P_SYNC) steps(std::true_type{}); else steps(std::false_type{});
     if (DEFER && tmax > 0) store_step(off_t - st_h, sv_st, h_st, c_st);      // the last step's
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
@@ -775,6 +779,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 *(unsigned short*)(base + 2 * PLANEB) = (unsigned short)(p3 >> 16);
             }
         }
+        if (X6P_SYNC) __syncthreads(); else
         lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
         if (CELL != CELL_GRU) hnew = hprev;
         if constexpr (RING) {                                     // loads first: see the progress note above
@@ -832,7 +837,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][NP - 1])); };
         // the half's producers have published this step; else re-read the counter and the k-blocks [i0, i1) fetched on spec
         auto ensure_half = [&](int half, int i0, int i1) {
-            if (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1)) {
+            if (!X6P_SYNC && __builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1)) {
                 unsigned long long w0 = 0;
                 if (PROF) w0 = clock64();
                 int spins = 0;
@@ -879,7 +884,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
                 acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]); X6P_GAP();
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]); X6P_GAP();
                 if (BDEF && i == 1) {                               // this step's dxt / dhi, from where the issue slots are free
                     __builtin_amdgcn_sched_barrier(0);
@@ -892,7 +897,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
                 acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
                 acc[2] = mfma16(dpl[s][0], W2[kb], acc[2]);
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
@@ -900,7 +905,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             acc[0] = mfma16(dpl[s][0], W3[kb], acc[0]);
             acc[1] = mfma16(dpl[s][NP - 1], W1[kb], acc[1]);
             acc[2] = mfma16(dpl[s][1], W2[kb], acc[2]);
-            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
+            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
             acc[0] = mfma16(dpl[s][0], W2[kb], acc[0]);
             acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
             acc[2] = mfma16(dpl[s][0], W1[kb], acc[2]);
@@ -917,7 +922,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         else dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
     };
-    if (roleA) steps(std::true_type{}); else steps(std::false_type{});
+    if (roleA && !X6P_SYNC) steps(std::true_type{}); else steps(std::false_type{});
     if constexpr (WT) publish_progress(prog_slot, prog_tag | a.t_lo);
     if constexpr (WT) {      // shader cycles and 100 MHz wall-clock ticks of this launch (block 0, wave 0): the chain's effective clock
         if (blockIdx.x == 0 && wave == 0 && lane == 0) {

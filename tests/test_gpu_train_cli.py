@@ -188,3 +188,44 @@ def test_which_options_train_on_device_built_batches(tmp_path, extra, native):
         nb.close()
     predictor.train(dataset, max_iter=12, progress=10 ** 9, autosave="None")      # twelve steps on those batches: finite costs or it raises
     predictor.engine.close()
+
+
+@pytest.mark.parametrize("extra", [["--clusters", "4", "--sampling", "8"],                                   # RNNCluster, --loss CCE over the samples
+                                   ["--clusters", "3", "--loss", "BPR", "--sampling", "8", "--c_sampling", "5", "--cluster_type", "softmax",
+                                    "--init_scale", "2.0", "--scale_growing_rate", "1.2", "--u_m", "adagrad", "--u_l", "0.1"],
+                                   ["--clusters", "5", "--loss", "Blackout", "--sampling", "10", "--cluster_type", "sigmoid", "--csn", "0.05",
+                                    "--ignore_clusters"]])
+def test_cluster_cli_end_to_end(tmp_path, extra):
+    # `train.py -m RNN --clusters C` (command_parser.py:114-115): both models train, the nine cluster metrics come back, checkpoints
+    # carry the two cluster arrays behind the network's list (rnn_cluster.py:510-537), recommendations come from inside the user's
+    # cluster (or from the whole catalogue with --ignore_clusters)
+    from sbr_amd import train as T
+    root = make_dataset(str(tmp_path / "ds"))
+    argv = ["-d", root, "-b", "8", "--max_length", "10", "--max_iter", "60", "--progress", "20", "--save", "All", "--r_t", "GRU",
+            "--r_l", "16"] + extra
+    metrics, elapsed, best_file = T.main(argv)
+    assert set(metrics) == {"recall", "cluster_recall", "sps", "cluster_sps", "ignored_items", "assr", "cluster_use", "cluster_use_std",
+                            "cluster_size"}
+    C = int(extra[1])
+    assert len(metrics["cluster_use"]) == C and int(np.sum(metrics["cluster_use"])) == 8      # eight validation users, one cluster each
+    assert 1.0 <= metrics["assr"] <= 30.0 * C
+    files = sorted(glob.glob(root + "models/*"))
+    assert len(files) == 3 and best_file in files and os.path.basename(files[0]).startswith("rnn_clusters%d_sc" % C)
+    params = pickle.load(open(files[-1], "rb"))
+    R, (Wc,) = params[-2], params[-1]
+    assert R.shape == (30, C) and Wc.shape == (16, C) and np.all(np.isfinite(R)) and np.all(np.isfinite(Wc))
+    assert all(isinstance(p, np.ndarray) and p.dtype == np.float32 for p in params[:-2])
+    from sbr_amd import options as parse
+    from sbr_amd.data import DataHandler
+    args = parse.command_parser(parse.predictor_command_parser, parse.training_command_parser, T.early_stopping_command_parser, argv=argv)
+    predictor = parse.get_predictor(args)
+    dataset = DataHandler(dirname=root)
+    predictor.prepare_model(dataset)
+    predictor.load(files[-1])
+    assert np.array_equal(predictor.head.get_params()[0], R)
+    assert set(np.concatenate(predictor.clusters).tolist()) == set(range(30))      # prepare_tests: every item lands in at least one cluster
+    seq = [[3, 4.0], [5, 4.0], [7, 4.0]]
+    rec, n_scored = predictor.top_k_recommendations(seq, k=5)
+    assert 1 <= len(rec) <= 5 and len(set(rec)) == len(rec) and not set(rec) & {3, 5, 7}
+    assert n_scored == (30 if "--ignore_clusters" in extra else len(predictor.clusters[int(predictor.head.select(1)[0])]))
+    predictor.head.close(); predictor.engine.close()
