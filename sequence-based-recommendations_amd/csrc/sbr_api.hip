@@ -158,8 +158,10 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         lay.tail_keys = std::max(1, std::min(8, sbr_scatter_lds_ids() / std::max(1, cfg.input_size)));
     lay.a_scnt = take((size_t)lay.tail_keys * cfg.input_size + 1); lay.a_soff = take((size_t)lay.tail_keys * cfg.input_size + 1);
     lay.a_scur = take((size_t)lay.tail_keys * cfg.input_size + 1);
+    lay.a_sP = take((size_t)cfg.input_size + 2);
     lay.a_sid = take((size_t)T * Bp * lay.F); lay.a_spos = take((size_t)T * Bp * lay.F);
-    lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, a gap of one line, the monitor's word
+    lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, (a gap), the chain's clock words
+    lay.a_done = take((size_t)SBR_DONE_COPIES * SBR_DONE_STRIDE);      // the monitor's word, replicated (sbr_common.h SbrPoll)
     // Row-sparse blocks (sbr_sparse.hip): the index-addressed rows of layer 0 (or of the embedding table) and, for the sampled
     // heads, the rows of W_out^T / b_out.  Taken when a step cannot touch every row anyway (more rows than candidates) or
     // when the flag forces it; SBR_FLAG_DENSE_UPDATE keeps the dense Lasagne-style pass over everything.
@@ -374,14 +376,25 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_TAIL_PUBLISH_EVERY"); h->tail_pub_every = e ? std::max(1, atoi(e)) : 2; }
     { const char* e = getenv("SBR_TAIL_SHORT_CHUNKS"); h->tail_short_chunks = e ? std::max(0, atoi(e)) : 3; }
     // (every switch is read here, once per handle: a test that flips one between two engines of a process gets what it asked for)
-    { const char* e = getenv("SBR_TAIL_GEOM"); h->tail_geom = e ? atof(e) : 2.6; }
+    if (getenv("SBR_TAIL_TRACE") && atoi(getenv("SBR_TAIL_TRACE"))) {      // tools/tail_trace.py
+        if (hipMalloc(&h->tail_trace, 16384 * sizeof(unsigned long long)) != hipSuccess) h->tail_trace = nullptr;
+        else (void)hipMemset(h->tail_trace, 0, 16384 * sizeof(unsigned long long));
+    }
+    { const char* e = getenv("SBR_TAIL_FENCE_KB"); h->tail_fence_kb = e ? std::max(0, std::min(160, atoi(e))) : 124; }
+    { const char* e = getenv("SBR_TAIL_EARLY_SORT"); h->tail_early_sort = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_TAIL_OUT_STREAM"); h->tail_out_stream = e ? atoi(e) : 0; }
     { const char* e = getenv("SBR_TAIL_FUSE_SLABS"); h->tail_fuse_slabs = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_SMALL_SLABS"); h->tail_small_slabs = e ? atoi(e) : 64; }
-    { const char* e = getenv("SBR_TAIL_SMALL_K"); h->tail_small_k = e ? std::max(32, atoi(e) / 32 * 32) : 128; }
+    { const char* e = getenv("SBR_TAIL_SLAB_GROWTH"); h->tail_slab_growth = e ? std::max(0.0, atof(e)) : 0.35; }
+    { const char* e = getenv("SBR_TAIL_SCATTER_LDS"); h->tail_scatter_lds = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_TAIL_GEOM"); h->tail_geom = e ? atof(e) : (h->tail_scatter_lds ? 1.6 : 2.6); }
+    { const char* e = getenv("SBR_TAIL_FIRST"); h->tail_first = e ? std::max(1, atoi(e)) : 6; }
+    { const char* e = getenv("SBR_TAIL_SCATTER_UNITS"); h->tail_scatter_units = e ? std::max(1, std::min(384, atoi(e))) : 192; }
+    { const char* e = getenv("SBR_TAIL_GEMM_GROUPS"); h->tail_gemm_groups = e ? std::max(1, atoi(e)) : 64; }
+    { const char* e = getenv("SBR_TAIL_SLAB_MAX"); h->tail_slab_max = e ? std::max(32, atoi(e) / 32 * 32) : 512; }
     { const char* e = getenv("SBR_FOLD_DH"); h->fold_dh = e ? atoi(e) != 0 : true; }
     { const char* e = getenv("SBR_WGRAD_F16"); h->wgrad_f16 = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_WGRAD_X6_WGS"); h->wgrad_x6_wgs = e ? atoi(e) : 512; }
-    h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr;
+    h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr; h->side3 = nullptr; h->ev_tail3 = nullptr; h->tail_sorted = false; h->out3 = false;
     h->step_open = false; h->tail_join_pending = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
@@ -405,6 +418,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_tail2, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->side3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
@@ -445,10 +460,14 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
     if (h->ev_tail2) (void)hipEventDestroy(h->ev_tail2);
     if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->side3) (void)hipStreamDestroy(h->side3);
+    if (h->ev_tail3) (void)hipEventDestroy(h->ev_tail3);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
     for (int c = 0; c < 2; ++c) if (h->ev_lag[c]) (void)hipEventDestroy(h->ev_lag[c]);
     if (h->lag_host) (void)hipHostFree(h->lag_host);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
+    if (h->tail_trace) (void)hipFree(h->tail_trace);
+    if (h->tail_slab_dev) (void)hipFree(h->tail_slab_dev);
     delete h;
 }
 
@@ -667,7 +686,10 @@ static int tail_plan(sbr_handle* h, int* ch_out) {
     SbrTChunks& tc = h->tail_bounds;
     tc.n = nc;
     tc.lo[0] = 0;
-    double pw = 1.0;
+    // LDS-row scatter-add (launch_scatter_lds_poll): a unit walks the chunks one after the other, so what counts is that chunk c is
+    // done when chunk c - 1 is released and that ONE round of rows is left behind the chain: the last chunk has SBR_TAIL_FIRST
+    // steps (default 6: ~8 entries per unit) and the sizes grow by SBR_TAIL_GEOM (default 1.6 here): 6, 10, 15, 25, then equal shares.
+    double pw = h->tail_scatter_lds ? (double)h->tail_first : 1.0;
     for (int c = 0; c < nc; ++c) {
         const int rem = y.T - tc.lo[c], left = nc - c;
         const int share = (rem + left - 1) / left;
@@ -680,6 +702,20 @@ static int tail_plan(sbr_handle* h, int* ch_out) {
     }
     for (int c = nc; c <= SBR_TCHUNKS_MAX; ++c) tc.lo[c] = y.T;
     return nc;
+}
+
+// behind the time-chunked sort of an overlapped tail (second side stream): the running cost of the ids, for the LDS-row scatter-add
+static int tail_cost_scan(sbr_handle* h) {
+    const Layout& y = h->lay;
+    h->tail_cost_scanned = false;
+    if (!h->tail_scatter_lds) return SBR_OK;
+    hipError_t e = hipSuccess;
+    if (launch_scatter_cost_scan(h->side2, (const int*)h->A(y.a_soff), (int*)h->A(y.a_sP), y.cfg.input_size, h->tail_nc, y.T * y.Bp * y.F,
+                                 y.G * y.layer[0].Hp, h->tail_scatter_units, &e)) {
+        if (e != hipSuccess) { sbr_set_error("HIP launch failed: %s", hipGetErrorString(e)); return SBR_EHIP; }
+        h->tail_cost_scanned = true;
+    }
+    return SBR_OK;
 }
 
 static inline void mark_on(sbr_handle* h, int i, hipStream_t st) {
@@ -845,6 +881,22 @@ extern "C" int sbr_forward(sbr_handle* h) {
                 SBR_LAUNCH(launch_sparse_catch_up_batch(s, sparse_rows(h, b), sparse_upd(h), h->bX, h->blen, y.T, y.Bp, y.F, (int)h->step_count));
     h->tail_nc = h->step_open ? tail_plan(h, &h->tail_ch) : 0;      // overlapped tail for this step? (never for predict / top-k)
     h->step_open = false;
+    h->tail_sorted = false;
+    // Overlapped tail, round 3.  Its consumers are throughput-bound once they have the chip's other 192 CUs to themselves (the
+    // fence below), so WHEN they start decides when the step ends -- and both waited behind work that does not need the chain:
+    // the scatter-add behind the 45 us of the time-chunked sort.  The sort needs nothing but the batch: it runs now, beside the
+    // forward chain, for one event record in front of it.  The forward chain claims its CUs' LDS while the sort (118 KB of LDS
+    // histogram per workgroup) runs beside it, so the two do not share CUs.  SBR_TAIL_EARLY_SORT=0: behind the output phase.
+    const bool tail_live = h->tail_nc >= 2 && h->tail_overlap == 1;
+    if (tail_live && h->tail_early_sort) {
+        SBR_HIP(hipEventRecord(h->ev_fork, s));
+        SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
+        SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
+                                       (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
+                                       h->tail_ch, h->tail_nc, &h->tail_bounds));
+        h->tail_sorted = true;
+        { const int rc = tail_cost_scan(h); if (rc != SBR_OK) return rc; }
+    }
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
         const LayerLayout& ly = y.layer[l];
@@ -868,6 +920,7 @@ extern "C" int sbr_forward(sbr_handle* h) {
             SBR_LAUNCH(launch_gemm(s, h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp, lo.Hp, 1, h->P(ly.p_Win), GHp, 1, h->A(ly.a_xt), GHp,
                                    y.T * y.Bp, GHp, lo.Hp, h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
         }
+        if (l == 0 && h->tail_sorted) ra.fence_kb = h->tail_fence_kb;
         SBR_LAUNCH(launch_rec_forward(s, ra, simple_rec(h)));
     }
     mark(h, 2);
@@ -914,6 +967,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
     if (R < y.Bp) SBR_HIP(hipMemsetAsync(h->A(y.a_dhlast), 0, (size_t)y.Bp * Hp * sizeof(float), s));   // padded rows carry no gradient
     h->side_pending = true;
     h->fill_done = false;
+    h->out3 = false;
     // Work on the side stream that needs only the batch: the sentinel fill of the cluster BPTT kernels' exchange arrays and
     // the sort for the embedding scatter-add (the scatter kernel waits for ev_sort).  With cluster kernels it starts now,
     // beside the output phase (its own fork event); otherwise it rides behind the ev_lg wait the side stream needs anyway
@@ -933,9 +987,12 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             // overlapped tail: the time-chunked sort runs on the SECOND side stream, which consumes it (scatter-add beside the
             // chain); that stream is released by the same record as the first one
             SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_lg_rec, 0));
-            SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
-                                           (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
-                                           h->tail_ch, h->tail_nc, &h->tail_bounds));
+            if (!h->tail_sorted) {
+                SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
+                                               (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
+                                               h->tail_ch, h->tail_nc, &h->tail_bounds));
+                { const int rc = tail_cost_scan(h); if (rc != SBR_OK) return rc; }
+            }
         } else if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
             SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                            y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
@@ -984,12 +1041,23 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
         if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
-        SBR_LAUNCH(launch_sum_cost(sd, h->A(y.a_rowcost), R, h->cost_ptr()));
+        // Overlapped tail, single-call step: the output layer's gradient kernels and its update (five launches, 50 - 60 us on one
+        // stream with its gaps) go to the SECOND side stream, in front of the scatter-add, so that the polling weight-gradient
+        // GEMM on `sd` starts with the chain instead of a third of it late (profiles/round3_l_timeline.txt, round3_z_timeline0.txt):
+        // the scatter-add's units catch up with what was released meanwhile in one pass, the GEMM's groups would carry the backlog
+        // to the end.  (A stream of their own was tried: with main, two side streams and the monitor's that is a fifth hardware
+        // queue, and two of them then share one -- profiles/round3_A_variants.txt.)  No split-K workspace for dW_out there: the
+        // polling GEMM owns ws2 meanwhile.
+        h->out3 = h->in_train_step && h->tail_nc >= 2 && h->tail_overlap == 1 && h->tail_out_stream;
+        hipStream_t so = h->out3 ? h->side2 : sd;
+        if (h->out3) SBR_HIP(hipStreamWaitEvent(so, h->ev_lg_rec, 0));
+        SBR_LAUNCH(launch_sum_cost(so, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
-        SBR_LAUNCH(launch_colsum_bias(sd, lg, R, N, Nl, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
-        SBR_LAUNCH(launch_gemm(sd, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, ws2, y.ws2_floats, sg));
-        SBR_HIP(hipEventRecord(h->ev_og, sd)); h->og_recorded = true;   // output-layer gradients + cost complete
+        SBR_LAUNCH(launch_colsum_bias(so, lg, R, N, Nl, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
+        SBR_LAUNCH(launch_gemm(so, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, h->out3 ? nullptr : ws2,
+                               h->out3 ? 0 : y.ws2_floats, sg));
+        SBR_HIP(hipEventRecord(h->ev_og, so)); h->og_recorded = true;   // output-layer gradients + cost complete
         // Single-call step, dense updates: the output layer is stepped right here, beside the BPTT chain (nothing reads W_out
         // any more: dh was computed in front of the record the side stream waited on); sbr_apply_update leaves the range
         // out.  C4: 46 us off the end of the step.  (The overlapped tail does the same itself; phase-by-phase callers --
@@ -1117,55 +1185,70 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             const bool gru = y.cfg.cell == SBR_CELL_GRU;
             int* words = (int*)h->A(y.a_prog);
             const int nwaves = (y.Bp / a.rpt) * 8;
-            int* done = words + nwaves + 64;
+            int* done = (int*)h->A(y.a_done);
             h->prog_epoch = (h->prog_epoch + 1) & 0x7FFFF; if (!h->prog_epoch) h->prog_epoch = 1;
             a.progress = words; a.prog_every = h->tail_pub_every; a.prog_epoch = h->prog_epoch;
             const int K = y.T * y.Bp;
             const int cap = (int)std::min<size_t>(256, y.ws2_floats / slab);
-            const int env_small = h->tail_small_slabs, env_ksmall = h->tail_small_k;
-            SbrPoll pl{words, nwaves, done, a.prog_epoch, y.Bp, a.fault, 0, env_ksmall};
-            pl.n_small = std::max(0, std::min(std::min(env_small, cap / 2), K / pl.k_small));
-            const int rest = K - pl.n_small * pl.k_small;
-            int k_big = 512;
-            while ((rest + k_big - 1) / k_big > cap - pl.n_small) k_big += 128;
-            const int n_big = std::max(1, (rest + k_big - 1) / k_big);
+            SbrPoll pl{words, nwaves, done, a.prog_epoch, y.Bp, a.fault, 0, 0, h->tail_trace, nullptr, 0};
+            if (h->tail_slab_key[0] != K || h->tail_slab_key[1] != cap || !h->tail_slab_dev) {      // (first step of this shape)
+                sbr_tail_slab_table(K, y.Bp, 255, h->tail_slab_growth, h->tail_slab_max, h->tail_slab_host);
+                if (!h->tail_slab_dev) SBR_HIP(hipMalloc(&h->tail_slab_dev, 260 * sizeof(int)));
+                SBR_HIP(hipMemcpy(h->tail_slab_dev, h->tail_slab_host.data(), h->tail_slab_host.size() * sizeof(int), hipMemcpyHostToDevice));
+                h->tail_slab_key[0] = K; h->tail_slab_key[1] = cap;
+            }
+            pl.slab_lo = h->tail_slab_dev;
+            pl.n_slabs = (int)h->tail_slab_host.size() - 1;
+            const int n_slabs = std::max(1, std::min(std::min(h->tail_gemm_groups, cap), pl.n_slabs));      // partials = persistent groups
             const bool upd_here = h->in_train_step;
             float* s1a = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
             auto upd_on = [&](hipStream_t st, size_t lo, size_t hi, size_t gap_at = (size_t)-1, size_t gap_len = 0) -> hipError_t {
                 return launch_update(st, y.cfg.updater, h->P(lo), h->Gd(lo), h->St(0, lo), s1a ? s1a + lo : nullptr, hi - lo - gap_len,
                                      y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1, gap_at, gap_len);
             };
+            if (!serial) a.fence_kb = h->tail_fence_kb;              // the chain's CUs are its own: the consumers take the other 192
             SBR_LAUNCH(launch_rec_backward(s, a, false));
             mark(h, 4);
             // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
             const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss));
-            if (out_early) SBR_LAUNCH(upd_on(sd, y.p_split, y.n_params));
+            if (out_early) {
+                SBR_LAUNCH(upd_on(h->out3 ? h->side2 : sd, y.p_split, y.n_params));
+                if (h->out3) SBR_HIP(hipEventRecord(h->ev_tail3, h->side2));
+            }
+            // the monitor: on a stream of its own behind nothing but the chain's first progress words (its own loop waits for them)
+            SBR_LAUNCH(launch_tail_monitor(serial ? s : h->side3, pl, a.t_lo));
             SBR_LAUNCH(launch_tail_gate(sd, words, nwaves, a.prog_epoch, y.T, a.fault));
             {
                 hipError_t we = hipSuccess;
-                if (!launch_gemm_slabs_x6_poll(sd, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, ly.Hp, GHp, K, ws2, n_big, k_big, GHp, slab,
+                if (!launch_gemm_slabs_x6_poll(sd, h->A(ly.a_hs), 1, ly.Hp, a.dxt, GHp, 1, ly.Hp, GHp, K, ws2, n_slabs, GHp, slab,
                                                gru ? a.dhi : nullptr, ly.Hp, gru ? 2 * ly.Hp : 0, &we, wg_f16 ? 2 : 3, 1.0f, wg_f16 ? 512.0f : 1.0f, pl)) {
                     sbr_set_error("overlapped tail: the weight-gradient GEMM rejected the shape"); return SBR_EINVAL;
                 }
                 SBR_LAUNCH(we);
             }
-            SBR_LAUNCH(launch_tail_gate(s2, done, 1, a.prog_epoch, 0xfff, a.fault));
+            if (!serial) SBR_LAUNCH(launch_tail_gate(s2, words, nwaves, a.prog_epoch, y.T, a.fault));
             // (tried and dropped: the last time chunk as a launch of its own behind the polling one, one wave per 16 entries on the
             // then idle chip -- the hot rows' atomics serialise there: 23 us for 6400 entries, profiles/round3_variants.txt call d)
+            hipError_t se = hipSuccess;
+            if (h->tail_cost_scanned && launch_scatter_lds_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                                               (const int*)h->A(y.a_soff), (const int*)h->A(y.a_sP), y.cfg.input_size, tnc,
+                                                               y.T * y.Bp * y.F, GHp, pl, h->tail_bounds, h->tail_scatter_units, &se)) {
+                SBR_LAUNCH(se);
+            } else
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
-                                                  0, &h->tail_bounds, h->tail_short_chunks));
+                                                  0, &h->tail_bounds, h->tail_short_chunks, !serial && h->tail_fence_kb > 0));
             if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
             // single-call step: the slab reduction IS the W_hid update (one launch, one pass less behind the chain); phase-by-phase
             // callers (data parallel) need the reduced gradient
             const int fuse_slabs = h->tail_fuse_slabs;
             if (upd_here && fuse_slabs && ly.p_peep - ly.p_Whid == slab && (slab & 3) == 0) {
-                SBR_LAUNCH(launch_update_from_slabs(sd, y.cfg.updater, ws2, pl.n_small + n_big, h->P(ly.p_Whid), h->St(0, ly.p_Whid),
+                SBR_LAUNCH(launch_update_from_slabs(sd, y.cfg.updater, ws2, n_slabs, h->P(ly.p_Whid), h->St(0, ly.p_Whid),
                                                     s1a ? s1a + ly.p_Whid : nullptr, slab, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
                                                     y.cfg.beta2, (long)h->step_count + 1));
             } else {
-                SBR_LAUNCH(launch_splitk_reduce(sd, ws2, pl.n_small + n_big, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
+                SBR_LAUNCH(launch_splitk_reduce(sd, ws2, n_slabs, ly.Hp, GHp, h->Gd(ly.p_Whid), GHp, nullptr));
                 if (upd_here) SBR_LAUNCH(upd_on(sd, ly.p_Whid, ly.p_peep));
             }
             SBR_HIP(hipEventRecord(h->ev_tail, sd));
@@ -1187,6 +1270,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_HIP(hipStreamWaitEvent(s, h->ev_tail2, 0));
             mark(h, 6);
             SBR_HIP(hipStreamWaitEvent(s, h->ev_tail, 0));
+            if (h->out3 && out_early) SBR_HIP(hipStreamWaitEvent(s, h->ev_tail3, 0));
+            else if (h->out3) SBR_HIP(hipStreamWaitEvent(s, h->ev_og, 0));
+            h->out3 = false;
             h->side_pending = false;
             continue;
         }
@@ -1617,6 +1703,8 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     if (nm == "batch_pop") { *dev_ptr = (void*)h->bpop; *n_floats = y.Bp; return SBR_OK; }
     if (nm == "batch_samples") { *dev_ptr = (void*)h->bsmp; *n_floats = y.S; return SBR_OK; }
     if (nm == "prof") { *dev_ptr = h->A(y.a_prof); *n_floats = (size_t)2 * (y.Bp / 16) * 16 * 8 * 2; return SBR_OK; }
+    if (nm == "tail_trace" && h->tail_trace) { *dev_ptr = h->tail_trace; *n_floats = 2 * 16384; return SBR_OK; }
+    if (nm == "tail_chain_clock") { *dev_ptr = (int*)h->A(y.a_prog) + (y.Bp / h->rpt) * 8 + 128; *n_floats = 8; return SBR_OK; }
     if (nm == "rowcost") { *dev_ptr = h->A(y.a_rowcost); *n_floats = y.Bp; return SBR_OK; }
     if (nm == "act" && y.S > 0) { *dev_ptr = h->A(y.a_act); *n_floats = (size_t)y.Bp * y.C; return SBR_OK; }
     for (int l = 0; l < y.L; ++l) {

@@ -112,8 +112,10 @@ struct Layout {
     size_t a_clx;                         // cluster handshake slots (ints)
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
+    size_t a_sP;                          // [input_size + 1] running cost of the ids (launch_scatter_lds_poll)
     int tail_keys;                        // time chunks the sort's key space was sized for (1: no tail overlap possible)
     size_t a_prog;                        // [Bp / 4 * 8] progress words of the running BPTT chain (tail overlap)
+    size_t a_done;                        // [SBR_DONE_COPIES * SBR_DONE_STRIDE] the monitor's word (the minimum over a_prog), replicated
 };
 
 int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err);
@@ -174,9 +176,21 @@ struct sbr_handle {
     int tail_pub_every;  // SBR_TAIL_PUBLISH_EVERY: time steps between two progress words of a chain wave (default 2)
     int tail_nc, tail_ch;   // this step: time chunks of the sort's keys / steps per chunk (0: plain keys)
     SbrTChunks tail_bounds; // ... and their bounds (tail_plan)
+    unsigned long long* tail_trace = nullptr;    // SBR_TAIL_TRACE=1: SbrPoll.trace
+    int tail_fence_kb;      // SBR_TAIL_FENCE_KB: LDS the chains claim while consumers / the sort run beside them (0: none)
+    int tail_early_sort;    // SBR_TAIL_EARLY_SORT: the time-chunked sort beside the forward chain
+    int tail_out_stream;    // SBR_TAIL_OUT_STREAM: output-layer gradients + update on a third side stream (single-call steps)
+    bool tail_sorted, out3; // this step: the sort already ran (sbr_forward) / the output layer's work is on side3
+    hipStream_t side3; hipEvent_t ev_tail3;      // side3: the overlapped tail's monitor (tail_monitor_kernel)
     int tail_short_chunks;  // time chunks (from t = 0) whose scatter-add entries are cut into short pieces (SBR_TAIL_SHORT_CHUNKS)
     double tail_geom;       // SBR_TAIL_GEOM: growth of the small time chunks near t = 0 (<= 1: equal chunks)
-    int tail_fuse_slabs, tail_small_slabs, tail_small_k;                  // SBR_TAIL_FUSE_SLABS / _SMALL_SLABS / _SMALL_K
+    bool tail_cost_scanned = false;                                       // this step's sort was followed by launch_scatter_cost_scan
+    int tail_first;                                                       // SBR_TAIL_FIRST: time steps of the last time chunk (LDS-row scatter-add)
+    int tail_scatter_lds, tail_scatter_units;                             // SBR_TAIL_SCATTER_LDS / SBR_TAIL_SCATTER_UNITS
+    int tail_gemm_groups;                                                 // SBR_TAIL_GEMM_GROUPS: persistent groups of the polling dW_hid GEMM
+    int tail_fuse_slabs, tail_slab_max;                                   // SBR_TAIL_FUSE_SLABS / SBR_TAIL_SLAB_MAX (rows)
+    double tail_slab_growth;                                              // SBR_TAIL_SLAB_GROWTH (k steps of a slab per time step of lead)
+    std::vector<int> tail_slab_host; int* tail_slab_dev = nullptr; int tail_slab_key[2] = {0, 0};   // the table of the last plan
     bool fold_dh;           // SBR_FOLD_DH
     int wgrad_f16, wgrad_x6_wgs;                                          // SBR_WGRAD_F16, SBR_WGRAD_X6_WGS
     int prog_epoch;
@@ -212,9 +226,17 @@ void sbr_set_error(const char* fmt, ...);
 // Consumers of a RUNNING BPTT chain (overlapped step tail): the chain's waves publish (epoch << 12) | t in words[0 .. n) once
 // all their time steps >= t are complete and written through (RecArgs.progress); ONE workgroup of the consuming GEMM
 // folds them into `done` = (epoch << 12) | max t, which every other consumer polls.  rows_per_step: K rows per time step.
-// Slabs of a polling GEMM are K-ascending with n_small slabs of k_small rows first (the time steps the chain reaches last:
-// short slabs = short tail), the rest of kchunk rows; workgroups take them from the far end.
-struct SbrPoll { const int* words; int n; int* done; int epoch; int rows_per_step; int* fault; int n_small, k_small; };
+// Slabs of a polling GEMM are K-ascending, slab z = rows [slab_lo[z], slab_lo[z + 1]) (a device table of multiples of 32, see
+// sbr_tail_slab_table: one k step of 32 rows for the time steps the chain reaches last, growing with the time the chain still
+// needs once a slab is released -- a slab must be DONE when the chain ends, not started); workgroups take them from the far end.
+// The monitor's word exists in SBR_DONE_COPIES copies, SBR_DONE_STRIDE ints apart (4 KB + 256 B: other pages AND other channels):
+// ~950 waves poll it with agent-scope loads, which are served by the memory side -- on ONE word every poll queues at the same
+// channel, and every load of the consumers that touches that channel waits behind them (profiles/round3_n_trace.txt: 2 - 10 us
+// per dependent load of the polling GEMM).  Each poller reads the copy its workgroup number selects.
+#define SBR_DONE_COPIES 32
+#define SBR_DONE_STRIDE 1088
+struct SbrPoll { const int* words; int n; int* done; int epoch; int rows_per_step; int* fault; int n_small, k_small;
+                 unsigned long long* trace; const int* slab_lo; int n_slabs; };    // trace (SBR_TAIL_TRACE=1, tools/tail_trace.py): 100 MHz stamps of the consumers' waits and ends
 
 // ---------------------------------------------------------------------------------------
 // Kernel launchers (each returns hipGetLastError())
@@ -253,8 +275,16 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo = 0, bool accumulate = false, int acc_chunk = 32);
 // all time chunks of a time-chunked sort in ONE launch beside the running chain: every wave waits for poll.done to reach the
 // time chunk of its entries (tch steps per chunk), rows are added with float atomics (an id may occur in every chunk)
+// the same without a global atomic per piece: `units` workgroups own id ranges of equal cost (P: n_ids + 1 ints of workspace, the
+// running cost) and accumulate their rows in LDS (sbr_misc.hip).  false = shape not supported, nothing launched.
+bool launch_scatter_cost_scan(hipStream_t s, const int* offs, int* P, int n_ids, int n_tchunks, int max_entries, int GHp, int units,
+                              hipError_t* err);
+hipError_t launch_tail_monitor(hipStream_t s, const SbrPoll& poll, int t_lo);
+bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, const int* P,
+                             int n_ids, int n_tchunks, int max_entries, int GHp, const SbrPoll& poll, const SbrTChunks& bounds,
+                             int units, hipError_t* err);
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
-                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0, const SbrTChunks* bounds = nullptr, int short_chunks = 0);
+                                      int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0, const SbrTChunks* bounds = nullptr, int short_chunks = 0, bool fence_on = false);
 
 // Tile-blocked activation layout [t][row tile of 16][column tile of 16][row 16][col 16] (floats):
 // the 16x16 tile one wave of the recurrent kernels owns is one contiguous KiB (8 full 128-B lines per
@@ -310,6 +340,8 @@ struct RecArgs {
     // (prog_epoch << 12) | t in progress[block * 8 + wave] once all its time steps >= t are complete: at launch (t = first
     // live step + 1 ...), whenever t is a multiple of prog_every, and t_lo at the end.  NULL: plain stores, no progress
     int* progress; int prog_every; int prog_epoch;
+    int fence_kb;           // rec_*_x6p: the workgroup claims this much of its CU's LDS (KiB; 0: what it needs) so that kernels which
+                            // run BESIDE the chain and use LDS themselves are placed on other CUs (overlapped step tail)
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
 #define SBR_X6P_FUSE_MAX_T 4096      // fused gather of rec_fwd_x6p: 4 rows x T row offsets in LDS
@@ -370,10 +402,14 @@ hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, 
 bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
                           int K, float* ws, int nsplit, long ws_ld, size_t slab_stride, const float* B2, long sbk2, int n_split,
                           hipError_t* err, int planes = 3, float sa = 1.0f, float sb = 1.0f);
-// the same as a consumer of the running chain: n_small + n_big slabs (SbrPoll), K = n_small * k_small + n_big * k_big at most
+// the same as a consumer of the running chain: poll.n_slabs slabs of K, poll.slab_lo[0 .. n_slabs] (device) their first rows,
+// shared by n_groups persistent groups of workgroups, each of which leaves ONE partial in ws (n_groups partials to reduce)
 bool launch_gemm_slabs_x6_poll(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
-                               int K, float* ws, int n_big, int k_big, long ws_ld, size_t slab_stride, const float* B2, long sbk2,
+                               int K, float* ws, int n_groups, long ws_ld, size_t slab_stride, const float* B2, long sbk2,
                                int n_split, hipError_t* err, int planes, float sa, float sb, const SbrPoll& poll);
+// host side of the table: lo[0] = 0 < lo[1] < ... < lo[n] = K, n <= cap.  A slab that starts at time step t has
+// max(1, floor(growth * t - 1)) k steps of 32 rows, at most max_rows / 32 (sizes scaled up until n <= cap).
+int sbr_tail_slab_table(int K, int rows_per_step, int cap, double growth, int max_rows, std::vector<int>& lo);
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias);
 

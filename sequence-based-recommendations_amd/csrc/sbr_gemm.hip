@@ -233,12 +233,26 @@ bool launch_gemm_slabs_x6(hipStream_t s, const float* A, long sam, long sak, con
                           planes, sa, sb);
 }
 bool launch_gemm_slabs_x6_poll(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M, int N,
-                               int K, float* ws, int n_big, int k_big, long ws_ld, size_t slab_stride, const float* B2, long sbk2,
+                               int K, float* ws, int n_groups, long ws_ld, size_t slab_stride, const float* B2, long sbk2,
                                int n_split, hipError_t* err, int planes, float sa, float sb, const SbrPoll& poll) {
-    if (g_gemm_exact_f32 || M <= 0 || N <= 0 || n_big < 1 || (k_big & 31) || (poll.k_small & 31)) return false;
-    if ((long)poll.n_small * poll.k_small + (long)n_big * k_big < K) return false;
-    return launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, poll.n_small + n_big, k_big, slab_stride, err, B2, sbk2,
+    if (g_gemm_exact_f32 || M <= 0 || N <= 0 || n_groups < 1 || !poll.slab_lo) return false;
+    return launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ws, ws_ld, M, N, K, nullptr, n_groups, 32, slab_stride, err, B2, sbk2,
                           n_split, false, planes, sa, sb, &poll);
+}
+int sbr_tail_slab_table(int K, int rows_per_step, int cap, double growth, int max_rows, std::vector<int>& lo) {
+    const int max_n = std::max(1, max_rows / 32);
+    for (double scale = 1.0; ; scale *= 1.5) {
+        lo.assign(1, 0);
+        for (int r = 0; r < K; ) {
+            const double t = (double)r / std::max(1, rows_per_step);
+            int n = (int)std::floor((growth * t - 1.0) * scale);
+            n = std::max((int)scale, std::min(max_n, n));
+            r += std::min(32 * n, K - r);
+            lo.push_back(r);
+        }
+        if ((int)lo.size() - 1 <= cap || scale > 1e6) break;
+    }
+    return (int)lo.size() - 1;
 }
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int nslabs, int M, int N, float* C, long ldc,
                                 const float* bias) {

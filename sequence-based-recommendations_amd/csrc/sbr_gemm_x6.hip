@@ -35,52 +35,54 @@ struct GemmX6Args {
     SbrPoll poll;                              // words != NULL: consumer of a running BPTT chain (sbr_common.h)
 };
 
-// Overlapped step tail.  Workgroup (0, 0, 0) is the MONITOR of the launch: it folds the chain's per-wave progress words into
-// `done` (relaxed agent-scope loads, one write-through store when the maximum moves) until the chain has finished, and only
-// then computes its own slab -- the one the chain completes last.  Every other workgroup polls `done` from one lane until
-// its slab's first time step is complete, then takes an agent-scope acquire (the chain stored write-through; this drops
-// whatever this CU / XCD still holds of those lines from the previous training step) and runs as usual.  Spins are
-// bounded (fault bit 3).  t_need: the slab's first time step.
-__device__ __forceinline__ void x6_poll_wait(const SbrPoll& pl, bool monitor, int t_need, int tid) {
-    __shared__ int s_part[4];
+// Overlapped step tail.  A workgroup polls the monitor's word `done` (tail_monitor_kernel, sbr_misc.hip; its copy of it: SbrPoll)
+// from one lane until the first time step of its next slab is complete.  Spins are bounded (fault bit 3).  t_need: the slab's
+// first time step.  seen: the last value of `done` this workgroup has read (0xfff before the first) -- a persistent
+// workgroup whose next slab is already released does not pay another round trip to the memory side.
+// The chain-written operand is then read with agent-coherent (sc1) loads -- x6_issue_sc1 -- and NOT behind an acquire fence:
+// on gfx950 that fence is `buffer_inv sc1`, which drops every non-coherent line of the XCD's L2 and takes ~15 000 cycles
+// (sbr_rec_cl.hip); the chain stored write-through, and sc1 loads are served by the memory side.
+__device__ __forceinline__ void x6_poll_wait(const SbrPoll& pl, int t_need, int tid, int& seen) {
+    __shared__ int s_seen;
+    if (seen <= t_need) return;                              // (uniform)
     const int tag = pl.epoch;
-    if (monitor) {
-        int last = 0x1000;
+    if (tid == 0) {
         const unsigned long long t0 = wall_clock64();
+        const int* mine = pl.done + ((blockIdx.z * 3 + blockIdx.x + blockIdx.y) & (SBR_DONE_COPIES - 1)) * SBR_DONE_STRIDE;
         for (;;) {
-            int m = 0;
-            for (int i = tid; i < pl.n; i += 256) {
-                const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
-            if ((tid & 63) == 0) s_part[tid >> 6] = m;
-            __syncthreads();
-            m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
-            __syncthreads();
-            if (m != last && m != 0xfff) {
-                if (tid == 0) __hip_atomic_store(pl.done, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = m;
-            }
-            if (m <= t_need) break;
-            if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
-            __builtin_amdgcn_s_sleep(4);
+            const int v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 12) == tag && (v & 0xfff) <= t_need) { s_seen = v & 0xfff; break; }
+            if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(pl.fault, 8); s_seen = 0; break; }
+            poll_sleep((v >> 12) == tag ? (v & 0xfff) - t_need : 64);
         }
-    } else {
-        if (tid == 0) {
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
-                const int v = __hip_atomic_load(pl.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 12) == tag && (v & 0xfff) <= t_need) break;
-                if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(pl.fault, 8); break; }
-                poll_sleep((v >> 12) == tag ? (v & 0xfff) - t_need : 64);
-            }
-        }
-        __syncthreads();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
+    seen = s_seen;
+    __syncthreads();
+}
+// 4 rows x 8 k as in x6_load (interior tiles only), with loads that every XCD's stores reach (sc1: served by the memory side,
+// not by a line this XCD's L2 may still hold from the previous training step).  The loads are invisible to the compiler's
+// waitcnt insertion: the registers stay where the loads put them until x6_sc1_landed() has waited, and only then become v.
+template <bool RFAST>
+__device__ __forceinline__ void x6_issue_sc1(const float* __restrict__ p, long stride, f32x4 (&t)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float* r = RFAST ? p + (long)i * stride : p + (long)(i >> 1) * stride + (i & 1) * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[i]) : "v"(r) : "memory");
+    }
+}
+template <bool RFAST>
+__device__ __forceinline__ void x6_sc1_landed(f32x4 (&t)[8], float (&v)[4][8]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t[i]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (RFAST) v[e][i] = t[i][e];
+            else v[i >> 1][(i & 1) * 4 + e] = t[i][e];
+        }
 }
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 x6_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) { return MFMA_BF16(a, b, c); }
@@ -130,7 +132,8 @@ __device__ __forceinline__ void x6_load(const float* __restrict__ p, long stride
 // even), ONE v_mfma_f32_16x16x32_bf16 per block with f32 accumulation -- the "bf16 MFMA output projection" of the 1 M-item
 // configuration (BASELINE.json configs[4]; SBR_FLAG_BF16_PROJECTION): logits to ~3e-3 of their spread instead of f32
 // rounding, a sixth of the matrix-pipe time and a third of the LDS traffic.
-template <int VA, bool RA, int VB, bool RB, int TW, int KH, int NP>
+// PL: consumer of a running BPTT chain (g.poll): both operands through x6_issue_sc1.
+template <int VA, bool RA, int VB, bool RB, int TW, int KH, int NP, bool PL = false>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     constexpr int TM = 32 * TW, TK = 32 * KH, ROW = 64 * KH + 16, PLANE = TM * ROW, KC = 4 * KH;
     using OPV = std::conditional_t<NP == 2, f16x8g, bf16x8>;
@@ -140,33 +143,33 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int j = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
-    int zz = blockIdx.z, kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    if (g.poll.words) {
-        const int nz = gridDim.z;
-        zz = nz - 1 - (int)blockIdx.z;                         // the last time steps are complete first
-        const bool monitor = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-        if (blockIdx.x == 0 && blockIdx.y == 0) { if (zz == nz - 1) zz = 0; else if (zz == 0) zz = nz - 1; }   // the monitor owns slab 0
-        const int ksz = zz < g.poll.n_small ? g.poll.k_small : g.kchunk;
-        kbeg = zz < g.poll.n_small ? zz * g.poll.k_small : g.poll.n_small * g.poll.k_small + (zz - g.poll.n_small) * g.kchunk;
-        kend = min(g.K, kbeg + ksz);
-        x6_poll_wait(g.poll, monitor, kbeg / g.poll.rows_per_step, threadIdx.x);
-    }
-
+    int zz = blockIdx.z;
     // loader role: A tile (waves 0,1) or B tile (waves 2,3); rows rg*4..+3, k-chunk kc*8..+7
     const bool ldB = tid >= 128;
     const int lt = tid & 127, rg = lt / KC, kc = lt % KC;
     const int r0 = (ldB ? n0 : m0) + rg * 4;
     const int nr = max(0, min(4, (ldB ? g.N : g.M) - r0));
     long srow = ldB ? g.sbn : g.sam, sk = ldB ? g.sbk : g.sak;
-    const float* src = (ldB ? g.B : g.A) + (long)r0 * srow + (long)(kbeg + kc * 8) * sk;   // advanced by TK k per step
-    if (ldB && g.B2 && r0 >= g.n_split) { sk = g.sbk2; src = g.B2 + (long)(r0 - g.n_split) * srow + (long)(kbeg + kc * 8) * sk; }
+    const float* base = (ldB ? g.B : g.A) + (long)r0 * srow;
+    if (ldB && g.B2 && r0 >= g.n_split) { sk = g.sbk2; base = g.B2 + (long)(r0 - g.n_split) * srow; }
+    const float* src = base;                               // advanced by TK k per step
     const long kstep = TK * sk;
     char* sdst = (ldB ? sB : sA) + (rg * 4) * ROW + kc * 16;
 
     float v[4][8];
+    f32x4 tq[PL ? 8 : 1];
+    int kbeg = 0, kend = 0;
     auto load = [&](int k0) {
         const int nk = max(0, min(8, kend - (k0 + kc * 8)));
-        if (ldB) x6_load<VB, RB>(src, RB ? sk : srow, nr, nk, v);
+        if constexpr (PL) {      // nk is 8 or 0 here (slab bounds and K are multiples of 8: launch_gemm_x6)
+            if (nk < 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tq[i] = f32x4{0, 0, 0, 0};
+            }
+            else if (ldB) x6_issue_sc1<RB>(src, RB ? sk : srow, tq);
+            else x6_issue_sc1<RA>(src, RA ? sk : srow, tq);
+        }
+        else if (ldB) x6_load<VB, RB>(src, RB ? sk : srow, nr, nk, v);
         else x6_load<VA, RA>(src, RA ? sk : srow, nr, nk, v);
         src += kstep;
     };
@@ -178,8 +181,13 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         for (int b = 0; b < TW; ++b) { acc[a][b] = z; if constexpr (NP == 2) acl[a][b] = z; }
     const float opscale = ldB ? g.sb : g.sa;
 
+    auto run_slab = [&]() {                               // acc += A[:, kbeg .. kend) . B[kbeg .. kend, :]
+    src = base + (long)(kbeg + kc * 8) * sk;
     if (kbeg < kend) load(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        if constexpr (PL) {
+            if (ldB) x6_sc1_landed<RB>(tq, v); else x6_sc1_landed<RA>(tq, v);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bf16x8 p1, p2, p3;
@@ -220,9 +228,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
                 }
             // smallest terms first: a1b3, a3b1, a2b2, a1b2, a2b1, a1b1; TW*TW independent accumulators per term
 #define X6_TERM(PA, PB) _Pragma("unroll") for (int mi = 0; mi < TW; ++mi) _Pragma("unroll") for (int ni = 0; ni < TW; ++ni) \
-                acc[mi][ni] = x6_mfma(a[PA][mi], b[PB][ni], acc[mi][ni]);
+                acc[mi][ni] = x6_mfma(b[PB][ni], a[PA][mi], acc[mi][ni]);
 #define X6_TERL(PA, PB) _Pragma("unroll") for (int mi = 0; mi < TW; ++mi) _Pragma("unroll") for (int ni = 0; ni < TW; ++ni) \
-                acl[mi][ni] = x6_mfma(a[PA][mi], b[PB][ni], acl[mi][ni]);
+                acl[mi][ni] = x6_mfma(b[PB][ni], a[PA][mi], acl[mi][ni]);
             if constexpr (NP == 1) { X6_TERM(0, 0) }
             else if constexpr (NP == 2) { X6_TERL(0, 1) X6_TERL(1, 0) X6_TERM(0, 0) }
             else { X6_TERM(0, NP - 1) X6_TERM(NP - 1, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0) }
@@ -232,21 +240,70 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         __syncthreads();
     }
 
+    };
+    if constexpr (PL) {
+        // Persistent groups: gridDim.z groups of workgroups (one per N / M tile each) share the nz slabs round-robin in the
+        // order the chain releases them (slab nz-1 first); a workgroup keeps its accumulators across its slabs and stores ONE
+        // partial at the end (slab `group` of the workspace).  So the launch occupies a FIXED number of workgroups, all
+        // resident from the start -- with one workgroup per slab the early, long slabs held the CUs' registers and the
+        // scatter-add beside this launch got its waves only when the chain had ended (profiles/round3_u_trace.txt).
+        const int nz = g.poll.n_slabs, groups = (int)gridDim.z, group = (int)blockIdx.z;
+        int seen = 0xfff;
+        for (int sl = nz - 1 - group; sl >= 0; sl -= groups) {
+            kbeg = g.poll.slab_lo[sl]; kend = min(g.K, g.poll.slab_lo[sl + 1]);
+            x6_poll_wait(g.poll, kbeg / g.poll.rows_per_step, tid, seen);
+            unsigned long long* tr = g.poll.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 ? g.poll.trace + 16 + 2 * sl : nullptr;
+            if (tr) tr[0] = wall_clock64();
+            run_slab();
+            if (tr) tr[1] = wall_clock64();
+        }
+        zz = group;
+    } else {
+        kbeg = blockIdx.z * g.kchunk; kend = min(g.K, kbeg + g.kchunk);
+        run_slab();
+    }
+    // The products above are mfma(B rows, A rows): the accumulators hold the TRANSPOSED 16x16 tiles, i.e. lane (j, q) has row
+    // m = j and the four consecutive columns n = 4q .. 4q+3 of each tile -- one 16-byte store per tile and lane, 64 contiguous
+    // bytes per row and quarter wave.  (Round 3: the untransposed form wrote 64 guarded dwords per lane, ~8 us of a workgroup's
+    // life whatever its K -- profiles/round3_s_trace.txt.)
     float* out = g.C + (size_t)zz * g.slab_stride;
+    const bool inner = (g.ldc & 3) == 0 && ((uintptr_t)out & 15) == 0 && m0 + TM <= g.M && n0 + TM <= g.N;   // uniform
+    auto tile_out = [&](int mi, int ni) -> f32x4 {
+        f32x4 val = acc[mi][ni];
+        if constexpr (NP == 2) {
 #pragma unroll
-    for (int mi = 0; mi < TW; ++mi)
+            for (int r = 0; r < 4; ++r) val[r] = fmaf(acl[mi][ni][r], 1.0f / 2048.0f, val[r]) * g.so;
+        }
+        return val;
+    };
+    if (inner && !g.bias) {                      // split-K slabs, whole tiles: nothing but the stores
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 16 * TW + mi * 16 + 4 * q + r;
-            if (m >= g.M) continue;
+        for (int mi = 0; mi < TW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TW; ++ni)
+                *(f32x4*)(out + (long)(m0 + wm * 16 * TW + mi * 16 + j) * g.ldc + n0 + wn * 16 * TW + ni * 16 + 4 * q) = tile_out(mi, ni);
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TW; ++mi) {
+            const int m = m0 + wm * 16 * TW + mi * 16 + j;
 #pragma unroll
             for (int ni = 0; ni < TW; ++ni) {
-                const int n = n0 + wn * 16 * TW + ni * 16 + j;
-                float val = acc[mi][ni][r];
-                if constexpr (NP == 2) val = fmaf(acl[mi][ni][r], 1.0f / 2048.0f, val) * g.so;
-                if (n < g.N) out[(long)m * g.ldc + n] = val + (g.bias ? g.bias[n] : 0.0f);
+                const int n = n0 + wn * 16 * TW + ni * 16 + 4 * q;
+                f32x4 val = tile_out(mi, ni);
+                if (g.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) val[r] += g.bias[n + r];
+                }
+                float* dst = out + (long)m * g.ldc + n;
+                if (inner) *(f32x4*)dst = val;
+                else if (m < g.M) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) dst[r] = val[r];
+                }
             }
         }
+    }
+    if (PL && g.poll.trace && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g.poll.trace[8 + (blockIdx.z & 7)] = wall_clock64();   // (end of a workgroup)
 }
 
 static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte loads along the unit-stride dimension
@@ -267,18 +324,22 @@ bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const flo
     const bool ra = sak != 1, rb = sbk != 1;                        // unit stride along the rows (m / n) instead of k
     if (!x6_aligned(A, ra ? sak : sam) || !x6_aligned(B, rb ? sbk : sbn)) return false;
     GemmX6Args g{A, sam, sak, B, sbk, sbn, C, ldc, slab_stride, M, N, K, kchunk, nsplit > 1 ? nullptr : bias, B2, sbk2, n_split,
-                 sa, sb, 1.0f / (sa * sb), SbrPoll{nullptr, 0, nullptr, 0, 1, nullptr, 0, 0}};
-    if (poll) { if (small || nsplit < 2) return false; g.poll = *poll; }
+                 sa, sb, 1.0f / (sa * sb), SbrPoll{nullptr, 0, nullptr, 0, 1, nullptr, 0, 0, nullptr, nullptr, 0}};
+    if (poll) {      // (interior tiles only: x6_issue_sc1)
+        if (small || nsplit < 1 || planes < 2 || (M & 127) || (N & 127) || (K & 7) || !poll->slab_lo || poll->n_slabs < 1) return false;
+        g.poll = *poll;
+    }
     const int tile = small ? 64 : 128;
     const dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, nsplit);
-#define X6_GO(TW, KH, NP) do { \
-        if (ra && rb) gemm_x6_kernel<4, true, 4, true, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
-        else if (ra) gemm_x6_kernel<4, true, 4, false, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
-        else if (rb) gemm_x6_kernel<4, false, 4, true, TW, KH, NP><<<grid, 256, 0, s>>>(g); \
-        else gemm_x6_kernel<4, false, 4, false, TW, KH, NP><<<grid, 256, 0, s>>>(g); } while (0)
-    if (planes == 1) { if (small) X6_GO(2, 2, 1); else X6_GO(4, 1, 1); }
-    else if (planes == 2) { if (small) X6_GO(2, 2, 2); else X6_GO(4, 1, 2); }
-    else if (small) X6_GO(2, 2, 3); else X6_GO(4, 1, 3);
+#define X6_GO(TW, KH, NP, PL) do { \
+        if (ra && rb) gemm_x6_kernel<4, true, 4, true, TW, KH, NP, PL><<<grid, 256, 0, s>>>(g); \
+        else if (ra) gemm_x6_kernel<4, true, 4, false, TW, KH, NP, PL><<<grid, 256, 0, s>>>(g); \
+        else if (rb) gemm_x6_kernel<4, false, 4, true, TW, KH, NP, PL><<<grid, 256, 0, s>>>(g); \
+        else gemm_x6_kernel<4, false, 4, false, TW, KH, NP, PL><<<grid, 256, 0, s>>>(g); } while (0)
+    if (poll) { if (planes == 2) X6_GO(4, 1, 2, true); else X6_GO(4, 1, 3, true); }
+    else if (planes == 1) { if (small) X6_GO(2, 2, 1, false); else X6_GO(4, 1, 1, false); }
+    else if (planes == 2) { if (small) X6_GO(2, 2, 2, false); else X6_GO(4, 1, 2, false); }
+    else if (small) X6_GO(2, 2, 3, false); else X6_GO(4, 1, 3, false);
 #undef X6_GO
     *err = hipGetLastError();
     return true;

@@ -477,20 +477,31 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
         const int t_need = tch.lo[min(__shfl(my_id, 0) / n_ids, SBR_TCHUNKS_MAX)];
         if (lane == 0) {
             const unsigned long long t0 = wall_clock64();
+            const int* mine = poll.done + ((blockIdx.x + 16) & (SBR_DONE_COPIES - 1)) * SBR_DONE_STRIDE;
             for (;;) {
-                const int v = __hip_atomic_load(poll.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((v >> 12) == poll.epoch && (v & 0xfff) <= t_need) break;
                 if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(poll.fault, 8); break; }
                 poll_sleep((v >> 12) == poll.epoch ? (v & 0xfff) - t_need : 64);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (no acquire fence: on gfx950 that is an invalidate of the XCD's whole L2, ~15 000 cycles, for every released wave -- the
+        // rows the chain wrote are read with sc1 loads below instead; sbr_gemm_x6.hip x6_poll_wait)
+        __builtin_amdgcn_wave_barrier();
+        if (poll.trace && lane == 0) {
+            const int k = min((it - wave_global) / n_waves, 3);
+            poll.trace[8192 + (wave_global * 4 + k) * 2] = wall_clock64();
+        }
     }
     f32x4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
     int cur_id = __shfl(my_id, 0);
+#ifndef SCAT_DEBUG_NOFLUSH
+#define SCAT_DEBUG_NOFLUSH 0      // 1 (tools/probes/variant_build.sh): the polling launch adds nothing -- WRONG gradients, for timing what its atomics cost
+#endif
     auto flush = [&](int key) {
+        if (POLL && SCAT_DEBUG_NOFLUSH) return;
         const bool owned = !POLL && offs[key] >= base && offs[key + 1] <= base + cnt;    // whole segment inside this chunk
         const int id = POLL ? key % n_ids : key - key_lo;
 #pragma unroll
@@ -515,8 +526,20 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int f4 = lane + 64 * v;
-                val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
+                if constexpr (POLL)      // (lanes past the row load its last piece: no branch around the asm; zeroed once landed)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(val[u][v]) : "v"(dxt + pos * R4 + min(f4, R4 - 1)) : "memory");
+                else val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
             }
+        }
+        if constexpr (POLL) {      // (the loads above are invisible to the compiler's waitcnt insertion)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < SCAT_FLY; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    asm volatile("" : "+v"(val[u][v]));
+                    if (lane + 64 * v >= R4) val[u][v] = f32x4{0, 0, 0, 0};
+                }
         }
 #pragma unroll
         for (int u = 0; u < SCAT_FLY; ++u) {
@@ -528,24 +551,234 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
         }
     }
     flush(cur_id);
+    if (POLL && poll.trace && lane == 0) {
+        const int k = min((it - wave_global) / n_waves, 3);
+        poll.trace[8192 + (wave_global * 4 + k) * 2 + 1] = wall_clock64();
+    }
     if (!POLL) break;
     }
 }
 
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
                                       int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll_in, int first_key,
-                                      const SbrTChunks* bounds, int short_chunks) {
+                                      const SbrTChunks* bounds, int short_chunks, bool fence_on) {
     const SbrTChunks tc = bounds ? *bounds : sbr_uniform_tchunks(tch, n_tchunks);
     SbrPoll poll = poll_in;
     poll.n_small = std::max(0, std::min(short_chunks, n_tchunks));      // (the field counts the GEMM's short slabs there; here: time chunks cut short)
 
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
-    static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 64;
+    static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 128;   // (round 3: 128 with the short pieces; 64 before)
     const int grid = std::max(1, std::min(wgs, ((max_entries + 7) / 8 + 3) / 4));
-#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tc, poll)
+    // (the LDS this launch asks for is a FENCE, not storage: with it a workgroup does not fit beside the BPTT chain's, which claims
+    // 124 KB of its CU's 160 for the same purpose -- sbr_rec_p.hip launch_bwd_p)
+    const size_t fence = fence_on ? (size_t)40 * 1024 : 0;
+#define SRP(NV) scat_reduce_kernel<NV, 32, true, true><<<grid, 256, fence, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, first_key, n_tchunks, tc, poll)
     if (nv <= 1) SRP(1); else if (nv <= 2) SRP(2); else if (nv <= 4) SRP(4); else return hipErrorInvalidValue;
 #undef SRP
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Overlapped step tail, round 3: the scatter-add WITHOUT one global atomic per piece and row.
+// The polling launch above adds every piece's row sums to dW_in with float atomics: an id occurs in every time chunk and its
+// entries are cut into pieces, ~10 000 flushes of 384 floats per C2 step.  On gfx950 agent-scope atomics are executed by the
+// memory side, and 4 M of them beside the chain cost the chain 13 us, the polling GEMM's last slabs 10 us and this launch's
+// own end 17 us (profiles/round3_w_trace.txt: the same step with the flush removed).
+// Here a workgroup OWNS a range of ids: it walks the time chunks in the order the chain releases them, adds the rows of its
+// ids' entries into accumulators in LDS (ds_add_f32), and stores each row ONCE when the chain has ended.  Ranges are cut in
+// COST space, cost(id) = max(entries of id over all chunks, floor): unit u owns [u Q, (u + 1) Q) of the running sum P, so that
+// units are balanced in entries and hold at most Q / floor + 2 ids (the LDS rows); an id that straddles a cut -- every hot id
+// does -- is shared: in EVERY chunk each sharing unit takes the same fraction of that id's entries (the cut is uniform in
+// time, so nobody is left with only the last time steps), and only those rows, at most two per unit, end in global atomics.
+// In the time-chunked sort the entries of a unit in one chunk are one contiguous range of the sorted array.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) scat_cost_scan_kernel(const int* __restrict__ offs, int n_ids, int n_tchunks, int floor_cost,
+                                                              int* __restrict__ P) {
+    __shared__ int part[1024];
+    const int per = (n_ids + 1023) / 1024, lo = threadIdx.x * per, hi = min(n_ids, lo + per);
+    int sum = 0;
+    for (int id = lo; id < hi; ++id) {
+        int tot = 0;
+        for (int c = 0; c < n_tchunks; ++c) tot += offs[c * n_ids + id + 1] - offs[c * n_ids + id];
+        sum += max(tot, floor_cost);
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;                               // exclusive
+    for (int id = lo; id < hi; ++id) {
+        int tot = 0;
+        for (int c = 0; c < n_tchunks; ++c) tot += offs[c * n_ids + id + 1] - offs[c * n_ids + id];
+        P[id] = run;
+        run += max(tot, floor_cost);
+    }
+    if (threadIdx.x == 1023) P[n_ids] = part[1023];
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid, const int* __restrict__ spos,
+                                                       const int* __restrict__ offs, const int* __restrict__ P, int n_ids, int n_tchunks,
+                                                       float* __restrict__ dWin, int R4, SbrTChunks tch, SbrPoll poll, int rows_lds) {
+    extern __shared__ float rows[];                                  // [rows_lds][4][R4]: component-major rows (no bank conflicts)
+    __shared__ int s_meta[4];
+    __shared__ int s_e0[SBR_TCHUNKS_MAX + 1], s_e1[SBR_TCHUNKS_MAX + 1], s_kf[SBR_TCHUNKS_MAX + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = P[n_ids], U = gridDim.x, Q = (total + U - 1) / U;
+    const int lo = blockIdx.x * Q, hi = min(total, lo + Q);
+    if (lo >= hi) return;
+    if (tid == 0) {                                                  // the ids of P that hold cost positions lo and hi - 1
+        int a = 0, b = n_ids - 1;
+        while (a < b) { const int m = (a + b + 1) >> 1; if (P[m] <= lo) a = m; else b = m - 1; }
+        s_meta[0] = a;
+        b = n_ids - 1;
+        while (a < b) { const int m = (a + b + 1) >> 1; if (P[m] <= hi - 1) a = m; else b = m - 1; }
+        s_meta[1] = a;
+    }
+    __syncthreads();
+    const int id_first = s_meta[0], id_last = s_meta[1];
+    int n_rows = id_last - id_first + 1;
+    if (n_rows > rows_lds) { if (tid == 0) atomicOr(poll.fault, 16); n_rows = rows_lds; }      // (cannot happen: launch_scatter_lds_poll sizes rows_lds)
+    const long num0 = lo - P[id_first], den0 = P[id_first + 1] - P[id_first];
+    const long num1 = hi - P[id_last], den1 = P[id_last + 1] - P[id_last];
+    const int RW = 4 * R4;
+    for (int i = tid; i < n_rows * RW; i += 256) rows[i] = 0.f;
+    if (tid < n_tchunks) {                                           // this unit's range of the sorted entries in every time chunk
+        const int kf = tid * n_ids + id_first, kl = tid * n_ids + id_last;
+        const int b0 = offs[kf], b1 = offs[kl];
+        s_e0[tid] = b0 + (int)(num0 * (offs[kf + 1] - b0) / den0);
+        s_e1[tid] = b1 + (int)(num1 * (offs[kl + 1] - b1) / den1);
+        s_kf[tid] = kf;
+    }
+    __syncthreads();
+    int seen = 0xfff;
+    const int* mine = poll.done + ((blockIdx.x + 16) & (SBR_DONE_COPIES - 1)) * SBR_DONE_STRIDE;
+    for (int c = n_tchunks - 1; c >= 0; --c) {
+        const int kf = s_kf[c], e0 = s_e0[c], e1 = s_e1[c];
+        if (e0 >= e1) continue;                                      // (uniform)
+        const int t_need = tch.lo[c];
+        // the first strip's keys and positions (written by the sort, long complete) are on their way while the workgroup waits
+        const int base_0 = e0 + wave * SCAT_FLY, cnt_0 = min(SCAT_FLY, e1 - base_0);
+        int key_0 = lane < cnt_0 ? sid[base_0 + lane] : -1;
+        int pos_0 = lane < cnt_0 ? spos[base_0 + lane] : 0;
+        if (seen > t_need) {                                         // the chain has not left this time chunk yet, as far as this workgroup knows
+            if (tid == 0) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    const int v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 12) == poll.epoch && (v & 0xfff) <= t_need) { s_meta[2] = v & 0xfff; break; }
+                    if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(poll.fault, 8); s_meta[2] = 0; break; }
+                    poll_sleep((v >> 12) == poll.epoch ? (v & 0xfff) - t_need : 64);
+                }
+            }
+            __syncthreads();
+            seen = s_meta[2];
+            __syncthreads();
+        }
+        if (poll.trace && tid == 0) poll.trace[8192 + (blockIdx.x * 16 + c) * 2] = wall_clock64();
+        // strips of SCAT_FLY entries, round-robin over the four waves; rows read with sc1 loads (no acquire fence: scat_reduce_kernel)
+        for (int base = base_0; base < e1; base += 4 * SCAT_FLY) {
+            const int cnt = min(SCAT_FLY, e1 - base);
+            const int my_key = base == base_0 ? key_0 : (lane < cnt ? sid[base + lane] : -1);
+            const int my_pos = base == base_0 ? pos_0 : (lane < cnt ? spos[base + lane] : 0);
+            f32x4 val[SCAT_FLY][NV];
+#pragma unroll
+            for (int u = 0; u < SCAT_FLY; ++u) {
+                const size_t pos = (size_t)__shfl(my_pos, min(u, cnt - 1));
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(val[u][v]) : "v"(dxt + pos * R4 + min(lane + 64 * v, R4 - 1)) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < SCAT_FLY; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(val[u][v]));
+            f32x4 acc[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
+            int cur = __shfl(my_key, 0);
+            auto flush = [&](int key) {
+                float* r = rows + (size_t)min(key - kf, n_rows - 1) * RW;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int f4 = lane + 64 * v;
+                    if (f4 < R4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(r + e * R4 + f4, acc[v][e]);
+                    }
+                    acc[v] = f32x4{0, 0, 0, 0};
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < SCAT_FLY; ++u) {
+                if (u < cnt) {                                       // (uniform)
+                    const int k = __shfl(my_key, u);
+                    if (k != cur) { flush(cur); cur = k; }
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
+                }
+            }
+            flush(cur);
+        }
+        if (poll.trace && tid == 0) poll.trace[8192 + (blockIdx.x * 16 + c) * 2 + 1] = wall_clock64();
+    }
+    __syncthreads();
+    // one store per row; the (at most two) rows shared with the neighbouring units go by atomics
+    for (int r = wave; r < n_rows; r += 4) {
+        const bool shared = (r == 0 && num0 > 0) || (r == n_rows - 1 && num1 < den1);
+        const float* src = rows + (size_t)r * RW;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f4 = lane + 64 * v;
+            f32x4 x = f32x4{0, 0, 0, 0};
+            if (f4 < R4) { x[0] = src[f4]; x[1] = src[R4 + f4]; x[2] = src[2 * R4 + f4]; x[3] = src[3 * R4 + f4]; }
+            const bool nz = x[0] != 0.f || x[1] != 0.f || x[2] != 0.f || x[3] != 0.f;
+            if (f4 < R4 && nz) {
+                float* dst = dWin + ((size_t)(id_first + r) * R4 + f4) * 4;
+                if (shared) { atomicAdd(dst, x[0]); atomicAdd(dst + 1, x[1]); atomicAdd(dst + 2, x[2]); atomicAdd(dst + 3, x[3]); }
+                else *(f32x4*)dst = x;
+            }
+        }
+    }
+    if (poll.trace && tid == 0) poll.trace[8192 + (blockIdx.x * 16 + 15) * 2] = wall_clock64();
+}
+
+// LDS rows and cost floor of a launch: ids of an average unit = 16, + the ids the floor admits.  false: shape not supported.
+static bool scat_lds_plan(int n_ids, int n_tchunks, int max_entries, int GHp, int units, int* floor_cost, int* rows_lds) {
+    const int R4 = GHp / 4, nv = (R4 + 63) / 64;
+    if ((GHp & 3) || nv > 2 || n_tchunks < 1 || n_tchunks > SBR_TCHUNKS_MAX || units < 1) return false;
+    const int rows0 = 16;
+    *floor_cost = std::max(1, (max_entries + units * rows0 - 1) / (units * rows0));
+    const long q_max = ((long)max_entries + (long)n_ids * *floor_cost + units - 1) / units;
+    *rows_lds = (int)(q_max / *floor_cost) + 3;
+    return (size_t)*rows_lds * GHp * sizeof(float) <= 120 * 1024;
+}
+// behind the time-chunked sort (same stream): the running cost P[0 .. n_ids] of the ids.  false = launch_scatter_lds_poll will refuse too.
+bool launch_scatter_cost_scan(hipStream_t s, const int* offs, int* P, int n_ids, int n_tchunks, int max_entries, int GHp, int units,
+                              hipError_t* err) {
+    int floor_cost = 0, rows_lds = 0;
+    if (!scat_lds_plan(n_ids, n_tchunks, max_entries, GHp, units, &floor_cost, &rows_lds)) return false;
+    scat_cost_scan_kernel<<<1, 1024, 0, s>>>(offs, n_ids, n_tchunks, floor_cost, P);
+    *err = hipGetLastError();
+    return true;
+}
+// false: the shape does not fit (rows too long for the LDS) -- the caller launches launch_scatter_reduce_poll instead
+bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, const int* P,
+                             int n_ids, int n_tchunks, int max_entries, int GHp, const SbrPoll& poll, const SbrTChunks& bounds,
+                             int units, hipError_t* err) {
+    int floor_cost = 0, rows_lds = 0;
+    if (!scat_lds_plan(n_ids, n_tchunks, max_entries, GHp, units, &floor_cost, &rows_lds)) return false;
+    const int R4 = GHp / 4, nv = (R4 + 63) / 64;
+    const size_t lds = (size_t)rows_lds * GHp * sizeof(float);
+    if (nv <= 1) scat_lds_kernel<1><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds);
+    else scat_lds_kernel<2><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds);
+    *err = hipGetLastError();
+    return true;
 }
 
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
@@ -583,6 +816,41 @@ __global__ void __launch_bounds__(512) tail_gate_kernel(const int* __restrict__ 
             __builtin_amdgcn_s_sleep(8);
         }
     }
+}
+
+// The MONITOR of an overlapped step tail: one workgroup on a stream of its own folds the chain's per-wave progress words into
+// `done` = (epoch << 12) | max t (SBR_DONE_COPIES copies, sbr_common.h SbrPoll) for as long as the chain runs -- relaxed
+// agent-scope loads, stores only when the maximum moves -- and leaves when every wave has reached t_lo.  (Rounds 2 / 3a: a
+// workgroup of the polling GEMM did this; the consumers then depended on WHEN that launch got onto the chip.)
+__global__ void __launch_bounds__(256) tail_monitor_kernel(SbrPoll pl, int t_lo) {
+    __shared__ int s_part[4];
+    const int tid = threadIdx.x, tag = pl.epoch;
+    int last = 0x1000;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        int m = 0;
+        for (int i = tid; i < pl.n; i += 256) {
+            const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);          // (a wave that has not published this step yet: nothing complete)
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) s_part[tid >> 6] = m;
+        __syncthreads();
+        m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+        __syncthreads();
+        if (m != last && m != 0xfff) {
+            if (tid < SBR_DONE_COPIES) __hip_atomic_store(pl.done + tid * SBR_DONE_STRIDE, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = m;
+        }
+        if (m <= t_lo) break;
+        if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+hipError_t launch_tail_monitor(hipStream_t s, const SbrPoll& poll, int t_lo) {
+    tail_monitor_kernel<<<1, 256, 0, s>>>(poll, t_lo);
+    return hipGetLastError();
 }
 
 hipError_t launch_tail_gate(hipStream_t s, const int* progress, int n, int epoch, int target, int* fault) {

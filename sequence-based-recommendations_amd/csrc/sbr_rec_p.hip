@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     if constexpr (WT) {      // shader cycles and 100 MHz wall-clock ticks of this launch (block 0, wave 0): the chain's effective clock
         if (blockIdx.x == 0 && wave == 0 && lane == 0) {
             unsigned long long* c = (unsigned long long*)(a.progress + gridDim.x * 8 + 128);
-            c[0] = clock64() - wt_c0; c[1] = wall_clock64() - wt_r0;
+            c[0] = clock64() - wt_c0; c[1] = wall_clock64() - wt_r0; c[2] = wt_r0; c[3] = wall_clock64();
         }
     }
     else if constexpr (RING) wait_vm<0>();                       // (the last iterations' clamped loads)
@@ -998,6 +998,7 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         lds = ((lds + 255) & ~(size_t)255) + (size_t)R * a.T * 4;
         lds = ((lds + 255) & ~(size_t)255) + (size_t)8 * 4 * Gates<CELL>::G * 256;
     }
+    if (a.fence_kb > 0 && a.Bp / R <= 192 && (size_t)a.fence_kb * 1024 > lds && a.fence_kb <= 160) lds = (size_t)a.fence_kb * 1024;   // see launch_bwd_p
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1022,6 +1023,14 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G;
     size_t lds = 2 * 3 * R * (size_t)(G * HP * 2 + 32) + 64;
     lds = ((lds + 255) & ~(size_t)255) + 8 * 4 * (size_t)(G == 1 ? 1 : 5) * 256;             // + the prefetch ring (PD = 4 stages per wave)
+    // Overlapped tail: the chain's workgroup claims most of its CU's LDS, so that the consumers that run beside it -- the polling
+    // weight-gradient GEMM (40 KB of LDS per workgroup, MFMAs on the same SIMDs) and the scatter-add (which asks for LDS it does not
+    // use, for this purpose) -- are placed on the other 192 CUs instead of sharing the chain's matrix pipes, issue slots and L1
+    // path.  SBR_TAIL_FENCE_KB=0: no fence (round 2).
+    if (a.fence_kb > 0 && a.Bp / R <= 192) {      // (one workgroup per CU must still leave CUs to the consumers: up to B = 768)
+        const size_t fence = (size_t)a.fence_kb * 1024;
+        if (fence > lds && fence <= 160 * 1024) lds = fence;
+    }
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
         (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
