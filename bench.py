@@ -423,7 +423,7 @@ def main():
         if args.pmc_json:
             try:
                 pmc = json.load(open(args.pmc_json))["kernels"]
-                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel", "scatter": "scat_reduce_kernel"}[dom]
+                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel", "scatter": "scat_"}[dom]
                 traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if key in k)
                 traffic_src = os.path.relpath(args.pmc_json, ROOT)
             except Exception as ex:
@@ -435,7 +435,7 @@ def main():
                      "--batch", str(B), "--max_length", str(T)]
             pmc = counter_passes(child, log)
             if pmc:
-                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel", "scatter": "scat_reduce_kernel"}[dom]
+                key = {"rec_fwd": "rec_fwd_", "rec_bwd": "rec_bwd_", "gather": "gather_xt_kernel", "scatter": "scat_"}[dom]
                 hit = [v for k, v in pmc.items() if key in k]
                 if hit:
                     traffic = hit[0]["hbm_bytes"]

@@ -206,6 +206,24 @@ def test_overlapped_step_tail_kernels_on_one_stream(monkeypatch):
     check(PU.compare_step("GRU", [128], "CCE", N=300, B=37, T=70, scale=0.1, zipf=True, gap=1e-4), tol_g=2e-4)
 
 
+@pytest.mark.parametrize("env", [
+    {"SBR_TAIL_SCATTER_LDS": "0"},                                  # the scatter-add with one global atomic per piece and row (rounds 2 / 3a)
+    {"SBR_TAIL_SCATTER_UNITS": "7"},                                # few units: many ids per unit (LDS rows), hot ids shared by all of them
+    {"SBR_TAIL_SCATTER_UNITS": "384"},                              # more units than ids with entries: empty units, every id shared
+    {"SBR_TAIL_GEMM_GROUPS": "3", "SBR_TAIL_SLAB_MAX": "64"},       # three persistent groups walk ~50 slabs each
+    {"SBR_TAIL_SLAB_GROWTH": "4", "SBR_TAIL_FIRST": "1"},           # long slabs almost at once; one-step last time chunk
+    {"SBR_TAIL_OUT_STREAM": "1"},                                   # output-layer kernels in front of the scatter-add instead of the GEMM
+], ids=lambda e: ",".join("%s=%s" % (k[9:], v) for k, v in e.items()))
+def test_overlapped_step_tail_consumer_shapes(env, monkeypatch):
+    # the consumers of the chain (persistent polling GEMM over the slab table, LDS-row scatter-add over cost-balanced units,
+    # sbr_backward_recurrent) away from their default shapes: same gradients, same updated parameters
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert _tail_chunks("GRU", 70) == 4
+    check(PU.compare_step("GRU", [128], "CCE", N=300, B=37, T=70, scale=0.1, zipf=True, gap=1e-4), tol_g=2e-4)
+    check(PU.compare_step("Vanilla", [128], "CCE", N=40, B=5, T=64, scale=0.05), tol_g=2e-4)     # 40 ids, 320 entries: every id is hot
+
+
 def test_overlapped_step_tail_is_not_taken_where_it_does_not_apply():
     assert _tail_chunks("GRU", 40) == 0                                   # short sequences
     assert _tail_chunks("LSTM", 70, H=50) == 0                            # the 128-unit kernels only
