@@ -639,6 +639,7 @@ def main():
             log("train loop: %.4f ms/iteration" % (per_it * 1e3))
         except Exception as ex:
             log("train loop leg skipped:", ex)
+            result["train_loop_error"] = repr(ex)[:400]
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)          # (C stdio buffers of the libraries: out through the redirected descriptor)

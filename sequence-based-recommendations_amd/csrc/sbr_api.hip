@@ -893,7 +893,7 @@ extern "C" int sbr_forward(sbr_handle* h) {
         SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
         SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
                                        (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
-                                       h->tail_ch, h->tail_nc, &h->tail_bounds));
+                                       h->tail_ch, h->tail_nc, &h->tail_bounds, &h->scnt_zero_n));
         h->tail_sorted = true;
         { const int rc = tail_cost_scan(h); if (rc != SBR_OK) return rc; }
     }
@@ -990,13 +990,13 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             if (!h->tail_sorted) {
                 SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
                                                (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
-                                               h->tail_ch, h->tail_nc, &h->tail_bounds));
+                                               h->tail_ch, h->tail_nc, &h->tail_bounds, &h->scnt_zero_n));
                 { const int rc = tail_cost_scan(h); if (rc != SBR_OK) return rc; }
             }
         } else if (!(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) || y.E || y.n_sparse) {
             SBR_LAUNCH(launch_scatter_sort(sd, h->bX, h->blen, y.T, y.Bp, y.F,
                                            y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff), (int*)h->A(y.a_scur),
-                                           (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0));
+                                           (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), y.E ? 1 : 0, 0, 1, nullptr, &h->scnt_zero_n));
             if (y.D == 2 && !y.E)   // the backwards direction scatters with the reversed ids (a_Xr was written by forward_bi)
                 SBR_LAUNCH(launch_scatter_sort(sd, (const int*)h->A(y.a_Xr), h->blen, y.T, y.Bp, y.F, y.cfg.input_size,
                                                (int*)h->A(y.a_s2cnt), (int*)h->A(y.a_s2off), (int*)h->A(y.a_s2cur),

@@ -481,7 +481,7 @@ extern "C" int sbr_dataset_noise_pass(sbr_dataset* d, float dropout, float swap,
     }
     if (d->d_rate && !d->d_rate_n) SBR_HIP(hipMalloc(&d->d_rate_n, std::max<int64_t>(d->nnz, 1) * sizeof(int)));
     // batches of the previous pass may still be reading the previous copy: the stream orders the kernel behind them
-    (void)hipFuncSetAttribute((const void*)bb_noise_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SBR_DYN_LDS(bb_noise_kernel, lds);
     bb_noise_kernel<<<(unsigned)d->n_users, 64, lds, d->stream>>>(d->d_items, d->d_rate, d->d_off, d->d_items_n, d->d_rate ? d->d_rate_n : nullptr,
                                                                    d->d_len_n, dropout, swap, shuf, shuf_std, ratings_perturb,
                                                                    seed * 0x9E3779B97F4A7C15ull + 0x5EEDull);

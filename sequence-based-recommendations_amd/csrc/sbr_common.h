@@ -185,6 +185,7 @@ struct sbr_handle {
     int tail_short_chunks;  // time chunks (from t = 0) whose scatter-add entries are cut into short pieces (SBR_TAIL_SHORT_CHUNKS)
     double tail_geom;       // SBR_TAIL_GEOM: growth of the small time chunks near t = 0 (<= 1: equal chunks)
     bool tail_cost_scanned = false;                                       // this step's sort was followed by launch_scatter_cost_scan
+    int scnt_zero_n = 0;                                                  // leading counters of a_scnt known to be zero (launch_scatter_sort)
     int tail_first;                                                       // SBR_TAIL_FIRST: time steps of the last time chunk (LDS-row scatter-add)
     int tail_scatter_lds, tail_scatter_units;                             // SBR_TAIL_SCATTER_LDS / SBR_TAIL_SCATTER_UNITS
     int tail_gemm_groups;                                                 // SBR_TAIL_GEMM_GROUPS: persistent groups of the polling dW_hid GEMM
@@ -233,6 +234,11 @@ void sbr_set_error(const char* fmt, ...);
 // ~950 waves poll it with agent-scope loads, which are served by the memory side -- on ONE word every poll queues at the same
 // channel, and every load of the consumers that touches that channel waits behind them (profiles/round3_n_trace.txt: 2 - 10 us
 // per dependent load of the polling GEMM).  Each poller reads the copy its workgroup number selects.
+// Dynamic LDS above the default limit needs the function attribute -- once per kernel and size, not per launch (a driver call
+// each: six of them per training step before round 3c, on a path whose host side is as long as its device side).  One static
+// per expansion site, i.e. per kernel; one process drives one GPU.
+#define SBR_DYN_LDS(KERNEL, LDS) do { static int sbr_dyn_lds_set_ = -1; if ((int)(LDS) > sbr_dyn_lds_set_) { \
+        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); sbr_dyn_lds_set_ = (int)(LDS); } } while (0)
 #define SBR_DONE_COPIES 32
 #define SBR_DONE_STRIDE 1088
 struct SbrPoll { const int* words; int n; int* done; int epoch; int rows_per_step; int* fault; int n_small, k_small;
@@ -253,7 +259,8 @@ hipError_t launch_scatter_rows(hipStream_t s, float* dWin, const float* dxt, con
 // concatenated, not summed)
 // tch > 0: time-chunked keys (t / tch) * n_ids + id over n_tchunks chunks (cnt / offs / cur then hold n_tchunks * n_ids + 1 ints)
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos, int concat = 0, int tch = 0, int n_tchunks = 1, const SbrTChunks* bounds = nullptr);
+                               int* offs, int* cur, int* sid, int* spos, int concat = 0, int tch = 0, int n_tchunks = 1, const SbrTChunks* bounds = nullptr,
+                               int* cnt_zero_n = nullptr);
 int sbr_scatter_lds_ids();     // largest key space the LDS-histogram sort takes
 // overlapped step tail: wait (bounded) until every progress word of the running BPTT chain is (epoch, <= target)
 hipError_t launch_tail_gate(hipStream_t s, const int* progress, int n, int epoch, int target, int* fault);

@@ -268,7 +268,7 @@ __global__ void scat_count_kernel(const int* __restrict__ X, const int* __restri
 // thread turns its run into prefixes in place, and the result leaves with coalesced stores.  Otherwise (large catalogues):
 // one block-wide scan per 1024 counters, coalesced accesses throughout.
 template <bool LDS>
-__global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__ cnt, int n, int* __restrict__ offs,
+__global__ void __launch_bounds__(1024) scat_scan_kernel(int* __restrict__ cnt, int n, int* __restrict__ offs,
                                                          int* __restrict__ cur) {
     extern __shared__ int stage[];
     __shared__ int wsum[16];
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(1024) scat_scan_kernel(const int* __restrict__
         if (threadIdx.x == 0) offs[n] = carry_s;
         return;
     }
-    for (int i = threadIdx.x; i < n; i += 1024) stage[i] = cnt[i];
+    for (int i = threadIdx.x; i < n; i += 1024) { stage[i] = cnt[i]; cnt[i] = 0; }     // (zero again: the next sort of this shape needs no memset)
     __syncthreads();
     const int per = (n + 1023) / 1024;
     const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
@@ -392,24 +392,29 @@ __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restric
 int sbr_scatter_lds_ids() { return SCAT_LDS_IDS; }
 
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
-                               int* offs, int* cur, int* sid, int* spos, int concat, int tch, int n_tchunks, const SbrTChunks* bounds) {
+                               int* offs, int* cur, int* sid, int* spos, int concat, int tch, int n_tchunks, const SbrTChunks* bounds,
+                               int* cnt_zero_n) {
     const int ipc = n_ids;                          // ids per time chunk
     SbrTChunks tc = bounds ? *bounds : sbr_uniform_tchunks(tch, n_tchunks);
     if (tch > 0) {
         n_ids *= n_tchunks;                         // key space
         if (n_ids > SCAT_LDS_IDS || tc.n != n_tchunks || tc.n > SBR_TCHUNKS_MAX || tc.lo[0] != 0 || tc.lo[tc.n] < T) return hipErrorInvalidValue;
     }
-    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), s);
-    if (e != hipSuccess) return e;
+    // cnt_zero_n: how many leading counters the previous user of `cnt` left at zero (the LDS-path scan clears what it reads)
+    if (!(cnt_zero_n && *cnt_zero_n >= n_ids)) {
+        hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
+    if (cnt_zero_n) *cnt_zero_n = n_ids <= SCAT_LDS_IDS ? n_ids : 0;
     const int total = T * Bp * F;
     if (n_ids <= SCAT_LDS_IDS) {
         const int per_block = 4096;
         const int grid = (total + per_block - 1) / per_block;
         const size_t lds = (size_t)n_ids * sizeof(int);
-        (void)hipFuncSetAttribute((const void*)scat_count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)scat_fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SBR_DYN_LDS(scat_count_lds_kernel, lds);
+        SBR_DYN_LDS(scat_fill_lds_kernel, lds);
         scat_count_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cnt, tc, ipc);
-        (void)hipFuncSetAttribute((const void*)scat_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SBR_DYN_LDS(scat_scan_kernel<true>, lds);
         scat_scan_kernel<true><<<1, 1024, lds, s>>>(cnt, n_ids, offs, cur);
         scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat, tc, ipc);
     } else {
@@ -775,8 +780,8 @@ bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const
     if (!scat_lds_plan(n_ids, n_tchunks, max_entries, GHp, units, &floor_cost, &rows_lds)) return false;
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
     const size_t lds = (size_t)rows_lds * GHp * sizeof(float);
-    if (nv <= 1) scat_lds_kernel<1><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds);
-    else scat_lds_kernel<2><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds);
+    if (nv <= 1) { SBR_DYN_LDS(scat_lds_kernel<1>, lds); scat_lds_kernel<1><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds); }
+    else { SBR_DYN_LDS(scat_lds_kernel<2>, lds); scat_lds_kernel<2><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds); }
     *err = hipGetLastError();
     return true;
 }
@@ -956,7 +961,7 @@ hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, c
     if (rows <= 0) return hipSuccess;
     const size_t lds = (size_t)N * sizeof(float);
     if (lds <= 150 * 1024) {
-        (void)hipFuncSetAttribute((const void*)softmax_cce_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SBR_DYN_LDS(softmax_cce_lds_kernel, lds);
         softmax_cce_lds_kernel<<<rows, 1024, lds, s>>>(logits, bout, target, pop, rowcost, N, ld, Bglobal);
         return hipGetLastError();
     }
@@ -1034,7 +1039,7 @@ hipError_t launch_margin_loss(hipStream_t s, float* logits, const float* bout, c
                               int Bglobal, int loss, float balance, int unique) {
     if (rows <= 0) return hipSuccess;
     const size_t lds = (size_t)(NT + T) * (sizeof(int) + sizeof(float));
-    (void)hipFuncSetAttribute((const void*)margin_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SBR_DYN_LDS(margin_loss_kernel, lds);
     margin_loss_kernel<<<rows, 256, lds, s>>>(logits, bout, target, NT, X, len, T, F, dflt, rowcost, N, ld, Bglobal, loss, balance, unique);
     return hipGetLastError();
 }

@@ -1307,7 +1307,7 @@ static hipError_t launch_fwd_cell(hipStream_t s, const RecArgs& a, bool simple) 
     if (sbr_rec_x6q_ok(a)) return launch_rec_forward_x6q(s, a);
     const int nblk = a.Bp / 16;
 #define LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, ...) do { \
-        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        SBR_DYN_LDS(KERNEL, (LDS)); \
         KERNEL<<<GRID, BLOCK, LDS, s>>>(__VA_ARGS__); } while (0)
     if (!a.f32_mfma && (Hp == 32 || Hp == 64 || Hp == 128)) {
         const size_t l6 = (size_t)Gates<CELL>::G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 16 * (size_t)(Hp * 2 + 32);

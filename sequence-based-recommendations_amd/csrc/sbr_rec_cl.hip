@@ -1600,7 +1600,7 @@ static inline int cl_grid(const RecArgs& a, int C, int R) {
 }
 
 #define CL_LAUNCH(KERNEL, C, R, LDS) do { \
-        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        SBR_DYN_LDS(KERNEL, (LDS)); \
         KERNEL<<<cl_grid(a, C, R), 256, LDS, s>>>(a); } while (0)
 
 template <int CELL, int HP>

@@ -1001,7 +1001,7 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
     if (a.fence_kb > 0 && a.Bp / R <= 192 && (size_t)a.fence_kb * 1024 > lds && a.fence_kb <= 160) lds = (size_t)a.fence_kb * 1024;   // see launch_bwd_p
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
-        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        SBR_DYN_LDS(KERNEL, lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool fuse = a.gX != nullptr;
     const bool f16 = x6p_f16_fwd(a);
@@ -1033,7 +1033,7 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     }
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
-        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        SBR_DYN_LDS(KERNEL, lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool ext = a.dh_ext != nullptr;
     const bool f16 = x6p_f16_bwd(a);                               // fp16 x3 products for the BPTT chain

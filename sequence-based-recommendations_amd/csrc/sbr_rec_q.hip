@@ -472,7 +472,7 @@ bool sbr_rec_x6q_ok(const RecArgs& a) {
 }
 
 #define X6Q_LAUNCH(KERNEL, THREADS, LDS) do { \
-        (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        SBR_DYN_LDS(KERNEL, (LDS)); \
         KERNEL<<<nb, THREADS, LDS, s>>>(a); } while (0)
 
 template <int CELL, int HQ>

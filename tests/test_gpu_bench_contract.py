@@ -107,5 +107,6 @@ def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_l
     assert t["bytes_per_step"] > t["algorithmic_bytes_per_step"] > 1e8 and t["ratio"] == pytest.approx(t["bytes_per_step"] / t["algorithmic_bytes_per_step"], rel=1e-2)
     s_ = d["sustained"]
     assert s_["seconds"] >= 1.5 and s_["steps"] >= 1000 and s_["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=0.1)
+    assert "train_loop" in d, d.get("train_loop_error")
     tl = d["train_loop"]
     assert tl["iterations"] == 1000 and tl["ms_per_iteration"] < 2 * d["ms_per_step"] and tl["value"] > 2e5
