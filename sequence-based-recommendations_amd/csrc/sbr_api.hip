@@ -387,6 +387,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_TAIL_SLAB_GROWTH"); h->tail_slab_growth = e ? std::max(0.0, atof(e)) : 0.35; }
     { const char* e = getenv("SBR_TAIL_SCATTER_LDS"); h->tail_scatter_lds = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_TAIL_GEOM"); h->tail_geom = e ? atof(e) : (h->tail_scatter_lds ? 1.6 : 2.6); }
+    { const char* e = getenv("SBR_TAIL_MONITOR_IN_UNITS"); h->tail_mon_units = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_TAIL_FIRST"); h->tail_first = e ? std::max(1, atoi(e)) : 6; }
     { const char* e = getenv("SBR_TAIL_SCATTER_UNITS"); h->tail_scatter_units = e ? std::max(1, std::min(384, atoi(e))) : 192; }
     { const char* e = getenv("SBR_TAIL_GEMM_GROUPS"); h->tail_gemm_groups = e ? std::max(1, atoi(e)) : 64; }
@@ -1216,7 +1217,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 if (h->out3) SBR_HIP(hipEventRecord(h->ev_tail3, h->side2));
             }
             // the monitor: on a stream of its own behind nothing but the chain's first progress words (its own loop waits for them)
-            SBR_LAUNCH(launch_tail_monitor(serial ? s : h->side3, pl, a.t_lo));
+            // ... unless the scatter-add launch carries it (default where that launch is the LDS-row one and has its own stream)
+            const bool mon_in_units = !serial && h->tail_mon_units && h->tail_cost_scanned;
+            if (!mon_in_units) SBR_LAUNCH(launch_tail_monitor(serial ? s : h->side3, pl, a.t_lo));
             SBR_LAUNCH(launch_tail_gate(sd, words, nwaves, a.prog_epoch, y.T, a.fault));
             {
                 hipError_t we = hipSuccess;
@@ -1232,7 +1235,8 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             hipError_t se = hipSuccess;
             if (h->tail_cost_scanned && launch_scatter_lds_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                                (const int*)h->A(y.a_soff), (const int*)h->A(y.a_sP), y.cfg.input_size, tnc,
-                                                               y.T * y.Bp * y.F, GHp, pl, h->tail_bounds, h->tail_scatter_units, &se)) {
+                                                               y.T * y.Bp * y.F, GHp, pl, h->tail_bounds, h->tail_scatter_units, &se,
+                                                               mon_in_units, a.t_lo)) {
                 SBR_LAUNCH(se);
             } else
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),

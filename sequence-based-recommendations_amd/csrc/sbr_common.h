@@ -186,6 +186,7 @@ struct sbr_handle {
     double tail_geom;       // SBR_TAIL_GEOM: growth of the small time chunks near t = 0 (<= 1: equal chunks)
     bool tail_cost_scanned = false;                                       // this step's sort was followed by launch_scatter_cost_scan
     int scnt_zero_n = 0;                                                  // leading counters of a_scnt known to be zero (launch_scatter_sort)
+    int tail_mon_units;                                                   // SBR_TAIL_MONITOR_IN_UNITS: the monitor is a workgroup of the scatter-add launch
     int tail_first;                                                       // SBR_TAIL_FIRST: time steps of the last time chunk (LDS-row scatter-add)
     int tail_scatter_lds, tail_scatter_units;                             // SBR_TAIL_SCATTER_LDS / SBR_TAIL_SCATTER_UNITS
     int tail_gemm_groups;                                                 // SBR_TAIL_GEMM_GROUPS: persistent groups of the polling dW_hid GEMM
@@ -289,7 +290,7 @@ bool launch_scatter_cost_scan(hipStream_t s, const int* offs, int* P, int n_ids,
 hipError_t launch_tail_monitor(hipStream_t s, const SbrPoll& poll, int t_lo);
 bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, const int* P,
                              int n_ids, int n_tchunks, int max_entries, int GHp, const SbrPoll& poll, const SbrTChunks& bounds,
-                             int units, hipError_t* err);
+                             int units, hipError_t* err, bool monitor = false, int t_lo = 0);      // monitor: one more workgroup, the tail's monitor
 hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs,
                                       int n_ids, int n_tchunks, int tch, int max_entries, int GHp, int Bp, const SbrPoll& poll, int first_key = 0, const SbrTChunks* bounds = nullptr, int short_chunks = 0, bool fence_on = false);
 

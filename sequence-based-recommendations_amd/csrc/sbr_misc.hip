@@ -597,6 +597,33 @@ hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* d
 // time, so nobody is left with only the last time steps), and only those rows, at most two per unit, end in global atomics.
 // In the time-chunked sort the entries of a unit in one chunk are one contiguous range of the sorted array.
 // ---------------------------------------------------------------------------------------------------------------------
+// the monitor's loop (tail_monitor_kernel below; one workgroup of 256 threads): see there
+__device__ __forceinline__ void tail_monitor_loop(const SbrPoll& pl, int t_lo) {
+    __shared__ int s_part[4];
+    const int tid = threadIdx.x, tag = pl.epoch;
+    int last = 0x1000;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        int m = 0;
+        for (int i = tid; i < pl.n; i += 256) {
+            const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);          // (a wave that has not published this step yet: nothing complete)
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) s_part[tid >> 6] = m;
+        __syncthreads();
+        m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+        __syncthreads();
+        if (m != last && m != 0xfff) {
+            if (tid < SBR_DONE_COPIES) __hip_atomic_store(pl.done + tid * SBR_DONE_STRIDE, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = m;
+        }
+        if (m <= t_lo) break;
+        if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
 __global__ void __launch_bounds__(1024) scat_cost_scan_kernel(const int* __restrict__ offs, int n_ids, int n_tchunks, int floor_cost,
                                                               int* __restrict__ P) {
     __shared__ int part[1024];
@@ -628,13 +655,19 @@ __global__ void __launch_bounds__(1024) scat_cost_scan_kernel(const int* __restr
 template <int NV>
 __global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid, const int* __restrict__ spos,
                                                        const int* __restrict__ offs, const int* __restrict__ P, int n_ids, int n_tchunks,
-                                                       float* __restrict__ dWin, int R4, SbrTChunks tch, SbrPoll poll, int rows_lds) {
+                                                       float* __restrict__ dWin, int R4, SbrTChunks tch, SbrPoll poll, int rows_lds,
+                                                       int monitor, int t_lo) {
+    // monitor != 0: workgroup 0 -- the first on the chip -- is the tail's MONITOR (tail_monitor_loop) and nothing else; the
+    // units are workgroups 1 .. gridDim.x - 1.  No stream of its own then: under a process group's streams a third busy side
+    // stream shared a hardware queue with another one and the data-parallel step took twice as long (profiles/round3_M_dp.txt).
+    if (monitor && blockIdx.x == 0) { tail_monitor_loop(poll, t_lo); return; }
+    const int unit = (int)blockIdx.x - (monitor ? 1 : 0);
     extern __shared__ float rows[];                                  // [rows_lds][4][R4]: component-major rows (no bank conflicts)
     __shared__ int s_meta[4];
     __shared__ int s_e0[SBR_TCHUNKS_MAX + 1], s_e1[SBR_TCHUNKS_MAX + 1], s_kf[SBR_TCHUNKS_MAX + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int total = P[n_ids], U = gridDim.x, Q = (total + U - 1) / U;
-    const int lo = blockIdx.x * Q, hi = min(total, lo + Q);
+    const int total = P[n_ids], U = (int)gridDim.x - (monitor ? 1 : 0), Q = (total + U - 1) / U;
+    const int lo = unit * Q, hi = min(total, lo + Q);
     if (lo >= hi) return;
     if (tid == 0) {                                                  // the ids of P that hold cost positions lo and hi - 1
         int a = 0, b = n_ids - 1;
@@ -661,7 +694,7 @@ __global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__
     }
     __syncthreads();
     int seen = 0xfff;
-    const int* mine = poll.done + ((blockIdx.x + 16) & (SBR_DONE_COPIES - 1)) * SBR_DONE_STRIDE;
+    const int* mine = poll.done + ((unit + 16) & (SBR_DONE_COPIES - 1)) * SBR_DONE_STRIDE;
     for (int c = n_tchunks - 1; c >= 0; --c) {
         const int kf = s_kf[c], e0 = s_e0[c], e1 = s_e1[c];
         if (e0 >= e1) continue;                                      // (uniform)
@@ -684,7 +717,7 @@ __global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__
             seen = s_meta[2];
             __syncthreads();
         }
-        if (poll.trace && tid == 0) poll.trace[8192 + (blockIdx.x * 16 + c) * 2] = wall_clock64();
+        if (poll.trace && tid == 0) poll.trace[8192 + (unit * 16 + c) * 2] = wall_clock64();
         // strips of SCAT_FLY entries, round-robin over the four waves; rows read with sc1 loads (no acquire fence: scat_reduce_kernel)
         for (int base = base_0; base < e1; base += 4 * SCAT_FLY) {
             const int cnt = min(SCAT_FLY, e1 - base);
@@ -730,7 +763,7 @@ __global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__
             }
             flush(cur);
         }
-        if (poll.trace && tid == 0) poll.trace[8192 + (blockIdx.x * 16 + c) * 2 + 1] = wall_clock64();
+        if (poll.trace && tid == 0) poll.trace[8192 + (unit * 16 + c) * 2 + 1] = wall_clock64();
     }
     __syncthreads();
     // one store per row; the (at most two) rows shared with the neighbouring units go by atomics
@@ -750,7 +783,7 @@ __global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__
             }
         }
     }
-    if (poll.trace && tid == 0) poll.trace[8192 + (blockIdx.x * 16 + 15) * 2] = wall_clock64();
+    if (poll.trace && tid == 0) poll.trace[8192 + (unit * 16 + 15) * 2] = wall_clock64();
 }
 
 // LDS rows and cost floor of a launch: ids of an average unit = 16, + the ids the floor admits.  false: shape not supported.
@@ -775,13 +808,13 @@ bool launch_scatter_cost_scan(hipStream_t s, const int* offs, int* P, int n_ids,
 // false: the shape does not fit (rows too long for the LDS) -- the caller launches launch_scatter_reduce_poll instead
 bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, const int* P,
                              int n_ids, int n_tchunks, int max_entries, int GHp, const SbrPoll& poll, const SbrTChunks& bounds,
-                             int units, hipError_t* err) {
+                             int units, hipError_t* err, bool monitor, int t_lo) {
     int floor_cost = 0, rows_lds = 0;
     if (!scat_lds_plan(n_ids, n_tchunks, max_entries, GHp, units, &floor_cost, &rows_lds)) return false;
-    const int R4 = GHp / 4, nv = (R4 + 63) / 64;
+    const int R4 = GHp / 4, nv = (R4 + 63) / 64, grid = units + (monitor ? 1 : 0), mon = monitor ? 1 : 0;
     const size_t lds = (size_t)rows_lds * GHp * sizeof(float);
-    if (nv <= 1) { SBR_DYN_LDS(scat_lds_kernel<1>, lds); scat_lds_kernel<1><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds); }
-    else { SBR_DYN_LDS(scat_lds_kernel<2>, lds); scat_lds_kernel<2><<<units, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds); }
+    if (nv <= 1) { SBR_DYN_LDS(scat_lds_kernel<1>, lds); scat_lds_kernel<1><<<grid, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds, mon, t_lo); }
+    else { SBR_DYN_LDS(scat_lds_kernel<2>, lds); scat_lds_kernel<2><<<grid, 256, lds, s>>>((const f32x4*)dxt, sid, spos, offs, P, n_ids, n_tchunks, dWin, R4, bounds, poll, rows_lds, mon, t_lo); }
     *err = hipGetLastError();
     return true;
 }
@@ -827,32 +860,7 @@ __global__ void __launch_bounds__(512) tail_gate_kernel(const int* __restrict__ 
 // `done` = (epoch << 12) | max t (SBR_DONE_COPIES copies, sbr_common.h SbrPoll) for as long as the chain runs -- relaxed
 // agent-scope loads, stores only when the maximum moves -- and leaves when every wave has reached t_lo.  (Rounds 2 / 3a: a
 // workgroup of the polling GEMM did this; the consumers then depended on WHEN that launch got onto the chip.)
-__global__ void __launch_bounds__(256) tail_monitor_kernel(SbrPoll pl, int t_lo) {
-    __shared__ int s_part[4];
-    const int tid = threadIdx.x, tag = pl.epoch;
-    int last = 0x1000;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        int m = 0;
-        for (int i = tid; i < pl.n; i += 256) {
-            const int v = __hip_atomic_load(pl.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m = max(m, (v >> 12) == tag ? (v & 0xfff) : 0xfff);          // (a wave that has not published this step yet: nothing complete)
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
-        if ((tid & 63) == 0) s_part[tid >> 6] = m;
-        __syncthreads();
-        m = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
-        __syncthreads();
-        if (m != last && m != 0xfff) {
-            if (tid < SBR_DONE_COPIES) __hip_atomic_store(pl.done + tid * SBR_DONE_STRIDE, (tag << 12) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = m;
-        }
-        if (m <= t_lo) break;
-        if (wall_clock64() - t0 > SBR_POLL_TICKS) { if (tid == 0) atomicOr(pl.fault, 8); break; }
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
+__global__ void __launch_bounds__(256) tail_monitor_kernel(SbrPoll pl, int t_lo) { tail_monitor_loop(pl, t_lo); }
 hipError_t launch_tail_monitor(hipStream_t s, const SbrPoll& poll, int t_lo) {
     tail_monitor_kernel<<<1, 256, 0, s>>>(poll, t_lo);
     return hipGetLastError();
