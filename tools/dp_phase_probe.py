@@ -60,6 +60,8 @@ def body():
     def phases_then_small():
         phases(); dist.all_reduce(t_small, async_op=True).wait()
     timed("five phase calls + all_reduce of 4 KB on the current stream", phases_then_small)
+    if os.environ.get("PROBE_SHORT", "0") != "0":
+        dist.destroy_process_group(); eng.close(); return
     timed("five phase calls, process group alive", phases)
     timed("single call, process group alive", single)
     from sbr_amd.parallel import DataParallel
