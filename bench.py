@@ -268,13 +268,13 @@ def main():
             step(args.warmup + i, exposed=ex)
         DataParallel.exposed_us(ex)
         dp_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
-                   "collectives_per_step": {"dense_buckets": len(dp._views()["out"]) + (2 if "win" in dp._views() else len(dp._views()["rec"])),
+                   "collectives_per_step": {"dense_buckets": len(dp._views()["out"]) + len(dp._views()["rec"]),
                                             "sparse_blocks": dp._nsparse},
                    "exposed_us_per_step": {k: round(v / n_sv, 2) for k, v in sorted(ex.items())},
-                   "note": "exposed = time the engine's stream waited for the collective (HIP events around each wait, survey pass "
-                           "of %d steps); buckets: out = output layer (issued behind the side stream, runs beside the BPTT chain), "
-                           "win / rest = W_in behind the scatter stream, the rest behind the slab-reduction stream (overlapped "
-                           "tail), rec = the recurrent part in one bucket otherwise" % n_sv}
+                   "note": "exposed = time the engine's stream waited for the side stream's collectives (HIP events around the wait, "
+                           "survey pass of %d steps); the collectives are sync ops enqueued on the engine's side stream: out = output "
+                           "layer (behind its gradient kernels, beside the BPTT chain), rec = the recurrent part once scatter-add, "
+                           "slab reduction and the chain's partial sums are in; sparse = row-sparse blocks (engine stream)" % n_sv}
     eng.enable_timing(True, only=dom_phase)
 
     def timed_region(first, n=None):

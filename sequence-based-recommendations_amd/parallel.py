@@ -5,11 +5,12 @@ section is summed with an all-reduce (backend "nccl" = RCCL over xGMI on MI355X,
 CPU tests), and every rank applies the identical optimizer step to its replica.
 
 Overlap: the output-layer gradients (W_out, b_out + the cost scalar that rides at the end of the
-section) are final after `loss_backward_output`, so their all-reduce is launched asynchronously
-and runs on RCCL's stream while the BPTT chain of `backward_recurrent` executes; the recurrent
-part follows.  With the HIP engine the first collective is ordered behind the engine's SIDE stream
-(where those gradients are produced), so the main stream goes straight on to the BPTT chain instead
-of waiting for them (`sbr_set_deferred_join`, include/sbr_rnn.h).  The sampled heads need the targets of ALL rows on every rank (Blackout's softmax
+section) are final after `loss_backward_output`, so their all-reduce is issued right then and runs
+while the BPTT chain of `backward_recurrent` executes; the recurrent part follows.  With the HIP
+engine every collective is a sync op issued under the engine's SIDE stream (where those gradients are
+produced): torch enqueues a sync collective on the current stream, so the main stream goes straight on
+to the BPTT chain instead of waiting (`sbr_set_deferred_join`, include/sbr_rnn.h), and no stream of
+the process group's own is involved -- a round trip through one cost the step 0.45 ms (train_step).  The sampled heads need the targets of ALL rows on every rank (Blackout's softmax
 spans every target column, rnn_sampling.py:68-72,137): `gather_targets` all-gathers B int32.
 
 Row-sparse blocks with the lazy-exact updaters (rmsprop / adadelta / nesterov / adam): a row's missed zero-gradient steps are
@@ -91,9 +92,8 @@ class DataParallel(object):
                 self._sp_all[b] = (torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device),
                                    torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device))
             ids_all, rows_all = self._sp_all[b]
-            w1 = dist.all_gather(list(ids_all.unbind(0)), ids, group=self.group, async_op=True)
-            w2 = dist.all_gather(list(rows_all.unbind(0)), rows, group=self.group, async_op=True)
-            w1.wait(); w2.wait()
+            dist.all_gather(list(ids_all.unbind(0)), ids, group=self.group)      # (sync ops: on the current stream, see train_step)
+            dist.all_gather(list(rows_all.unbind(0)), rows, group=self.group)
             e.sparse_unpack_add_all(b, ids_all, rows_all, self.world)      # one call: rank order, counts read on the device
             return
         ids, rows, n = e.sparse_pack(b)
@@ -107,9 +107,8 @@ class DataParallel(object):
         ids_m, rows_m = ids[:m].contiguous(), rows[:m].contiguous()
         gids = [torch.empty_like(ids_m) for _ in range(self.world)]
         grows = [torch.empty_like(rows_m) for _ in range(self.world)]
-        w1 = dist.all_gather(gids, ids_m, group=self.group, async_op=True)
-        w2 = dist.all_gather(grows, rows_m, group=self.group, async_op=True)
-        w1.wait(); w2.wait()
+        dist.all_gather(gids, ids_m, group=self.group)
+        dist.all_gather(grows, rows_m, group=self.group)
         for r in range(self.world):
             e.sparse_unpack_add(b, gids[r], grows[r], counts[r])
 
@@ -119,66 +118,71 @@ class DataParallel(object):
             out_r, rec_r = self._ranges()
             g = self.grads
             self._vw = dict(out=[g[lo:hi] for lo, hi in out_r], rec=[g[lo:hi] for lo, hi in rec_r])
-            if self.tail is not None and len(rec_r) == 1:
-                (wi_lo, wi_hi), (wh_lo, wh_hi) = self.tail
-                lo, hi = rec_r[0]
-                assert lo == wi_lo and wi_hi <= wh_lo and wh_hi <= hi
-                self._vw["win"], self._vw["rest"] = g[wi_lo:wi_hi], g[wi_hi:hi]
         return self._vw
 
     def train_step(self, exposed=None):
         """One step on the batch already set on the engine; returns nothing (cost: read_cost()).
         exposed: a dict -- the step then brackets the wait for every collective with events on the engine's stream and adds
-        the microseconds the stream really stood still for each bucket ("out", "rec", "win", "rest", "sparse"); a survey mode
+        the microseconds the stream really stood still for each bucket ("rec": the join behind the side stream's collectives,
+        "sparse": the row-sparse exchange; the output layer's collective runs on the side stream and is never waited for alone); a survey mode
         (events cost the stream a few microseconds each: bench.py uses it outside its timed regions)."""
         e = self.engine
         if self.world == 1 and not self.dist.is_initialized():
             e.zero_grads(); e.forward(); e.loss_backward_output(); e.backward_recurrent(); e.apply_update()   # joins inside
             return
         vw = self._views()
-        red = lambda t: self.dist.all_reduce(t, group=self.group, async_op=True)
-        e.zero_grads()
-        e.forward()
-        e.loss_backward_output()
-        works = []                                       # (bucket name, work)
+        # Collectives are SYNC ops issued under the stream that has to carry them: this torch enqueues a sync collective on the
+        # current stream, with no stream of the process group's own and no events.  The async form (the group's stream, an event
+        # each way) cost the step +0.45 ms of DEVICE time on one rank -- a record / wait round trip through a foreign stream that
+        # shares a hardware queue with one of the engine's (tools/dp_sync_probe.py, profiles/round3_T_dp_sync_probe.txt: through a
+        # normal-priority torch stream 0.79 ms, through the engine's own side stream 0.46, the sync op on the engine's stream 0.45
+        # against 0.44 without any collective).  One communicator must not run two collectives at once, so all of a step's
+        # collectives go to ONE stream: the side stream where there is one (behind the output layer's gradient kernels first,
+        # beside the BPTT chain; then behind everything the recurrent part needs), the current stream otherwise.
+        red = lambda t: self.dist.all_reduce(t, group=self.group)
+        import contextlib
+        torch = None
         if self.side is not None:
             import torch
-            with torch.cuda.stream(self.side):       # RCCL waits for the side stream only; the main stream runs the chain
-                works += [("out", red(t)) for t in vw["out"]]
-            e.backward_recurrent()
-            if self.tail is None:
-                e.join_side()                        # weight-gradient kernels of the recurrent part
-            # (overlapped tail: no join here -- the collectives below follow the producing streams, sbr_apply_update joins)
-        else:
-            works += [("out", red(t)) for t in vw["out"]]
-            e.backward_recurrent()
-        if "win" in vw:
-            # two buckets, each behind the stream that finishes it: W_in behind the scatter-add (second side stream), and the
-            # contiguous rest -- biases and initial states (the chain's partial sums, main stream) around W_hid (slab
-            # reduction, side stream) -- behind the side stream once it has also waited for the main stream's share
-            import torch
-            with torch.cuda.stream(self.side2):
-                works.append(("win", red(vw["win"])))
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                works.append(("rest", red(vw["rest"])))
-        else:
-            works += [("rec", red(t)) for t in vw["rec"]]      # one bucket unless sparse blocks split the section
-        if exposed is None:
-            for b in range(self._nsparse):
-                self._exchange_sparse(b)
-            for _, w in works:
-                w.wait()
-        else:
-            import torch
-            def timed(name, fn):
+        on_side = (lambda: torch.cuda.stream(self.side)) if self.side is not None else contextlib.nullcontext
+
+        def wait(name, fn):                              # the engine's stream waits: bracketed in survey mode
+            if exposed is None or torch is None:
+                fn()
+            else:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); fn(); e1.record()
                 exposed.setdefault("_ev", []).append((name, e0, e1))
+        e.zero_grads()
+        e.forward()
+        e.loss_backward_output()
+        with on_side():                                  # output layer: final now; runs beside the BPTT chain on the side stream
+            for t in vw["out"]:
+                red(t)
+        e.backward_recurrent()
+        if self.side is not None:
+            cur = torch.cuda.current_stream()
+            if self.tail is None:
+                e.join_side()                            # weight-gradient kernels of the recurrent part: the current stream has them
+                self.side.wait_stream(cur)
+            else:
+                # overlapped tail: W_in is finished by the second side stream, W_hid by the first, biases and initial states (the
+                # chain's partial sums) by the main stream -- the side stream waits for the other two (sbr_apply_update joins)
+                self.side.wait_stream(self.side2)
+                self.side.wait_stream(cur)
+            with on_side():
+                for t in vw["rec"]:
+                    red(t)
+            wait("rec", lambda: cur.wait_stream(self.side))
+            # row-sparse blocks: packed and unpacked by the engine on ITS stream, so their all-gathers run there too (behind the
+            # wait above: one collective of the communicator at a time)
             for b in range(self._nsparse):
-                timed("sparse", lambda b=b: self._exchange_sparse(b))
-            for name, w in works:
-                timed(name, w.wait)
+                wait("sparse", lambda b=b: self._exchange_sparse(b))
+        else:
+            for t in vw["rec"]:
+                red(t)
+            for b in range(self._nsparse):
+                self._exchange_sparse(b)
         e.apply_update()
 
     @staticmethod

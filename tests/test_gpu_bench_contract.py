@@ -82,8 +82,8 @@ def test_gpus_2_starts_its_own_ranks():
     assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
     assert d["value"] == pytest.approx(512 / (d["ms_per_step"] * 1e-3), rel=2e-3)
     p = d["data_parallel"]
-    assert p["ranks"] == 2 and p["backend"] == "gloo" and p["collectives_per_step"]["dense_buckets"] == 3
-    assert set(p["exposed_us_per_step"]) == {"out", "win", "rest"} and all(v >= 0 for v in p["exposed_us_per_step"].values())
+    assert p["ranks"] == 2 and p["backend"] == "gloo" and p["collectives_per_step"]["dense_buckets"] == 2
+    assert set(p["exposed_us_per_step"]) == {"rec"} and all(v >= 0 for v in p["exposed_us_per_step"].values())
     assert d["roofline"]["kernel"] in ("rec_bwd", "rec_fwd") and d["roofline"]["launch_us"] > 0
 
 
@@ -93,6 +93,9 @@ def test_one_rank_through_the_data_parallel_step():
     check_common(d)
     p = d["data_parallel"]
     assert p["ranks"] == 1 and p["backend"] == "nccl"
+    # sync collectives on the engine's side stream: the step is not doubled by the process group's own stream (0.86 - 0.94 ms
+    # with the async form, profiles/round3_Q_dp_probe.txt, round3_U_dp_sync_probe2.txt)
+    assert d["ms_per_step"] < 0.65
 
 
 def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_line():
