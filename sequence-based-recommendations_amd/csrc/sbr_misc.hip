@@ -572,7 +572,7 @@ hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* d
     poll.n_small = std::max(0, std::min(short_chunks, n_tchunks));      // (the field counts the GEMM's short slabs there; here: time chunks cut short)
 
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
-    static const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 128;   // (round 3: 128 with the short pieces; 64 before)
+    const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 128;   // (round 3: 128 with the short pieces; 64 before)
     const int grid = std::max(1, std::min(wgs, ((max_entries + 7) / 8 + 3) / 4));
     // (the LDS this launch asks for is a FENCE, not storage: with it a workgroup does not fit beside the BPTT chain's, which claims
     // 124 KB of its CU's 160 for the same purpose -- sbr_rec_p.hip launch_bwd_p)
@@ -822,7 +822,7 @@ bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate, int acc_chunk) {
     const int R4 = GHp / 4;
-    static const int chunk_env = getenv("SBR_SCAT_CHUNK") ? atoi(getenv("SBR_SCAT_CHUNK")) : 0;
+    const int chunk_env = getenv("SBR_SCAT_CHUNK") ? atoi(getenv("SBR_SCAT_CHUNK")) : 0;
     const int chunk = (accumulate || key_lo) ? (acc_chunk == 16 ? 16 : 32) : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32);
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
