@@ -658,8 +658,9 @@ __global__ void __launch_bounds__(256) scat_lds_kernel(const f32x4* __restrict__
                                                        float* __restrict__ dWin, int R4, SbrTChunks tch, SbrPoll poll, int rows_lds,
                                                        int monitor, int t_lo) {
     // monitor != 0: workgroup 0 -- the first on the chip -- is the tail's MONITOR (tail_monitor_loop) and nothing else; the
-    // units are workgroups 1 .. gridDim.x - 1.  No stream of its own then: under a process group's streams a third busy side
-    // stream shared a hardware queue with another one and the data-parallel step took twice as long (profiles/round3_M_dp.txt).
+    // units are workgroups 1 .. gridDim.x - 1.  No stream of its own then -- hardware queues are few (a FOURTH side stream for
+    // the monitor halved the throughput of everything, profiles/round3_A_variants.txt), and this launch is the first of the
+    // tail on its stream anyway.
     if (monitor && blockIdx.x == 0) { tail_monitor_loop(poll, t_lo); return; }
     const int unit = (int)blockIdx.x - (monitor ? 1 : 0);
     extern __shared__ float rows[];                                  // [rows_lds][4][R4]: component-major rows (no bank conflicts)
