@@ -1163,12 +1163,14 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             // ---- Overlapped tail.  The chain (64 of 256 CUs at C2) stores dxt / dhi write-through and every wave publishes the
             // time step it has completed.  Two consumers run beside it on the idle CUs, ONE launch each, whose workgroups /
             // waves wait inside the kernel for the time steps they read (SbrPoll, sbr_common.h):
-            //   side stream   gate (returns once every wave of the chain has published: the chain is resident, spinning
-            //                 consumers can no longer keep it off the chip) -> dW_hid GEMM into split-K slabs, short slabs for
-            //                 the time steps the chain reaches last; its workgroup 0 folds the chain's progress words into
-            //                 the one word everybody else polls -> slab reduction (-> W_hid update)
-            //   second side   gate on that word (the monitor is running) -> embedding scatter-add over the time-chunked sort
-            //   stream        with float atomics (-> W_in update)
+            //   side stream   (the output layer's gradient kernels, left over from the loss phase ->) gate (returns once every wave
+            //                 of the chain has published: the chain is resident, spinning consumers can no longer keep it off the
+            //                 chip) -> dW_hid GEMM: persistent groups of workgroups share the K slabs of a table in the order the
+            //                 chain releases them, one partial each -> reduction of the partials (-> W_hid update)
+            //   second side   (the time-chunked sort and the ids' running cost, beside the FORWARD chain ->) the same gate ->
+            //   stream        embedding scatter-add: units that own id ranges of equal cost add their rows in LDS and store each
+            //                 once; workgroup 0 of that launch is the MONITOR, which folds the chain's progress words into the
+            //                 word every consumer polls (-> W_in update)
             //   main stream   chain -> bias / init-state partial sums (-> their update) -> joins both
             // In a single-call step every stream applies the optimizer to what it has produced (the output layer early, on
             // the side stream); phase-by-phase callers (data parallel) get complete gradients and update in sbr_apply_update.
