@@ -226,15 +226,15 @@ void sbr_set_error(const char* fmt, ...);
     sbr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return SBR_EHIP; } } while (0)
 
 // Consumers of a RUNNING BPTT chain (overlapped step tail): the chain's waves publish (epoch << 12) | t in words[0 .. n) once
-// all their time steps >= t are complete and written through (RecArgs.progress); ONE workgroup of the consuming GEMM
-// folds them into `done` = (epoch << 12) | max t, which every other consumer polls.  rows_per_step: K rows per time step.
+// all their time steps >= t are complete and written through (RecArgs.progress); ONE workgroup -- the MONITOR: workgroup 0 of
+// the scatter-add launch, or tail_monitor_kernel -- folds them into `done` = (epoch << 12) | max t, which every consumer polls.  rows_per_step: K rows per time step.
 // Slabs of a polling GEMM are K-ascending, slab z = rows [slab_lo[z], slab_lo[z + 1]) (a device table of multiples of 32, see
 // sbr_tail_slab_table: one k step of 32 rows for the time steps the chain reaches last, growing with the time the chain still
 // needs once a slab is released -- a slab must be DONE when the chain ends, not started); workgroups take them from the far end.
 // The monitor's word exists in SBR_DONE_COPIES copies, SBR_DONE_STRIDE ints apart (4 KB + 256 B: other pages AND other channels):
-// ~950 waves poll it with agent-scope loads, which are served by the memory side -- on ONE word every poll queues at the same
-// channel, and every load of the consumers that touches that channel waits behind them (profiles/round3_n_trace.txt: 2 - 10 us
-// per dependent load of the polling GEMM).  Each poller reads the copy its workgroup number selects.
+// hundreds of waves poll it with agent-scope loads, which are served by the memory side, and each poller reads the copy its
+// workgroup number selects.  (Built on the suspicion that ONE word makes every poll queue at one channel; the consumers' slow
+// loads of profiles/round3_n_trace.txt turned out to have other causes -- DESIGN.md 3a -- and the copies cost nothing.)
 // Dynamic LDS above the default limit needs the function attribute -- once per kernel and size, not per launch (a driver call
 // each: six of them per training step before round 3c, on a path whose host side is as long as its device side).  One static
 // per expansion site, i.e. per kernel; one process drives one GPU.

@@ -857,7 +857,8 @@ __global__ void __launch_bounds__(512) tail_gate_kernel(const int* __restrict__ 
     }
 }
 
-// The MONITOR of an overlapped step tail: one workgroup on a stream of its own folds the chain's per-wave progress words into
+// The MONITOR of an overlapped step tail (tail_monitor_loop: workgroup 0 of the LDS-row scatter-add launch; as this kernel on a stream
+// of its own where that launch is not taken, and on the one stream of the serial mode): one workgroup folds the chain's per-wave progress words into
 // `done` = (epoch << 12) | max t (SBR_DONE_COPIES copies, sbr_common.h SbrPoll) for as long as the chain runs -- relaxed
 // agent-scope loads, stores only when the maximum moves -- and leaves when every wave has reached t_lo.  (Rounds 2 / 3a: a
 // workgroup of the polling GEMM did this; the consumers then depended on WHEN that launch got onto the chip.)
