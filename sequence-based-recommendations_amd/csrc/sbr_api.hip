@@ -1566,9 +1566,15 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
 static int report_fault(sbr_handle* h, int fault) {
     if (!fault) return SBR_OK;
     (void)hipMemsetAsync(h->A(h->lay.a_fault), 0, sizeof(int), h->stream);
-    // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip)
+    // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip);
+    // bit 3: a consumer of the overlapped tail (or its monitor) waited for the chain for 1.5 s; bit 4: a unit of the LDS-row
+    // scatter-add was handed more ids than it has LDS rows for (launch_scatter_lds_poll sizes them: cannot happen)
+    if (fault & 16)
+        sbr_set_error("the LDS-row scatter-add of the overlapped tail ran out of rows (flag %d, results of this call invalid); rerun with "
+                      "SBR_TAIL_SCATTER_LDS=0", fault);
+    else
     sbr_set_error("a bounded wait inside the recurrent kernels gave up (flag %d, results of this call invalid); rerun with %s", fault,
-                  (fault & 1) ? "SBR_CLUSTER=0" : "SBR_X6_PIPE=0");
+                  (fault & 1) ? "SBR_CLUSTER=0" : (fault & 8) ? "SBR_TAIL_OVERLAP=0" : "SBR_X6_PIPE=0");
     return SBR_EHIP;
 }
 static int check_fault(sbr_handle* h) {        // synchronises the stream
