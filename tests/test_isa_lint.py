@@ -29,6 +29,21 @@ EXPECTED_WAIT = {"0": 22, "1": 22, "2": 7}
 EXPECTED_WAIT_FWD = {"0": 21, "1": 18, "2": 6}
 
 
+_ASM = {}
+
+
+def rec_p_asm():
+    """gfx950 assembly of csrc/sbr_rec_p.hip (one compile for all tests of this file)"""
+    if "text" not in _ASM:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "rec_p.s")
+            subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                                   "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
+                                   os.path.join(CSRC, "sbr_rec_p.hip")], stderr=subprocess.DEVNULL)
+            _ASM["text"] = open(out).read().splitlines()
+    return _ASM["text"]
+
+
 def loops_of(lines):
     """[(first, last) line index] of the depth-1 loops (the two role loops; the prologue's fill loops carry no MFMAs)."""
     out = []
@@ -47,12 +62,7 @@ def loops_of(lines):
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "rec_p.s")
-        subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                               "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
-                               os.path.join(CSRC, "sbr_rec_p.hip")], stderr=subprocess.DEVNULL)
-        text = open(out).read().splitlines()
+    text = rec_p_asm()
     starts = [(i, re.match(r"^_Z11rec_bwd_x6pILi(\d)ELb0ELb0ELb1ELi1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
               if re.match(r"^_Z11rec_bwd_x6pILi\dELb0ELb0ELb1ELi1EEv7RecArgs:", ln)]
     assert len(starts) == 3, "expected the LSTM, the GRU and the Vanilla instance of rec_bwd_x6p<.., WT>"
@@ -80,12 +90,7 @@ def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
 def test_lds_ring_of_the_fused_gather_in_the_forward_kernel():
     """rec_fwd_x6p<CELL, FUSE = true, PROF = false, F16 = true>: the W_in rows of later steps arrive in an LDS ring by LDS-DMA; the
     same invariants as for the backward kernel above."""
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "rec_p.s")
-        subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                               "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
-                               os.path.join(CSRC, "sbr_rec_p.hip")], stderr=subprocess.DEVNULL)
-        text = open(out).read().splitlines()
+    text = rec_p_asm()
     starts = [(i, re.match(r"^_Z11rec_fwd_x6pILi(\d)ELb1ELb0ELb1EEv7RecArgs:", ln).group(1)) for i, ln in enumerate(text)
               if re.match(r"^_Z11rec_fwd_x6pILi\dELb1ELb0ELb1EEv7RecArgs:", ln)]
     assert len(starts) == 3
@@ -104,3 +109,21 @@ def test_lds_ring_of_the_fused_gather_in_the_forward_kernel():
             assert want in code, (want, [c for c in code if c.startswith("s_waitcnt vmcnt")])
             assert "s_waitcnt vmcnt(0)" not in code
             assert not any(c.startswith("global_load_dword") for c in code), "a register-destination load is back in the step loop"
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+def test_two_mfmas_per_product_in_the_step_loops_of_the_c2_chains():
+    """Packed fp16 planes: a product of the 128-unit chains is TWO v_mfma_f32_16x16x32_f16, so a GRU step issues
+    3 gates x 4 k-blocks x 2 = 24 in the forward role loops and 12 in the backward ones (its gate gradients enter as the k
+    dimension: 3 x 128 / 32 = 12 k-blocks of ONE output tile, accumulated per plane pair).  Three MFMAs per product would be
+    36 / 18.  (tools/isa_stats.py prints the whole mix.)"""
+    text = rec_p_asm()
+    for pat, want in ((r"^_Z11rec_fwd_x6pILi1ELb1ELb0ELb1EEv7RecArgs:", 24), (r"^_Z11rec_bwd_x6pILi1ELb0ELb0ELb1ELi1EEv7RecArgs:", 12)):
+        st = next(i for i, ln in enumerate(text) if re.match(pat, ln))
+        end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
+        body = text[st:end + 1]
+        loops = loops_of(body)
+        assert len(loops) == 2
+        for lo, hi in loops:
+            n = sum(1 for ln in body[lo:hi] if ln.strip().startswith("v_mfma_f32_16x16x32_f16"))
+            assert n == want, (pat, n, want)
