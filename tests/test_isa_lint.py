@@ -114,8 +114,8 @@ def test_lds_ring_of_the_fused_gather_in_the_forward_kernel():
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 def test_two_mfmas_per_product_in_the_step_loops_of_the_c2_chains():
     """Packed fp16 planes: a product of the 128-unit chains is TWO v_mfma_f32_16x16x32_f16, so a GRU step issues
-    3 gates x 4 k-blocks x 2 = 24 in the forward role loops and 12 in the backward ones (its gate gradients enter as the k
-    dimension: 3 x 128 / 32 = 12 k-blocks of ONE output tile, accumulated per plane pair).  Three MFMAs per product would be
+    3 gates x 4 k-blocks x 2 = 24 in the forward role loops and 12 in the backward ones (a wave's share of the 384-deep
+    product of the gate gradients with W_hid^T: six k-blocks).  Three MFMAs per product would be
     36 / 18.  (tools/isa_stats.py prints the whole mix.)"""
     text = rec_p_asm()
     for pat, want in ((r"^_Z11rec_fwd_x6pILi1ELb1ELb0ELb1EEv7RecArgs:", 24), (r"^_Z11rec_bwd_x6pILi1ELb0ELb0ELb1ELi1EEv7RecArgs:", 12)):
