@@ -99,7 +99,7 @@ def test_c3_c4_full_length_chains_under_full_load():
     check(r, 1, rows=256)
 
 
-def test_c5_million_item_catalogue_against_the_id_compacted_oracle():
+def _c5_million_item_case(B, T, n, seed, grad_floor=1e-12):
     """BASELINE configs[4] at its own catalogue: 2 x LSTM-512, N = 1 000 000 items, sampled softmax.  W_in is 2.05e9 floats
     (8.2 GB: row byte offsets pass 2^31 at id 262 144 and 2^32 at id 524 288), far beyond what the dense float64 oracle holds.
     Only the rows a step gathers (sparse_lstm.py:368) and the sampled cells (sparse_lstm.py:50-54, rnn_sampling.py:188-191)
@@ -110,9 +110,9 @@ def test_c5_million_item_catalogue_against_the_id_compacted_oracle():
     row-sparse Adam steps (touched rows against the oracle, every other row bit-identical to what was set), ordered top-10."""
     import numpy as np
     from oracle import rnn_oracle as O
-    NBIG, B, T, S, n = 1000000, 64, 12, 32, 1200
+    NBIG, S = 1000000, 32
     cell, layers, loss = "LSTM", [512, 512], "Blackout"
-    params, cfg, batch = PU.build_case(cell, layers, loss, n, B, T, S=S, seed=29, zipf=True, scale=0.02)
+    params, cfg, batch = PU.build_case(cell, layers, loss, n, B, T, S=S, seed=seed, zipf=True, scale=0.02, full=T > 100)
     _plant_duplicate_cells(batch)
     rng = np.random.default_rng(7)
     planted = np.array([0, 262143, 262144, 524287, 524288, NBIG - 1])
@@ -159,14 +159,16 @@ def test_c5_million_item_catalogue_against_the_id_compacted_oracle():
                 sub = g[:, big].copy(); g[:, big] = 0.0; rest = g
             else:
                 sub = g
-            assert PU.rel_err(sub, og) <= 1e-5, nm
+            assert PU.rel_err(sub, og, grad_floor) <= 1e-5, (nm, PU.rel_err(sub, og, grad_floor))
             assert rest is None or not rest.any(), nm                           # rows no id of the batch names: exactly zero
         del grads
         upd = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)
         oparams = [p.copy() for p in params]
-        for _ in range(2):
-            O.train_function(oparams, cfg, upd, ob)
-            eng.train_step(sync=True)
+        upd.apply(oparams, ograds)                     # step 1 of the oracle: the gradients computed above (same parameters)
+        del ograds
+        eng.train_step(sync=True)
+        O.train_function(oparams, cfg, upd, ob)
+        eng.train_step(sync=True)
         new = eng.get_all_param_values()
         touched = {"l0.W_in": np.unique(batch["X"][batch["mask"] > 0]),
                    "out": np.unique(np.concatenate([batch["target"].ravel(), batch["samples"].ravel()]))}
@@ -204,3 +206,18 @@ def test_c5_million_item_catalogue_against_the_id_compacted_oracle():
         assert np.array_equal(ids[rows], big[oids[rows]])
     finally:
         eng.close()
+
+
+def test_c5_million_item_catalogue_against_the_id_compacted_oracle():
+    # T shortened to what the float64 oracle does in seconds; the planted ids, byte boundaries and duplicate cells as above
+    _c5_million_item_case(B=64, T=12, n=1200, seed=29)
+
+
+def test_c5_as_benched_full_load_against_the_id_compacted_oracle():
+    """BASELINE configs[4] exactly as bench.py --config c5 runs it: B = 256 rows, T = 200 steps, N = 1 000 000 -- 512 resident
+    workgroups of rec_*_c16<., 512> (two per CU), the four-slot exchange ring reused fifty times, both layers
+    (recurrent_layers.py:57-68, 94-104; sparse_lstm.py:293-495).  The compact catalogue holds the ids the 51 200 positions
+    name plus bystanders; the float64 oracle needs ~1 TFLOP per pass (minutes of CPU).  grad_floor as in
+    test_c3_c4_full_length_chains_under_full_load: 200 steps from the loss the initial states' gradients have decayed to the
+    fp16 split's absolute floor."""
+    _c5_million_item_case(B=256, T=200, n=40000, seed=31, grad_floor=4e-7)

@@ -118,8 +118,12 @@ def test_engine_agrees_with_the_reference_code(path):
         assert rel(eng.predict_function(batch["X"], batch["mask"]), z["scores"]) <= TOL_LOGITS
         k = 5
         top = -np.sort(-z["test_scores"], axis=1)[:, :k + 1]
-        if np.all(top[:, :-1] - top[:, 1:] > 1e-5 * top[:, :1]):          # ranked items well separated: ids are bit-exact
-            ids = eng.test_function((batch["X"], batch["mask"]), k=k, exclude_seen=(2 if margin else 1) if int(z["unique"]) else 0)
-            assert np.array_equal(ids, np.argsort(-z["test_scores"], axis=1, kind="stable")[:, :k])
+        # ids are bit-exact on every row whose ranked scores are well separated; a fixture without such a row would compare
+        # nothing, so that is a failure of the fixture, not a pass
+        sep = np.all(top[:, :-1] - top[:, 1:] > 1e-5 * np.abs(top[:, :1]), axis=1)
+        if not sep.any():
+            pytest.fail("no row of %s has its %d best scores separated: the top-k assertion would be vacuous" % (os.path.basename(path), k + 1))
+        ids = eng.test_function((batch["X"], batch["mask"]), k=k, exclude_seen=(2 if margin else 1) if int(z["unique"]) else 0)
+        assert np.array_equal(ids[sep], np.argsort(-z["test_scores"], axis=1, kind="stable")[sep, :k])
     finally:
         eng.close()
