@@ -73,6 +73,13 @@
 #ifndef X6P_PACK
 #define X6P_PACK 1       // 0: the fp16 forms with three MFMAs per product (round 2), for same-box A/B runs (SBR_LIB)
 #endif
+#ifndef X6P_SPARSE
+#define X6P_SPARSE 1     // packed planes on the 2:4-sparse matrix instruction: ONE v_smfmac_f32_16x16x64_f16 per (gate, k-block), see
+#endif                   // "Sparse planes" below; 0: two dense MFMAs (round 3)
+#ifndef X6P_SP_INIT
+#define X6P_SP_INIT 0    // sparse forms: the accumulators' initial value (bias | zeros) comes from LDS (ds_read_b128 at the top of the step;
+                         // bit 0: forward, bit 1: backward) or from VALU moves (0)
+#endif
 
 namespace {
 
@@ -86,9 +93,26 @@ constexpr int HP = 128, R = 4, KBH = HP / 32;
 // in [-1, 1], weights far below; relative precision decays below |a| ~ 1e-4 * 2^-13 (absolute floor 1.5e-11), which is
 // why only the FORWARD chain uses it: gradients span too many binades without a per-row scale.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
 constexpr float F16_LO = 2048.0f;
+// "Sparse planes" (round 4): one matrix instruction per (gate, k-block).  v_smfmac_f32_16x16x64_f16 multiplies a 2:4-sparse A (16 x 64,
+// stored compressed as 16 x 32 + two index bits per kept element) with a dense B (64 x 16) in the 16 cycles the dense 16x16x32 takes
+// (tools/probes/smfmac_probe.hip, profiles/round4_a_probe_smfmac.txt: 200 cycles per 12, one dependent accumulator chain included).
+// The 4-row tile's sixteen A rows are (batch row, copy c); with the index bits each copy picks its OWN half of a B operand that
+// interleaves the two weight planes: every group of four dense K positions is (W1[k], W2[k], W1[k+1], W2[k+1]), copy c keeps
+// positions (P, 2 + P) with P = c & 1 and carries plane c >> 1 of the activations.  One instruction then leaves
+//     accumulator element 0: a1 w1     1: a1 w2     2: a2 w1     3: a2 w2 (below f32 rounding, unused)
+// for the lane's (row, unit) -- the three products the packed form needs two dense MFMAs for.  Operand layout, found with one-hot
+// operands by the probe: A lane (i, qa) holds the kept elements of dense k = 16 qa .. 16 qa + 15 (eight values: real k = 8 qa + r,
+// one ds_read_b128 of the plane as before), index field r at bits [2r + 1 : 2r] of the lane's own index register (ABID picks the 16-bit
+// half; both halves are filled); B lane (j, qb) element e holds dense k = 32 (e >> 3) + 8 qb + (e & 7), i.e. plane e & 1 of
+// real k = 16 (e >> 3) + 4 qb + ((e & 7) >> 1).  smfmac accumulates in place (no C operand): a step's accumulators start from
+// {bias, 0, 0, 0} by moves (X6P_SP_INIT 0) or LDS reads (1).
+__device__ __forceinline__ f32x4 smfmac16(const f16x8& a, const f16x16& b, const f32x4& c, int idx) {
+    return __builtin_amdgcn_smfmac_f32_16x16x64_f16(a, b, c, idx, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) { return MFMA_BF16(a, b, c); }
-__device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
+[[maybe_unused]] __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 // v must be a value the compiler cannot look through (callers pin it with an empty asm): when it can see the expression
@@ -126,6 +150,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;      // operand fragment: fp16 (two planes) or bf16 (three planes)
     constexpr int NP = F16 ? 2 : 3;
     constexpr bool PK = F16 && X6P_PACK;                     // packed planes: two MFMAs per product, see "Packed planes" above
+    constexpr bool SP = PK && X6P_SPARSE;                    // ... one sparse instruction per product, see "Sparse planes" above
     constexpr int G = Gates<CELL>::G, KB = KBH, GHP = G * HP;
     static_assert(G <= 3 || F16, "three W_hid planes of four gates do not fit the register file: an LSTM runs on the two fp16 planes only");
     constexpr int HROW = HP * 2 + 32, PLANEB = R * HROW, BUFB = 3 * PLANEB;
@@ -148,7 +173,23 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, 16));
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));  // workgroup-uniform: all four rows
 
-    OPV W1[G][KB], W2[G][KB], W3[F16 ? 1 : G][F16 ? 1 : KB];   // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
+    OPV W1[SP ? 1 : G][SP ? 1 : KB], W2[SP ? 1 : G][SP ? 1 : KB], W3[F16 ? 1 : G][F16 ? 1 : KB];   // B operands: lane (j, q) holds W[kb*32 + 8q + e][unit j]
+    f16x16 WS[SP ? G : 1][SP ? KB : 1];                  // SP: both planes interleaved, lane (j, q) holds real k = 16 (e >> 3) + 4 q + ((e & 7) >> 1)
+    if constexpr (SP) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float sc = (CELL == CELL_GRU && g < 2) ? X6P_NLOG2E : 1.0f;
+                    float w = sc * a.Whid[(size_t)(kb * 32 + 16 * (r >> 2) + 4 * q + (r & 3)) * GHP + g * HP + u];
+                    _Float16 b1, b2;
+                    asm("" : "+v"(w));                       // see split2_f16 (not volatile)
+                    split2_f16(w, b1, b2);
+                    WS[g][kb][2 * r] = b1; WS[g][kb][2 * r + 1] = b2;
+                }
+    } else
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -190,7 +231,9 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     }
     const unsigned lds_pub = (unsigned)(q * HROW + u * 2);            // where this lane's h goes inside a plane set
     // A operand: tile row m = j holds batch row j >> 2; PK: plane j & 1 of it (rows 4r + 2, 4r + 3 repeat rows 4r, 4r + 1)
-    const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16 + (PK ? (j & 1) * PLANEB : 0));
+    // (SP: tile rows 4r, 4r + 1 hold plane 0, rows 4r + 2, 4r + 3 plane 1; the row's index bits choose the weight plane)
+    const unsigned lds_rd = (unsigned)((j >> 2) * HROW + q * 16 + (SP ? ((j >> 1) & 1) * PLANEB : PK ? (j & 1) * PLANEB : 0));
+    const int spidx = (j & 1) ? (int)0xDDDDDDDDu : (int)0x88888888u;      // kept positions of every group of four: (1, 3) / (0, 2)
     auto publish_h = [&](int buf) {
         char* base = hbuf + buf * BUFB + lds_pub;
         if constexpr (F16) {
@@ -252,6 +295,14 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) x[g] = ldf(xt_t, bo_x, g * HP * 4);
     };
+    // SP, X6P_SP_INIT: {bias, 0, 0, 0} of every (gate, unit) in LDS -- a step's accumulators start as one ds_read_b128 each
+    const f32x4* bz_lane = (const f32x4*)(smem_p + (FUSE ? ((xring_off + 8 * XPD * XSTG + 255) & ~255) : XOFF_OFF)) + u;
+    if constexpr (SP && (X6P_SP_INIT & 1)) {
+        if (q == 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) ((f32x4*)bz_lane)[g * HP] = biasv[g];
+        }
+    }
     if constexpr (FUSE) {
         for (int i = threadIdx.x; i < R * T; i += 512) {
             const int r = i / T;
@@ -322,6 +373,12 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             bo_nxt2 = xo_row[min(t + XPD + 1, T - 1)];
         }
         // ---- N1
+        f32x4 acc0[G];                                            // SP: what the step's accumulators start from
+        if constexpr (SP && (X6P_SP_INIT & 1)) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc0[g] = bz_lane[g * HP];
+        }
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
         OPV hp[KB][3];
         int fl[2];
@@ -378,7 +435,30 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         f32x4 acc[G], acl[G];                                     // acl: the low-order products of the fp16 form
 #define X6P_TERM(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = mfma16(HOP, WOP, acc[g]);
 #define X6P_TERL(HOP, WOP) _Pragma("unroll") for (int g = 0; g < G; ++g) acl[g] = mfma16(HOP, WOP, acl[g]);
-        if constexpr (PK) {
+        if constexpr (SP) {
+            // acc[g]: {h1 w1 (+ bias), h1 w2, h2 w1, h2 w2}: one sparse instruction per (gate, k-block)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = (X6P_SP_INIT & 1) ? acc0[g] : biasv[g];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb == KB / 2 && RA) ensure_half(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (PROF && tl && t == 100) tl[1 + kb] = clock64();
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK >= 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = smfmac16(hp[kb][0], WS[g][kb], acc[g], spidx);
+                if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acc[g][2], 1.0f / F16_LO, acc[g][0]);
+        } else if constexpr (PK) {
             // acc[g][0] = h1 w1 (+ bias), acc[g][1] = h2 w1, acl[g][0] = h1 w2 (acl[g][1] = h2 w2: below f32 rounding, dropped)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -557,6 +637,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     using OPV = std::conditional_t<F16, f16x8, bf16x8>;
     constexpr int NP = F16 ? 2 : 3;
     constexpr bool PK = F16 && X6P_PACK;                 // packed planes: two MFMAs per product ("Packed planes" above)
+    constexpr bool SP = PK && X6P_SPARSE;                // ... one sparse instruction per product ("Sparse planes" above)
     constexpr int G = Gates<CELL>::G, GHP = G * HP, KB = GHP / 32, KU = HP / 32;     // KU k-blocks per gate
     static_assert(G <= 3 || F16, "three W_hid planes of four gates do not fit the register file: an LSTM runs on the two fp16 planes only");
     constexpr int DROW = GHP * 2 + 32, PLANEB = R * DROW, BUFB = NP * PLANEB;
@@ -580,7 +661,23 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     tmax = max(tmax, __shfl_xor(tmax, 16));
     tmax = __builtin_amdgcn_readfirstlane(max(tmax, __shfl_xor(tmax, 32)));
 
-    OPV W1[KB], W2[KB], W3[F16 ? 1 : KB];               // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
+    OPV W1[SP ? 1 : KB], W2[SP ? 1 : KB], W3[F16 ? 1 : KB];               // B operands: lane (j, q) holds W_hid[unit j][kb*32 + 8q + e]
+    f16x16 WS[SP ? KB : 1];                              // SP: both planes interleaved, columns kb*32 + 16 (e >> 3) + 4 q + ((e & 7) >> 1)
+    if constexpr (SP) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const float* src = a.Whid + (size_t)u * GHP + kb * 32 + 4 * q;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float w = r < 4 ? lo[r & 3] : hi[r & 3];
+                _Float16 b1, b2;
+                asm("" : "+v"(w));                       // see split2_f16 (not volatile)
+                split2_f16(w, b1, b2);
+                WS[kb][2 * r] = b1; WS[kb][2 * r + 1] = b2;
+            }
+        }
+    } else
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const float* src = a.Whid + (size_t)u * GHP + kb * 32 + 8 * q;
@@ -605,7 +702,9 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     const unsigned bo_g = (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;
     const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;
-    const unsigned lds_pub = (unsigned)(q * DROW + u * 2), lds_rd = (unsigned)((j >> 2) * DROW + q * 16 + (PK ? (j & 1) * PLANEB : 0));
+    const unsigned lds_pub = (unsigned)(q * DROW + u * 2),
+                   lds_rd = (unsigned)((j >> 2) * DROW + q * 16 + (SP ? ((j >> 1) & 1) * PLANEB : PK ? (j & 1) * PLANEB : 0));
+    const int spidx = (j & 1) ? (int)0xDDDDDDDDu : (int)0x88888888u;      // SP: kept positions of every group of four, see rec_fwd_x6p
 
     const bool first = a.t_hi >= T, last = a.t_lo <= 0;          // first / last launch of the chunked chain
     float dh = 0.f, dc = 0.f;
@@ -649,6 +748,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     // not in flight yet when the ring is read
     constexpr bool BDEF = RING && PK && X6P_BWD_DEFER;
     constexpr int VMN = (BDEF ? 0 : NST) + (PD - 1) * (NLI + NST);   // younger than the loads of the step being taken
+    const f32x4* zslot = (const f32x4*)(smem_p + RING_OFF + 8 * PD * STG);      // SP, X6P_SP_INIT: sixteen zero bytes behind the ring
+    if (SP && (X6P_SP_INIT & 2) && threadIdx.x == 0) *(f32x4*)zslot = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned ring_wave = (unsigned)(size_t)(smem_p + RING_OFF) + (unsigned)wave * (PD * STG);
     const char* ring_lane = smem_p + RING_OFF + wave * (PD * STG) + lane * 4;
     // Two 16-byte-per-lane pieces per step instead of five dword ones (a piece costs its issue slot whatever it moves): the
@@ -853,6 +954,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
             use(i0);
         };
+        f32x4 accz = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP && (X6P_SP_INIT & 2)) { asm volatile("" ::: "memory"); accz = *zslot; }
         load_flag(0);
 #pragma unroll
         for (int i = 0; i < LA; ++i) load_kb(i);
@@ -874,6 +977,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         // ---- M
         const f32x4 z4 = f32x4{0, 0, 0, 0};
         f32x4 acc[3] = {z4, z4, z4};
+        if constexpr (SP && (X6P_SP_INIT & 2)) acc[0] = accz;     // (in-place accumulation: zeros by one LDS read, issued in the N phase)
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             const int s = i % NS, kb = korder(i);
@@ -882,7 +986,20 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 load_kb(i + LA);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
+            if constexpr (SP) {       // acc[0]: {d1 w1, d1 w2, d2 w1, d2 w2}, one dependent chain (full issue rate: smfmac_probe)
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one instruction early
+                acc[0] = smfmac16(dpl[s][0], WS[kb], acc[0], spidx);
+                if (BDEF && i == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const char* dx_t = (const char*)a.dxt + offx_st;
+                    st_si<0, WT>(dx_t, bo_x, dxi_st[0]);
+                    if (G > 1) st_si<HP * 4, WT>(dx_t, bo_x, dxi_st[G > 1 ? 1 : 0]);
+                    if (G > 2) st_si<2 * HP * 4, WT>(dx_t, bo_x, dxi_st[G > 2 ? 2 : 0]);
+                    if (G > 3) st_si<3 * HP * 4, WT>(dx_t, bo_x, dxi_st[G > 3 ? 3 : 0]);
+                    if (CELL == CELL_GRU) st_si<0, WT>((const char*)a.dhi + offh_st, bo_h, dhc_st);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
                 acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]); X6P_GAP();
                 if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]); X6P_GAP();
@@ -917,7 +1034,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         asm volatile("s_nop 15");                                 // MFMA D -> VALU read hazard
         __builtin_amdgcn_s_setprio(3);
         if (PROF) p_m += clock64() - q_n;
-        if constexpr (PK) dh += fmaf(acc[0][1] + acc[1][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
+        if constexpr (SP) dh += fmaf(acc[0][1] + acc[0][2], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
+        else if constexpr (PK) dh += fmaf(acc[0][1] + acc[1][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
         else if constexpr (F16) dh += fmaf(acc[1][0] + acc[2][0], 1.0f / F16_LO, acc[0][0]) * (1.0f / F16_DSCALE);
         else dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
@@ -978,7 +1096,7 @@ static bool x6p_f16_bwd(const RecArgs& a) {     // the operand that carries grad
     return (fe ? atoi(fe) != 0 : true) && a.clip > 0.0f && a.clip <= 100.0f;
 }
 
-int sbr_rec_x6p_f16_terms() { return X6P_PACK ? 2 : 3; }
+int sbr_rec_x6p_f16_terms() { return X6P_PACK ? (X6P_SPARSE ? 1 : 2) : 3; }
 
 bool sbr_rec_x6p_ok(const RecArgs& a) {
     if (!a.x6_pipe || a.f32_mfma || a.Hp != HP || a.rpt != R || !a.x6_split) return false;
@@ -998,6 +1116,7 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         lds = ((lds + 255) & ~(size_t)255) + (size_t)R * a.T * 4;
         lds = ((lds + 255) & ~(size_t)255) + (size_t)8 * 4 * Gates<CELL>::G * 256;
     }
+    if (X6P_PACK && X6P_SPARSE && (X6P_SP_INIT & 1)) lds = ((lds + 255) & ~(size_t)255) + (size_t)Gates<CELL>::G * HP * 16;   // + the accumulators' initial values
     if (a.fence_kb > 0 && a.Bp / R <= 192 && (size_t)a.fence_kb * 1024 > lds && a.fence_kb <= 160) lds = (size_t)a.fence_kb * 1024;   // see launch_bwd_p
     const int nb = a.Bp / R;
 #define X6P_LAUNCH(KERNEL) do { \
@@ -1023,6 +1142,7 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G;
     size_t lds = 2 * 3 * R * (size_t)(G * HP * 2 + 32) + 64;
     lds = ((lds + 255) & ~(size_t)255) + 8 * 4 * (size_t)(G == 1 ? 1 : 5) * 256;             // + the prefetch ring (PD = 4 stages per wave)
+    lds += 256;                                                                               // + the zero slot of the sparse form
     // Overlapped tail: the chain's workgroup claims most of its CU's LDS, so that the consumers that run beside it -- the polling
     // weight-gradient GEMM (40 KB of LDS per workgroup, MFMAs on the same SIMDs) and the scatter-add (which asks for LDS it does not
     // use, for this purpose) -- are placed on the other 192 CUs instead of sharing the chain's matrix pipes, issue slots and L1

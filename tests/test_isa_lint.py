@@ -55,7 +55,7 @@ def loops_of(lines):
         members = [j for j, l2 in enumerate(lines) if re.search(r"Header=%s\b" % name, l2)]
         last = max(members) if members else i
         end = next((j for j in range(last + 1, len(lines)) if re.match(r"^\.LBB\d+_\d+:", lines[j])), len(lines))
-        if any("v_mfma" in l2 for l2 in lines[i:end]):
+        if any("v_mfma" in l2 or "v_smfmac" in l2 for l2 in lines[i:end]):
             out.append((i, end))
     return out
 

@@ -10,6 +10,7 @@
 #   phases                       in-kernel phase counters of the C2 chains                  -> <tag>_rec_phases.txt
 #   trace                        device-side stamps of the overlapped tail's consumers      -> <tag>_tail_trace.txt
 #   test:<pytest -k expr|all>[:ENV=v,..][:file]   pytest -m gpu                             -> <tag>_tests_<n>.txt
+#   cmp:<spec>[;<spec>...]     tools/cmp_case.py on each spec (CELL:H[,H2]:B:T:key=value..., ';' between specs) -> <tag>_cmp.txt
 #   bg:<job>                     the job in the background (joined at the end of the call)
 tag=$1; shift
 repo=${GRAFT_REPO_ROOT:-/root/repo}
@@ -71,6 +72,8 @@ print({k: d.get(k) for k in ('value','ms_per_step','repeats','sustained','train_
            if [ "$a" = all ]; then sel=""; else sel="-k"; fi
            env $envs timeout 2700 python -m pytest ${c:-tests} -m gpu -q --durations=8 $sel ${sel:+"$a"} > $out/${tag}_tests_$nt.txt 2>&1
            echo "== tests [$a] $envs"; tail -14 $out/${tag}_tests_$nt.txt | cut -c1-250 ;;
+    cmp)   specs=$(echo "${1#cmp:}" | tr ';' ' ')
+           timeout 1800 python tools/cmp_case.py $specs >> $out/${tag}_cmp.txt 2>&1; tail -20 $out/${tag}_cmp.txt | cut -c1-400 ;;
     *) echo "unknown job $1" ;;
   esac
 }

@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_isa_lint import loops_of          # noqa: E402  (the same loop finder the lint uses)
 
-CLASSES = [("mfma", r"^v_mfma"), ("valu", r"^v_(?!mfma)"), ("salu", r"^s_(?!waitcnt|cbranch|branch|nop|sleep|barrier|endpgm)"),
+CLASSES = [("mfma", r"^v_s?mfmac?"), ("valu", r"^v_(?!mfma|smfmac)"), ("salu", r"^s_(?!waitcnt|cbranch|branch|nop|sleep|barrier|endpgm)"),
            ("lds read", r"^ds_read"), ("lds write / other", r"^ds_(?!read)"), ("lds-dma load", r"^global_load_lds"),
            ("global load", r"^global_load_(?!lds)"), ("global store", r"^global_store|^global_atomic"),
            ("waitcnt", r"^s_waitcnt"), ("branch", r"^s_cbranch|^s_branch"), ("nop / sleep", r"^s_nop|^s_sleep")]
