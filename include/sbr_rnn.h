@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 7
+#define SBR_ABI_VERSION 8
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -294,6 +294,12 @@ int sbr_enable_timing(sbr_handle* h, int on);
  * MFMA tile), "rec_workgroups_fwd" / "_bwd" (workgroups of the launch = CUs it can occupy). */
 int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
+/* Chain-only timing (ABI 8; tooling: bench.py prices the recurrent chain kernels of stacked layers apart from the dense GEMMs
+ * between them).  on = 1: from now on every launch of a recurrent chain kernel -- the compiled scan of sparse_lstm.py:425 /
+ * recurrent_layers.py:57-68 and its gradient, any layer, either direction -- is bracketed by a HIP-event pair (up to 256 launches);
+ * on = 0: stop and report us[0] / us[1] = device time summed over the forward / backward chain launches since the start,
+ * n[0] / n[1] = the number of launches (us, n may be NULL with on = 1).  A survey facility: the records delay the stream. */
+int sbr_chain_times(sbr_handle* h, int on, float us[2], int n[2]);
 
 /* ------------------------------------------------------------------------------------------------
  * Native batch builder: replaces SequenceGenerator + _gen_mini_batch + _prepare_input

@@ -398,6 +398,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr; h->side3 = nullptr; h->ev_tail3 = nullptr; h->tail_sorted = false; h->out3 = false;
     h->step_open = false; h->tail_join_pending = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
+    memset(h->ev_ch, 0, sizeof(h->ev_ch)); h->ch_n = 0; h->chain_timing = false;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
@@ -451,6 +452,8 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (!h) return;
     for (int r = 0; r < sbr_handle::kRing; ++r)
         for (int i = 0; i < SBR_N_PHASES; ++i) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    for (int r = 0; r < sbr_handle::kChain; ++r)
+        for (int i = 0; i < 2; ++i) if (h->ev_ch[r][i]) (void)hipEventDestroy(h->ev_ch[r][i]);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -719,6 +722,16 @@ static int tail_cost_scan(sbr_handle* h) {
     return SBR_OK;
 }
 
+// sbr_chain_times: events around one chain launch (dir 0 = forward, 1 = backward); `which` 0 in front of it, 1 behind it
+static inline void chain_mark(sbr_handle* h, hipStream_t st, int dir, int which) {
+    if (!h->chain_timing || h->ch_n >= sbr_handle::kChain) return;
+    hipEvent_t& e = h->ev_ch[h->ch_n][which];
+    if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; return; }
+    (void)hipEventRecord(e, st);
+    if (which == 1) { h->ch_dir[h->ch_n] = (unsigned char)dir; h->ch_n += 1; }
+}
+#define SBR_LAUNCH_CHAIN(DIR, STREAM, CALL) do { chain_mark(h, STREAM, DIR, 0); SBR_LAUNCH(CALL); chain_mark(h, STREAM, DIR, 1); } while (0)
+
 static inline void mark_on(sbr_handle* h, int i, hipStream_t st) {
     if (i == 0) h->marks_shared = 0;
     if ((h->marks_shared >> i) & 1) return;              // this step's mark i was recorded by record_shared
@@ -787,7 +800,7 @@ static int forward_bi(sbr_handle* h) {
                                        h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
             }
             if (l == 0 && d == 1) mark(h, 1);
-            SBR_LAUNCH(launch_rec_forward(s, ra, simple_rec(h)));
+            SBR_LAUNCH_CHAIN(0, s, launch_rec_forward(s, ra, simple_rec(h)));
         }
         const LayerLayout& lf = y.layer[2 * l]; const LayerLayout& lb = y.layer[2 * l + 1];
         if (l + 1 < y.L) {
@@ -821,7 +834,7 @@ static int backward_bi(sbr_handle* h) {
             a.dh_last = l == y.L - 1 ? h->A(y.a_dhl[d]) : nullptr;
             a.dh_ext = l < y.L - 1 ? h->A(ly.a_dhext) : nullptr;
             const int nblk = sbr_rec_bwd_blocks(a, simple_rec(h));
-            SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
+            SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, simple_rec(h)));
             if (l == 0 && d == 1) mark(h, 4);
             SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
                                                   h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
@@ -922,7 +935,7 @@ extern "C" int sbr_forward(sbr_handle* h) {
                                    y.T * y.Bp, GHp, lo.Hp, h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
         }
         if (l == 0 && h->tail_sorted) ra.fence_kb = h->tail_fence_kb;
-        SBR_LAUNCH(launch_rec_forward(s, ra, simple_rec(h)));
+        SBR_LAUNCH_CHAIN(0, s, launch_rec_forward(s, ra, simple_rec(h)));
     }
     mark(h, 2);
     h->fwd_done = true;
@@ -1210,7 +1223,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                      y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1, gap_at, gap_len);
             };
             if (!serial) a.fence_kb = h->tail_fence_kb;              // the chain's CUs are its own: the consumers take the other 192
-            SBR_LAUNCH(launch_rec_backward(s, a, false));
+            SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, false));
             mark(h, 4);
             // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
             const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss));
@@ -1285,7 +1298,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
-                SBR_LAUNCH(launch_rec_backward(s, a, false));
+                SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, false));
                 SBR_HIP(hipStreamWaitEvent(sd, record_shared(h, h->ev_chunk[c], (l == 0 && c == nc - 1) ? 4 : -1), 0));
                 // dW_hid [Hp][G*Hp] += hs[t]^T . dhi[t] over the chunk's positions (hs slot t = h_{t-1})
                 const float* hsc = h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp;
@@ -1317,7 +1330,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_LAUNCH(launch_rec_reduce_partials(sm, a.part, nc * nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
                                                   h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
         } else {
-            SBR_LAUNCH(launch_rec_backward(s, a, simple_rec(h)));
+            SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, simple_rec(h)));
             if (l == 0) mark(h, 4);
             SBR_LAUNCH(launch_rec_reduce_partials(s, a.part, nblk, y.G, ly.Hp, y.cfg.cell, h->Gd(ly.p_b), h->Gd(ly.p_peep),
                                                   h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
@@ -1822,6 +1835,26 @@ extern "C" int sbr_enable_timing(sbr_handle* h, int on) {
     CHECK_ARG(on >= 0 && on <= SBR_N_PHASES, "on = %d: 0 off, 1 every phase, 2 + p only phase p", on);
     h->timing = on != 0; h->ring_used = 0; h->ring_cur = 0;
     h->timing_marks = on == 1 ? 0xffu : on >= 2 ? (3u << (on - 2)) : 0u;      // a phase lies between marks p and p + 1
+    return SBR_OK;
+}
+
+// Chain-only timing: on = 1 starts collecting an event pair around every launch of a recurrent chain kernel (all layers, both
+// directions; up to 256 launches), on = 0 stops and reports.  us[0] / us[1]: device time summed over the forward / backward chain
+// launches since the start; n[0] / n[1]: how many launches that was (divide by the steps run in between).  A survey facility
+// like sbr_enable_timing(h, 1): the records cost the stream a few microseconds each.
+extern "C" int sbr_chain_times(sbr_handle* h, int on, float us[2], int n[2]) {
+    CHECK_ARG(h, "null handle");
+    if (on) { h->ch_n = 0; h->chain_timing = true; return SBR_OK; }
+    CHECK_ARG(us && n, "null argument");
+    h->chain_timing = false;
+    SBR_HIP(hipDeviceSynchronize());
+    us[0] = us[1] = 0.f; n[0] = n[1] = 0;
+    for (int r = 0; r < h->ch_n; ++r) {
+        float ms = 0.f;
+        if (!h->ev_ch[r][0] || !h->ev_ch[r][1] || hipEventElapsedTime(&ms, h->ev_ch[r][0], h->ev_ch[r][1]) != hipSuccess) continue;
+        us[h->ch_dir[r] & 1] += ms * 1000.f; n[h->ch_dir[r] & 1] += 1;
+    }
+    h->ch_n = 0;
     return SBR_OK;
 }
 

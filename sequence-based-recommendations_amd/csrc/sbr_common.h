@@ -210,6 +210,12 @@ struct sbr_handle {
     hipEvent_t ev[kRing][SBR_N_PHASES];
     int ring_used;       // train steps recorded since timing was enabled
     int ring_cur;        // set used by the step in flight
+    // chain-only timing (sbr_chain_times): an event pair around every launch of a recurrent chain kernel, any layer, either direction
+    static const int kChain = 256;
+    hipEvent_t ev_ch[kChain][2];
+    unsigned char ch_dir[kChain];
+    int ch_n = 0;
+    bool chain_timing = false;
     float* P(size_t off) const { return arena + lay.s_params + off; }
     float* Gd(size_t off) const { return arena + lay.s_grads + off; }
     float* St(int k, size_t off) const { return arena + lay.s_state + (size_t)k * lay.n_params + off; }

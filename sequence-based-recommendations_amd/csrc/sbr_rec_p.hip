@@ -77,7 +77,7 @@
 #define X6P_SPARSE 1     // packed planes on the 2:4-sparse matrix instruction: ONE v_smfmac_f32_16x16x64_f16 per (gate, k-block), see
 #endif                   // "Sparse planes" below; 0: two dense MFMAs (round 3)
 #ifndef X6P_SP_INIT
-#define X6P_SP_INIT 0    // sparse forms: the accumulators' initial value (bias | zeros) comes from LDS (ds_read_b128 at the top of the step;
+#define X6P_SP_INIT 1    // sparse forms: the accumulators' initial value (bias | zeros) comes from LDS (ds_read_b128 at the top of the step;
                          // bit 0: forward, bit 1: backward) or from VALU moves (0)
 #endif
 

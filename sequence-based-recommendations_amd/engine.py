@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 7
+SBR_ABI_VERSION = 8
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
@@ -60,7 +60,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_set_default_target",
            "sbr_train_step", "sbr_train_step_lagged", "sbr_lagged_flush", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
-           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_query",
+           "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_chain_times", "sbr_query",
            "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
            "sbr_sparse_unpack_add", "sbr_dense_ranges", "sbr_sparse_pack_device", "sbr_sparse_unpack_add_all",
            "sbr_cluster_create", "sbr_cluster_destroy", "sbr_cluster_set_params", "sbr_cluster_get_params", "sbr_cluster_get_grads",
@@ -116,6 +116,7 @@ def load_library(path=None):
     lib.sbr_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_size_t]
     lib.sbr_enable_timing.argtypes = [vp, ctypes.c_int]
     lib.sbr_phase_times.argtypes = [vp, f32p]
+    lib.sbr_chain_times.argtypes = [vp, ctypes.c_int, f32p, ctypes.POINTER(ctypes.c_int)]
     i64p = ctypes.POINTER(ctypes.c_int64)
     lib.sbr_query.argtypes = [vp, ctypes.c_char_p, i64p]
     lib.sbr_debug_gemm.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64,
@@ -769,6 +770,16 @@ class RNNEngine(object):
         us = (ctypes.c_float * SBR_N_PHASES)()
         self._check(self.lib.sbr_phase_times(self.h, us))
         return dict(zip(PHASE_NAMES, [float(v) for v in us]))
+
+    def chain_timing(self, on=True):
+        """on: bracket every launch of a recurrent chain kernel (any layer, either direction) with a HIP-event pair from now on;
+        off: stop and return {"fwd_us", "bwd_us": device time summed over the launches, "fwd_launches", "bwd_launches"}."""
+        if on:
+            self._check(self.lib.sbr_chain_times(self.h, 1, None, None))
+            return None
+        us, n = (ctypes.c_float * 2)(), (ctypes.c_int * 2)()
+        self._check(self.lib.sbr_chain_times(self.h, 0, us, n))
+        return {"fwd_us": float(us[0]), "bwd_us": float(us[1]), "fwd_launches": int(n[0]), "bwd_launches": int(n[1])}
 
 
 # ------------------------------------------------------------------------------------------------ RNNCluster's cluster head
