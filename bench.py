@@ -240,6 +240,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if not np.isfinite(eng.read_cost()):       # (also raises on a device-side fault flag: a broken kernel build ends here, not after the regions)
+        raise ValueError("Cost is NaN")
     log("warmup done")
     # survey pass (untimed, after the warm-up): every phase bracketed by HIP events -> the per-phase table and the name of
     # the dominant kernel.  Eight event records per step cost the stream ~40 us at C2, so the timed region below brackets

@@ -364,7 +364,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         const char* xs = getenv("SBR_X6_SPLIT");
         h->x6_split = xs ? atoi(xs) != 0 : 1;
         const char* xp = getenv("SBR_X6_PIPE");
-        h->x6_pipe = xp ? atoi(xp) : 2;   // 0: barrier kernels (x6s), 1: pipelined without the matrix-pipe gate, 2: with it
+        h->x6_pipe = xp ? atoi(xp) : 1;   // 0: barrier kernels (x6s), 1: pipelined without the matrix-pipe gate, 2: with it (rounds 1-3: with
+                                          // one sparse instruction per k-block the partner's phase is over long before, the gate only costs its read)
         const char* fg = getenv("SBR_FUSE_GATHER");
         h->fuse_gather = fg ? atoi(fg) != 0 : 1;
     }

@@ -28,6 +28,9 @@ __device__ __forceinline__ void lds_inc(unsigned addr, int one) {
 __device__ __forceinline__ void st_s(const void* ubase, unsigned boff, float v) {
     asm volatile("global_store_dword %0, %1, %2" :: "v"(boff), "v"(v), "s"(ubase) : "memory");
 }
+__device__ __forceinline__ void st_s4(const void* ubase, unsigned boff, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(boff), "v"(v), "s"(ubase) : "memory");
+}
 // WT: write-through (sc1) -- the value reaches memory that every XCD sees, for consumers that read it while this kernel
 // is still running (MI355X_MICROARCH.md, inter-workgroup visibility)
 template <int IMM, bool WT = false>

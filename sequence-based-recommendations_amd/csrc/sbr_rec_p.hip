@@ -45,10 +45,10 @@
 #define X6P_DBG 0        // timing experiments only (tools/probes/x6p_variants.sh): wrong results by design
 #endif
 #ifndef X6P_BWD_NS
-#define X6P_BWD_NS 2     // backward: operand slots / k-blocks fetched ahead of their MFMAs
+#define X6P_BWD_NS 4     // backward: operand slots / k-blocks fetched ahead of their MFMAs
 #endif
 #ifndef X6P_BWD_LA
-#define X6P_BWD_LA 1
+#define X6P_BWD_LA 3     // (round 4: with one sparse instruction per k-block an LDS read one k-block ahead left every iteration waiting for it: 155 -> 136 us)
 #endif
 #ifndef X6P_MFMA_NOP
 #define X6P_MFMA_NOP -1  // >= 0: s_nop N behind every MFMA of the packed forms (experiment: does the partner's gate math get the issue port?)
@@ -59,7 +59,7 @@
 #define X6P_GAP() do { } while (0)
 #endif
 #ifndef X6P_FWD_V2
-#define X6P_FWD_V2 2     // forward, packed form: 1 = the input row (+ bias) rides in as the MFMA C operand, 2 = the stores of step
+#define X6P_FWD_V2 6     // forward, packed form: 1 = the input row (+ bias) rides in as the MFMA C operand, 2 = the stores of step
 #endif                   // t - 1 are issued inside the MFMA phase of step t, 4 = the next row offset is read before the MFMAs
 #ifndef X6P_BWD_DEFER
 #define X6P_BWD_DEFER 0  // backward, ring forms: the stores of step t leave from inside its own MFMA phase (behind the first k-block)
@@ -67,6 +67,15 @@
 #ifndef X6P_FWD_TOK
 #define X6P_FWD_TOK 1    // forward, packed form: waves 4-7 open the pipe gate this many MFMA groups (of G) before their last MFMA
 #endif
+#ifndef X6P_G4
+#define X6P_G4 1         // the four saved gate values of a (t, row, unit) as ONE 16-byte element [t][row][unit][4] in the region of RecArgs.g[0..3]
+#endif                   // (forward: one dwordx4 store per lane and step instead of four; backward: one ds_read_b128 from the ring); 0: round 3's four arrays
+#ifndef X6P_ROLES
+#define X6P_ROLES 1      // 0: waves 0-3 run the loop of waves 4-7 too (all operands fetched at the top of the step, no pipe gate)
+#endif
+#ifndef X6P_TOK_EARLY
+#define X6P_TOK_EARLY 1  // the pipe gate's token is read together with the step's first operand reads: a separate read was one exposed LDS
+#endif                   // round trip (~140 cycles) per step of waves 0-3, and the token is there long before (profiles/round4_d_rec_phases.txt)
 #ifndef X6P_SYNC
 #define X6P_SYNC 0       // 1: one workgroup barrier per step instead of the counters / the pipe gate / the role split (experiment:
 #endif                   // with two MFMAs per product the matrix phase is short enough for the synchronous schedule to compete)
@@ -165,6 +174,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const int T = a.T, Bp = a.Bp;
     if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
     const bool roleA = wave < 4;                         // waves w and w + 4 share a SIMD; the older one owns the pipe
+    int spin_limit = X6P_SPIN_LIMIT;                     // (drops to 64 once this wave has raised the fault flag)
     const unsigned lds_tok = (unsigned)(size_t)(tok + (wave & 3));
     const int one = 1;
 
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
 
     // per-lane byte offsets, computed once; the per-step part of every address is uniform and advances on the SALU
     const unsigned bo_h = (unsigned)(row * HP + u) * 4u;                                       // hs rows
-    const unsigned bo_g = (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;                 // saved activations
+    const unsigned bo_g = X6P_G4 ? (unsigned)(row * HP + u) * 16u : (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;   // saved activations
     const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;                                      // xt rows (not fused)
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;                      // bytes per time step
 
@@ -275,7 +285,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     // the address arithmetic (a 64-bit multiply-add, a 64-bit add) sat on the VALU beside the partner's MFMA stream:
     // 177 us against 153 us for the same kernel reading a pre-gathered xt.
     // Per iteration the wave issues: stores of step t (NSF) < the DMA piece of step t + XPD.
-    constexpr int XPD = 4, NSF = CELL == CELL_VANILLA ? 1 : (CELL == CELL_LSTM ? 6 : 5), XSTG = G * 256;
+    constexpr int XPD = 4, NSF = CELL == CELL_VANILLA ? 1 : (CELL == CELL_LSTM ? 2 : 1) + (X6P_G4 ? 1 : 4), XSTG = G * 256;
     constexpr int XOFF_OFF = (2 * BUFB + 64 + 255) & ~255;
     const int xring_off = (XOFF_OFF + R * T * 4 + 255) & ~255;
     unsigned* xo_tab = (unsigned*)(smem_p + XOFF_OFF);
@@ -331,8 +341,11 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     auto store_step = [&](size_t off, const float* svv, float hv, float cv) {
         if (X6P_DBG & 4) return;
         if (CELL != CELL_VANILLA) {
+            if constexpr (X6P_G4) st_s4((const char*)a.g[0] + 4 * off, bo_g, f32x4{svv[0], svv[1], svv[2], svv[3]});
+            else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) st_s((const char*)a.g[k] + off, bo_g, svv[k]);
+                for (int k = 0; k < 4; ++k) st_s((const char*)a.g[k] + off, bo_g, svv[k]);
+            }
         }
         st_s((const char*)a.hs + off + st_h, bo_h, hv);
         if (CELL == CELL_LSTM) st_s((const char*)a.cs + off + st_h, bo_h, cv);
@@ -342,6 +355,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     tmin = min(tmin, __shfl_xor(tmin, 16));
     tmin = __builtin_amdgcn_readfirstlane(min(tmin, __shfl_xor(tmin, 32)));
     const unsigned lds_cnt0 = (unsigned)(size_t)cnt;              // LDS addresses of the two publish counters
+    const unsigned my_cnt = roleA ? lds_cnt0 : lds_cnt0 + 4;      // (the wave's group, whichever loop it runs: X6P_ROLES)
     // One loop per role (waves 0-3 / 4-7): a role test inside the loop costs VALU instructions in every step, some
     // of them between MFMAs, and values defined under it get copies at the join (see sbr_rec_cl.hip).
     auto steps = [&](auto role_tag) {
@@ -382,8 +396,10 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
         OPV hp[KB][3];
         int fl[2];
-        auto load_half = [&](int half) {                          // counter first, then planes: the LDS keeps a wave's order
+        int tokv = 0;                                             // RA: the pipe gate's token, read with the first operands (one LDS
+        auto load_half = [&](int half) {                          // round trip instead of two).  Counter first, then planes: the LDS keeps a wave's order
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (X6P_TOK_EARLY && RA && half == 0) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 2 * half; kb < 2 * half + 2; ++kb) {
@@ -401,7 +417,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 do {
                     asm volatile("" ::: "memory");
                     load_half(half);
-                    if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 2); break; }   // bounded: never hang the GPU
+                    if (++spins > spin_limit) { atomicOr(a.fault, 2); spin_limit = 64; break; }   // bounded: never hang the GPU (and a broken launch ends soon)
                 } while (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * t);
                 if (PROF) p_spin += clock64() - w0;
             }
@@ -421,11 +437,11 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (RA && a.x6_pipe >= 2 && !(X6P_DBG & 32)) {
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
-            int v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
+            int v = X6P_TOK_EARLY ? tokv : __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
 #pragma clang loop unroll(disable)
             while (__builtin_amdgcn_readfirstlane(v) < t) {
                 v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 4); break; }
+                if (++spins > spin_limit) { atomicOr(a.fault, 4); spin_limit = 64; break; }
             }
             if (PROF) p_tok += clock64() - w0;
         }
@@ -572,7 +588,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (t + 1 < tmax) {
             publish_h((t + 1) & 1);
             if (X6P_SYNC) __syncthreads(); else
-            lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
+            lds_inc(my_cnt, one);
             if (PROF) p_seg[2] += clock64() - p_tb;
             if (PROF && tl && t == 100) tl[6] = clock64();
         }
@@ -590,7 +606,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         } else if (!(X6P_DBG & 2)) load_x(t + 1);
     }
     };
-    if (roleA && !X6P_SYNC) steps(std::true_type{}); else steps(std::false_type{});
+    if (roleA && !X6P_SYNC && X6P_ROLES) steps(std::true_type{}); else steps(std::false_type{});
     if (DEFER && tmax > 0) store_step(off_t - st_h, sv_st, h_st, c_st);      // the last step's
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
@@ -653,6 +669,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     const float clip = a.clip;
     if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
     const bool roleA = wave < 4;
+    int spin_limit = X6P_SPIN_LIMIT;
     const unsigned lds_tok = (unsigned)(size_t)(tok + (wave & 3));
     const int one = 1;
 
@@ -699,7 +716,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     }
 
     const unsigned bo_h = (unsigned)(row * HP + u) * 4u;
-    const unsigned bo_g = (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;
+    const unsigned bo_g = X6P_G4 ? (unsigned)(row * HP + u) * 16u : (unsigned)sbr_blocked_index(0, row, u, Bp, HP) * 4u;
     const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;
     const unsigned lds_pub = (unsigned)(q * DROW + u * 2),
@@ -759,7 +776,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     // gate arrays' distance from hs rides in the lanes' offsets (same arena, same bytes per step: sbr_rec_x6p_tail_ok).
     unsigned bo_ga = 0;
     const unsigned bo_hs4 = (unsigned)((blockIdx.x * R + ((lane >> 2) & 3)) * HP + wave * 16 + (lane & 3) * 4) * 4u;
-    if (CELL != CELL_VANILLA) {
+    // X6P_G4: the gate values are one 16-byte element per (row, unit): lane (j, q) fetches ITS OWN element (it lands at + 16 lane and is
+    // read back by one ds_read_b128); a step is 4 x the bytes of hs, so the piece has its own scalar base
+    if (X6P_G4) bo_ga = bo_g;
+    else if (CELL != CELL_VANILLA) {
         const unsigned b0 = (unsigned)sbr_blocked_index(0, blockIdx.x * R, wave * 16, Bp, HP) * 4u;     // the wave's block
         const int k = lane >> 4;
         const char* gk = k == 0 ? (const char*)a.g[0] : k == 1 ? (const char*)a.g[1] : k == 2 ? (const char*)a.g[2] : (const char*)a.g[3];
@@ -769,7 +789,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         const unsigned m = ring_wave + (unsigned)slot * STG;
         const char* base = sbase + o;
         lds_dma_x4(m, base, bo_hs4, 0xFFFFull);
-        if (CELL != CELL_VANILLA) lds_dma_x4(m + 256, base, bo_ga, ~0ull);
+        if (CELL != CELL_VANILLA) {
+            if constexpr (X6P_G4) lds_dma_x4(m + 256, (const char*)a.g[0] + 4 * o, bo_ga, ~0ull);
+            else lds_dma_x4(m + 256, base, bo_ga, ~0ull);
+        }
     };
     // The ring is read one iteration BEFORE the values are used (at the bottom of the iteration in front, into the registers
     // the gate math has just released), so that the LDS latency runs under the MFMA phase: read at the top of the
@@ -779,15 +802,25 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         const char* p = ring_lane + slot * STG;
         hprev = *(const float*)p;
         if (CELL != CELL_VANILLA) {
+            if constexpr (X6P_G4) {
+                const f32x4 v = *(const f32x4*)(p + 256 + lane * 12);      // (p is ring + 4 lane: the element sits at ring + 256 + 16 lane)
+                sv[0] = v[0]; sv[1] = v[1]; sv[2] = v[2]; sv[3] = v[3];
+            } else {
             sv[0] = *(const float*)(p + 256); sv[1] = *(const float*)(p + 512);
             sv[2] = *(const float*)(p + 768); sv[3] = *(const float*)(p + 1024);
+            }
         }
     };
     auto load_saved = [&](size_t o) {                            // activations of the step at byte offset o = t * st_h
         hprev = ldf(sbase + o, bo_h);
         if (CELL != CELL_VANILLA) {
+            if constexpr (X6P_G4) {
+                const f32x4 v = *(const f32x4*)((const char*)a.g[0] + 4 * o + (size_t)bo_g);
+                sv[0] = v[0]; sv[1] = v[1]; sv[2] = v[2]; sv[3] = v[3];
+            } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) sv[k] = ldf((const char*)a.g[k] + o, bo_g);
+            }
         }
         if (EXT) dhe = ldf((const char*)a.dh_ext + o, bo_h);
     };
@@ -832,6 +865,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
     auto korder = [](int i) { return (i % NH) / 2 * KU + (i % NH) % 2 + (i / NH) * 2; };
     size_t off_h = (size_t)(t_live - 1) * st_h, off_x = (size_t)(t_live - 1) * st_x;   // of step t
     const unsigned lds_cnt0 = (unsigned)(size_t)cnt;
+    const unsigned my_cnt = roleA ? lds_cnt0 : lds_cnt0 + 4;
     float dxi_st[G], dhc_st = 0.f; size_t offx_st = 0, offh_st = 0;      // BDEF: what the MFMA phase stores
 #pragma unroll
     for (int g = 0; g < G; ++g) dxi_st[g] = 0.f;
@@ -881,7 +915,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
         }
         if (X6P_SYNC) __syncthreads(); else
-        lds_inc(RA ? lds_cnt0 : lds_cnt0 + 4, one);
+        lds_inc(my_cnt, one);
         if (CELL != CELL_GRU) hnew = hprev;
         if constexpr (RING) {                                     // loads first: see the progress note above
             __builtin_amdgcn_sched_barrier(0);
@@ -931,8 +965,10 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             dpl[s][1] = PK ? dpl[s][0] : *(const OPV*)(db + kb * 64 + PLANEB);
             if constexpr (NP == 3) dpl[s][2] = *(const OPV*)(db + kb * 64 + 2 * PLANEB);
         };
+        int tokv = 0;                                             // RA: the pipe gate's token, read with the first flag (see rec_fwd_x6p)
         auto load_flag = [&](int half) {
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (X6P_TOK_EARLY && RA && half == 0) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
         };
         auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][NP - 1])); };
@@ -948,7 +984,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                     load_flag(half);
 #pragma unroll
                     for (int i = i0; i < i1; ++i) load_kb(i);
-                    if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 2); break; }
+                    if (++spins > spin_limit) { atomicOr(a.fault, 2); spin_limit = 64; break; }
                 } while (__builtin_amdgcn_readfirstlane(fl[half]) < 4 * (n + 1));
                 if (PROF) p_spin += clock64() - w0;
             }
@@ -965,11 +1001,11 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         if (RA && a.x6_pipe >= 2) {                               // the matrix-pipe gate, see rec_fwd_x6p
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
-            int v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
+            int v = X6P_TOK_EARLY ? tokv : __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
 #pragma clang loop unroll(disable)
             while (__builtin_amdgcn_readfirstlane(v) < n) {
                 v = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (++spins > X6P_SPIN_LIMIT) { atomicOr(a.fault, 4); break; }
+                if (++spins > spin_limit) { atomicOr(a.fault, 4); spin_limit = 64; break; }
             }
             if (PROF) p_tok += clock64() - w0;
         }
@@ -1040,7 +1076,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         else dh += acc[0][0] + acc[1][0] + acc[2][0];
     }
     };
-    if (roleA && !X6P_SYNC) steps(std::true_type{}); else steps(std::false_type{});
+    if (roleA && !X6P_SYNC && X6P_ROLES) steps(std::true_type{}); else steps(std::false_type{});
     if constexpr (WT) publish_progress(prog_slot, prog_tag | a.t_lo);
     if constexpr (WT) {      // shader cycles and 100 MHz wall-clock ticks of this launch (block 0, wave 0): the chain's effective clock
         if (blockIdx.x == 0 && wave == 0 && lane == 0) {
@@ -1106,6 +1142,9 @@ bool sbr_rec_x6p_ok(const RecArgs& a) {
     if ((size_t)a.Bp * a.G * HP * 4 >= ((size_t)1 << 32)) return false;          // 32-bit per-lane byte offsets
     if (a.gX && (size_t)a.n_in * a.G * HP * 4 >= ((size_t)1 << 32)) return false; // ... also into W_in (fused gather)
     if (a.gX && a.T > SBR_X6P_FUSE_MAX_T) return false;                            // its row-offset table lives in LDS
+    if (X6P_G4 && a.cell != SBR_CELL_VANILLA && a.g[0])                            // one region [T][Bp][HP][4] under the four arrays
+        for (int k = 1; k < 4; ++k) if (a.g[k] != a.g[0] + (size_t)k * a.T * a.Bp * HP) return false;
+    if (X6P_G4 && (size_t)a.Bp * HP * 16 >= ((size_t)1 << 32)) return false;
     return true;
 }
 

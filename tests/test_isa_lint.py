@@ -25,8 +25,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # backward, PD = 4 stages; per step 2 load pieces + 4 stores (GRU, LSTM) / 1 + 1 (Vanilla): NST + (PD - 1) * (NLI + NST)
 EXPECTED_WAIT = {"0": 22, "1": 22, "2": 7}
 # forward with the fused gather (rec_fwd_x6p<CELL, FUSE, .., F16>), XPD = 4: (XPD - 1) * (stores of a step + 1 load piece);
-# stores of a step: h + four saved gate values (GRU), + c (LSTM), h alone (Vanilla)
-EXPECTED_WAIT_FWD = {"0": 21, "1": 18, "2": 6}
+# stores of a step: h + ONE 16-byte element of the four saved gate values (GRU), + c (LSTM), h alone (Vanilla)
+EXPECTED_WAIT_FWD = {"0": 12, "1": 9, "2": 6}
 
 
 _ASM = {}
@@ -45,18 +45,35 @@ def rec_p_asm():
 
 
 def loops_of(lines):
-    """[(first, last) line index] of the depth-1 loops (the two role loops; the prologue's fill loops carry no MFMAs)."""
-    out = []
+    """[(first, last) line index] of the depth-1 loops that carry matrix instructions (the two role loops; the prologue's fill
+    loops carry none): from the loop header's label to the last branch back into the loop (the blocks the compiler's loop comments
+    name, extended over every later branch that targets a label inside the range found so far)."""
+    labels = {}
     for i, ln in enumerate(lines):
-        m = re.match(r"^\.(LBB\d+_\d+):.*Loop Header: Depth=1", ln)
-        if not m:
-            continue
-        name = m.group(1)[1:]
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            labels[m.group(1)] = i
+    branches = []
+    for j, ln in enumerate(lines):
+        m = re.match(r"^\s+s_c?branch\S*\s+(\.LBB\d+_\d+)\s*$", ln)
+        if m and m.group(1) in labels:
+            branches.append((j, labels[m.group(1)]))
+    heads = [i for i, ln in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:.*Loop Header: Depth=1", ln)]
+    out = []
+    for n, i in enumerate(heads):
+        name = re.match(r"^\.L(BB\d+_\d+):", lines[i]).group(1)
         members = [j for j, l2 in enumerate(lines) if re.search(r"Header=%s\b" % name, l2)]
-        last = max(members) if members else i
-        end = next((j for j in range(last + 1, len(lines)) if re.match(r"^\.LBB\d+_\d+:", lines[j])), len(lines))
-        if any("v_mfma" in l2 or "v_smfmac" in l2 for l2 in lines[i:end]):
-            out.append((i, end))
+        first = min(members + [i])                                # (a rotated loop keeps blocks in front of its header label)
+        end = max(members + [i]) + 1
+        limit = min([h for h in heads if h > i] + [len(lines)])
+        grown = True
+        while grown:
+            grown = False
+            for j, tgt in branches:
+                if end <= j < limit and first <= tgt < end:
+                    end, grown = j + 1, True
+        if any("v_mfma" in l2 or "v_smfmac" in l2 for l2 in lines[first:end]):
+            out.append((first, end))
     return out
 
 
@@ -80,10 +97,12 @@ def test_lds_ring_prefetch_of_the_write_through_backward_kernel():
             assert any(c.startswith("global_load_lds_dwordx4") for c in code), "no LDS-DMA load in the role loop"
             assert want in code, (want, [c for c in code if c.startswith("s_waitcnt vmcnt")])
             assert "s_waitcnt vmcnt(0)" not in code, "a full wait inside the role loop drains the write-through stores"
-            # ring reads: the first ds_read of the loop body is behind the wait (the ring is read at the top of an iteration,
-            # the operand planes of the MFMA phase later)
-            first_read = next(i for i, c in enumerate(code) if c.startswith("ds_read"))
-            assert code.index(want) < first_read, "an LDS read sits in front of the hand-written wait"
+            # ring reads: pinned directly behind the wait by its memory clobber -- the row-major value (ds_read_b32) and, for the gated
+            # cells, the 16-byte element of the four saved gate values (ds_read_b128); a read hoisted above the wait would be missing here
+            w = code.index(want)
+            behind = [c for c in code[w + 1:w + 8] if c.startswith("ds_read")]
+            assert any(c.startswith("ds_read_b32") for c in behind), "the ring's reads do not follow the hand-written wait"
+            assert cell == "2" or any(c.startswith("ds_read_b128") for c in behind), "the saved gate values are not one 16-byte read behind the wait"
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
@@ -112,18 +131,19 @@ def test_lds_ring_of_the_fused_gather_in_the_forward_kernel():
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
-def test_two_mfmas_per_product_in_the_step_loops_of_the_c2_chains():
-    """Packed fp16 planes: a product of the 128-unit chains is TWO v_mfma_f32_16x16x32_f16, so a GRU step issues
-    3 gates x 4 k-blocks x 2 = 24 in the forward role loops and 12 in the backward ones (a wave's share of the 384-deep
-    product of the gate gradients with W_hid^T: six k-blocks).  Three MFMAs per product would be
-    36 / 18.  (tools/isa_stats.py prints the whole mix.)"""
+def test_one_sparse_matrix_instruction_per_product_in_the_step_loops_of_the_c2_chains():
+    """Sparse planes: a product of the 128-unit chains is ONE v_smfmac_f32_16x16x64_f16, so a GRU step issues
+    3 gates x 4 k-blocks = 12 in each forward role loop and 12 k-blocks (K = 384) = 12 in each backward one; the packed dense form
+    (round 3) had 24 / 24 v_mfma_f32_16x16x32_f16, three per product 36 / 36.  No dense MFMA is left in the loops.
+    (tools/isa_stats.py prints the whole mix.)"""
     text = rec_p_asm()
-    for pat, want in ((r"^_Z11rec_fwd_x6pILi1ELb1ELb0ELb1EEv7RecArgs:", 24), (r"^_Z11rec_bwd_x6pILi1ELb0ELb0ELb1ELi1EEv7RecArgs:", 12)):
+    for pat, want in ((r"^_Z11rec_fwd_x6pILi1ELb1ELb0ELb1EEv7RecArgs:", 12), (r"^_Z11rec_bwd_x6pILi1ELb0ELb0ELb1ELi1EEv7RecArgs:", 12)):
         st = next(i for i, ln in enumerate(text) if re.match(pat, ln))
         end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
         body = text[st:end + 1]
         loops = loops_of(body)
         assert len(loops) == 2
         for lo, hi in loops:
-            n = sum(1 for ln in body[lo:hi] if ln.strip().startswith("v_mfma_f32_16x16x32_f16"))
-            assert n == want, (pat, n, want)
+            n = sum(1 for ln in body[lo:hi] if ln.strip().startswith("v_smfmac_f32_16x16x64_f16"))
+            dense = sum(1 for ln in body[lo:hi] if ln.strip().startswith("v_mfma_"))
+            assert n == want and dense == 0, (pat, n, want, dense)

@@ -20,6 +20,7 @@ cd $repo
 export TMPDIR=/tmp
 SHORT="--no-cpu-baseline --no-pmc --sustained-seconds 0 --loop-iters 0 --repeats 3"
 nt=0
+nab=0
 line() {      # one bench line, printed compactly
   python - "$1" "$2" <<'P'
 import json, sys
@@ -45,9 +46,9 @@ job() {
     ab)    i=0
            for v in "$b" "$c" "$d" "$e"; do
              [ -z "$v" ] && continue
-             i=$((i+1)); envs=$(echo "$v" | tr ',' ' ')
-             f=$out/${tag}_${a}_ab${i}_bench
-             env $envs timeout 600 python bench.py --config $a $SHORT > $f.json 2> $f.err; line $f.json "$a $envs"
+             i=$((i+1)); nab=$((nab+1)); envs=$(echo "$v" | tr ',' ' ')
+             f=$out/${tag}_${a}_ab${nab}_bench
+             env $envs timeout 150 python bench.py --config $a $SHORT > $f.json 2> $f.err; line $f.json "$a $envs"
            done ;;
     full)  timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; tail -c 1200 $out/${tag}_bench.err
            python -c "
