@@ -74,6 +74,23 @@ def initial_parameters(cfg, rng):
     return initial_values(describe_params(cfg), rng)
 
 
+def arithmetic_note(eng):
+    """what the kernels this configuration selects do with an f32 product (from sbr_query, not a fixed string)"""
+    names = {0: "exact-f32 MFMA (v_mfma_f32_16x16x4_f32)", 1: "the two-plane fp16 split, planes packed into the rows of a 4-row tile, ONE 2:4-sparse "
+             "matrix instruction per product (v_smfmac_f32_16x16x64_f16: three plane products in its four accumulator rows)",
+             2: "the two-plane fp16 split, planes packed into the tile rows: two MFMAs per product", 3: "the two-plane fp16 split: three "
+             "MFMAs per product", 6: "the exact three-plane bf16 split: six MFMAs per product"}
+    try:
+        pf, pb = eng.query("rec_products_fwd"), eng.query("rec_products_bwd")
+        fam = {0: "triage", 1: "cluster (rec_*_c16 / _cl)", 2: "128-unit pipelined (rec_*_x6p)", 3: "32/64-unit (rec_*_x6q)", 4: "general"}.get(eng.query("rec_kernel"), "?")
+    except Exception:
+        return "f32 tensors and accumulation; f32-class split products on the fp16 / bf16 matrix pipe (DESIGN.md section 3)"
+    chain = names.get(pf, "%d terms" % pf) if pf == pb else "forward: %s; backward: %s" % (names.get(pf, pf), names.get(pb, pb))
+    return ("f32 tensors and accumulation; matrix products of f32 operands as splits on the fp16 / bf16 matrix pipe with f32-class error. "
+            "Recurrent chains of the top layer [%s kernels]: %s. Weight-gradient GEMM of the chain: fp16 split, three MFMAs; the other "
+            "GEMMs: bf16x6 (DESIGN.md section 3)" % (fam, chain))
+
+
 def counter_passes(argv_child, log):
     """HBM bytes per launch and kernel from two rocprofv3 --pmc passes of THIS command (child: --quick, few steps), FETCH_SIZE and
     WRITE_SIZE each in its own run with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3: the two do not fit one pass; on
@@ -121,6 +138,81 @@ def counter_passes(argv_child, log):
     return out
 
 
+def mfma_counter_pass(argv_child, log):
+    """Matrix-pipe utilisation from the SQ counters (north_star: "MFMA utilisation ... from rocprof counters"): one rocprofv3 --pmc
+    pass of THIS command (child: --quick) with SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES, --kernel-trace only.  MFMA_BUSY counts
+    matrix-pipe cycles summed over the chip's 1024 SIMDs (16 per v_mfma_f32_16x16x32 / v_smfmac_f32_16x16x64); SQ_BUSY_CYCLES sums
+    the 32 SQ instances (8 XCDs x 4 shader engines), so a kernel's length in shader cycles is SQ_BUSY / 32 and
+    utilisation of the whole chip = MFMA_BUSY / (1024 x SQ_BUSY / 32).  Returns {kernel: {...}} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="sbr_sq_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", SBR_TAIL_OVERLAP="2")
+    acc = {}
+    try:
+        cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "c", "--",
+               sys.executable, os.path.abspath(__file__)] + argv_child
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            log("MFMA counter pass failed (rc %d): %s" % (r.returncode, r.stderr[-300:]))
+            return None
+        for fn in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
+            with open(fn) as f:
+                for row in csv.DictReader(f):
+                    acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    except Exception as ex:
+        log("MFMA counter pass skipped:", ex)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k, c in acc.items():
+        mf, sq = c.get("SQ_VALU_MFMA_BUSY_CYCLES", []), c.get("SQ_BUSY_CYCLES", [])
+        if not mf or not sq or max(mf) <= 0:
+            continue
+        m, b = (sum(x[1:]) / (len(x) - 1) if len(x) > 1 else x[0] for x in (mf, sq))
+        out[k] = {"mfma_busy_cycles": int(m), "sq_busy_cycles": int(b), "launches": len(mf),
+                  "kernel_shader_cycles": int(b / 32.0), "mfma_util_of_chip": round(m / (32.0 * b), 5) if b > 0 else None}
+    return out
+
+
+def other_config_lines(log, budget_s=420.0):
+    """The other BASELINE configurations next to the headline one, each as a child run of this file (--brief: phase survey, chain-only
+    timing, three timed regions): {name: {ms_per_step, value, roofline_frac, ...}}.  C5 builds a 47 GB arena and draws 2.6e9 initial
+    values on the host first (~45 s); a configuration that does not fit the time budget is reported as skipped, with the reason."""
+    import subprocess
+    out, t_all = {}, time.perf_counter()
+    for name, limit in (("c1", 120), ("c4", 150), ("c3", 150), ("c5", 300)):
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 30:
+            out[name] = {"skipped": "time budget of the default run spent (%d s)" % budget_s}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--brief", "--steps", "20", "--warmup", "5",
+                                "--repeats", "3"], capture_output=True, text=True, timeout=min(limit, left))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf, ch = d.get("roofline") or {}, d.get("chains") or {}
+            out[name] = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                         "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_us")},
+                         "chains_us": {"rec_fwd": ch.get("rec_fwd_us"), "rec_bwd": ch.get("rec_bwd_us")},
+                         "outside_chains_us": ch.get("outside_chains_us"),
+                         "phases_us": {k: v for k, v in (d.get("phases_us") or {}).items() if k != "note"},
+                         "arithmetic": d["config"].get("arithmetic"), "wall_s": round(time.perf_counter() - t0, 1)}
+            log("other config %s: %.4f ms/step (%.0f s)" % (name, d["ms_per_step"], time.perf_counter() - t0))
+        except subprocess.TimeoutExpired:
+            out[name] = {"skipped": "child run exceeded %d s" % min(limit, left)}
+        except Exception as ex:
+            out[name] = {"skipped": repr(ex)[:200]}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N ...` started directly (no torch.distributed.run around it): start the N ranks here -- one
     process per GPU, rendezvous on 127.0.0.1 at a free port -- with this very command line; rank 0 prints the JSON line, the
@@ -163,10 +255,20 @@ def main():
                     "CPU legs (what the counter passes run as their child)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the one long region behind the timed ones (0: skip)")
     ap.add_argument("--loop-iters", type=int, default=1000, help="iterations of the end-to-end training-loop leg (0: skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch rows PER GPU (the global batch grows with N; the default and the driver's curve); strong: --batch "
+                         "is the GLOBAL batch, as the reference's -b is (rnn_one_hot.py:71: the cost is a mean over the batch), every "
+                         "rank holds --batch / N rows")
+    ap.add_argument("--brief", action="store_true", help="phase survey + timed regions + roofline only (what the default run starts "
+                    "for the other BASELINE configurations): no counter / sustained / train-loop / CPU / side-kernel legs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of BASELINE configs c1 / c3 / c4 / c5")
     ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the data-parallel step: nccl = RCCL over xGMI (one rank per GPU); gloo lets several "
                          "ranks share one device (RCCL refuses that) -- how the one-GPU test box exercises --gpus 2")
     args = ap.parse_args()
+    if args.brief:
+        args.no_pmc = args.no_cpu_baseline = args.no_other_configs = True
+        args.sustained_seconds, args.loop_iters = 0.0, 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
@@ -207,6 +309,10 @@ def main():
 
     cell, layers, n_items, loss, n_samples = CONFIGS[args.config]
     B, T = args.batch, args.max_length
+    if args.scaling == "strong":      # the reference's -b is the global batch: split it over the ranks
+        if args.batch % world:
+            raise SystemExit("--scaling strong: --batch %d is not a multiple of %d ranks" % (args.batch, world))
+        B = args.batch // world
     Bg = B * world
     eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=Bg, local_batch=B,
                     row_offset=rank * B, loss=loss, n_samples=n_samples, updater="adam", learning_rate=1e-3)
@@ -259,6 +365,21 @@ def main():
         dom_phase = max(cand, key=lambda k: survey[k])
     except Exception as ex:
         log("phase survey skipped:", ex)
+    # chain-only survey: event pairs around every launch of a recurrent chain kernel (all layers): what the roofline of stacked
+    # configurations is priced on, and `outside_chains_us`
+    chain = None
+    if survey is not None:
+        try:
+            n_ch = 6
+            eng.enable_timing(False)
+            eng.chain_timing(True)
+            for i in range(n_ch):
+                step(args.warmup + i)
+            ct = eng.chain_timing(False)
+            chain = {"rec_fwd": ct["fwd_us"] / n_ch, "rec_bwd": ct["bwd_us"] / n_ch,
+                     "launches_per_step": (ct["fwd_launches"] + ct["bwd_launches"]) / float(n_ch)}
+        except Exception as ex:
+            log("chain survey skipped:", ex)
     # data parallel: how long the engine's stream really stands still for each collective (events around every wait; a survey
     # pass like the one above, outside the timed regions)
     dp_info = None
@@ -339,7 +460,7 @@ def main():
     result = {
         "metric": "user-sequences/sec training (ML-1M shape, seq200 b256) at 1/2/4/8 GPUs",
         "value": round(value, 1), "unit": "user-sequences/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
         "repeats": {"n": len(region_s), "ms_per_step": [round(x / args.steps * 1e3, 4) for x in region_s],
                     "stddev_ms": round(float(np.std([x / args.steps * 1e3 for x in region_s])), 5),
                     "headline": "median region of --steps steps"},
@@ -348,10 +469,7 @@ def main():
                                "N=%d items, Zipf(1.0) ids, lengths=%s, %d rows per GPU"
                                % (args.config, cell, "-".join(map(str, layers)), T, B, loss, n_items, args.lengths, B),
                    "global_batch": Bg, "seq_len": T, "parallelism": "dp%d" % world, "last_cost": round(cost, 5),
-                   "arithmetic": "f32 tensors and accumulation; matrix products of f32 operands as splits on the fp16 / bf16 "
-                                 "matrix pipe with f32-class error: the two-plane fp16 split in both recurrent chains (planes packed into the "
-                                 "tile rows: two MFMAs per product) and the dW_hid GEMM (three), bf16x6 in the other GEMMs, "
-                                 "DESIGN.md section 3"},
+                   "arithmetic": arithmetic_note(eng)},
     }
 
     if sustained is not None:
@@ -362,7 +480,7 @@ def main():
         G = {"LSTM": 4, "GRU": 3, "Vanilla": 1}[cell]
         H = layers[0]
         Ltot = float(np.mean([hb["lengths"].sum() for hb in host_batches]))     # valid (t,row) positions per step
-        rec_flops = 2.0 * Ltot * H * G * H                                        # per recurrent kernel launch
+        rec_flops = sum(2.0 * Ltot * Hl * G * Hl for Hl in layers)                # the chain kernels of ALL layers, per direction
         row_bytes = G * H * 4.0
         kernels = {
             "gather": {"bound": "hbm", "alg": Ltot * (row_bytes * 2 + 4), "unit": "GB/s"},       # read row + write xt
@@ -397,6 +515,11 @@ def main():
                                           "the rows it adds to" % (tail_chunks, last if last > 0 else "1 / %d" % tail_chunks, T))
         for k, v in kernels.items():
             us = phases[k]
+            if chain is not None and k in ("rec_fwd", "rec_bwd") and (len(layers) > 1 or k != dom_phase):
+                # stacked layers: the phase also holds the dense GEMMs between the layers; the roofline prices the chain KERNELS
+                # (sum over the layers' launches, HIP-event pairs around each: sbr_chain_times), the phase time is kept beside it
+                v["phase_us"] = round(us, 2)
+                us = chain[k]
             peak = HBM_PEAK_GBS if v["bound"] == "hbm" else F32_MFMA_PEAK_TFLOPS
             ach = (v["alg"] / (us * 1e-6)) / (1e9 if v["bound"] == "hbm" else 1e12) if us > 0 else 0.0
             v.update(us=round(us, 2), achieved=round(ach, 3), peak=peak, frac=round(ach / peak, 5))
@@ -471,6 +594,32 @@ def main():
             alg_k = Ltot * (row_bytes + nsave * H * 4.0) if dom == "rec_fwd" else Ltot * (nsave * H * 4.0 + row_bytes + (H * 4.0 if cell == "GRU" else 0.0))
             result["roofline"]["traffic_over_algorithmic"] = round(traffic / alg_k, 3)
             result["roofline"]["algorithmic_bytes"] = int(alg_k)
+        if chain is not None:
+            result["chains"] = {"rec_fwd_us": round(chain["rec_fwd"], 2), "rec_bwd_us": round(chain["rec_bwd"], 2),
+                                "launches_per_step": chain["launches_per_step"],
+                                "outside_chains_us": round(ms_per_step * 1e3 - chain["rec_fwd"] - chain["rec_bwd"], 1),
+                                "note": "device time of the recurrent chain kernels alone (HIP-event pair around every launch, all layers; "
+                                        "survey pass), and what is left of ms_per_step outside them"}
+        if world == 1 and not args.quick and not args.no_pmc:
+            mc = mfma_counter_pass(["--steps", "6", "--warmup", "2", "--repeats", "1", "--quick", "--config", args.config, "--lengths", args.lengths,
+                                    "--batch", str(B), "--max_length", str(T)], log)
+            if mc:
+                keep = {}
+                for k, v in mc.items():
+                    if "rec_fwd" in k or "rec_bwd" in k or "gemm_x6_kernel" in k or "gemm_kernel" in k:
+                        name = k.split("(")[0].replace("void ", "")[-70:]
+                        if "rec_" in k:
+                            try:
+                                wgs = eng.query("rec_workgroups_fwd" if "rec_fwd" in k else "rec_workgroups_bwd")
+                                v["mfma_util_of_active_cus"] = round(v["mfma_util_of_chip"] * N_CUS / min(N_CUS, wgs), 5)
+                            except Exception:
+                                pass
+                        keep[name] = v
+                result["mfma_counters"] = {"kernels": keep,
+                                           "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES child pass of this command (--quick --steps 6, "
+                                                   "SBR_TAIL_OVERLAP=2), mean over the launches after the first; mfma_util_of_chip = MFMA_BUSY / (1024 SIMDs x "
+                                                   "SQ_BUSY / 32 SQ instances); the logits projection of this configuration is the gemm_x6_kernel<4, false, 4, "
+                                                   "false, ...> launch, its backward pair the <.., true, ..> ones"}
         result["phases_us"] = {k: round(v, 2) for k, v in phases.items() if k != "total"}
         result["phases_us"]["note"] = ("%s: HIP events over the timed region; the other phases: survey pass of %d steps with "
                                        "every phase bracketed (those event records lengthen a step, so the phases do not add "
@@ -642,6 +791,13 @@ def main():
         except Exception as ex:
             log("train loop leg skipped:", ex)
             result["train_loop_error"] = repr(ex)[:400]
+    if (rank == 0 and world == 1 and not args.quick and not args.force_dp and not args.no_other_configs and args.config == "c2"
+            and (B, T, args.lengths) == (256, 200, "full")):
+        try:
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_config_lines(log)
+        except Exception as ex:
+            result["other_configs"] = {"error": repr(ex)[:300]}
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)          # (C stdio buffers of the libraries: out through the redirected descriptor)

@@ -70,6 +70,10 @@
 #ifndef X6P_G4
 #define X6P_G4 1         // the four saved gate values of a (t, row, unit) as ONE 16-byte element [t][row][unit][4] in the region of RecArgs.g[0..3]
 #endif                   // (forward: one dwordx4 store per lane and step instead of four; backward: one ds_read_b128 from the ring); 0: round 3's four arrays
+#ifndef X6P_SPEC1
+#define X6P_SPEC1 0      // forward, sparse form: waves 0-3 fetch the second half of the operands at the top of the step too, on spec (measured:
+                         // rec_fwd 113.5 -> 117 us -- two more ds_read_b128 per wave and step on an LDS pipe that is the busy resource)
+#endif
 #ifndef X6P_ROLES
 #define X6P_ROLES 1      // 0: waves 0-3 run the loop of waves 4-7 too (all operands fetched at the top of the step, no pipe gate)
 #endif
@@ -399,7 +403,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         int tokv = 0;                                             // RA: the pipe gate's token, read with the first operands (one LDS
         auto load_half = [&](int half) {                          // round trip instead of two).  Counter first, then planes: the LDS keeps a wave's order
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (X6P_TOK_EARLY && RA && half == 0) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (X6P_TOK_EARLY && RA && half == 0 && a.x6_pipe >= 2) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 2 * half; kb < 2 * half + 2; ++kb) {
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                                "v"(hp[2 * half + 1][0]), "v"(hp[2 * half + 1][1]), "v"(hp[2 * half + 1][2]));
         };
         load_half(0);
-        if (!RA) load_half(1);
+        if (!RA || (SP && X6P_SPEC1)) load_half(1);               // (waves 0-3, SP: on spec -- their partners' half is normally published by now)
         ensure_half(0);
         if (!RA) ensure_half(1);
         // The matrix pipe serves the OLDER wave of a SIMD pair first, strictly (tools/probes/mfma_share_probe.hip: two
@@ -460,17 +464,17 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (kb == KB / 2 && RA) ensure_half(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK >= 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK >= 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] = smfmac16(hp[kb][0], WS[g][kb], acc[g], spidx);
-                if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
+                if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below; X6P_SPEC1: only if the read at the top came too early
                     __builtin_amdgcn_sched_barrier(0);
-                    load_half(1);
+                    if (!X6P_SPEC1 || __builtin_amdgcn_readfirstlane(fl[1]) < 4 * t) load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acc[g][2], 1.0f / F16_LO, acc[g][0]);
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (kb == KB / 2 && RA) ensure_half(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) { acl[g] = mfma16(hp[kb][0], W2[g][kb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acl[g]); X6P_GAP(); }
                 if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
@@ -489,12 +493,12 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) { acc[g] = mfma16(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]); X6P_GAP(); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acl[g][0], 1.0f / F16_LO, acc[g][0]);
@@ -514,7 +518,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 X6P_TERL(hp[kb][0], W2[g][kb])
-                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
                 if (kb == 0) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W1[g][kb], biasv[g]);
@@ -546,7 +550,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             // cycles at GRU) before the last one is issued, so that less of that reaction time is idle matrix pipe.  Not
             // earlier: an older wave that starts while this one still has MFMAs to issue stalls them for its whole first
             // half (measured: 2 G MFMAs early gains nothing in the forward, 3 terms early loses 5 us).
-            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             X6P_TERM(hp[kb][0], W1[g][kb])
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -953,7 +957,8 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         unsigned long long q_n = 0;
         if (PROF) { q_n = clock64(); p_n += q_n - q_top; }
         // ---- operands: a ring of NS k-block slots, fetched LA k-blocks ahead of their MFMAs; the pipe gate
-        constexpr int NS = X6P_BWD_NS, LA = X6P_BWD_LA;   // round 2, three MFMAs per block: 3 slots +1 us, two k-blocks ahead +7 us (more LDS reads in flight)
+        constexpr int LA = X6P_BWD_LA < NH ? X6P_BWD_LA : NH - 1, NS = LA < X6P_BWD_NS ? X6P_BWD_NS : LA + 1;   // (a Vanilla step has four k-blocks: the lookahead stays inside a half)
+        static_assert(LA >= 1 && NS > LA, "operand ring");
         const char* db = lds + lds_rd;
         OPV dpl[NS][NP];
         int fl[2];
@@ -968,7 +973,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         int tokv = 0;                                             // RA: the pipe gate's token, read with the first flag (see rec_fwd_x6p)
         auto load_flag = [&](int half) {
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (X6P_TOK_EARLY && RA && half == 0) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (X6P_TOK_EARLY && RA && half == 0 && a.x6_pipe >= 2) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
         };
         auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][NP - 1])); };
@@ -1023,7 +1028,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SP) {       // acc[0]: {d1 w1, d1 w2, d2 w1, d2 w2}, one dependent chain (full issue rate: smfmac_probe)
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one instruction early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one instruction early
                 acc[0] = smfmac16(dpl[s][0], WS[kb], acc[0], spidx);
                 if (BDEF && i == 1) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1037,7 +1042,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 }
             } else if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
                 acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]); X6P_GAP();
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]); X6P_GAP();
                 if (BDEF && i == 1) {                               // this step's dxt / dhi, from where the issue slots are free
                     __builtin_amdgcn_sched_barrier(0);
@@ -1050,7 +1055,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
                 acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
                 acc[2] = mfma16(dpl[s][0], W2[kb], acc[2]);
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
@@ -1058,7 +1063,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             acc[0] = mfma16(dpl[s][0], W3[kb], acc[0]);
             acc[1] = mfma16(dpl[s][NP - 1], W1[kb], acc[1]);
             acc[2] = mfma16(dpl[s][1], W2[kb], acc[2]);
-            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
+            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
             acc[0] = mfma16(dpl[s][0], W2[kb], acc[0]);
             acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
             acc[2] = mfma16(dpl[s][0], W1[kb], acc[2]);
