@@ -255,6 +255,8 @@ def main():
                     "CPU legs (what the counter passes run as their child)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the one long region behind the timed ones (0: skip)")
     ap.add_argument("--loop-iters", type=int, default=1000, help="iterations of the end-to-end training-loop leg (0: skip)")
+    ap.add_argument("--flags", type=int, default=0, help="SBR_FLAG_* bits for the engine (include/sbr_rnn.h), e.g. 384 = bf16 output "
+                    "projection + bf16 layer GEMMs (BASELINE configs[4]); the line's dtype then says so")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch rows PER GPU (the global batch grows with N; the default and the driver's curve); strong: --batch "
                          "is the GLOBAL batch, as the reference's -b is (rnn_one_hot.py:71: the cost is a mean over the batch), every "
@@ -315,7 +317,7 @@ def main():
         B = args.batch // world
     Bg = B * world
     eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=Bg, local_batch=B,
-                    row_offset=rank * B, loss=loss, n_samples=n_samples, updater="adam", learning_rate=1e-3)
+                    row_offset=rank * B, loss=loss, n_samples=n_samples, updater="adam", learning_rate=1e-3, flags=args.flags)
     params = initial_parameters(eng.cfg, np.random.default_rng(42))
     eng.set_all_param_values(params)
 
@@ -464,7 +466,7 @@ def main():
         "repeats": {"n": len(region_s), "ms_per_step": [round(x / args.steps * 1e3, 4) for x in region_s],
                     "stddev_ms": round(float(np.std([x / args.steps * 1e3 for x in region_s])), 5),
                     "headline": "median region of --steps steps"},
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if not (args.flags & 384) else "f32 with bf16-input GEMMs (flags %d)" % args.flags, "data": "synthetic",
         "config": {"workload": "%s: train.py -m RNN --r_t %s --r_l %s --max_length %d -b %d --loss %s --u_m adam, "
                                "N=%d items, Zipf(1.0) ids, lengths=%s, %d rows per GPU"
                                % (args.config, cell, "-".join(map(str, layers)), T, B, loss, n_items, args.lengths, B),

@@ -94,6 +94,11 @@ typedef struct sbr_config {
  * softmax and predict / top-k of every head.  Scores then carry bf16 input rounding (~3e-3 of their spread) instead of
  * float32 rounding; gradients still come from the float32-class kernels. */
 #define SBR_FLAG_BF16_PROJECTION 128
+/* The dense GEMMs between stacked recurrent layers (recurrent_layers.py:94-104: layer l >= 2 reads the hidden states of layer
+ * l - 1 through a dense W_in; its backward pair dW_in = h^T . dxt and dh = dxt . W_in^T) on plain bf16 operands with f32
+ * accumulation, one MFMA per product (BASELINE configs[4]: "bf16 MFMA output projection (and bf16 layer-2 input GEMM)").  Default:
+ * the f32-class two-plane fp16 split (three MFMAs).  Gradients then carry bf16 input rounding (~4e-3 relative per product). */
+#define SBR_FLAG_BF16_LAYERS 256
 
 typedef struct sbr_handle sbr_handle;
 

@@ -661,6 +661,20 @@ static RecArgs rec_args(sbr_handle* h, int l) {
     return a;
 }
 static inline bool simple_rec(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_REC; }
+// Operand planes of the dense GEMMs around the recurrent layers (layer >= 2 input projection and its backward pair, the logits):
+// their operands are hidden states in [-1, 1] (not behind a rectifier), weights, and -- in the backward pair -- gate gradients
+// that have passed the reference's clip at +-100 (recurrent_layers.py:19): the two-plane fp16 split, three MFMAs per product, f32-class
+// (SBR_GEMM_F16=0: bf16x6 as in rounds 1-3).  SBR_FLAG_BF16_LAYERS: plain bf16 operands, one MFMA (BASELINE configs[4]).
+static inline bool layer_gemm_f16(const sbr_handle* h, bool with_gradient) {
+    const Layout& y = h->lay;
+    static const int on = [] { const char* e = getenv("SBR_GEMM_F16"); return e ? atoi(e) : 1; }();
+    if (!on || y.cfg.cell == SBR_CELL_VANILLA) return false;
+    return !with_gradient || (y.cfg.grad_clip > 0.0f && y.cfg.grad_clip <= 100.0f);
+}
+static inline void layer_gemm_hint(const sbr_handle* h, bool grad_a, bool grad_b) {
+    if (h->lay.cfg.flags & SBR_FLAG_BF16_LAYERS) sbr_gemm_hint(1, 1.0f, 1.0f);
+    else if (layer_gemm_f16(h, grad_a || grad_b)) sbr_gemm_hint(2, grad_a ? 512.0f : 1.0f, grad_b ? 512.0f : 1.0f);
+}
 static inline bool simple_gemm(const sbr_handle* h) { return h->lay.cfg.flags & SBR_FLAG_SIMPLE_GEMM; }
 // Overlapped step tail: time chunks for this step (0 = not taken) and steps per chunk.  Taken for a single index-input layer
 // served by rec_bwd_x6p's progress-publishing form, dense updates, the bf16x6 weight-gradient GEMM and one BPTT launch.
@@ -932,6 +946,7 @@ extern "C" int sbr_forward(sbr_handle* h) {
             mark(h, 1);
         } else {   // dense layers: xt = hid_out(l-1) . W_in + b  (Lasagne precompute_input [3P], recurrent_layers.py:94-104)
             const LayerLayout& lo = y.layer[l - 1];
+            layer_gemm_hint(h, false, false);
             SBR_LAUNCH(launch_gemm(s, h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp, lo.Hp, 1, h->P(ly.p_Win), GHp, 1, h->A(ly.a_xt), GHp,
                                    y.T * y.Bp, GHp, lo.Hp, h->P(ly.p_b), nullptr, 0, simple_gemm(h)));
         }
@@ -1031,6 +1046,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
         const bool bf16p = (y.cfg.flags & SBR_FLAG_BF16_PROJECTION) && !sg;
         if (bf16p) sbr_gemm_set_planes(1);
+        else if (layer_gemm_f16(h, false)) sbr_gemm_hint(2, 1.0f, 1.0f);      // h in [-1, 1] x weights
         const hipError_t ge = launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg);
         sbr_gemm_set_planes(3);
         SBR_LAUNCH(ge);
@@ -1370,8 +1386,10 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         } else {
             const LayerLayout& lo = y.layer[l - 1];
             const float* xin = h->A(lo.a_hs) + (size_t)y.Bp * lo.Hp;     // input at step t = h^{l-1}_t = slot t+1
+            layer_gemm_hint(h, false, true);                     // dW_in = h^{l-1 T} . dxt
             SBR_LAUNCH(launch_gemm(s, xin, 1, lo.Hp, a.dxt, GHp, 1, h->Gd(ly.p_Win), GHp, lo.Hp, GHp, TB, nullptr, ws,
                                    y.ws_floats, sg));
+            layer_gemm_hint(h, true, false);                     // dh^{l-1} = dxt . W_in^T
             SBR_LAUNCH(launch_gemm(s, a.dxt, GHp, 1, h->P(ly.p_Win), 1, GHp, h->A(lo.a_dhext), lo.Hp, TB, lo.Hp, GHp, nullptr,
                                    nullptr, 0, sg));
         }

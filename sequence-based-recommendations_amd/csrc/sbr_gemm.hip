@@ -207,6 +207,13 @@ static bool g_gemm_exact_f32 = false;
 void sbr_gemm_set_exact_f32(bool on) { g_gemm_exact_f32 = on; }
 static int g_gemm_planes = 3;
 void sbr_gemm_set_planes(int planes) { g_gemm_planes = planes == 1 ? 1 : 3; }
+// Hint for the NEXT launch_gemm call only (consumed and cleared by it; a handle is not thread-safe): the operand planes of the
+// tiled kernel -- 2: the two-plane fp16 split (three MFMAs per product instead of bf16x6's six) for operands the caller knows to be
+// bounded: hidden states behind tanh / sigmoid gates, weights, gradients that have passed the clip at +-100, with sa / sb the
+// power-of-two scales that bring A / B into fp16's range (gemm_x6_kernel NP = 2); 1: plain bf16 operands, split-K allowed (the
+// layer GEMMs under SBR_FLAG_BF16_LAYERS).  0: none (bf16x6).
+static int g_hint_planes = 0; static float g_hint_sa = 1.0f, g_hint_sb = 1.0f;
+void sbr_gemm_hint(int planes, float sa, float sb) { g_hint_planes = planes; g_hint_sa = sa; g_hint_sb = sb; }
 
 // split-K partial products only: writes exactly `nsplit` slabs [z][M][N] at ws (no reduction)
 hipError_t launch_gemm_slabs(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, int M,
@@ -263,6 +270,8 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
                        long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats, bool simple,
                        int a_blk_Bp, int b_blk_Bp, int* keep_slabs) {
     if (keep_slabs) *keep_slabs = 0;
+    const int hint_planes = g_hint_planes; const float hint_sa = g_hint_sa, hint_sb = g_hint_sb;
+    g_hint_planes = 0; g_hint_sa = g_hint_sb = 1.0f;
     if (M <= 0 || N <= 0) return hipSuccess;
     GemmArgs g{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, a_blk_Bp, b_blk_Bp, K, nullptr, (long)N, (size_t)M * N};
     if (simple) {
@@ -300,7 +309,7 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
         if (small) plan(64, ns, kc);
         hipError_t e = hipSuccess;
         if (launch_gemm_x6(s, A, sam, sak, B, sbk, sbn, ns > 1 ? ws : C, ns > 1 ? (long)N : ldc, M, N, K, bias, ns, kc,
-                           (size_t)M * N, &e, nullptr, 0, 0, small)) {
+                           (size_t)M * N, &e, nullptr, 0, 0, small, hint_planes ? hint_planes : 3, hint_sa, hint_sb)) {
             if (e == hipSuccess && ns > 1) {
                 if (keep_slabs && !bias) *keep_slabs = ns;                // the consumer adds the slabs
                 else e = splitk_reduce(s, ws, ns, M, N, C, ldc, bias);

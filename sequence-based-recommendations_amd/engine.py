@@ -40,6 +40,7 @@ FLAG_F32_MFMA = 16
 FLAG_SPARSE_UPDATE = 32      # row-sparse optimizer steps for every block that exists (default: where a step cannot touch every row)
 FLAG_DENSE_UPDATE = 64       # never: lasagne's dense pass over every parameter
 FLAG_BF16_PROJECTION = 128   # output projection on plain bf16 operands (one MFMA per block) -- training forward of CCE, predict, top-k
+FLAG_BF16_LAYERS = 256       # the dense GEMMs between stacked layers (input projection of layer >= 2 and its backward pair) on plain bf16 operands
 
 
 class SbrConfig(ctypes.Structure):
