@@ -255,7 +255,7 @@ def main():
                     "CPU legs (what the counter passes run as their child)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the one long region behind the timed ones (0: skip)")
     ap.add_argument("--loop-iters", type=int, default=1000, help="iterations of the end-to-end training-loop leg (0: skip)")
-    ap.add_argument("--flags", type=int, default=0, help="SBR_FLAG_* bits for the engine (include/sbr_rnn.h), e.g. 384 = bf16 output "
+    ap.add_argument("--flags", type=int, default=int(os.environ.get("SBR_BENCH_FLAGS", "0")), help="SBR_FLAG_* bits for the engine (include/sbr_rnn.h), e.g. 384 = bf16 output "
                     "projection + bf16 layer GEMMs (BASELINE configs[4]); the line's dtype then says so")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch rows PER GPU (the global batch grows with N; the default and the driver's curve); strong: --batch "
