@@ -160,11 +160,12 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_scur = take((size_t)lay.tail_keys * cfg.input_size + 1);
     lay.a_sP = take((size_t)cfg.input_size + 2);
     lay.a_sid = take((size_t)T * Bp * lay.F); lay.a_spos = take((size_t)T * Bp * lay.F);
-    {   // wide index-input rows: the range scatter-add's partial rows (launch_scatter_range)
+    {   // wide index-input rows: the partial rows of the long segments' pieces (launch_scatter_wide)
         const int ghp0 = G * lay.layer[0].Hp;
-        const bool wide0 = !lay.E && ghp0 >= 512 && ghp0 <= 4096;
-        lay.a_srpart = wide0 ? take((size_t)SBR_SCAT_RANGES * 2 * ghp0) : 0;
-        lay.a_srid = wide0 ? take((size_t)SBR_SCAT_RANGES * 2) : 0;
+        const bool wide0 = !lay.E && ghp0 >= 512 && ghp0 <= 8192;
+        lay.sr_slots = wide0 ? (int)((size_t)T * Bp * lay.F / 64 + 2) : 0;
+        lay.a_srpart = wide0 ? take((size_t)lay.sr_slots * ghp0) : 0;
+        lay.a_srid = wide0 ? take((size_t)lay.sr_slots * 4 + 8) : 0;
     }
     lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, (a gap), the chain's clock words
     lay.a_done = take((size_t)SBR_DONE_COPIES * SBR_DONE_STRIDE);      // the monitor's word, replicated (sbr_common.h SbrPoll)
@@ -1387,9 +1388,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 if (sm == s) SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));      // (the sort ran on the side stream)
                 hipError_t se = hipSuccess;
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
-                if (range_on && y.a_srpart && launch_scatter_range(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
-                                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, GHp, h->A(y.a_srpart),
-                                                                   (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) {
+                if (range_on && y.a_srpart && launch_scatter_wide(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                                                  (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp,
+                                                                  h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) {
                     SBR_LAUNCH(se);
                 } else
                 SBR_LAUNCH(launch_scatter_reduce(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),

@@ -113,7 +113,7 @@ struct Layout {
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
     size_t a_sP;                          // [input_size + 1] running cost of the ids (launch_scatter_lds_poll)
-    size_t a_srpart, a_srid;              // range scatter-add of wide rows: partial rows [SBR_SCAT_RANGES][2][G*Hp], their ids (0: not used)
+    size_t a_srpart, a_srid; int sr_slots;   // scatter-add of wide rows: partial rows of the long segments' pieces, counters + records (0: not used)
     int tail_keys;                        // time chunks the sort's key space was sized for (1: no tail overlap possible)
     size_t a_prog;                        // [Bp / 4 * 8] progress words of the running BPTT chain (tail overlap)
     size_t a_done;                        // [SBR_DONE_COPIES * SBR_DONE_STRIDE] the monitor's word (the minimum over a_prog), replicated
@@ -285,10 +285,9 @@ hipError_t launch_split_cols(hipStream_t s, const float* src, float* a, float* b
 // (out_b == NULL: W arbitrary, only the sum d is written to out_f -- the embedding case)
 hipError_t launch_uncat(hipStream_t s, const float* f, const float* r, const int* len, float* out_f, float* out_b, int T, int Bp,
                         int W, int Hp);
-// wide rows (G*Hp >= 512): range scatter-add, two passes, no atomics (sbr_misc.hip); false: not served
-bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
-                          int GHp, float* part, int* part_id, int n_ranges, hipError_t* err);
-#define SBR_SCAT_RANGES 512
+// wide rows (G*Hp >= 512): segment-parallel scatter-add, no atomics on rows (sbr_misc.hip); false: not served
+bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
+                         int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err);
 // key_lo / accumulate: the entries of the keys [key_lo, key_lo + n_ids) of a time-chunked sort, ADDED to dWin
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo = 0, bool accumulate = false, int acc_chunk = 32);

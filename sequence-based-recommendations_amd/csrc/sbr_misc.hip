@@ -821,108 +821,155 @@ bool launch_scatter_lds_poll(hipStream_t s, float* dWin, const float* dxt, const
 }
 
 // ---------------------------------------------------------------------------------------
-// Wide rows (G*Hp >= 512 floats: the cluster layers, C3 / C4 / C5): "range" scatter-add, two passes, no atomics, fixed order.
+// Wide rows (G*Hp >= 512 floats: the cluster layers, C3 / C4 / C5): segment-parallel scatter-add, no atomics on rows, fixed order.
 // The wave-per-32-entries kernel above adds every segment that is not wholly inside a chunk with float atomics; with Zipf ids
 // the hot rows' segments span hundreds of chunks and their adds serialise at the memory side (C4: 199 us for 210 MB of rows,
-// 1 TB/s; C5 571 us).  Here a workgroup owns a contiguous RANGE of the sorted entries, a thread owns one 16-byte piece of
-// the row (a 1024-float row = one piece per thread: every row load is one fully coalesced 4 KB access, SCATR_FLY rows in
-// flight), the range is walked once with the running sum in registers.  Segments inside the range are stored straight to
-// dW_in; the range's FIRST and LAST segment -- the only ones another range can share -- go to a partial-row slab
-// [range][2][row] with their ids beside them, and the merge pass (one workgroup per partial slot; the leader of a run of
-// equal ids sums the run in slot order) writes those rows.  Every row has exactly one writer and a fixed summation order:
-// the gradient is bit-reproducible.  (sparse_lstm.py:368: the AdvancedIncSubtensor the reference's backward builds.)
+// 1 TB/s; C5 571 us) -- while most segments of a large catalogue are ONE entry, i.e. a row copy.  Three launches:
+//   heads   one wave per sorted entry; a wave whose entry is not the first of its id leaves at once.  The head of a segment of
+//           <= SCATW_SHORT entries sums its rows (SCATW_FLY in flight, 16 bytes per lane and piece) and stores dW_in[id]; the head
+//           of a longer segment claims ceil(len / SCATW_SHORT) slots of the partial-row slab (one atomic on a counter) and files
+//           (id, first entry, length, first slot) in the list of long segments
+//   pieces  one workgroup per slab slot: the SCATW_SHORT entries of that piece -> the slot's partial row
+//   merge   one workgroup per long segment: its slots summed in order -> dW_in[id]
+// Every row has one writer and a fixed summation order (the slot numbers depend on which head reached the counter first, the sums
+// do not): the gradient is bit-reproducible.  At most entries / SCATW_SHORT slots and long segments exist.
+// (sparse_lstm.py:368: the AdvancedIncSubtensor the reference's backward builds.)
 // ---------------------------------------------------------------------------------------
-#define SCATR_FLY 8
+#define SCATW_SHORT 64
+#define SCATW_FLY 4
+struct ScatLong { int id, first, len, slot; };
 template <int NV>
-__global__ void __launch_bounds__(256) scat_range_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
-                                                         const int* __restrict__ spos, const int* __restrict__ total_p,
-                                                         float* __restrict__ dWin, int R4, f32x4* __restrict__ part,
-                                                         int* __restrict__ part_id) {
-    const int total = *total_p, nr = gridDim.x, w = blockIdx.x, tid = threadIdx.x;
-    const int E = (total + nr - 1) / nr;
-    const int lo = min(total, w * E), hi = min(total, lo + E);
-    if (lo >= hi) { if (tid < 2) part_id[2 * w + tid] = -1; return; }
+__global__ void __launch_bounds__(256) scat_heads_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
+                                                         const int* __restrict__ spos, const int* __restrict__ offs, int n_ids,
+                                                         float* __restrict__ dWin, int R4, int* __restrict__ counters,
+                                                         ScatLong* __restrict__ longs) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), total = offs[n_ids];
+    if (e >= total) return;
+    const int id = sid[e];
+    if (e > 0 && sid[e - 1] == id) return;               // not the head of its segment
+    const int len = offs[id + 1] - offs[id];
+    if (len > SCATW_SHORT) {
+        if (lane == 0) {
+            const int np = (len + SCATW_SHORT - 1) / SCATW_SHORT;
+            const int slot = atomicAdd(counters, np), k = atomicAdd(counters + 1, 1);
+            longs[k] = ScatLong{id, e, len, slot};
+        }
+        return;
+    }
     f32x4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
-    const int first_id = sid[lo], last_id = sid[hi - 1];
-    int cur = first_id;
-    bool in_first = true;
-    auto flush = [&](int id, bool last) {              // uniform arguments
-        f32x4* dst = (in_first || last) ? part + ((size_t)(2 * w + (in_first ? 0 : 1)) * R4)
-                                        : (f32x4*)dWin + (size_t)id * R4;
+    for (int i = 0; i < len; i += SCATW_FLY) {
+        f32x4 val[SCATW_FLY][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int f4 = tid + 256 * v;
-            if (f4 < R4) dst[f4] = acc[v];
-            acc[v] = f32x4{0, 0, 0, 0};
-        }
-        in_first = false;
-    };
-    for (int i = lo; i < hi; i += SCATR_FLY) {
-        f32x4 val[SCATR_FLY][NV];
-        int ids[SCATR_FLY];
+        for (int u = 0; u < SCATW_FLY; ++u) {
+            if (i + u < len) {                           // uniform (most segments of a large catalogue are one entry: a row copy)
+                const size_t pos = (size_t)spos[e + i + u];
 #pragma unroll
-        for (int u = 0; u < SCATR_FLY; ++u) {
-            const int e = min(i + u, hi - 1);
-            ids[u] = sid[e];
-            const size_t pos = (size_t)spos[e];
+                for (int v = 0; v < NV; ++v) {
+                    const int f4 = lane + 64 * v;
+                    val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
+                }
+            } else {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int f4 = tid + 256 * v;
-                val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
+                for (int v = 0; v < NV; ++v) val[u][v] = f32x4{0, 0, 0, 0};
             }
         }
 #pragma unroll
-        for (int u = 0; u < SCATR_FLY; ++u) {
-            if (i + u < hi) {                            // uniform
-                const int id = __builtin_amdgcn_readfirstlane(ids[u]);
-                if (id != cur) { flush(cur, false); cur = id; }
+        for (int u = 0; u < SCATW_FLY; ++u)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const int f4 = lane + 64 * v; if (f4 < R4) ((f32x4*)dWin)[(size_t)id * R4 + f4] = acc[v]; }
+}
+
+// one workgroup per slab slot: blockIdx.x = slot; the segment that owns it is found by a scan of the (short) list
+template <int NV>
+__global__ void __launch_bounds__(256) scat_pieces_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ spos,
+                                                          const int* __restrict__ counters, const ScatLong* __restrict__ longs,
+                                                          f32x4* __restrict__ part, int R4) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    if (slot >= counters[0]) return;
+    const int nl = counters[1];
+    __shared__ int s_seg;
+    if (tid == 0) s_seg = -1;
+    __syncthreads();
+    for (int k = tid; k < nl; k += 256) {
+        const ScatLong L = longs[k];
+        if (slot >= L.slot && slot < L.slot + (L.len + SCATW_SHORT - 1) / SCATW_SHORT) s_seg = k;
+    }
+    __syncthreads();
+    if (s_seg < 0) return;
+    const ScatLong L = longs[s_seg];
+    const int lo = L.first + (slot - L.slot) * SCATW_SHORT, hi = min(L.first + L.len, lo + SCATW_SHORT);
+    f32x4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
+    for (int i = lo; i < hi; i += 8) {
+        f32x4 val[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t pos = (size_t)spos[min(i + u, hi - 1)];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0}; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i + u < hi) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
             }
-        }
     }
-    const bool single = in_first;                        // the whole range is one segment: it went (goes) to slot 0
-    flush(cur, true);
-    if (tid == 0) { part_id[2 * w] = first_id; part_id[2 * w + 1] = single ? -1 : last_id; }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) part[(size_t)slot * R4 + f4] = acc[v]; }
 }
 
 template <int NV>
-__global__ void __launch_bounds__(256) scat_range_merge_kernel(const f32x4* __restrict__ part, const int* __restrict__ part_id,
-                                                               int n_slots, float* __restrict__ dWin, int R4) {
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const int id = part_id[p];
-    if (id < 0) return;
-    // previous slot that holds a row: the last segment of the range in front, or (that range being one segment) its first
-    int prev = -2;
-    if (p & 1) prev = part_id[p - 1];
-    else if (p >= 2) prev = part_id[p - 1] >= 0 ? part_id[p - 1] : part_id[p - 2];
-    if (prev == id) return;                              // not the leader of its run
+__global__ void __launch_bounds__(256) scat_long_merge_kernel(const f32x4* __restrict__ part, const int* __restrict__ counters,
+                                                              const ScatLong* __restrict__ longs, float* __restrict__ dWin, int R4) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (k >= counters[1]) return;
+    const ScatLong L = longs[k];
+    const int np = (L.len + SCATW_SHORT - 1) / SCATW_SHORT;
     f32x4 acc[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; acc[v] = f4 < R4 ? part[(size_t)p * R4 + f4] : f32x4{0, 0, 0, 0}; }
-    for (int q = p + 1; q < n_slots; ++q) {
-        const int iq = part_id[q];
-        if (iq < 0) continue;
-        if (iq != id) break;
+    for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
+    for (int p0 = 0; p0 < np; p0 += 8) {
+        f32x4 val[8][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) acc[v] += part[(size_t)q * R4 + f4]; }
+        for (int u = 0; u < 8; ++u) {
+            const size_t sl = (size_t)(L.slot + min(p0 + u, np - 1));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; val[u][v] = f4 < R4 ? part[sl * R4 + f4] : f32x4{0, 0, 0, 0}; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + u < np) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
+            }
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) ((f32x4*)dWin)[(size_t)id * R4 + f4] = acc[v]; }
+    for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) ((f32x4*)dWin)[(size_t)L.id * R4 + f4] = acc[v]; }
 }
 
-// part: n_ranges * 2 * GHp floats, part_id: n_ranges * 2 ints; false: shape not served (the caller takes launch_scatter_reduce)
-bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
-                          int GHp, float* part, int* part_id, int n_ranges, hipError_t* err) {
-    const int R4 = GHp / 4, nv = (R4 + 255) / 256;
-    if ((GHp & 3) || GHp < 512 || nv > 4 || !part || !part_id || n_ranges < 1) return false;
-    const int* total_p = offs + n_ids;
-#define SRG(NV) do { scat_range_kernel<NV><<<n_ranges, 256, 0, s>>>((const f32x4*)dxt, sid, spos, total_p, dWin, R4, (f32x4*)part, part_id); \
-                     scat_range_merge_kernel<NV><<<2 * n_ranges, 256, 0, s>>>((const f32x4*)part, part_id, 2 * n_ranges, dWin, R4); } while (0)
-    if (nv <= 1) SRG(1); else if (nv <= 2) SRG(2); else SRG(4);
-#undef SRG
+// part: n_slots * GHp floats (n_slots >= max_entries / SCATW_SHORT + 1); aux: 2 counters + n_slots ScatLong records (ints);
+// false: shape not served (the caller takes launch_scatter_reduce)
+bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
+                         int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err) {
+    const int R4 = GHp / 4, nvw = (R4 + 63) / 64, nvb = (R4 + 255) / 256;
+    if ((GHp & 3) || GHp < 512 || nvw > 8 || !part || !aux || n_slots < max_entries / SCATW_SHORT + 1) return false;
+    if (hipMemsetAsync(aux, 0, 2 * sizeof(int), s) != hipSuccess) { *err = hipGetLastError(); return true; }
+    int* counters = aux; ScatLong* longs = (ScatLong*)(aux + 4);
+    const int gh = (max_entries + 3) / 4;
+#define SW(NVW, NVB) do { \
+        scat_heads_kernel<NVW><<<gh, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, counters, longs); \
+        scat_pieces_kernel<NVB><<<n_slots, 256, 0, s>>>((const f32x4*)dxt, spos, counters, longs, (f32x4*)part, R4); \
+        scat_long_merge_kernel<NVB><<<n_slots, 256, 0, s>>>((const f32x4*)part, counters, longs, dWin, R4); } while (0)
+    if (nvw <= 2) SW(2, 1); else if (nvw <= 4) SW(4, 1); else SW(8, 2);
+#undef SW
     *err = hipGetLastError();
     return true;
 }
