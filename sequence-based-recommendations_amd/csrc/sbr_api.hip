@@ -1319,11 +1319,27 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             h->side_pending = false;
             continue;
         }
+        bool scat_early = false;      // wide rows, tail not swapped: the scatter-add ran on the side stream in FRONT of the weight-gradient GEMM
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
                 SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, false));
                 SBR_HIP(hipStreamWaitEvent(sd, record_shared(h, h->ev_chunk[c], (l == 0 && c == nc - 1) ? 4 : -1), 0));
+                // The scatter-add is the head of the step's critical tail (scatter -> W_in's optimizer pass) and the side stream has
+                // the higher priority: launched on the main stream beside the GEMM it got CUs only as the GEMM's workgroups retired
+                // (C4: 180 us for 50 us of work, profiles/round4_k_c4_timeline.txt).  So it goes first, on the side stream; the main
+                // stream waits for its event, the GEMM follows it.
+                static const int scat_first = [] { const char* e = getenv("SBR_SCAT_FIRST"); return e ? atoi(e) : 1; }();
+                if (scat_first && l == 0 && nc == 1 && sw == sd && sm == s && !y.E && y.a_srpart && !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
+                    hipError_t se = hipSuccess;
+                    if (launch_scatter_wide(sd, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                                            (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp,
+                                            h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) {
+                        SBR_LAUNCH(se);
+                        SBR_HIP(hipEventRecord(h->ev_tail, sd));
+                        scat_early = true;
+                    }
+                }
                 // dW_hid [Hp][G*Hp] += hs[t]^T . dhi[t] over the chunk's positions (hs slot t = h_{t-1})
                 const float* hsc = h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp;
                 const int Kc = (a.t_hi - a.t_lo) * y.Bp;
@@ -1385,6 +1401,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
                 SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, h->bX, a.len, y.T, y.Bp, y.F, GHp));
             } else {
+                if (scat_early) { SBR_HIP(hipStreamWaitEvent(s, h->ev_tail, 0)); mark_on(h, 6, sm); continue; }
                 if (sm == s) SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));      // (the sort ran on the side stream)
                 hipError_t se = hipSuccess;
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
