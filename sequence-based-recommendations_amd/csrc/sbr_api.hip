@@ -1087,7 +1087,9 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // queue, and two of them then share one -- profiles/round3_A_variants.txt.)  No split-K workspace for dW_out there: the
         // polling GEMM owns ws2 meanwhile.
         h->out3 = h->in_train_step && h->tail_nc >= 2 && h->tail_overlap == 1 && h->tail_out_stream;
-        hipStream_t so = h->out3 ? h->side2 : sd;
+        // SBR_TAIL_OUT_STREAM=2: ... or the monitor's stream, which is idle while the scatter-add launch carries the monitor
+        h->out3_stream = (h->tail_out_stream == 2 && h->tail_mon_units && h->tail_cost_scanned) ? h->side3 : h->side2;
+        hipStream_t so = h->out3 ? h->out3_stream : sd;
         if (h->out3) SBR_HIP(hipStreamWaitEvent(so, h->ev_lg_rec, 0));
         SBR_LAUNCH(launch_sum_cost(so, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
@@ -1252,8 +1254,8 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
             const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss));
             if (out_early) {
-                SBR_LAUNCH(upd_on(h->out3 ? h->side2 : sd, y.p_split, y.n_params));
-                if (h->out3) SBR_HIP(hipEventRecord(h->ev_tail3, h->side2));
+                SBR_LAUNCH(upd_on(h->out3 ? h->out3_stream : sd, y.p_split, y.n_params));
+                if (h->out3) SBR_HIP(hipEventRecord(h->ev_tail3, h->out3_stream));
             }
             // the monitor: on a stream of its own behind nothing but the chain's first progress words (its own loop waits for them)
             // ... unless the scatter-add launch carries it (default where that launch is the LDS-row one and has its own stream)

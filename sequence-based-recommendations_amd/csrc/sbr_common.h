@@ -182,6 +182,7 @@ struct sbr_handle {
     int tail_early_sort;    // SBR_TAIL_EARLY_SORT: the time-chunked sort beside the forward chain
     int tail_out_stream;    // SBR_TAIL_OUT_STREAM: output-layer gradients + update on a third side stream (single-call steps)
     bool tail_sorted, out3; // this step: the sort already ran (sbr_forward) / the output layer's work is on side3
+    hipStream_t out3_stream;   // this step: the stream of the output layer's gradient kernels when they left the side stream (out3)
     hipStream_t side3; hipEvent_t ev_tail3;      // side3: the overlapped tail's monitor (tail_monitor_kernel)
     int tail_short_chunks;  // time chunks (from t = 0) whose scatter-add entries are cut into short pieces (SBR_TAIL_SHORT_CHUNKS)
     double tail_geom;       // SBR_TAIL_GEOM: growth of the small time chunks near t = 0 (<= 1: equal chunks)

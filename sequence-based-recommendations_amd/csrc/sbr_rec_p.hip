@@ -38,25 +38,14 @@
 // the backward (+15 us), a delay at the gate or a signal more than one MFMA term early (+5 .. +35 us; one term early is what runs, -4 us), splitting the backward over K instead
 // of over the output units (every gate-math step would then need all eight waves' partial sums: no overlap left).
 // The backward's 36 operand reads per wave and step (K = 384; the forward has 12) are not what holds it back: with half
-// of them skipped (X6P_DBG 64) rec_bwd takes 256 instead of 263 us, with three quarters skipped (128) 250 us.
+// of them skipped (a probe build, round 1) rec_bwd takes 256 instead of 263 us, with three quarters skipped 250 us.
 #include "sbr_rec_p.h"
 
-#ifndef X6P_DBG
-#define X6P_DBG 0        // timing experiments only (tools/probes/x6p_variants.sh): wrong results by design
-#endif
 #ifndef X6P_BWD_NS
 #define X6P_BWD_NS 4     // backward: operand slots / k-blocks fetched ahead of their MFMAs
 #endif
 #ifndef X6P_BWD_LA
 #define X6P_BWD_LA 3     // (round 4: with one sparse instruction per k-block an LDS read one k-block ahead left every iteration waiting for it: 155 -> 136 us)
-#endif
-#ifndef X6P_MFMA_NOP
-#define X6P_MFMA_NOP -1  // >= 0: s_nop N behind every MFMA of the packed forms (experiment: does the partner's gate math get the issue port?)
-#endif
-#if X6P_MFMA_NOP >= 0
-#define X6P_GAP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" :: "n"(X6P_MFMA_NOP)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define X6P_GAP() do { } while (0)
 #endif
 #ifndef X6P_FWD_V2
 #define X6P_FWD_V2 6     // forward, packed form: 1 = the input row (+ bias) rides in as the MFMA C operand, 2 = the stores of step
@@ -214,7 +203,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 float w = sc * a.Whid[(size_t)(kb * 32 + 8 * q + e) * GHP + g * HP + u];
                 if constexpr (F16) {
                     _Float16 b1, b2;
-                    if (!(X6P_DBG & 256)) asm("" : "+v"(w));            // see split2_f16.  NOT volatile: volatile asms keep their order and
+                    asm("" : "+v"(w));                                  // see split2_f16.  NOT volatile: volatile asms keep their order and
                                                                         // serialised the 96 loads of this prologue (+20 us per launch)
                     split2_f16(w, b1, b2);
                     W1[g][kb][e] = b1; W2[g][kb][e] = b2;
@@ -231,11 +220,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     const unsigned bo_x = (unsigned)(row * GHP + u) * 4u;                                      // xt rows (not fused)
     const size_t st_h = (size_t)Bp * HP * 4, st_x = (size_t)Bp * GHP * 4;                      // bytes per time step
 
-    // X6P_DBG 1024 / 2048 / 512: values kept alive across the kernel only to move the operand tuples to other registers
-    // (same instructions, see DESIGN.md: 177 vs 198 us between two register assignments)
-    double dbg_pair = 0.0; float dbg_one = 0.f;
-    if (X6P_DBG & 1024) { dbg_pair = (double)blockIdx.x; asm volatile("" : "+v"(dbg_pair)); }
-    if (X6P_DBG & 2048) { dbg_one = (float)blockIdx.x; asm volatile("" : "+v"(dbg_one)); }
     float h = a.hinit[u];
     stf(a.hs, bo_h, h);
     float c = 0.f, pi = 0.f, pf = 0.f, po = 0.f;                 // LSTM: cell state and the peepholes of this lane's unit
@@ -343,7 +327,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     constexpr bool DEFER = PK && (X6P_FWD_V2 & 2);
     float sv_st[4] = {0.f, 0.f, 0.f, 0.f}, h_st = 0.f, c_st = 0.f;
     auto store_step = [&](size_t off, const float* svv, float hv, float cv) {
-        if (X6P_DBG & 4) return;
         if (CELL != CELL_VANILLA) {
             if constexpr (X6P_G4) st_s4((const char*)a.g[0] + 4 * off, bo_g, f32x4{svv[0], svv[1], svv[2], svv[3]});
             else {
@@ -364,10 +347,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
     // of them between MFMAs, and values defined under it get copies at the join (see sbr_rec_cl.hip).
     auto steps = [&](auto role_tag) {
     constexpr bool RA = decltype(role_tag)::value;
-    // X6P_DBG 4096 / 8192 / 16384: position of the loop in the instruction stream (256-byte boundary, + 32, + 64 bytes)
-    if (X6P_DBG & 4096) asm volatile(".p2align 8");
-    if (X6P_DBG & 8192) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
-    if (X6P_DBG & 16384) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
     int xslot = 0;                                                // FUSE: ring slot of step t = t % XPD
     for (int t = 0; t < tmax; ++t) {
         if (PROF) p_ta = clock64();
@@ -413,7 +392,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             }
         };
         auto ensure_half = [&](int half) {                        // the four producers of this half have published h_t
-            if (!(X6P_DBG & 32) && !X6P_SYNC && __builtin_amdgcn_readfirstlane(fl[half]) < 4 * t) {
+            if (!X6P_SYNC && __builtin_amdgcn_readfirstlane(fl[half]) < 4 * t) {
                 unsigned long long w0 = 0;
                 if (PROF) w0 = clock64();
                 int spins = 0;
@@ -438,7 +417,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         // as soon as its own group's k-blocks were there would starve its partner's last MFMAs, whose results
         // everybody waits for: so it holds back until the partner has issued its whole step.  Waves 4-7 need no gate,
         // they only ever get the gaps.
-        if (RA && a.x6_pipe >= 2 && !(X6P_DBG & 32)) {
+        if (RA && a.x6_pipe >= 2) {
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
             int v = X6P_TOK_EARLY ? tokv : __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
@@ -487,7 +466,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
                 if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                for (int g = 0; g < G; ++g) { acl[g] = mfma16(hp[kb][0], W2[g][kb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acl[g]); X6P_GAP(); }
+                for (int g = 0; g < G; ++g) { acl[g] = mfma16(hp[kb][0], W2[g][kb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acl[g]); }
                 if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
                     __builtin_amdgcn_sched_barrier(0);
                     load_half(1);
@@ -495,7 +474,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 }
                 if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                for (int g = 0; g < G; ++g) { acc[g] = mfma16(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]); X6P_GAP(); }
+                for (int g = 0; g < G; ++g) { acc[g] = mfma16(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
                 if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
@@ -607,7 +586,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             xslot = xslot + 1 == XPD ? 0 : xslot + 1;
             if constexpr (PK && (X6P_FWD_V2 & 4)) bo_nxt = bo_nxt2 + bo_lane;
             else bo_nxt = xo_row[min(t + XPD + 1, T - 1)] + bo_lane;
-        } else if (!(X6P_DBG & 2)) load_x(t + 1);
+        } else load_x(t + 1);
     }
     };
     if (roleA && !X6P_SYNC && X6P_ROLES) steps(std::true_type{}); else steps(std::false_type{});
@@ -617,9 +596,6 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         if (CELL == CELL_LSTM) stf((char*)a.cs + off_t + st_h, bo_h, c);
         off_t += st_h;
     }
-    if ((X6P_DBG & 512) && T < 0) a.fault[1] = (int)threadIdx.x;  // keeps the live-in v0 where it is
-    if (X6P_DBG & 1024) asm volatile("" :: "v"(dbg_pair));
-    if (X6P_DBG & 2048) asm volatile("" :: "v"(dbg_one));
     if (PROF && lane == 0 && blockIdx.x < (unsigned)(a.Bp >> 4)) {
         unsigned long long* o = a.prof + ((size_t)blockIdx.x * 16 + wave) * 8;
         const unsigned long long tot = clock64() - p_c0;
@@ -964,8 +940,6 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         int fl[2];
         auto load_kb = [&](int i) {
             const int kb = korder(i), s = i % NS;
-            if ((X6P_DBG & 64) && (i & 1)) { for (int pp = 0; pp < NP; ++pp) dpl[s][pp] = dpl[s ^ 1][pp]; return; }   // half the LDS reads
-            if ((X6P_DBG & 128) && (i % 4)) { for (int pp = 0; pp < NP; ++pp) dpl[s][pp] = dpl[s ^ 1][pp]; return; }  // a quarter
             dpl[s][0] = *(const OPV*)(db + kb * 64);
             dpl[s][1] = PK ? dpl[s][0] : *(const OPV*)(db + kb * 64 + PLANEB);
             if constexpr (NP == 3) dpl[s][2] = *(const OPV*)(db + kb * 64 + 2 * PLANEB);
@@ -1041,9 +1015,9 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
-                acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]); X6P_GAP();
+                acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]);
                 if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
-                acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]); X6P_GAP();
+                acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
                 if (BDEF && i == 1) {                               // this step's dxt / dhi, from where the issue slots are free
                     __builtin_amdgcn_sched_barrier(0);
                     const char* dx_t = (const char*)a.dxt + offx_st;

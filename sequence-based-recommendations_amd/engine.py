@@ -440,6 +440,10 @@ class RNNEngine(object):
                                             ctypes.c_size_t(self.arena.numel() * 4),
                                             ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
         self.h = handle
+        # data-parallel guard (parallel.DataParallel sets it with more than one rank): calls that bring lazily stepped rows of the
+        # row-sparse blocks up to date must then be made by every rank at the same step, through DataParallel's collectives
+        self.dp_guard = False
+        self._dp_collective = False
         self.n_params = self.lib.sbr_num_params(self.h)
         self.param_descs = describe_params(cfg, self.lib)
         self.param_shapes = []
@@ -523,8 +527,17 @@ class RNNEngine(object):
         self._check(fn(self.h, len(arrays), self._ptr_array(arrays)))
         return arrays
 
+    def _rank_local_flush(self, what):
+        """predict / top-k / export / flush replay the zero-gradient steps lazily stepped rows have missed; WHERE a replay is split
+        changes float32 roundings, so with several data-parallel ranks a rank-local call would fork the replicas."""
+        if self.dp_guard and not self._dp_collective and self.query("sparse_blocks") > 0:
+            raise RuntimeError("%s on one data-parallel rank only would bring lazily stepped rows up to date on this replica alone: "
+                               "call DataParallel.%s on every rank at the same step (sequence-based-recommendations_amd/parallel.py)"
+                               % (what, what))
+
     def get_all_param_values(self):
         """lasagne.layers.get_all_param_values(l_out) (rnn_base.py:476)."""
+        self._rank_local_flush("get_all_param_values")
         return self._get(self.lib.sbr_get_params)
 
     def get_all_grad_values(self):
@@ -640,6 +653,7 @@ class RNNEngine(object):
 
     def predict_function(self, X, mask):
         """scores (rows, N): softmax probabilities for CCE, raw activations for sampled heads."""
+        self._rank_local_flush("predict_function")
         n = self.set_batch(X, mask)
         out = np.empty((n, self.n_items), dtype=np.float32)
         self._check(self.lib.sbr_predict_scores(self.h, 0, ctypes.c_void_p(out.ctypes.data)))
@@ -654,6 +668,7 @@ class RNNEngine(object):
     def test_function(self, theano_inputs, k=10, exclude_seen=True):
         """ids = test_function(theano_inputs, k) (rnn_base.py:205-209): ordered top-k of
         softmax * (1 - exclude), for every row (the reference feeds one row at a time)."""
+        self._rank_local_flush("test_function")
         X, mask = theano_inputs[0], theano_inputs[1]
         n = self.set_batch(X, mask)
         ids = np.empty((n, k), dtype=np.int32)
@@ -673,6 +688,7 @@ class RNNEngine(object):
     # ---------------------------------------------------------------- row-sparse blocks (include/sbr_rnn.h)
     def flush_lazy(self):
         """Every lazily stepped row current through the last applied step (sbr_flush_lazy)."""
+        self._rank_local_flush("flush_lazy")
         self._check(self.lib.sbr_flush_lazy(self.h))
 
     def sparse_blocks(self):
@@ -842,6 +858,12 @@ class ClusterHead(object):
         if self.h:
             self.lib.sbr_cluster_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_params(self, R, Wc):
         R = np.ascontiguousarray(R, dtype=np.float32); Wc = np.ascontiguousarray(Wc, dtype=np.float32)

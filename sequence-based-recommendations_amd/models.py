@@ -645,7 +645,29 @@ class RNNCluster(RNNBase):
         cost = self.engine.train_step(sync=True)
         self.head.forward_backward(target, cluster_samples, read_cost=False)      # on the user representations of that step's forward
         self.head.apply_update()
+        self._drop_hard_clusters()               # the hard clusters / embeddings cached by prepare_tests belong to the old parameters
         return cost
+
+    def _drop_hard_clusters(self):
+        for a in ("clusters", "clusters_reverse_index", "clusters_embeddings", "clusters_bias"):
+            if hasattr(self, a):
+                delattr(self, a)
+
+    def close(self):
+        """device arrays of the cluster head (several N x C float arrays) and of the engine"""
+        if getattr(self, "head", None) is not None:
+            self.head.close()
+            self.head = None
+        sup = getattr(super(RNNCluster, self), "close", None)
+        if sup is not None:
+            sup()
+
+    def __del__(self):
+        try:
+            if getattr(self, "head", None) is not None:
+                self.head.close()
+        except Exception:
+            pass
 
     def _ranked(self, scores, k):
         return np.argpartition(-scores, range(k), axis=-1)[..., :k]

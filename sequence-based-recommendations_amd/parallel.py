@@ -15,8 +15,17 @@ spans every target column, rnn_sampling.py:68-72,137): `gather_targets` all-gath
 
 Row-sparse blocks with the lazy-exact updaters (rmsprop / adadelta / nesterov / adam): a row's missed zero-gradient steps are
 replayed when the row is next read, and WHERE that happens splits the replay (a short loop below 32 steps, closed forms above):
-calls that bring rows up to date on one rank only -- get_params / save, predict / top-k, flush_lazy -- must therefore be made by
-every rank at the same step if the replicas are to stay bit-identical (they stay equal to float32 rounding either way).
+calls that bring rows up to date on one rank only -- get_params / save, predict / top-k, flush_lazy -- would let the replicas
+drift apart by float32 roundings.  So with more than one rank the engine is GUARDED (`engine.dp_guard`): those calls raise when
+made on the engine directly and are offered here as collectives -- `flush_lazy`, `test_function`, `predict_function`,
+`get_all_param_values` -- which every rank must enter at the same step (a barrier in front: a rank that enters alone waits for the
+others instead of silently forking the replicas; tests/test_dp_gloo.py, tests/test_gpu_dp_two_ranks.py::*_midrun_*).
+
+Where the output layer's all-reduce is issued: small buckets (C2: 1.9 MB) right behind its gradient kernels, on the side stream,
+beside the BPTT chain; buckets above `OUT_EARLY_BYTES` (a 26 744 x 256 W_out is 27 MB: ~0.2 ms on a ring over xGMI) would sit in
+that stream's queue IN FRONT of the weight-gradient kernels `backward_recurrent` enqueues there and hold them back for as long, so
+they are issued behind that work instead, back to back with the recurrent bucket.  The placement relies on this torch (2.10)
+enqueueing a SYNC collective on the current stream; no >1-GPU box was available to the builder to measure either placement.
 
 `engine` is anything with the RNNEngine phase methods -- the CPU tests pass an oracle-backed
 stand-in, production passes engine.RNNEngine.
@@ -33,6 +42,8 @@ class DataParallel(object):
         self.grads, self.split = engine.section("grads")
         # stream-level overlap needs the engine's side stream and device tensors (RCCL); the gloo CPU tests use a
         # stand-in engine without either
+        if self.world > 1 and hasattr(engine, "dp_guard"):
+            engine.dp_guard = True                       # rank-local flushes of lazily stepped rows now raise (module docstring)
         self.side = self.side2 = None
         self.tail = None
         if hasattr(engine, "side_stream") and getattr(self.grads, "is_cuda", False):
@@ -44,6 +55,31 @@ class DataParallel(object):
             if hasattr(engine, "side_stream2") and engine.query("tail_streams") == 1:
                 self.side2 = engine.side_stream2()
                 self.tail = engine.tail_ranges()
+
+    OUT_EARLY_BYTES = 8 << 20      # output-layer buckets up to this size are reduced beside the BPTT chain (module docstring)
+
+    # ---- collectives that bring lazily stepped rows up to date: every rank enters them at the same step
+    def _collective(self, name, *a, **kw):
+        e = self.engine
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+        e._dp_collective = True
+        try:
+            return getattr(e, name)(*a, **kw)
+        finally:
+            e._dp_collective = False
+
+    def flush_lazy(self):
+        return self._collective("flush_lazy")
+
+    def test_function(self, *a, **kw):
+        return self._collective("test_function", *a, **kw)
+
+    def predict_function(self, *a, **kw):
+        return self._collective("predict_function", *a, **kw)
+
+    def get_all_param_values(self):
+        return self._collective("get_all_param_values")
 
     @staticmethod
     def shard(batch_size, world, rank):
@@ -86,7 +122,16 @@ class DataParallel(object):
         if not hasattr(self, "_sp_info"):
             self._sp_info, self._sp_all = e.sparse_blocks(), {}
         n_rows, width, cap = self._sp_info[b]
-        if hasattr(e, "sparse_pack_device") and cap * width * 4 <= self.INBAND_BYTES:
+        if not hasattr(self, "_sp_same_cap"):
+            # the in-band form all-gathers fixed-capacity buffers and strides every rank's slice by THIS rank's capacity: shards
+            # that differ by a row can round to different capacities (Bp = local rows rounded up to 16), so the ranks agree once,
+            # here, whether all of them hold the same capacity for every block; if not, the counted form serves the block
+            caps = torch.tensor([c for _, _, c in self._sp_info], dtype=torch.int64, device=self.grads.device)
+            lo, hi = caps.clone(), caps.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            self._sp_same_cap = [bool(x) for x in (lo == hi).tolist()]
+        if hasattr(e, "sparse_pack_device") and self._sp_same_cap[b] and cap * width * 4 <= self.INBAND_BYTES:
             ids, rows = e.sparse_pack_device(b)          # ids[0] = the count; enqueued, not waited for
             if b not in self._sp_all:                     # persistent gather targets: [world][1 + cap], [world][cap][width]
                 self._sp_all[b] = (torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device),
@@ -153,12 +198,14 @@ class DataParallel(object):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); fn(); e1.record()
                 exposed.setdefault("_ev", []).append((name, e0, e1))
+        out_early = sum(t.numel() for t in vw["out"]) * 4 <= self.OUT_EARLY_BYTES
         e.zero_grads()
         e.forward()
         e.loss_backward_output()
-        with on_side():                                  # output layer: final now; runs beside the BPTT chain on the side stream
-            for t in vw["out"]:
-                red(t)
+        if out_early:
+            with on_side():                              # output layer: final now; runs beside the BPTT chain on the side stream
+                for t in vw["out"]:
+                    red(t)
         e.backward_recurrent()
         if self.side is not None:
             cur = torch.cuda.current_stream()
@@ -171,7 +218,7 @@ class DataParallel(object):
                 self.side.wait_stream(self.side2)
                 self.side.wait_stream(cur)
             with on_side():
-                for t in vw["rec"]:
+                for t in ([] if out_early else vw["out"]) + vw["rec"]:
                     red(t)
             wait("rec", lambda: cur.wait_stream(self.side))
             # row-sparse blocks: packed and unpacked by the engine on ITS stream, so their all-gathers run there too (behind the
@@ -179,7 +226,7 @@ class DataParallel(object):
             for b in range(self._nsparse):
                 wait("sparse", lambda b=b: self._exchange_sparse(b))
         else:
-            for t in vw["rec"]:
+            for t in ([] if out_early else vw["out"]) + vw["rec"]:
                 red(t)
             for b in range(self._nsparse):
                 self._exchange_sparse(b)

@@ -181,3 +181,88 @@ def test_shard_covers_the_batch():
         spans = [DataParallel.shard(B, W, r) for r in range(W)]
         assert spans[0][0] == 0 and spans[-1][1] == B
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+
+def _worker_caps(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbr_amd.parallel import DataParallel
+    B, T, N, S = 7, 5, 17, 4                      # 7 rows over 2 ranks: shards of 4 and 3
+    params, cfg, batch = PU.build_case("GRU", [6], "BPR", N, B, T, S=S, seed=12)
+    lo, hi = DataParallel.shard(B, world, rank)
+    # capacities as the engine derives them from the local shard (rows rounded up): they differ between the ranks
+    eng = InbandSparseOracleEngine([p.copy() for p in params], cfg, "adam", B, lo, cap=N + 3 * rank)
+    dp = DataParallel(eng, dist)
+    ob = PU.oracle_batch(batch)
+    tgt = ob["target"]                              # (unequal shards: the test hands every rank all targets)
+    for _ in range(2):
+        eng.set_batch(dict(X=ob["X"][lo:hi], mask=ob["mask"][lo:hi], target=tgt, samples=ob["samples"], pop=ob["pop"][lo:hi]))
+        dp.train_step()
+    assert dp._sp_same_cap == [False, False] and not getattr(dp, "_sp_all", {})     # both blocks took the counted form
+    np.savez(out % rank, **{"p%d" % i: p for i, p in enumerate(eng.params)})
+    dist.destroy_process_group()
+
+
+def test_unequal_shard_capacities_take_the_counted_exchange(tmp_path):
+    """the in-band sparse exchange all-gathers fixed-capacity buffers and strides every rank's slice by the LOCAL
+    capacity; shards that differ by a row can have different capacities.  The ranks agree once on whether their capacities match;
+    if not, the counted form (which gathers max(counts) rows) serves the block -- no mismatched all_gather, same result."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "cap%d.npz")
+    mp.spawn(_worker_caps, args=(2, port, out), nprocs=2, join=True)
+    B, T, N, S = 7, 5, 17, 4
+    params, cfg, batch = PU.build_case("GRU", [6], "BPR", N, B, T, S=S, seed=12)
+    upd = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+    for _ in range(2):
+        O.train_function(params, cfg, upd, PU.oracle_batch(batch))
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for i, p in enumerate(params):
+        assert np.allclose(r0["p%d" % i], p, rtol=1e-10, atol=1e-14)
+        assert np.array_equal(r0["p%d" % i], r1["p%d" % i])
+
+
+class _GuardedStub(object):
+    """the engine side of the data-parallel guard, without a GPU: RNNEngine's own method, a stand-in for the rest"""
+    from sbr_amd.engine import RNNEngine as _E
+    _rank_local_flush = _E._rank_local_flush
+
+    def __init__(self):
+        self.dp_guard, self._dp_collective, self.calls = False, False, []
+
+    def query(self, what):
+        return 2
+
+    def section(self, name):
+        return torch.zeros(4, dtype=torch.float64), 2
+
+    def test_function(self, x, k=3):
+        self._rank_local_flush("test_function")
+        self.calls.append(("test_function", k))
+        return k
+
+    def flush_lazy(self):
+        self._rank_local_flush("flush_lazy")
+        self.calls.append(("flush_lazy",))
+
+
+def _worker_guard(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbr_amd.parallel import DataParallel
+    eng = _GuardedStub()
+    dp = DataParallel(eng, dist)
+    assert eng.dp_guard
+    with pytest.raises(RuntimeError, match="DataParallel.test_function"):
+        eng.test_function(None)                      # rank-local: refused
+    assert dp.test_function(None, k=7) == 7           # the collective: both ranks enter it
+    dp.flush_lazy()
+    assert eng.calls == [("test_function", 7), ("flush_lazy",)] and not eng._dp_collective
+    dist.destroy_process_group()
+
+
+def test_rank_local_flush_is_refused_and_the_collective_form_works():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_guard, args=(2, port), nprocs=2, join=True)

@@ -87,6 +87,15 @@ def test_gpus_2_starts_its_own_ranks():
     assert d["roofline"]["kernel"] in ("rec_bwd", "rec_fwd") and d["roofline"]["launch_us"] > 0
 
 
+def test_strong_scaling_splits_the_global_batch_and_says_so():
+    # the reference's -b is the GLOBAL batch (the cost is a mean over it, rnn_one_hot.py:71).  --scaling strong keeps
+    # --batch as that global batch and gives every rank batch / N rows; the line is labelled accordingly
+    d = run("--gpus", "2", "--dp-backend", "gloo", "--scaling", "strong", "--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0")
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    assert d["config"]["global_batch"] == 256 and "128 rows per GPU" in d["config"]["workload"]
+    assert d["value"] == pytest.approx(256 / (d["ms_per_step"] * 1e-3), rel=2e-3)
+
+
 def test_one_rank_through_the_data_parallel_step():
     # --force-dp: the phase-by-phase step with its collectives (RCCL, one rank) instead of the single-call step
     d = run("--force-dp", "--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0")
@@ -95,7 +104,10 @@ def test_one_rank_through_the_data_parallel_step():
     assert p["ranks"] == 1 and p["backend"] == "nccl"
     # sync collectives on the engine's side stream: the step is not doubled by the process group's own stream (0.86 - 0.94 ms
     # with the async form, profiles/round3_Q_dp_probe.txt, round3_U_dp_sync_probe2.txt)
-    assert d["ms_per_step"] < 0.65
+    # ... asserted as a RATIO to the single-call step measured in this same run on this same box (an absolute bound depends on the
+    # box and its clocks): phase calls + two collectives of one rank cost the step well under half of itself
+    single = run("--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0", "--no-pmc", "--loop-iters", "0", "--no-other-configs")
+    assert d["ms_per_step"] < 1.5 * single["ms_per_step"], (d["ms_per_step"], single["ms_per_step"])
 
 
 def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_line():
@@ -113,3 +125,15 @@ def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_l
     assert "train_loop" in d, d.get("train_loop_error")
     tl = d["train_loop"]
     assert tl["iterations"] == 1000 and tl["ms_per_iteration"] < 2 * d["ms_per_step"] and tl["value"] > 2e5
+    # round 4: the chain kernels alone (event pairs around their launches), the matrix pipe's busy cycles from the SQ counters, and
+    # the other BASELINE configurations as child runs
+    ch = d["chains"]
+    assert ch["rec_fwd_us"] > 0 and ch["rec_bwd_us"] > 0 and 0 < ch["outside_chains_us"] < d["ms_per_step"] * 1e3
+    mk = d["mfma_counters"]["kernels"]
+    assert any("rec_bwd" in k for k in mk) and any("gemm_x6_kernel" in k for k in mk)
+    assert all(0 < v["mfma_util_of_chip"] < 1 for v in mk.values())
+    oc = d["other_configs"]
+    assert set(oc) == {"c1", "c3", "c4", "c5"}
+    for name, v in oc.items():
+        assert "skipped" in v or (v["ms_per_step"] > 0 and 0 < v["roofline"]["frac"] < 1 and v["outside_chains_us"] > 0), (name, v)
+    assert "skipped" not in oc["c1"] and "skipped" not in oc["c4"]

@@ -95,3 +95,57 @@ def test_two_ranks_on_one_gpu_equal_the_single_engine_step(tmp_path, name):
     for i, p in enumerate(ref):
         assert np.array_equal(r0["p%d" % i], r1["p%d" % i]), i          # replicas stay bit-identical
         assert PU.rel_err(r0["p%d" % i], p) <= 2e-5, (i, PU.rel_err(r0["p%d" % i], p))
+
+
+
+def _worker_midrun(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbr_amd.parallel import DataParallel
+    cell, layers, loss, N, B, T, S, updater = "GRU", [128], "CCE", 300, 64, 40, 0, "adam"
+    params, cfg, _ = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=31, scale=0.05)
+    lo, hi = DataParallel.shard(B, world, rank)
+    eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater, local_batch=hi - lo, row_offset=lo, flags=SPARSE_FLAG)
+    try:
+        eng.set_all_param_values(params)
+        dp = DataParallel(eng, dist)
+        assert eng.dp_guard
+        # six steps on batches that touch different rows (so rows go untouched for several steps: lazy Adam replays), a ranking
+        # in the middle: through the collective on both ranks
+        raised = False
+        for step in range(6):
+            _, _, batch = PU.build_case(cell, layers, loss, N, B, T, S=S, seed=100 + step, scale=0.05)
+            eng.set_batch(batch["X"][lo:hi], batch["mask"][lo:hi], batch["target"][lo:hi], None, batch["pop"][lo:hi])
+            dp.train_step()
+            if step == 2:
+                if rank == 0:
+                    try:
+                        eng.test_function((batch["X"][lo:hi], batch["mask"][lo:hi]), k=5)      # alone: refused
+                    except RuntimeError:
+                        raised = True
+                ids = dp.test_function((batch["X"][lo:hi], batch["mask"][lo:hi]), k=5)          # together
+                assert ids.shape == (hi - lo, 5)
+        assert raised or rank != 0
+        np.savez(out % rank, **{"p%d" % i: p for i, p in enumerate(dp.get_all_param_values())})
+    finally:
+        eng.close()
+        dist.destroy_process_group()
+
+
+def test_midrun_ranking_through_the_collective_keeps_lazily_stepped_replicas_bit_identical(tmp_path):
+    """Row-sparse Adam (lazy-exact): a top-k in the middle of a run replays the missed zero-gradient steps of every row.  Made on
+    one rank only it would split that rank's replays differently from the others' (float32 roundings: the replicas fork); the
+    guarded engine refuses the rank-local call, DataParallel.test_function makes it on both ranks, and after three more steps the
+    replicas are bit-identical."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "mid%d.npz")
+    mp.spawn(_worker_midrun, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert len(r0.files) > 3
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
