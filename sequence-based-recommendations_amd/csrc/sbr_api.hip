@@ -410,7 +410,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
-    h->out_early = false; h->dh_slabs_n = 0;
+    h->out_early = false; h->win_early = false; h->dh_slabs_n = 0;
     h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
@@ -1173,6 +1173,21 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // BPTT in time chunks when the bf16x6 kernel runs: dW_hid of a finished chunk is computed on the side
         // stream (190 idle CUs) while the chain continues
         const size_t slab = (size_t)ly.Hp * GHp;
+        // Dense single-call step of a large index-input layer (C4: 27 M floats of W_in, 139 us of optimizer pass at the HBM roof behind
+        // the scatter-add): the rows this batch does not touch -- two thirds of them with Zipf ids -- have a zero gradient whatever
+        // the chain computes, so their optimizer step runs NOW, on the side stream beside the chain (behind the sort that knows
+        // them); sbr_apply_update then steps only the touched rows.  Same kernel arithmetic: bit-identical to the one dense pass.
+        {
+            static const int early_on = [] { const char* e = getenv("SBR_EARLY_UPDATE"); return e ? atoi(e) : 1; }();
+            if (early_on && h->in_train_step && l == 0 && y.L * y.D == 1 && !y.E && !y.n_sparse && !sg && !simple_rec(h) && h->tail_nc < 2 &&
+                !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && (size_t)y.cfg.input_size * GHp >= ((size_t)4 << 20)) {
+                float* s1a = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+                SBR_LAUNCH(launch_update_rows(sd, y.cfg.updater, h->P(ly.p_Win), h->Gd(ly.p_Win), h->St(0, ly.p_Win), s1a ? s1a + ly.p_Win : nullptr,
+                                              y.cfg.input_size, GHp, (const int*)h->A(y.a_soff), 0, y.cfg.learning_rate, y.cfg.rho,
+                                              y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
+                h->win_early = true;
+            }
+        }
         int nc = (sbr_rec_bwd_chunkable(a, simple_rec(h)) && y.T >= 64 && !sg) ? h->bwd_chunks : 1;
         int nsl = (int)std::min<size_t>(h->wgrad_slices / nc, y.ws2_floats / (slab * nc));   // K-slices (= workgroups of the wgrad kernel)
         if (nsl < 1) nc = 1;
@@ -1555,6 +1570,21 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
                              y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
     };
     const size_t p_end = h->out_early ? y.p_split : y.n_params;     // the output layer was stepped beside the BPTT chain
+    // [0, hi) of the parameter section; where the untouched rows of W_in were stepped beside the chain (win_early,
+    // sbr_backward_recurrent), only the touched rows of that block are left
+    auto upd_front = [&](size_t hi) -> hipError_t {
+        if (!h->win_early) return upd(0, hi);
+        const LayerLayout& l0 = y.layer[0];
+        const int GHp0 = y.G * l0.Hp;
+        const size_t w_end = l0.p_Win + (size_t)y.cfg.input_size * GHp0;
+        hipError_t e = upd(0, l0.p_Win);
+        if (e != hipSuccess) return e;
+        e = launch_update_rows(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
+                               y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), 1, y.cfg.learning_rate, y.cfg.rho,
+                               y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
+        if (e != hipSuccess) return e;
+        return hi > w_end ? upd(w_end, hi) : hipSuccess;
+    };
     if (y.n_sparse) {
         // dense pass over everything outside the sparse blocks, then one row-sparse step per block over the rows this step
         // touched: the scatter's sorted ids / the sampled cells, or (data parallel) the ids gathered from every rank
@@ -1602,12 +1632,16 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         if (y.L * y.D == 1 && y.n_params - y.layer[0].p_peep <= ((size_t)1 << 20)) {
             // small output layer (C2: 0.47 M floats): two launches instead of three; a large one (C4: 6.8 M) is better
             // updated while dW_hid finishes
-            SBR_LAUNCH(upd(0, y.layer[0].p_Whid));                         // W_in, b: main-stream gradients only
+            SBR_LAUNCH(upd_front(y.layer[0].p_Whid));                     // W_in, b: main-stream gradients only
             { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
             SBR_LAUNCH(upd(y.layer[0].p_Whid, p_end));                    // W_hid, peepholes, initial states, output layer
         } else {
             SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
             size_t pos = 0;
+            if (h->win_early) {      // (one layer: sbr_backward_recurrent) W_in's touched rows, then b
+                SBR_LAUNCH(upd_front(y.layer[0].p_Whid));
+                pos = y.layer[0].p_peep;
+            } else
             for (int l = 0; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
             SBR_LAUNCH(upd(pos, p_end));
             { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
@@ -1615,9 +1649,9 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         }
     } else {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
-        SBR_LAUNCH(upd(0, p_end));
+        SBR_LAUNCH(upd_front(p_end));
     }
-    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false;
+    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false; h->win_early = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;

@@ -148,6 +148,7 @@ struct sbr_handle {
     bool og_recorded;    // ev_og marks the output-layer gradients of this step complete
     bool fill_done;      // the cluster BPTT sentinel fill of this step was issued on the side stream (ev_fill)
     bool out_early;      // this step's output-layer parameters were stepped on the side stream beside the BPTT chain
+    bool win_early;      // this step's untouched W_in rows were stepped on the side stream beside the BPTT chain (dense, single-call step)
     int dh_slabs_n;      // > 0: dh_last of this step sits in the main workspace as that many unreduced split-K slabs
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
@@ -460,6 +461,8 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
                                 const int* cells, int C, int Hp);
 // optimizers (lasagne.updates.* [3P], update_manager.py:24-82)
 // n elements starting at p / g / s0 / s1, skipping gap_len elements after the first gap_at (two ranges, one launch)
+hipError_t launch_update_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
+                              const int* offs, int touched, float lr, float rho, float b1, float b2, long t);
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);
 // ... of a block whose gradient is still split-K slabs [nslabs][n] (16-byte aligned, n % 4 == 0): reduction + step in one launch

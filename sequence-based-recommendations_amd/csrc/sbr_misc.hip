@@ -1498,6 +1498,34 @@ hipError_t launch_update_from_slabs(hipStream_t s, int updater, const float* ws,
     return hipGetLastError();
 }
 
+// The dense optimizer pass over an item-indexed block [n_rows][row_floats], for the rows the step's batch touches (touched = 1)
+// or for all the others (0): offs = the scatter's segment offsets (row r has entries iff offs[r + 1] > offs[r]).  A row the batch
+// does not touch has a zero gradient whatever the BPTT chain computes, so its step (Lasagne steps EVERY row: update_manager.py:24-82)
+// can run beside the chain; the arithmetic is update_kernel's, element for element.
+__global__ void update_rows_kernel(int updater, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
+                                   float* __restrict__ s1, int n_rows, int row_floats, const int* __restrict__ offs, int touched,
+                                   float lr, float rho, float b1, float b2, float a_t) {
+    const size_t n = (size_t)n_rows * row_floats;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (unsigned)row_floats);
+        if ((offs[r + 1] > offs[r]) != (touched != 0)) continue;
+        const float gi = g[i];
+        g[i] = 0.0f;
+        update_element(updater, gi, p, s0, s1, i, lr, rho, b1, b2, a_t);
+    }
+}
+hipError_t launch_update_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
+                              const int* offs, int touched, float lr, float rho, float b1, float b2, long t) {
+    if (n_rows <= 0) return hipSuccess;
+    float a_t = 0.0f;
+    if (updater == SBR_UPD_ADAM)
+        a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    const size_t n = (size_t)n_rows * row_floats;
+    const int grid = (int)min((size_t)256 * 16, (n + 255) / 256);
+    update_rows_kernel<<<grid, 256, 0, s>>>(updater, p, g, s0, s1, n_rows, row_floats, offs, touched, lr, rho, b1, b2, a_t);
+    return hipGetLastError();
+}
+
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n, float lr,
                          float rho, float b1, float b2, long t, size_t gap_at, size_t gap_len) {
     if (n == 0) return hipSuccess;
