@@ -1178,7 +1178,10 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // the chain computes, so their optimizer step runs NOW, on the side stream beside the chain (behind the sort that knows
         // them); sbr_apply_update then steps only the touched rows.  Same kernel arithmetic: bit-identical to the one dense pass.
         {
-            static const int early_on = [] { const char* e = getenv("SBR_EARLY_UPDATE"); return e ? atoi(e) : 1; }();
+            // MEASURED SLOWER, off by default (profiles/round4_o_c4_timeline.txt): the 0.65 GB the early pass streams through the L2s
+            // beside the chain cost rec_bwd_c16 86 us (512 -> 598: its exchange rings live in those L2s), more than the 90 us the
+            // shorter pass behind the scatter-add saves: C4 1.375 -> 1.41 ms.  SBR_EARLY_UPDATE=1 runs it.
+            static const int early_on = [] { const char* e = getenv("SBR_EARLY_UPDATE"); return e ? atoi(e) : 0; }();
             if (early_on && h->in_train_step && l == 0 && y.L * y.D == 1 && !y.E && !y.n_sparse && !sg && !simple_rec(h) && h->tail_nc < 2 &&
                 !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && (size_t)y.cfg.input_size * GHp >= ((size_t)4 << 20)) {
                 float* s1a = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;

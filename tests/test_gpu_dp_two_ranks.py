@@ -66,7 +66,8 @@ def _worker(rank, world, port, name, out):
             costs.append(eng.read_cost())
         if flags:      # which form of the sparse exchange ran
             assert len(getattr(dp, "_sp_all", {})) == (0 if "counted" in name else len(eng.sparse_blocks()))
-        np.savez(out % rank, costs=np.array(costs), **{"p%d" % i: p for i, p in enumerate(eng.get_all_param_values())})
+        # (the export brings lazily stepped rows up to date: through the collective, on both ranks at once -- see parallel.py)
+        np.savez(out % rank, costs=np.array(costs), **{"p%d" % i: p for i, p in enumerate(dp.get_all_param_values())})
     finally:
         eng.close()
         dist.destroy_process_group()
