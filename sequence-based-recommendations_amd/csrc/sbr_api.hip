@@ -163,7 +163,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     {   // wide index-input rows: the partial rows of the long segments' pieces (launch_scatter_wide)
         const int ghp0 = G * lay.layer[0].Hp;
         const bool wide0 = !lay.E && ghp0 >= 512 && ghp0 <= 8192;
-        lay.sr_slots = wide0 ? (int)((size_t)T * Bp * lay.F / 64 + 2) : 0;
+        lay.sr_slots = wide0 ? std::max((int)((size_t)T * Bp * lay.F / 64 + 2), 2 * SBR_SCAT_RANGES) : 0;
         lay.a_srpart = wide0 ? take((size_t)lay.sr_slots * ghp0) : 0;
         lay.a_srid = wide0 ? take((size_t)lay.sr_slots * 4 + 8) : 0;
     }
@@ -1349,7 +1349,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 // the higher priority: launched on the main stream beside the GEMM it got CUs only as the GEMM's workgroups retired
                 // (C4: 180 us for 50 us of work, profiles/round4_k_c4_timeline.txt).  So it goes first, on the side stream; the main
                 // stream waits for its event, the GEMM follows it.
-                static const int scat_first = [] { const char* e = getenv("SBR_SCAT_FIRST"); return e ? atoi(e) : 1; }();
+                // (SBR_SCAT_FIRST=1; measured no better: the optimizer pass over W_in then shares the chip with the GEMM instead, 139 ->
+                // 239 us at C4: profiles/round4_l_c4_timeline.txt.  Off by default.)
+                static const int scat_first = [] { const char* e = getenv("SBR_SCAT_FIRST"); return e ? atoi(e) : 0; }();
                 if (scat_first && l == 0 && nc == 1 && sw == sd && sm == s && !y.E && y.a_srpart && !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
                     hipError_t se = hipSuccess;
                     if (launch_scatter_wide(sd, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
@@ -1425,7 +1427,14 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 if (sm == s) SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));      // (the sort ran on the side stream)
                 hipError_t se = hipSuccess;
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
-                if (range_on && y.a_srpart && launch_scatter_wide(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
+                // SBR_SCAT_RANGE: 1 (default) = the range form up to 1024-float rows, the atomic kernel beyond (C5: measured 8.35 against
+                // 8.44 - 8.48 ms with either new form); 2 = the segment-parallel form; 0 = the atomic kernel everywhere
+                if (range_on == 1 && y.a_srpart && GHp <= 1024 &&
+                    launch_scatter_range(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
+                                         y.cfg.input_size, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) {
+                    SBR_LAUNCH(se);
+                } else
+                if (range_on == 2 && y.a_srpart && launch_scatter_wide(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp,
                                                                   h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) {
                     SBR_LAUNCH(se);

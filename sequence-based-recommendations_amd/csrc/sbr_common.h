@@ -287,7 +287,11 @@ hipError_t launch_split_cols(hipStream_t s, const float* src, float* a, float* b
 // (out_b == NULL: W arbitrary, only the sum d is written to out_f -- the embedding case)
 hipError_t launch_uncat(hipStream_t s, const float* f, const float* r, const int* len, float* out_f, float* out_b, int T, int Bp,
                         int W, int Hp);
-// wide rows (G*Hp >= 512): segment-parallel scatter-add, no atomics on rows (sbr_misc.hip); false: not served
+// wide rows (G*Hp >= 512), form 1: range scatter-add, two passes, no atomics (sbr_misc.hip); false: not served
+bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
+                          int GHp, float* part, int* part_id, int n_ranges, hipError_t* err);
+#define SBR_SCAT_RANGES 512
+// form 2: segment-parallel scatter-add, no atomics on rows; false: not served
 bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
                          int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err);
 // key_lo / accumulate: the entries of the keys [key_lo, key_lo + n_ids) of a time-chunked sort, ADDED to dWin

@@ -974,6 +974,116 @@ bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int
     return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide rows, form 1 ("range" scatter-add; default for G*Hp <= 1024: C3 / C4): two passes, no atomics, fixed order.
+// (Form 2, the segment-parallel kernels above, is the faster one ALONE -- 100 against 164 us at C4 -- but this one keeps its pace beside the
+// weight-gradient GEMM it shares the chip with after the BPTT chain: 512 persistent workgroups instead of 12 800 short ones; measured
+// C4 1.315 ms with it against 1.372 with form 2 on the same stream and 1.370 with form 2 alone in front of the GEMM: profiles/round4_variants_wide.txt.)
+// The wave-per-32-entries kernel above adds every segment that is not wholly inside a chunk with float atomics; with Zipf ids
+// the hot rows' segments span hundreds of chunks and their adds serialise at the memory side (C4: 199 us for 210 MB of rows,
+// 1 TB/s; C5 571 us).  Here a workgroup owns a contiguous RANGE of the sorted entries, a thread owns one 16-byte piece of
+// the row (a 1024-float row = one piece per thread: every row load is one fully coalesced 4 KB access, SCATR_FLY rows in
+// flight), the range is walked once with the running sum in registers.  Segments inside the range are stored straight to
+// dW_in; the range's FIRST and LAST segment -- the only ones another range can share -- go to a partial-row slab
+// [range][2][row] with their ids beside them, and the merge pass (one workgroup per partial slot; the leader of a run of
+// equal ids sums the run in slot order) writes those rows.  Every row has exactly one writer and a fixed summation order:
+// the gradient is bit-reproducible.  (sparse_lstm.py:368: the AdvancedIncSubtensor the reference's backward builds.)
+// ---------------------------------------------------------------------------------------
+#define SCATR_FLY 8
+template <int NV>
+__global__ void __launch_bounds__(256) scat_range_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
+                                                         const int* __restrict__ spos, const int* __restrict__ total_p,
+                                                         float* __restrict__ dWin, int R4, f32x4* __restrict__ part,
+                                                         int* __restrict__ part_id) {
+    const int total = *total_p, nr = gridDim.x, w = blockIdx.x, tid = threadIdx.x;
+    const int E = (total + nr - 1) / nr;
+    const int lo = min(total, w * E), hi = min(total, lo + E);
+    if (lo >= hi) { if (tid < 2) part_id[2 * w + tid] = -1; return; }
+    f32x4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
+    const int first_id = sid[lo], last_id = sid[hi - 1];
+    int cur = first_id;
+    bool in_first = true;
+    auto flush = [&](int id, bool last) {              // uniform arguments
+        f32x4* dst = (in_first || last) ? part + ((size_t)(2 * w + (in_first ? 0 : 1)) * R4)
+                                        : (f32x4*)dWin + (size_t)id * R4;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f4 = tid + 256 * v;
+            if (f4 < R4) dst[f4] = acc[v];
+            acc[v] = f32x4{0, 0, 0, 0};
+        }
+        in_first = false;
+    };
+    for (int i = lo; i < hi; i += SCATR_FLY) {
+        f32x4 val[SCATR_FLY][NV];
+        int ids[SCATR_FLY];
+#pragma unroll
+        for (int u = 0; u < SCATR_FLY; ++u) {
+            const int e = min(i + u, hi - 1);
+            ids[u] = sid[e];
+            const size_t pos = (size_t)spos[e];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int f4 = tid + 256 * v;
+                val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SCATR_FLY; ++u) {
+            if (i + u < hi) {                            // uniform
+                const int id = __builtin_amdgcn_readfirstlane(ids[u]);
+                if (id != cur) { flush(cur, false); cur = id; }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
+            }
+        }
+    }
+    const bool single = in_first;                        // the whole range is one segment: it went (goes) to slot 0
+    flush(cur, true);
+    if (tid == 0) { part_id[2 * w] = first_id; part_id[2 * w + 1] = single ? -1 : last_id; }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) scat_range_merge_kernel(const f32x4* __restrict__ part, const int* __restrict__ part_id,
+                                                               int n_slots, float* __restrict__ dWin, int R4) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int id = part_id[p];
+    if (id < 0) return;
+    // previous slot that holds a row: the last segment of the range in front, or (that range being one segment) its first
+    int prev = -2;
+    if (p & 1) prev = part_id[p - 1];
+    else if (p >= 2) prev = part_id[p - 1] >= 0 ? part_id[p - 1] : part_id[p - 2];
+    if (prev == id) return;                              // not the leader of its run
+    f32x4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; acc[v] = f4 < R4 ? part[(size_t)p * R4 + f4] : f32x4{0, 0, 0, 0}; }
+    for (int q = p + 1; q < n_slots; ++q) {
+        const int iq = part_id[q];
+        if (iq < 0) continue;
+        if (iq != id) break;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) acc[v] += part[(size_t)q * R4 + f4]; }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) ((f32x4*)dWin)[(size_t)id * R4 + f4] = acc[v]; }
+}
+
+// part: n_ranges * 2 * GHp floats, part_id: n_ranges * 2 ints; false: shape not served (the caller takes launch_scatter_reduce)
+bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
+                          int GHp, float* part, int* part_id, int n_ranges, hipError_t* err) {
+    const int R4 = GHp / 4, nv = (R4 + 255) / 256;
+    if ((GHp & 3) || GHp < 512 || nv > 4 || !part || !part_id || n_ranges < 1) return false;
+    const int* total_p = offs + n_ids;
+#define SRG(NV) do { scat_range_kernel<NV><<<n_ranges, 256, 0, s>>>((const f32x4*)dxt, sid, spos, total_p, dWin, R4, (f32x4*)part, part_id); \
+                     scat_range_merge_kernel<NV><<<2 * n_ranges, 256, 0, s>>>((const f32x4*)part, part_id, 2 * n_ranges, dWin, R4); } while (0)
+    if (nv <= 1) SRG(1); else if (nv <= 2) SRG(2); else SRG(4);
+#undef SRG
+    *err = hipGetLastError();
+    return true;
+}
+
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate, int acc_chunk) {
     const int R4 = GHp / 4;
