@@ -667,12 +667,16 @@ def main():
                 raise RuntimeError("--quick")
             import ctypes
             Hl = layers[-1]
-            A, Bm = torch.randn(B, Hl, device=dev), torch.randn(n_items, Hl, device=dev)
+            # operands like the step's: hidden states in [-1, 1], weights; the kernel the step's logits GEMM takes (the two-plane fp16
+            # split, three MFMAs per product, unless SBR_GEMM_F16=0 or a rectified Vanilla layer keeps bf16x6: six)
+            A, Bm = torch.tanh(torch.randn(B, Hl, device=dev)), 0.1 * torch.randn(n_items, Hl, device=dev)
             C = torch.empty(B, n_items, device=dev)
+            proj_f16 = os.environ.get("SBR_GEMM_F16", "1") != "0" and cell != "Vanilla"
+            proj_mode, proj_terms = (3, 3) if proj_f16 else (0, 6)
 
             def proj():
                 rc = eng.lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), Hl, 1,
-                                            Bm.data_ptr(), 1, Hl, C.data_ptr(), n_items, B, n_items, Hl, None, None, 0, 0)
+                                            Bm.data_ptr(), 1, Hl, C.data_ptr(), n_items, B, n_items, Hl, None, None, 0, proj_mode)
                 assert rc == 0
             for _ in range(3):
                 proj()
@@ -686,8 +690,9 @@ def main():
             kernels["output_projection"] = {"bound": "mfma", "unit": "TFLOP/s", "us": round(us, 2), "achieved": round(tf, 3),
                                             "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 5),
                                             "shape": "M=%d N=%d K=%d" % (B, n_items, Hl),
-                                            "matrix_pipe": {"issued_tflops": round(6 * tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                                                            "frac": round(6 * tf / BF16_MFMA_PEAK_TFLOPS, 5), "terms_per_f32_product": 6}}
+                                            "matrix_pipe": {"issued_tflops": round(proj_terms * tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                                            "frac": round(proj_terms * tf / BF16_MFMA_PEAK_TFLOPS, 5),
+                                                            "terms_per_f32_product": proj_terms}}
 
             def proj_bf16():      # SBR_FLAG_BF16_PROJECTION's kernel: plain bf16 operands, one MFMA per block
                 rc = eng.lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), Hl, 1,
