@@ -144,6 +144,8 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_ws = take(lay.ws_floats);
     lay.ws2_floats = 4 * lay.ws_floats;          // up to 256 weight-gradient slabs
     lay.a_ws2 = take(lay.ws2_floats);
+    lay.ws3_floats = std::min(lay.ws2_floats, (size_t)16 * lay.N * lay.HLt);      // (the polling weight-gradient GEMM owns ws2 meanwhile)
+    lay.a_ws3 = take(lay.ws3_floats);
     lay.a_X = take((size_t)Bp * T * lay.F);
     lay.a_len = take(Bp);
     lay.a_tgt = take((size_t)std::max(lay.Bg, Bp) * lay.NT);
@@ -1095,8 +1097,8 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
         SBR_LAUNCH(launch_colsum_bias(so, lg, R, N, Nl, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
-        SBR_LAUNCH(launch_gemm(so, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, h->out3 ? nullptr : ws2,
-                               h->out3 ? 0 : y.ws2_floats, sg));
+        SBR_LAUNCH(launch_gemm(so, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, h->out3 ? h->A(y.a_ws3) : ws2,
+                               h->out3 ? y.ws3_floats : y.ws2_floats, sg));
         SBR_HIP(hipEventRecord(h->ev_og, so)); h->og_recorded = true;   // output-layer gradients + cost complete
         // Single-call step, dense updates: the output layer is stepped right here, beside the BPTT chain (nothing reads W_out
         // any more: dh was computed in front of the record the side stream waited on); sbr_apply_update leaves the range

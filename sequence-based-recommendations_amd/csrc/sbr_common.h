@@ -106,6 +106,7 @@ struct Layout {
     size_t a_Wc, a_bc, a_act, a_dWc, a_dbc; // sampled heads: [C][HLp], [C], [Bp][C], [C][HLp], [C]
     size_t a_ws; size_t ws_floats;        // split-K workspace (main stream)
     size_t a_ws2; size_t ws2_floats;      // split-K workspace of the side stream (output-layer + weight gradients)
+    size_t a_ws3; size_t ws3_floats;      // split-K workspace of the output layer's dW_out GEMM when it runs on a stream of its own (SBR_TAIL_OUT_STREAM)
     size_t a_csum;                        // [16][max(N,C)] column-sum partials
     size_t a_prof;                        // [2][nblk][16][4] uint64 in-kernel cycle counters (fwd, bwd)
     size_t a_fault;                       // int: a cluster exchange wait timed out
