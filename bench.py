@@ -182,13 +182,13 @@ def mfma_counter_pass(argv_child, log):
     return out
 
 
-def other_config_lines(log, budget_s=420.0):
+def other_config_lines(log, names=("c1", "c4", "c3", "c5"), budget_s=420.0):
     """The other BASELINE configurations next to the headline one, each as a child run of this file (--brief: phase survey, chain-only
     timing, three timed regions): {name: {ms_per_step, value, roofline_frac, ...}}.  C5 builds a 47 GB arena and draws 2.6e9 initial
     values on the host first (~45 s); a configuration that does not fit the time budget is reported as skipped, with the reason."""
     import subprocess
     out, t_all = {}, time.perf_counter()
-    for name, limit in (("c1", 120), ("c4", 150), ("c3", 150), ("c5", 300)):
+    for name, limit in ((n, {"c1": 120, "c4": 150, "c3": 150, "c5": 300}[n]) for n in names):
         left = budget_s - (time.perf_counter() - t_all)
         if left < 30:
             out[name] = {"skipped": "time budget of the default run spent (%d s)" % budget_s}
@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--brief", action="store_true", help="phase survey + timed regions + roofline only (what the default run starts "
                     "for the other BASELINE configurations): no counter / sustained / train-loop / CPU / side-kernel legs")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of BASELINE configs c1 / c3 / c4 / c5")
+    ap.add_argument("--other-configs", default="c1,c4,c3,c5", help="which of them the default run starts (comma-separated, in this order)")
     ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the data-parallel step: nccl = RCCL over xGMI (one rank per GPU); gloo lets several "
                          "ranks share one device (RCCL refuses that) -- how the one-GPU test box exercises --gpus 2")
@@ -802,7 +803,7 @@ def main():
             and (B, T, args.lengths) == (256, 200, "full")):
         try:
             torch.cuda.empty_cache()
-            result["other_configs"] = other_config_lines(log)
+            result["other_configs"] = other_config_lines(log, [n for n in args.other_configs.split(",") if n in ("c1", "c3", "c4", "c5")])
         except Exception as ex:
             result["other_configs"] = {"error": repr(ex)[:300]}
     try:

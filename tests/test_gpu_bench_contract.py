@@ -13,8 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(*extra, other_configs=False):
-    # (the child runs of the other BASELINE configurations -- C5 alone builds a 47 GB arena -- only where a test looks at them)
-    extra = list(extra) + ([] if other_configs else ["--no-other-configs"])
+    # (the child runs of the other BASELINE configurations only where a test looks at them, and there without C5, which alone
+    # builds a 47 GB arena and draws 2.6e9 initial values: ~40 s; the driver's own default run carries all four)
+    extra = list(extra) + (["--other-configs", "c1,c4,c3"] if other_configs else ["--no-other-configs"])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"] + list(extra),
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -137,7 +138,7 @@ def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_l
     assert any("rec_bwd" in k for k in mk) and any("gemm_x6_kernel" in k for k in mk)
     assert all(0 < v["mfma_util_of_chip"] < 1 for v in mk.values())
     oc = d["other_configs"]
-    assert set(oc) == {"c1", "c3", "c4", "c5"}
+    assert set(oc) == {"c1", "c3", "c4"}
     for name, v in oc.items():
         assert "skipped" in v or (v["ms_per_step"] > 0 and 0 < v["roofline"]["frac"] < 1 and v["outside_chains_us"] > 0), (name, v)
     assert "skipped" not in oc["c1"] and "skipped" not in oc["c4"]
