@@ -1178,7 +1178,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // Dense single-call step of a large index-input layer (C4: 27 M floats of W_in, 139 us of optimizer pass at the HBM roof behind
         // the scatter-add): the rows this batch does not touch -- two thirds of them with Zipf ids -- have a zero gradient whatever
         // the chain computes, so their optimizer step runs NOW, on the side stream beside the chain (behind the sort that knows
-        // them); sbr_apply_update then steps only the touched rows.  Same kernel arithmetic: bit-identical to the one dense pass.
+        // them); sbr_apply_update then steps only the touched rows.  Same arithmetic per element as the one dense pass.
         {
             // MEASURED SLOWER, off by default (profiles/round4_o_c4_timeline.txt): the 0.65 GB the early pass streams through the L2s
             // beside the chain cost rec_bwd_c16 86 us (512 -> 598: its exchange rings live in those L2s), more than the 90 us the
