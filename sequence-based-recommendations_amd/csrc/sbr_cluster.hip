@@ -29,6 +29,7 @@ struct sbr_cluster {
     unsigned long long noise_ctr;
     int J;                                           // cells of the last forward (B + samples)
     int hard_valid;
+    int dR_clean;                                    // dR is all zeros: the optimizer kernel clears every gradient it consumes (no N x C memset per step)
 };
 
 extern void sbr_set_error(const char* fmt, ...);
@@ -230,7 +231,7 @@ extern "C" sbr_cluster* sbr_cluster_create(const sbr_cluster_config* cfg, void* 
     if (c.updater < 0 || c.updater > SBR_UPD_ADAM) { sbr_set_error("Unknown update option"); return nullptr; }
     sbr_cluster* k = new (std::nothrow) sbr_cluster();
     if (!k) return nullptr;
-    k->cfg = c; k->stream = (hipStream_t)stream; k->step = 0; k->scale = c.scale; k->noise_ctr = 0; k->J = 0; k->hard_valid = 0;
+    k->cfg = c; k->stream = (hipStream_t)stream; k->step = 0; k->scale = c.scale; k->noise_ctr = 0; k->J = 0; k->hard_valid = 0; k->dR_clean = 0;
     const size_t N = c.n_items, C = c.n_clusters, H = c.n_hidden, B = c.batch_size, J = B + c.max_samples;
     const size_t nR = N * C, nW = H * C;
     float** f[] = {&k->R, &k->Wc, &k->dR, &k->dWc, &k->sR[0], &k->sR[1], &k->sWc[0], &k->sWc[1], &k->z, &k->p, &k->M, &k->sm, &k->sg,
@@ -292,7 +293,8 @@ extern "C" int sbr_cluster_forward_backward(sbr_cluster* k, const float* h_dev, 
     cl_score_kernel<<<B, 256, 0, s>>>(k->p, k->M, C, J, k->score);
     CL_HIP(launch_sampled_loss(s, k->score, nullptr, k->ones, k->rowcost, B, B, n_samples, 0, c.loss, B));      // score -> d cost / d score
     cl_sum_kernel<<<1, 256, 0, s>>>(k->rowcost, B, k->cost);
-    CL_HIP(hipMemsetAsync(k->dR, 0, (size_t)c.n_items * C * sizeof(float), s));
+    if (!k->dR_clean) CL_HIP(hipMemsetAsync(k->dR, 0, (size_t)c.n_items * C * sizeof(float), s));      // (only where no update ran in between)
+    k->dR_clean = 0;
     cl_back_p_kernel<<<B, 256, lds, s>>>(k->score, k->M, k->p, C, J, k->scale, k->dz);
     cl_back_wc_kernel<<<H, 256, 0, s>>>(h_dev, ld_h, c.hidden_split, off2, k->dz, B, C, k->dWc);
     cl_back_m_kernel<<<J, 64, 0, s>>>(k->score, k->p, k->sm, k->sg, k->ids, B, C, J, k->scale, c.cluster_type, k->dR);
@@ -314,6 +316,7 @@ extern "C" int sbr_cluster_apply_update(sbr_cluster* k) {      // self.updater(c
     CL_HIP(launch_update(k->stream, c.updater, k->R, k->dR, k->sR[0], two ? k->sR[1] : nullptr, (size_t)c.n_items * c.n_clusters,
                          c.learning_rate, c.rho, c.beta1, c.beta2, k->step));
     k->hard_valid = 0;
+    k->dR_clean = 1;                                 // update_kernel has cleared dR (and dWc)
     return SBR_OK;
 }
 
