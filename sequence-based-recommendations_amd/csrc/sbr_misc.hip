@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(256) scat_long_merge_kernel(const f32x4* __res
 // false: shape not served (the caller takes launch_scatter_reduce)
 bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
                          int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err) {
-    const int R4 = GHp / 4, nvw = (R4 + 63) / 64, nvb = (R4 + 255) / 256;
+    const int R4 = GHp / 4, nvw = (R4 + 63) / 64;
     if ((GHp & 3) || GHp < 512 || nvw > 8 || !part || !aux || n_slots < max_entries / SCATW_SHORT + 1) return false;
     if (hipMemsetAsync(aux, 0, 2 * sizeof(int), s) != hipSuccess) { *err = hipGetLastError(); return true; }
     int* counters = aux; ScatLong* longs = (ScatLong*)(aux + 4);
