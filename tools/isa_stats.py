@@ -47,9 +47,23 @@ def main():
                         break
                 else:
                     rest += 1
+            # fast path: without the blocks of the bounded-spin loops (depth-2 loops: taken only while a producer is late) and the
+            # blocks that raise the fault flag -- what a step issues when nobody waits
+            fast, skip = 0, False
+            for ln in body[lo:hi]:
+                if re.match(r"^\.LBB\d+_\d+:|^; %bb\.", ln):
+                    skip = "Depth=2" in ln
+                st = ln.strip()
+                if not ln.startswith("\t") or st.startswith((";", ".")):
+                    continue
+                if "global_atomic_or" in st:
+                    skip = True
+                if not skip and not re.match(r"^v_s?mfmac?", st):
+                    fast += 1
             total = len(code)
             non = total - counts.get("mfma", 0)
-            print("  role loop %d: %d instructions per step, %d of them not MFMA" % (n, total, non))
+            print("  role loop %d: %d instructions in the loop's range, %d of them not MFMA; %d not MFMA outside the bounded-spin loops and fault blocks"
+                  % (n, total, non, fast))
             print("    " + ", ".join("%s %d" % (k, counts[k]) for k, _ in CLASSES if k in counts) + (", other %d" % rest if rest else ""))
             mf = counts.get("mfma", 0)
             print("    issue estimate: %d MFMAs x 16 cycles = %d cycles of matrix pipe; %d other instructions x >= 4 cycles = >= %d cycles of issue"
