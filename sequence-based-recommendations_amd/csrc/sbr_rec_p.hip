@@ -63,6 +63,10 @@
 #define X6P_SPEC1 0      // forward, sparse form: waves 0-3 fetch the second half of the operands at the top of the step too, on spec (measured:
                          // rec_fwd 113.5 -> 117 us -- two more ds_read_b128 per wave and step on an LDS pipe that is the busy resource)
 #endif
+#ifndef X6P_H1_AT
+#define X6P_H1_AT 0      // forward, sparse form, waves 0-3: the second operand half is requested behind the instructions of this k-block (1: the
+#endif                   // last one in front of its use, as in rounds 1 - 3 -- with three instructions per k-block that read's whole round trip was
+                         // exposed: rec_fwd 115.0; 0: one k-block earlier: 112.8 us; -1: in front of the first k-block's instructions: 113.5)
 #ifndef X6P_ROLES
 #define X6P_ROLES 1      // 0: waves 0-3 run the loop of waves 4-7 too (all operands fetched at the top of the step, no pipe gate)
 #endif
@@ -444,9 +448,13 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
                 if (!RA && kb == KB - 1 && X6P_FWD_TOK >= 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (X6P_H1_AT < 0 && kb == 0 && RA) {             // the second operand half: requested in FRONT of the first k-block's instructions
+                    load_half(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] = smfmac16(hp[kb][0], WS[g][kb], acc[g], spidx);
-                if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below; X6P_SPEC1: only if the read at the top came too early
+                if (X6P_H1_AT >= 0 && kb == (X6P_H1_AT < KB / 2 - 1 ? X6P_H1_AT : KB / 2 - 1) && RA) {   // ... or behind those of k-block X6P_H1_AT
                     __builtin_amdgcn_sched_barrier(0);
                     if (!X6P_SPEC1 || __builtin_amdgcn_readfirstlane(fl[1]) < 4 * t) load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
