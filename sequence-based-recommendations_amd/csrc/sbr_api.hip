@@ -165,10 +165,12 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     {   // wide index-input rows: the partial rows of the long segments' pieces (launch_scatter_wide)
         const int ghp0 = G * lay.layer[0].Hp;
         const bool wide0 = !lay.E && ghp0 >= 512 && ghp0 <= 8192;
-        lay.sr_slots = wide0 ? std::max((int)((size_t)T * Bp * lay.F / 64 + 2), 2 * SBR_SCAT_RANGES) : 0;
+        lay.sr_slots = wide0 ? std::max(sbr_scatter_wide_slots((size_t)T * Bp * lay.F), 2 * SBR_SCAT_RANGES) : 0;
         lay.a_srpart = wide0 ? take((size_t)lay.sr_slots * ghp0) : 0;
         lay.a_srid = wide0 ? take((size_t)lay.sr_slots * 4 + 8) : 0;
+        lay.a_tmark = wide0 ? take((size_t)cfg.input_size) : 0;      // (dense blocks: which rows the batch touches, without its sort)
     }
+    lay.a_hstat = take((size_t)256 * 64);
     lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, (a gap), the chain's clock words
     lay.a_done = take((size_t)SBR_DONE_COPIES * SBR_DONE_STRIDE);      // the monitor's word, replicated (sbr_common.h SbrPoll)
     // Row-sparse blocks (sbr_sparse.hip): the index-addressed rows of layer 0 (or of the embedding table) and, for the sampled
@@ -413,6 +415,13 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
     h->out_early = false; h->win_early = false; h->dh_slabs_n = 0;
+    { const char* e = getenv("SBR_SCAT_FUSE"); h->scat_fuse = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_WIN_REST"); h->win_rest = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_SPARSE_OUT_EARLY"); h->sparse_out_early = e ? atoi(e) : 1; }
+    h->win_fused = false; h->win_rest_pending = false; h->win_rest_done = false; h->cells_early = false; h->wout_early = false;
+    h->ev_cells = nullptr; h->mark_epoch = 0;
+    { const char* e = getenv("SBR_HEAD_FUSE"); h->head_fuse = e ? atoi(e) : 1; }
+    h->head_epoch = 0;
     h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
@@ -432,6 +441,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&h->side3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_tail3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_cells, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
@@ -476,6 +486,7 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->side3) (void)hipStreamDestroy(h->side3);
     if (h->ev_tail3) (void)hipEventDestroy(h->ev_tail3);
+    if (h->ev_cells) (void)hipEventDestroy(h->ev_cells);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
     for (int c = 0; c < 2; ++c) if (h->ev_lag[c]) (void)hipEventDestroy(h->ev_lag[c]);
     if (h->lag_host) (void)hipHostFree(h->lag_host);
@@ -746,6 +757,26 @@ static int tail_cost_scan(sbr_handle* h) {
     return SBR_OK;
 }
 
+// Will the scatter-add of this (single-call) step apply the optimizer to the DENSE index-input block of layer 0 itself
+// (launch_scatter_wide_step + a zero-gradient pass over the untouched rows)?  Decided by ONE function: the pass over the untouched
+// rows may run long before the scatter-add (SBR_WIN_REST=2: between the chains), and a step in which one ran without the other
+// would step rows twice or not at all -- sbr_backward_recurrent fails loudly if its own conditions disagree.
+static bool dense_scatter_step_ok(const sbr_handle* h, bool in_step) {
+    const Layout& y = h->lay;
+    static const int early_on = [] { const char* e = getenv("SBR_EARLY_UPDATE"); return e ? atoi(e) : 0; }();
+    static const int scat_first = [] { const char* e = getenv("SBR_SCAT_FIRST"); return e ? atoi(e) : 0; }();
+    static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
+    if (!h->scat_fuse || !h->win_rest || !in_step || early_on || scat_first || range_on == 0) return false;
+    if (y.D != 1 || y.E || !y.a_srpart || !y.a_tmark || h->tail_nc >= 2) return false;
+    if (simple_gemm(h) || simple_rec(h) || (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) return false;
+    for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 0) return false;
+    const int GHp = y.G * y.layer[0].Hp;
+    if ((GHp & 3) || GHp < 512 || GHp > 2048) return false;                       // launch_scatter_wide_step's shapes
+    // small one-layer models may keep the scatter-add on the side stream (swapped tail, sbr_backward_recurrent) and step W_in there
+    if (y.L == 1 && !y.n_sparse && y.n_params <= ((size_t)4 << 20) && h->swap_tail) return false;
+    return true;
+}
+
 // sbr_chain_times: events around one chain launch (dir 0 = forward, 1 = backward); `which` 0 in front of it, 1 behind it
 static inline void chain_mark(sbr_handle* h, hipStream_t st, int dir, int which) {
     if (!h->chain_timing || h->ch_n >= sbr_handle::kChain) return;
@@ -918,8 +949,28 @@ extern "C" int sbr_forward(sbr_handle* h) {
             if (y.sparse[b].kind == 0)
                 SBR_LAUNCH(launch_sparse_catch_up_batch(s, sparse_rows(h, b), sparse_upd(h), h->bX, h->blen, y.T, y.Bp, y.F, (int)h->step_count));
     h->tail_nc = h->step_open ? tail_plan(h, &h->tail_ch) : 0;      // overlapped tail for this step? (never for predict / top-k)
+    const bool training = h->step_open;
     h->step_open = false;
     h->tail_sorted = false;
+    // Sampled heads with lazily stepped W_out rows: which cells the step samples depends on the batch only, and catching their
+    // rows up is a chain of dependent replays per row (C3: 81 us, C5: 94 us for 288 rows) that sat on the main stream between the
+    // forward chain and the head.  It runs now on the side stream, beside the forward chain; sbr_loss_backward_output waits for
+    // its event (long complete by then).  SBR_SPARSE_OUT_EARLY=0: as before.
+    h->cells_early = false;
+    bool forked = false;
+    if (training && h->sparse_out_early && sparse_lazy(h) && y.S > 0 && y.cfg.loss != SBR_LOSS_CCE && !SBR_LOSS_IS_MARGIN(y.cfg.loss)) {
+        int kb = -1;
+        for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 1) kb = b;
+        if (kb >= 0) {
+            SBR_HIP(hipEventRecord(h->ev_fork, s)); forked = true;      // (device-resident batches are produced on the main stream)
+            SBR_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            int* cells = (int*)h->A(y.a_cells);
+            SBR_LAUNCH(launch_build_cells(h->side, h->btgt, h->bsmp, y.Bg, y.S, cells));
+            SBR_LAUNCH(launch_sparse_catch_up_list(h->side, sparse_rows(h, kb), sparse_upd(h), cells, nullptr, y.C, y.C, (int)h->step_count));
+            SBR_HIP(hipEventRecord(h->ev_cells, h->side));
+            h->cells_early = true;
+        }
+    }
     // Overlapped tail, round 3.  Its consumers are throughput-bound once they have the chip's other 192 CUs to themselves (the
     // fence below), so WHEN they start decides when the step ends -- and both waited behind work that does not need the chain:
     // the scatter-add behind the 45 us of the time-chunked sort.  The sort needs nothing but the batch: it runs now, beside the
@@ -927,7 +978,7 @@ extern "C" int sbr_forward(sbr_handle* h) {
     // histogram per workgroup) runs beside it, so the two do not share CUs.  SBR_TAIL_EARLY_SORT=0: behind the output phase.
     const bool tail_live = h->tail_nc >= 2 && h->tail_overlap == 1;
     if (tail_live && h->tail_early_sort) {
-        SBR_HIP(hipEventRecord(h->ev_fork, s));
+        if (!forked) SBR_HIP(hipEventRecord(h->ev_fork, s));
         SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
         SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
                                        (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
@@ -1049,11 +1100,53 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
         const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
     }
+    // SBR_WIN_REST=2: the zero-gradient step of the rows of a dense W_in this batch does not name runs NOW, on the second side
+    // stream beside the head's kernels (which leave HBM idle), from marks that need the batch only (the sort is still running)
+    h->win_rest_done = false;
+    if (h->win_rest == 2 && dense_scatter_step_ok(h, h->in_train_step)) {
+        const LayerLayout& l0 = y.layer[0];
+        const int GHp0 = y.G * l0.Hp;
+        if (!fill_needed) SBR_HIP(hipEventRecord(h->ev_fork, s));
+        SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
+        h->mark_epoch += 1;
+        SBR_LAUNCH(launch_mark_rows(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_tmark), h->mark_epoch));
+        SBR_LAUNCH(launch_update_untouched_rows(h->side2, y.cfg.updater, h->P(l0.p_Win), h->St(0, l0.p_Win),
+                                                y.n_state_arrays > 1 ? h->St(1, l0.p_Win) : nullptr, y.cfg.input_size, GHp0, nullptr,
+                                                (const int*)h->A(y.a_tmark), h->mark_epoch, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
+                                                y.cfg.beta2, (long)h->step_count + 1));
+        SBR_HIP(hipEventRecord(h->ev_tail2, h->side2));
+        h->win_rest_pending = true; h->win_rest_done = true;
+    }
     if (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss)) {      // dense heads: full softmax, or RNNMargin's linear layer
         float* lg = h->A(y.a_logits);
         const int Nl = (N + 3) & ~3;               // row stride of the logits / dlogits buffer
         // logits = h . W_out (+ b inside the softmax kernel): DenseLayer (rnn_one_hot.py:65)
         const bool bf16p = (y.cfg.flags & SBR_FLAG_BF16_PROJECTION) && !sg;
+        // critical path: dh = dlogits . W_out^T feeds the BPTT chain.  Where the chain is rec_bwd_x6p, the split-K slabs of the dh
+        // GEMM stay unreduced and the chain's prologue adds them: one launch (7 us + its gap) less in front of it
+        int keep = 0;
+        bool fold = false;
+        if (!sg && y.D == 1 && R == y.Bp && !simple_rec(h)) {
+            const bool fold_on = h->fold_dh;
+            RecArgs ra = rec_args(h, y.L - 1);
+            fold = fold_on && sbr_rec_x6p_ok(ra) && !sbr_rec_cluster_ok(ra);
+        }
+        // Round 5: logits, softmax + CCE and dh in ONE launch whose workgroups exchange the row statistics inside the kernel
+        // (sbr_head.hip; exact-f32 products); its dh leaves as split-K slabs -- folded into the chain's prologue as above, or
+        // reduced here.  Shapes it does not serve (and SBR_HEAD_FUSE=0) keep the three launches below.
+        bool head_done = false;
+        if (h->head_fuse && y.cfg.loss == SBR_LOSS_CCE && !sg && !bf16p && !(y.cfg.flags & SBR_FLAG_F32_MFMA) && y.D == 1 && R == y.Bp) {
+            int nsl = 0; hipError_t he = hipSuccess;
+            h->head_epoch += 1; if (!h->head_epoch) h->head_epoch = 1;
+            if (launch_head_cce(s, hl, h->P(y.p_WoutT), h->P(y.p_bout), tgt, h->bpop, lg, h->A(y.a_rowcost), ws, y.ws_floats,
+                                (unsigned*)h->A(y.a_hstat), (int*)h->A(y.a_fault), y.Bp, N, Nl, Hp, y.Bg, h->head_epoch, &nsl, &he)) {
+                SBR_LAUNCH(he);
+                head_done = true;
+                if (fold) keep = nsl;
+                else SBR_LAUNCH(launch_splitk_reduce(s, ws, nsl, y.Bp, Hp, h->A(y.a_dhlast), Hp, nullptr));
+            }
+        }
+        if (!head_done) {
         if (bf16p) sbr_gemm_set_planes(1);
         else if (layer_gemm_f16(h, false)) sbr_gemm_hint(2, 1.0f, 1.0f);      // h in [-1, 1] x weights
         const hipError_t ge = launch_gemm(s, hl, Hp, 1, h->P(y.p_WoutT), 1, Hp, lg, Nl, R, N, Hp, nullptr, nullptr, 0, sg);
@@ -1064,17 +1157,9 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
                                           y.Bg, y.cfg.loss, y.cfg.balance, y.cfg.unique));
         else
         SBR_LAUNCH(launch_softmax_cce(s, lg, h->P(y.p_bout), tgt, h->bpop, h->A(y.a_rowcost), R, N, Nl, y.Bg));
-        // critical path: dh = dlogits . W_out^T feeds the BPTT chain.  Where the chain is rec_bwd_x6p, the split-K slabs of this
-        // GEMM stay unreduced and the chain's prologue adds them: one launch (7 us + its gap) less in front of it
-        int keep = 0;
-        bool fold = false;
-        if (!sg && y.D == 1 && R == y.Bp && !simple_rec(h)) {
-            const bool fold_on = h->fold_dh;
-            RecArgs ra = rec_args(h, y.L - 1);
-            fold = fold_on && sbr_rec_x6p_ok(ra) && !sbr_rec_cluster_ok(ra);
-        }
         SBR_LAUNCH(launch_gemm(s, lg, Nl, 1, h->P(y.p_WoutT), Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, N, nullptr, ws, y.ws_floats, sg, 0, 0,
                                fold ? &keep : nullptr));
+        }
         h->dh_slabs_n = keep;
         // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
         // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
@@ -1114,11 +1199,15 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         const int C = y.C;
         int* cells = (int*)h->A(y.a_cells);
         float *Wc = h->A(y.a_Wc), *bc = h->A(y.a_bc), *act = h->A(y.a_act), *dWc = h->A(y.a_dWc), *dbc = h->A(y.a_dbc);
+        if (h->cells_early) SBR_HIP(hipStreamWaitEvent(s, h->ev_cells, 0));      // built and caught up beside the forward chain (sbr_forward)
+        else {
         SBR_LAUNCH(launch_build_cells(s, tgt, h->bsmp, y.Bg, y.S, cells));
         if (sparse_lazy(h))      // ... and so must the rows of W_out^T / b_out the sampled cells gather
             for (int b = 0; b < y.n_sparse; ++b)
                 if (y.sparse[b].kind == 1)
                     SBR_LAUNCH(launch_sparse_catch_up_list(s, sparse_rows(h, b), sparse_upd(h), cells, nullptr, C, C, (int)h->step_count));
+        }
+        h->cells_early = false;
         SBR_LAUNCH(launch_gather_rows(s, h->P(y.p_WoutT), h->P(y.p_bout), cells, C, Hp, Wc, bc));
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, Wc, 1, Hp, act, C, R, C, Hp, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->bpop, h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
@@ -1134,6 +1223,18 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
             const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
         }
+        // Single-call step: the head's row-sparse block (W_out^T rows + b_out of the sampled cells) has its complete gradient now
+        // and nothing reads those rows any more (dh is computed): its step runs on the side stream beside the BPTT chain instead
+        // of at the end of the step (C3: 35 us, C5: 41 us); sbr_apply_update leaves the block out.
+        h->wout_early = false;
+        if (h->in_train_step && h->sparse_out_early)
+            for (int b = 0; b < y.n_sparse; ++b)
+                if (y.sparse[b].kind == 1 && !h->sp_exchanged[b]) {
+                    SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
+                    SBR_LAUNCH(launch_sparse_step_list(sd, sparse_rows(h, b), sparse_upd(h), (const int*)h->A(y.a_cells), nullptr, C, C,
+                                                       (int)h->step_count + 1));
+                    h->wout_early = true;
+                }
     }
     mark(h, 3);
     if (h->deferred_join && !h->in_train_step) {
@@ -1342,11 +1443,13 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             continue;
         }
         bool scat_early = false;      // wide rows, tail not swapped: the scatter-add ran on the side stream in FRONT of the weight-gradient GEMM
+        hipEvent_t ev_chain_end = nullptr;      // this layer: the main-stream record behind its (last) BPTT launch
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
                 a.t_hi = (int)((long)y.T * (nc - c) / nc); a.t_lo = (int)((long)y.T * (nc - c - 1) / nc); a.chunk = c;
                 SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, false));
-                SBR_HIP(hipStreamWaitEvent(sd, record_shared(h, h->ev_chunk[c], (l == 0 && c == nc - 1) ? 4 : -1), 0));
+                ev_chain_end = record_shared(h, h->ev_chunk[c], (l == 0 && c == nc - 1) ? 4 : -1);
+                SBR_HIP(hipStreamWaitEvent(sd, ev_chain_end, 0));
                 // The scatter-add is the head of the step's critical tail (scatter -> W_in's optimizer pass) and the side stream has
                 // the higher priority: launched on the main stream beside the GEMM it got CUs only as the GEMM's workgroups retired
                 // (C4: 180 us for 50 us of work, profiles/round4_k_c4_timeline.txt).  So it goes first, on the side stream; the main
@@ -1428,6 +1531,57 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 if (scat_early) { SBR_HIP(hipStreamWaitEvent(s, h->ev_tail, 0)); mark_on(h, 6, sm); continue; }
                 if (sm == s) SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));      // (the sort ran on the side stream)
                 hipError_t se = hipSuccess;
+                // Single-call step, wide index-input rows: the scatter-add steps the rows it completes (launch_scatter_wide_step,
+                // sbr_misc.hip) -- row-sparse blocks (C3 / C5: the separate touched-rows kernel disappears) and dense ones (C4: the
+                // 140 us pass over all of W_in becomes the touched rows' step here + a zero-gradient pass over the others on the
+                // second side stream, beside this kernel and the weight-gradient GEMM).  SBR_SCAT_FUSE=0: scatter-add, then steps.
+                {
+                    int kb0 = -1;
+                    for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 0) kb0 = b;
+                    const bool dense_blk = kb0 < 0;
+                    static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
+                    const bool fuse = dense_blk ? dense_scatter_step_ok(h, h->in_train_step)
+                                                : (h->scat_fuse && h->in_train_step && y.D == 1 && y.a_srpart && !sg && !simple_rec(h) &&
+                                                   range_on != 0 && GHp <= 2048 && !h->sp_exchanged[kb0]);
+                    if (h->win_rest_done && !(fuse && sm == s)) {
+                        sbr_set_error("internal: the untouched rows of W_in were stepped but the scatter-add does not step the others");
+                        return SBR_ESTATE;
+                    }
+                    if (fuse && sm == s) {
+                        SbrScatStep st; memset(&st, 0, sizeof(st));
+                        st.p = h->P(ly.p_Win); st.s0 = h->St(0, ly.p_Win); st.s1 = y.n_state_arrays > 1 ? h->St(1, ly.p_Win) : nullptr;
+                        st.last = dense_blk ? nullptr : (int*)h->A(y.sparse[kb0].a_last);
+                        st.updater = y.cfg.updater; st.t_to = (int)h->step_count + 1;
+                        st.lr = y.cfg.learning_rate; st.rho = y.cfg.rho; st.b1 = y.cfg.beta1; st.b2 = y.cfg.beta2;
+                        st.a_t = y.cfg.updater == SBR_UPD_ADAM
+                                     ? (float)((double)st.lr * sqrt(1.0 - pow((double)st.b2, (double)st.t_to)) / (1.0 - pow((double)st.b1, (double)st.t_to)))
+                                     : 0.0f;
+                        if (!launch_scatter_wide_step(sm, st, a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
+                                                      y.cfg.input_size, y.T * y.Bp * y.F, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) {
+                            sbr_set_error("internal: launch_scatter_wide_step refused a shape dense_scatter_step_ok admits (G*Hp = %d)", GHp);
+                            return SBR_ESTATE;
+                        }
+                        {
+                            SBR_LAUNCH(se);
+                            h->win_fused = true;
+                            if (dense_blk && !h->win_rest_done) {
+                                // the rows this batch does not name: zero-gradient step, no gradient traffic.  On side2 behind the sort
+                                // and the chain (the record the side stream waited on), or (SBR_WIN_REST=3) right here behind the scatter-add
+                                hipStream_t sr = h->win_rest == 3 ? sm : h->side2;
+                                if (sr != sm) {
+                                    SBR_HIP(hipStreamWaitEvent(sr, h->ev_sort, 0));
+                                    if (ev_chain_end) SBR_HIP(hipStreamWaitEvent(sr, ev_chain_end, 0));
+                                }
+                                SBR_LAUNCH(launch_update_untouched_rows(sr, y.cfg.updater, st.p, st.s0, st.s1, y.cfg.input_size, GHp,
+                                                                        (const int*)h->A(y.a_soff), nullptr, 0, st.lr, st.rho, st.b1, st.b2,
+                                                                        (long)st.t_to));
+                                if (sr != sm) { SBR_HIP(hipEventRecord(h->ev_tail2, sr)); h->win_rest_pending = true; }
+                            }
+                            mark_on(h, 6, sm);
+                            continue;
+                        }
+                    }
+                }
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
                 // SBR_SCAT_RANGE: 1 (default) = the range form up to 1024-float rows, the atomic kernel beyond (C5: measured 8.35 against
                 // 8.44 - 8.48 ms with either new form); 2 = the segment-parallel form; 0 = the atomic kernel everywhere
@@ -1587,12 +1741,13 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     // [0, hi) of the parameter section; where the untouched rows of W_in were stepped beside the chain (win_early,
     // sbr_backward_recurrent), only the touched rows of that block are left
     auto upd_front = [&](size_t hi) -> hipError_t {
-        if (!h->win_early) return upd(0, hi);
+        if (!h->win_early && !h->win_fused) return upd(0, hi);
         const LayerLayout& l0 = y.layer[0];
         const int GHp0 = y.G * l0.Hp;
         const size_t w_end = l0.p_Win + (size_t)y.cfg.input_size * GHp0;
         hipError_t e = upd(0, l0.p_Win);
         if (e != hipSuccess) return e;
+        if (h->win_fused) return hi > w_end ? upd(w_end, hi) : hipSuccess;      // every row of the block has been stepped (scatter-add + side2)
         e = launch_update_rows(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
                                y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), 1, y.cfg.learning_rate, y.cfg.rho,
                                y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
@@ -1614,6 +1769,9 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         for (int b = 0; b < y.n_sparse; ++b) {
             const SparseBlockLayout& sb = y.sparse[b];
             const SbrSparseRows rows = sparse_rows(h, b);
+            if ((sb.kind == 0 && h->win_fused) || (sb.kind == 1 && h->wout_early)) {
+                // stepped already: by the scatter-add (sbr_backward_recurrent) / beside the BPTT chain (sbr_loss_backward_output)
+            } else
             if (h->sp_exchanged[b]) {
                 SBR_LAUNCH(launch_sparse_step_list(h->stream, rows, sparse_upd(h), (const int*)h->A(sb.a_cand), nullptr, h->sp_ncand[b],
                                                    h->sp_ncand[b], (int)h->step_count));
@@ -1652,11 +1810,12 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         } else {
             SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
             size_t pos = 0;
-            if (h->win_early) {      // (one layer: sbr_backward_recurrent) W_in's touched rows, then b
+            int l_from = 0;
+            if (h->win_early || h->win_fused) {      // layer 0: W_in's touched rows (win_early) / nothing of W_in (win_fused), then b
                 SBR_LAUNCH(upd_front(y.layer[0].p_Whid));
-                pos = y.layer[0].p_peep;
-            } else
-            for (int l = 0; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
+                pos = y.layer[0].p_peep; l_from = 1;
+            }
+            for (int l = l_from; l < y.L * y.D; ++l) { SBR_LAUNCH(upd(pos, y.layer[l].p_Whid)); pos = y.layer[l].p_peep; }
             SBR_LAUNCH(upd(pos, p_end));
             { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
             for (int l = 0; l < y.L * y.D; ++l) SBR_LAUNCH(upd(y.layer[l].p_Whid, y.layer[l].p_peep));
@@ -1665,7 +1824,9 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(upd_front(p_end));
     }
+    if (h->win_rest_pending) { SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_tail2, 0)); h->win_rest_pending = false; }
     h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false; h->win_early = false;
+    h->win_fused = false; h->win_rest_done = false; h->wout_early = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;
@@ -1682,6 +1843,10 @@ static int report_fault(sbr_handle* h, int fault) {
     // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip);
     // bit 3: a consumer of the overlapped tail (or its monitor) waited for the chain for 1.5 s; bit 4: a unit of the LDS-row
     // scatter-add was handed more ids than it has LDS rows for (launch_scatter_lds_poll sizes them: cannot happen)
+    if (fault & 32)
+        sbr_set_error("the fused output head (sbr_head.hip) waited 1.5 s for the row statistics of its other workgroups (flag %d, results of "
+                      "this call invalid): its grid was not co-resident; rerun with SBR_HEAD_FUSE=0", fault);
+    else
     if (fault & 16)
         sbr_set_error("the LDS-row scatter-add of the overlapped tail ran out of rows (flag %d, results of this call invalid); rerun with "
                       "SBR_TAIL_SCATTER_LDS=0", fault);
@@ -1878,6 +2043,20 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         RecArgs a = rec_args(h, 0);
         *value = (y.E == 0 && y.F == 1 && h->fuse_gather && sbr_rec_fwd_can_fuse_gather(a, simple_rec(h))) ? 1 : 0;
     } else if (w == "rows_per_workgroup") *value = h->rpt;
+    else if (w == "head_fused") {      // would a full batch of a training step take the one-launch head (sbr_head.hip)?  (its column chunks, or 0)
+        int cc = 0, cw = 0; size_t lds = 0;
+        *value = (h->head_fuse && y.cfg.loss == SBR_LOSS_CCE && !simple_gemm(h) && !(y.cfg.flags & (SBR_FLAG_BF16_PROJECTION | SBR_FLAG_F32_MFMA)) &&
+                  y.D == 1 && y.B == y.Bp && sbr_head_plan(y.Bp, y.N, y.HLt, &cc, &cw, &lds) && (size_t)cc * y.Bp * y.HLt <= y.ws_floats) ? cc : 0;
+    }
+    else if (w == "scatter_step") {    // sbr_train_step: does the scatter-add step layer 0's index-input block itself? 0 no, 1 dense block, 2 row-sparse block
+        int kb0 = -1;
+        for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 0) kb0 = b;
+        static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
+        const int GHp0 = y.G * y.layer[0].Hp;
+        if (kb0 < 0) *value = dense_scatter_step_ok(h, true) ? 1 : 0;
+        else *value = (h->scat_fuse && y.D == 1 && !y.E && y.a_srpart && !simple_gemm(h) && !simple_rec(h) && range_on != 0 && GHp0 <= 2048 &&
+                       !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && h->tail_nc < 2) ? 2 : 0;
+    }
     else if (w == "cluster") { RecArgs a = rec_args(h, (y.L - 1) * y.D); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
     else if (w == "rec_kernel") {   // family serving the top layer: 0 triage, 1 cluster, 2 x6p (128 units), 3 x6q (32/64), 4 other
         RecArgs a = rec_args(h, (y.L - 1) * y.D);

@@ -1,0 +1,254 @@
+// The full-softmax head of one training step in ONE launch (round 5): logits = h_last . W_out + b, softmax +
+// categorical cross-entropy and its gradient, dh = dlogits . W_out^T  (rnn_one_hot.py:65-71: DenseLayer(softmax) +
+// categorical_crossentropy / target popularity, mean over the batch).
+//
+// Before: three dependent launches on the main stream between the two recurrent chains -- logits GEMM (9 us at C2), softmax +
+// CCE (6 us), dh GEMM (10 us) -- with their launch gaps: 34 us of a 342 us step in which nothing else could run
+// (profiles/round4_z_c2_timeline.txt).  The work itself is 0.24 GFLOP per GEMM and 3.8 MB of logits: latency, not throughput.
+//
+// Here a workgroup owns 16 batch rows x one CHUNK of the catalogue (CW columns, a multiple of 16), and the grid -- row blocks x
+// column chunks, at most one workgroup per CU: at most 256 -- is co-resident, so the softmax's row statistics cross the chunks
+// inside the kernel:
+//   0. the chunk's rows of W_out^T [CW][HP] (item-major: a row is contiguous) go to LDS once, f32, row stride HP + 4 floats;
+//      every wave keeps its 16 rows of h_last in registers as the MFMA's B operand.
+//   1. logits tile by tile (a wave takes the 16-column tiles wave, wave + 4, ...): D[item][row] = sum_k W[item][k] h[row][k] on
+//      v_mfma_f32_16x16x4_f32 (exact f32 products -- no operand split, nothing to bound), one ds_read_b128 per four
+//      instructions (k slot q of instruction m is k0 + 4 q + m).  A lane ends with four consecutive items of one batch row, the
+//      tile stays in registers.
+//   2. row max / sum of exponentials over the chunk (lanes -> waves through LDS), published as one 16-byte piece per (row block,
+//      chunk, row) whose dwords validate themselves against this launch's epoch (value, value ^ epoch: no ordering needed, a
+//      torn piece is simply not valid yet); every workgroup of the row block polls the CC pieces of its rows (agent-scope loads,
+//      bounded by the wall clock: fault bit 5 instead of a hang) and combines them in chunk order -- every workgroup the same
+//      bits.
+//   3. dlogits = (softmax - onehot) / (pop B) from the registers, stored once (the output layer's gradient kernels on the side
+//      stream read them); the row's cost by the lane that holds its target column.
+//   4. dh[row][k] = sum_items dlogits[row][item] W[item][k] with the SAME LDS image (item = reduction index: one ds_read_b32 per
+//      instruction, conflict-free at stride HP + 4) and the dlogits registers as the B operand exactly as phase 3 left them
+//      (k slot q of instruction e of tile t is item 16 t + 4 q + e); the four waves' partial sums meet in LDS and leave as ONE
+//      split-K slab [Bp][HP] per chunk -- what rec_bwd_x6p's prologue already adds up (RecArgs.dh_slabs), else
+//      gemm_splitk_reduce follows.
+// Served: CCE, one direction, full batches (rows == Bp), HP in {32, 64, 128}, and a catalogue whose chunk fits LDS
+// (CW (HP + 4) 4 bytes + 3 KB <= 160 KB with CC = min(16, 256 / (Bp / 16)) chunks: N <= 4 864 at B = 256, HP = 128: C1, C2).  Everything
+// else keeps the three launches.  SBR_HEAD_FUSE=0 switches it off.
+#include "sbr_common.h"
+#include "sbr_rec_p.h"
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HeadArgs {
+    const float* h;        // [Bp][HP] h_last
+    const float* W;        // [N][HP]  W_out^T
+    const float* b;        // [N]
+    const int* tgt;        // [Bp]
+    const float* pop;      // [Bp]
+    float* dlog;           // [Bp][Nl]
+    float* rowcost;        // [Bp]
+    float* slabs;          // [CC][Bp][HP]
+    unsigned* stats;       // [RB][CC][16][4]
+    int* fault;
+    int N, Nl, CW, CC, RB, Bp;
+    float inv_Bg;
+    unsigned epoch;
+};
+
+#define HEAD_NT 5          // tiles per wave at most (CW <= 320)
+#define HEAD_LOG2E 1.4426950408889634f
+
+template <int HP>
+__global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LDW = HP + 4, KG = HP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    // workgroups of one chunk share its W rows: keep them on one XCD (workgroup ids go round-robin over the 8 XCDs)
+    int rb, cc;
+    if ((a.CC & 7) == 0) { const int x = blockIdx.x & 7, li = blockIdx.x >> 3; cc = x * (a.CC >> 3) + li / a.RB; rb = li % a.RB; }
+    else { cc = blockIdx.x / a.RB; rb = blockIdx.x % a.RB; }
+    const int n_lo = cc * a.CW, ntiles = a.CW >> 4;
+    float* Wl = lds;                                                   // [CW][LDW]  (later: the waves' partial dh [4][16][HP])
+    const int wl_floats = max(a.CW * LDW, 64 * HP);
+    float* red = lds + wl_floats;                                      // [4][16][2] wave stats, then [CC][16][2] chunk stats
+    // ---- 0. W chunk -> LDS (rows beyond the catalogue: zeros), h rows -> registers
+    {
+        constexpr int P = HP / 4;                                      // 16-byte pieces per row
+        const int total = a.CW * P;
+        for (int i0 = tid; i0 < total; i0 += 256 * 6) {
+            f32x4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
+                v[u] = (i < total && n_lo + r < a.N) ? *(const f32x4*)(a.W + (size_t)(n_lo + r) * HP + 4 * c4) : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
+                if (i < total) *(f32x4*)(Wl + r * LDW + 4 * c4) = v[u];
+            }
+        }
+    }
+    const int row = rb * 16 + j;
+    f32x4 hb[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) hb[g] = *(const f32x4*)(a.h + (size_t)row * HP + 16 * g + 4 * q);
+    const int y = a.tgt[row];
+    const float scale = a.inv_Bg / a.pop[row];
+    __syncthreads();
+    // ---- 1. logits of this wave's tiles
+    f32x4 lg[HEAD_NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < HEAD_NT; ++i) {
+        const int t = wave + 4 * i;
+        lg[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (t < ntiles) {                                              // wave-uniform
+            f32x4 acc = {0, 0, 0, 0};
+            const float* wr = Wl + (16 * t + j) * LDW + 4 * q;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const f32x4 wv = *(const f32x4*)(wr + 16 * g);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m], hb[g][m], acc, 0, 0, 0);
+            }
+            asm volatile("s_nop 15");                                  // MFMA D -> VALU read (see sbr_gemm.hip)
+            const int c0 = n_lo + 16 * t + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (c0 + r < a.N) ? acc[r] + a.b[c0 + r] : -INFINITY;
+                lg[i][r] = v; mx = fmaxf(mx, v);
+            }
+        }
+    }
+    // ---- 2. row statistics: lanes of a row (q = 0..3), waves, chunks
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float se = 0.0f;
+    if (mx > -INFINITY) {
+#pragma unroll
+        for (int i = 0; i < HEAD_NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) se += __builtin_amdgcn_exp2f((lg[i][r] - mx) * HEAD_LOG2E);      // (-inf -> 0)
+    }
+    se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+    if (q == 0) { red[(wave * 16 + j) * 2] = mx; red[(wave * 16 + j) * 2 + 1] = se; }
+    __syncthreads();
+    if (tid < 16) {                                                    // this chunk's (max, sum) of row tid, published
+        float m = -INFINITY, s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, red[(w * 16 + tid) * 2]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = red[(w * 16 + tid) * 2];
+            if (mw > -INFINITY) s += red[(w * 16 + tid) * 2 + 1] * __builtin_amdgcn_exp2f((mw - m) * HEAD_LOG2E);
+        }
+        unsigned* p = a.stats + ((size_t)(rb * a.CC + cc) * 16 + tid) * 4;
+        const unsigned mb = __float_as_uint(m), sb = __float_as_uint(s);
+        __hip_atomic_store(p + 0, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, mb ^ a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 2, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 3, sb ^ a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                   // (red is rewritten below)
+    if (tid < a.CC * 16) {
+        const int c = tid >> 4, r = tid & 15;
+        const unsigned* p = a.stats + ((size_t)(rb * a.CC + c) * 16 + r) * 4;
+        const unsigned long long t0 = wall_clock64();
+        unsigned d0, d1, d2, d3;
+        for (;;) {
+            d0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((d0 ^ d1) == a.epoch && (d2 ^ d3) == a.epoch) break;
+            if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(a.fault, 32); d0 = __float_as_uint(0.0f); d2 = __float_as_uint(1.0f); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        red[(c * 16 + r) * 2] = __uint_as_float(d0); red[(c * 16 + r) * 2 + 1] = __uint_as_float(d2);
+    }
+    __syncthreads();
+    float M = -INFINITY, S = 0.0f;
+    for (int c = 0; c < a.CC; ++c) M = fmaxf(M, red[(c * 16 + j) * 2]);
+    for (int c = 0; c < a.CC; ++c) {                                   // chunk order: the same bits in every workgroup of the row block
+        const float mc = red[(c * 16 + j) * 2];
+        if (mc > -INFINITY) S += red[(c * 16 + j) * 2 + 1] * __builtin_amdgcn_exp2f((mc - M) * HEAD_LOG2E);
+    }
+    const float inv = 1.0f / S;
+    // ---- 3. dlogits (in the registers of the tile), the row's cost
+#pragma unroll
+    for (int i = 0; i < HEAD_NT; ++i) {
+        const int t = wave + 4 * i;
+        if (t < ntiles) {
+            const int c0 = n_lo + 16 * t + 4 * q;
+            f32x4 d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = lg[i][r];
+                const float p = __builtin_amdgcn_exp2f((v - M) * HEAD_LOG2E) * inv;      // (column beyond the catalogue: 0)
+                const bool hit = c0 + r == y;
+                d[r] = (p - (hit ? 1.0f : 0.0f)) * scale;
+                if (hit) a.rowcost[row] = (logf(S) + M - v) * scale;
+            }
+            lg[i] = d;
+            if (c0 < a.N) *(f32x4*)(a.dlog + (size_t)row * a.Nl + c0) = d;
+        } else lg[i] = f32x4{0, 0, 0, 0};
+    }
+    // ---- 4. dh partial of this chunk
+    f32x4 da[KG];
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt) da[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < HEAD_NT; ++i) {
+        const int t = wave + 4 * i;
+        if (t < ntiles) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* wr = Wl + (16 * t + 4 * q + e) * LDW + j;
+#pragma unroll
+                for (int kt = 0; kt < KG; ++kt) da[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * kt], lg[i][e], da[kt], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_nop 15");
+    __syncthreads();                                                   // every wave has read its W rows: the image becomes the partials
+    float* part = Wl + (size_t)wave * 16 * HP;
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt) *(f32x4*)(part + j * HP + 16 * kt + 4 * q) = da[kt];
+    __syncthreads();
+    float* slab = a.slabs + ((size_t)cc * a.Bp + (size_t)rb * 16) * HP;
+    for (int i = tid; i < 16 * HP / 4; i += 256) {
+        const f32x4 s0 = *(const f32x4*)(Wl + 4 * i), s1 = *(const f32x4*)(Wl + 16 * HP + 4 * i);
+        const f32x4 s2 = *(const f32x4*)(Wl + 32 * HP + 4 * i), s3 = *(const f32x4*)(Wl + 48 * HP + 4 * i);
+        *(f32x4*)(slab + 4 * i) = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// chunks / chunk width for this shape; false: not served
+bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes) {
+    if (!(Hp == 32 || Hp == 64 || Hp == 128) || Bp < 16 || (Bp & 15) || Bp > 4096 || N < 1) return false;
+    const int RB = Bp / 16;
+    if (RB > 256) return false;
+    const int cc = std::min(16, 256 / RB);
+    if (cc < 1) return false;
+    const int cw = ((N + cc - 1) / cc + 15) / 16 * 16;
+    if (cw > 16 * 4 * HEAD_NT) return false;
+    const size_t fl = (size_t)std::max(cw * (Hp + 4), 64 * Hp) + 2 * 16 * std::max(4, cc) + 64;
+    if (fl * 4 > 160 * 1024) return false;
+    *CC = cc; *CW = cw; *lds_bytes = fl * 4;
+    return true;
+}
+
+// slabs: CC * Bp * Hp floats; stats: (Bp / 16) * CC * 64 unsigned; false: shape not served, nothing launched
+bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const float* bout, const int* tgt, const float* pop, float* dlogits,
+                     float* rowcost, float* slabs, size_t slab_floats, unsigned* stats, int* fault, int Bp, int N, int Nl, int Hp, int Bglobal,
+                     unsigned epoch, int* n_slabs, hipError_t* err) {
+    int CC = 0, CW = 0; size_t lds = 0;
+    if (!sbr_head_plan(Bp, N, Hp, &CC, &CW, &lds) || (size_t)CC * Bp * Hp > slab_floats || epoch == 0) return false;
+    HeadArgs a;
+    a.h = h; a.W = WoutT; a.b = bout; a.tgt = tgt; a.pop = pop; a.dlog = dlogits; a.rowcost = rowcost; a.slabs = slabs; a.stats = stats;
+    a.fault = fault; a.N = N; a.Nl = Nl; a.CW = CW; a.CC = CC; a.RB = Bp / 16; a.Bp = Bp; a.inv_Bg = 1.0f / (float)Bglobal; a.epoch = epoch;
+    const int grid = a.RB * CC;
+    if (Hp == 128) { SBR_DYN_LDS(head_cce_kernel<128>, lds); head_cce_kernel<128><<<grid, 256, lds, s>>>(a); }
+    else if (Hp == 64) { SBR_DYN_LDS(head_cce_kernel<64>, lds); head_cce_kernel<64><<<grid, 256, lds, s>>>(a); }
+    else { SBR_DYN_LDS(head_cce_kernel<32>, lds); head_cce_kernel<32><<<grid, 256, lds, s>>>(a); }
+    *n_slabs = CC;
+    *err = hipGetLastError();
+    return true;
+}

@@ -1348,7 +1348,7 @@ bool sbr_rec_fwd_can_fuse_gather(const RecArgs& a, bool simple) {
     if (simple || a.f32_mfma) return false;
     if (sbr_rec_cluster_ok(a)) return true;               // rec_fwd_cl gathers its own rows too
     if (!(Hp == 32 || Hp == 64 || Hp == 128)) return false;
-    if (sbr_rec_x6p_ok(a) && a.T > SBR_X6P_FUSE_MAX_T) return false;   // rec_fwd_x6p keeps the tile's row offsets in LDS
+    if (sbr_rec_x6p_ok(a) && !sbr_rec_x6p_fuse_ok(a)) return false;    // rec_fwd_x6p: row offsets in LDS (T), 32-bit offsets into W_in (n_in)
     const size_t l4 = (size_t)a.G * (Hp / 32) * (Hp / 16) * 1024 + 2 * 3 * 4 * (size_t)(Hp * 2 + 32);
     return a.rpt == 4 && a.x6_split && l4 <= 160 * 1024;
 }

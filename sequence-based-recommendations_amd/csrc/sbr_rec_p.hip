@@ -1127,12 +1127,18 @@ bool sbr_rec_x6p_ok(const RecArgs& a) {
     // fp16 forms (one answer for the forward and the backward launch of a step: they share the saved activations' layout)
     if (a.G > 3 && !(x6p_f16_fwd(a) && x6p_f16_bwd(a))) return false;
     if ((size_t)a.Bp * a.G * HP * 4 >= ((size_t)1 << 32)) return false;          // 32-bit per-lane byte offsets
-    if (a.gX && (size_t)a.n_in * a.G * HP * 4 >= ((size_t)1 << 32)) return false; // ... also into W_in (fused gather)
-    if (a.gX && a.T > SBR_X6P_FUSE_MAX_T) return false;                            // its row-offset table lives in LDS
+    // (NOT a function of a.gX: the forward and the backward launch of a step must get the same answer -- they share the saved
+    // gates' layout (X6P_G4).  Whether the gather can be fused is sbr_rec_fwd_can_fuse_gather's decision, made before gX is set;
+    // launch_fwd_p refuses a fused launch outside those bounds instead of silently taking another kernel family.)
     if (X6P_G4 && a.cell != SBR_CELL_VANILLA && a.g[0])                            // one region [T][Bp][HP][4] under the four arrays
         for (int k = 1; k < 4; ++k) if (a.g[k] != a.g[0] + (size_t)k * a.T * a.Bp * HP) return false;
     if (X6P_G4 && (size_t)a.Bp * HP * 16 >= ((size_t)1 << 32)) return false;
     return true;
+}
+
+// the fused gather of rec_fwd_x6p: 32-bit per-lane byte offsets into W_in, and the tile's row-offset table (R x T) in LDS
+bool sbr_rec_x6p_fuse_ok(const RecArgs& a) {
+    return (size_t)a.n_in * a.G * HP * 4 < ((size_t)1 << 32) && a.T <= SBR_X6P_FUSE_MAX_T;
 }
 
 template <int CELL>
@@ -1149,6 +1155,7 @@ static hipError_t launch_fwd_p(hipStream_t s, const RecArgs& a) {
         SBR_DYN_LDS(KERNEL, lds); \
         KERNEL<<<nb, 512, lds, s>>>(a); } while (0)
     const bool fuse = a.gX != nullptr;
+    if (fuse && !sbr_rec_x6p_fuse_ok(a)) return hipErrorInvalidValue;          // (sbr_rec_fwd_can_fuse_gather says when)
     const bool f16 = x6p_f16_fwd(a);
     if constexpr (CELL == CELL_LSTM) {
         if (!f16) return hipErrorInvalidValue;                     // (sbr_rec_x6p_ok says when)

@@ -123,7 +123,7 @@ def params_ok(r, steps=2, bar=1e-3, tol_g=1e-4):
 
 def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater="adam", flags=0, full=False,
                  reg=0.0, steps=2, popscale=1.0, scale=None, emb=0, bi=False, zipf=False, k=None, gap=0.0, tweak=None,
-                 balance=1.0, unique=True, default_target=None, grad_floor=1e-12):
+                 balance=1.0, unique=True, default_target=None, grad_floor=1e-12, queries=()):
     """Returns dict of relative errors (engine float32 vs oracle float64).
     grad_floor: added to the largest oracle magnitude of a gradient array before dividing -- arrays far smaller than it are
     compared absolutely (the fp16 split of the BPTT chain's gradient operand has an absolute floor, csrc/sbr_rec_p.hip).
@@ -141,6 +141,8 @@ def compare_step(cell, layers, loss, N, B, T, S=0, seed=0, F=1, n_opt=0, updater
     obatch = margin_oracle_batch(batch, N, balance, unique, default_target) if margin else oracle_batch(batch)
     out = {}
     try:
+        for qn in queries:      # which kernels this engine selected (sbr_query): out["q:<name>"]
+            out["q:" + qn] = float(eng.query(qn))
         eng.set_all_param_values(params)
         back = eng.get_all_param_values()
         out["param_roundtrip"] = max(rel_err(a, b) for a, b in zip(back, params))
