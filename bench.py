@@ -182,34 +182,62 @@ def mfma_counter_pass(argv_child, log):
     return out
 
 
-def other_config_lines(log, names=("c1", "c4", "c3", "c5"), budget_s=420.0):
+def strong_scaling_pieces(log, budget_s=150.0):
+    """Single-rank steps at the per-GPU shares of a FIXED global batch of 256 (the reference's -b: SURVEY 8e strong scaling) -- what a
+    rank of a 2 / 4 / 8-GPU job computes between its collectives: C2 and C4 at B_local = 128 / 64 / 32, child runs of this file
+    (--quick: timed regions only).  The chains are 2 T dependent steps whatever the rows, so these do not shrink like 1 / N."""
+    import subprocess
+    out, t_all = {}, time.perf_counter()
+    for name in ("c2", "c4"):
+        for bl in (128, 64, 32):
+            key = "%s_b%d" % (name, bl)
+            if budget_s - (time.perf_counter() - t_all) < 15:
+                out[key] = {"skipped": "time budget spent"}
+                continue
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--quick", "--batch", str(bl), "--steps", "20",
+                                    "--warmup", "5", "--repeats", "3"], capture_output=True, text=True, timeout=60)
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                out[key] = {"ranks_of_global_256": 256 // bl, "rows_per_rank": bl, "ms_per_step": d["ms_per_step"],
+                            "sequences_per_s_per_rank": d["value"]}
+                log("strong-scaling piece %s: %.4f ms/step" % (key, d["ms_per_step"]))
+            except Exception as ex:
+                out[key] = {"skipped": repr(ex)[:200]}
+    out["note"] = ("measured on ONE GPU (no collective): the compute of one rank of an N-rank job at global batch 256; an N-GPU step is this "
+                   "plus the exposed part of its gradient exchange (DESIGN.md section 6: modelled, never measured on more than one GPU)")
+    return out
+
+
+def other_config_lines(log, names=("c1", "c4", "c3", "c5", "c5_bf16"), budget_s=520.0):
     """The other BASELINE configurations next to the headline one, each as a child run of this file (--brief: phase survey, chain-only
     timing, three timed regions): {name: {ms_per_step, value, roofline_frac, ...}}.  C5 builds a 47 GB arena and draws 2.6e9 initial
     values on the host first (~45 s); a configuration that does not fit the time budget is reported as skipped, with the reason."""
     import subprocess
     out, t_all = {}, time.perf_counter()
-    for name, limit in ((n, {"c1": 120, "c4": 150, "c3": 150, "c5": 300}[n]) for n in names):
+    for key, limit in ((n, {"c1": 120, "c4": 150, "c3": 150, "c5": 300, "c5_bf16": 300}[n]) for n in names):
+        # "c5_bf16": BASELINE configs[4] on the arithmetic it names -- bf16 MFMA output projection and bf16 layer GEMMs (--flags 384)
+        name, extra = (key, []) if key != "c5_bf16" else ("c5", ["--flags", "384"])
         left = budget_s - (time.perf_counter() - t_all)
         if left < 30:
-            out[name] = {"skipped": "time budget of the default run spent (%d s)" % budget_s}
+            out[key] = {"skipped": "time budget of the default run spent (%d s)" % budget_s}
             continue
         t0 = time.perf_counter()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--brief", "--steps", "20", "--warmup", "5",
-                                "--repeats", "3"], capture_output=True, text=True, timeout=min(limit, left))
+                                "--repeats", "3"] + extra, capture_output=True, text=True, timeout=min(limit, left))
             d = json.loads(r.stdout.strip().splitlines()[-1])
             rf, ch = d.get("roofline") or {}, d.get("chains") or {}
-            out[name] = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+            out[key] = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "dtype": d.get("dtype"),
                          "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_us")},
                          "chains_us": {"rec_fwd": ch.get("rec_fwd_us"), "rec_bwd": ch.get("rec_bwd_us")},
                          "outside_chains_us": ch.get("outside_chains_us"),
                          "phases_us": {k: v for k, v in (d.get("phases_us") or {}).items() if k != "note"},
                          "arithmetic": d["config"].get("arithmetic"), "wall_s": round(time.perf_counter() - t0, 1)}
-            log("other config %s: %.4f ms/step (%.0f s)" % (name, d["ms_per_step"], time.perf_counter() - t0))
+            log("other config %s: %.4f ms/step (%.0f s)" % (key, d["ms_per_step"], time.perf_counter() - t0))
         except subprocess.TimeoutExpired:
-            out[name] = {"skipped": "child run exceeded %d s" % min(limit, left)}
+            out[key] = {"skipped": "child run exceeded %d s" % min(limit, left)}
         except Exception as ex:
-            out[name] = {"skipped": repr(ex)[:200]}
+            out[key] = {"skipped": repr(ex)[:200]}
     return out
 
 
@@ -264,7 +292,8 @@ def main():
     ap.add_argument("--brief", action="store_true", help="phase survey + timed regions + roofline only (what the default run starts "
                     "for the other BASELINE configurations): no counter / sustained / train-loop / CPU / side-kernel legs")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of BASELINE configs c1 / c3 / c4 / c5")
-    ap.add_argument("--other-configs", default="c1,c4,c3,c5", help="which of them the default run starts (comma-separated, in this order)")
+    ap.add_argument("--other-configs", default="c1,c4,c3,c5,c5_bf16", help="which of them the default run starts (comma-separated, in this order; "
+                    "c5_bf16 = C5 with --flags 384: bf16 output projection + bf16 layer GEMMs, the arithmetic BASELINE configs[4] names)")
     ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the data-parallel step: nccl = RCCL over xGMI (one rank per GPU); gloo lets several "
                          "ranks share one device (RCCL refuses that) -- how the one-GPU test box exercises --gpus 2")
@@ -661,6 +690,19 @@ def main():
                                                  "note": "gather_xt_kernel alone (SBR_FUSE_GATHER=0 engine, same batch): rows in, xt out"}
                 except Exception as ex:
                     log("unfused gather timing skipped:", ex)
+                # ... and the scatter-add of the embedding gradient on its own (sbr_debug_scatter: the step's stand-alone form for this
+                # shape over the same batch, nothing beside it): bytes = the dxt rows read + the ids + the gradient rows written
+                try:
+                    us_s, n_ent, n_rows_w = eng.debug_scatter(20)
+                    gb_s = n_ent * (row_bytes + 4.0) + n_rows_w * row_bytes
+                    kernels["scatter_unfused"] = {"bound": "hbm", "unit": "GB/s", "us": round(us_s, 2), "entries": n_ent, "rows_written": n_rows_w,
+                                                  "achieved": round(gb_s / (us_s * 1e-6) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                                                  "frac": round(gb_s / (us_s * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                                  "note": "the stand-alone scatter-add launch(es) of this shape alone on the chip (sort excluded): dxt rows "
+                                                          "+ ids in, one gradient row per distinct id out; the step itself runs it beside the BPTT chain "
+                                                          "(kernels.scatter = what is left of it behind the chain)"}
+                except Exception as ex:
+                    log("stand-alone scatter-add timing skipped:", ex)
         # the dense output projection on its own (logits = h . W_out^T, rnn_one_hot.py:65): the same kernel the step
         # runs, timed with HIP events on this shape (north_star: MFMA utilisation of the output projection)
         try:
@@ -803,9 +845,13 @@ def main():
             and (B, T, args.lengths) == (256, 200, "full")):
         try:
             torch.cuda.empty_cache()
-            result["other_configs"] = other_config_lines(log, [n for n in args.other_configs.split(",") if n in ("c1", "c3", "c4", "c5")])
+            result["other_configs"] = other_config_lines(log, [n for n in args.other_configs.split(",") if n in ("c1", "c3", "c4", "c5", "c5_bf16")])
         except Exception as ex:
             result["other_configs"] = {"error": repr(ex)[:300]}
+        try:
+            result["strong_scaling_model"] = strong_scaling_pieces(log)
+        except Exception as ex:
+            result["strong_scaling_model"] = {"error": repr(ex)[:300]}
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)          # (C stdio buffers of the libraries: out through the redirected descriptor)

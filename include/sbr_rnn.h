@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 8
+#define SBR_ABI_VERSION 9
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -306,6 +306,13 @@ int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
  * on = 0: stop and report us[0] / us[1] = device time summed over the forward / backward chain launches since the start,
  * n[0] / n[1] = the number of launches (us, n may be NULL with on = 1).  A survey facility: the records delay the stream. */
 int sbr_chain_times(sbr_handle* h, int on, float us[2], int n[2]);
+/* The scatter-add of the embedding gradient ON ITS OWN (ABI 9; tooling: bench.py's `kernels.scatter_unfused`, north_star "achieved
+ * HBM GB/s on the embedding gather/scatter"): the gradient of sparse_lstm.py:368's gather (AdvancedIncSubtensor), layer 0's
+ * dW_in[X[b][t][f]][:] += dxt[t][b][:] over the current batch, as the step's stand-alone form for this shape runs it -- counting
+ * sort of the ids once, then `reps` launches of the scatter-add on the engine's stream between two HIP events, nothing beside
+ * them; *us = mean microseconds per launch, *entries = valid (t, b, f) positions, *rows = distinct ids (gradient rows written).
+ * dxt holds whatever the last backward pass left; the gradient block is cleared again afterwards.  Index-input layer 0 only. */
+int sbr_debug_scatter(sbr_handle* h, int reps, float* us, int64_t* entries, int64_t* rows);
 
 /* ------------------------------------------------------------------------------------------------
  * Native batch builder: replaces SequenceGenerator + _gen_mini_batch + _prepare_input

@@ -415,12 +415,16 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
     h->out_early = false; h->win_early = false; h->dh_slabs_n = 0;
-    { const char* e = getenv("SBR_SCAT_FUSE"); h->scat_fuse = e ? atoi(e) : 1; }
+    // (default 0: measured no gain -- C4 1.324 -> 1.375, C3 1.484 -> 1.485, C5 equal: the fused kernel's waves hold a row's state
+    // beside its dxt rows and run at 1.5 - 2.3 TB/s where the two-pass form streams the state at 3.6 - 6.2; profiles/round5_a_*)
+    { const char* e = getenv("SBR_SCAT_FUSE"); h->scat_fuse = e ? atoi(e) : 0; }
     { const char* e = getenv("SBR_WIN_REST"); h->win_rest = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_SPARSE_OUT_EARLY"); h->sparse_out_early = e ? atoi(e) : 1; }
     h->win_fused = false; h->win_rest_pending = false; h->win_rest_done = false; h->cells_early = false; h->wout_early = false;
     h->ev_cells = nullptr; h->mark_epoch = 0;
     { const char* e = getenv("SBR_HEAD_FUSE"); h->head_fuse = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_OUT_FUSE"); h->out_fuse = e ? atoi(e) : 1; }
+    h->out_stepped = false;
     h->head_epoch = 0;
     h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
@@ -1178,12 +1182,29 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         h->out3_stream = (h->tail_out_stream == 2 && h->tail_mon_units && h->tail_cost_scanned) ? h->side3 : h->side2;
         hipStream_t so = h->out3 ? h->out3_stream : sd;
         if (h->out3) SBR_HIP(hipStreamWaitEvent(so, h->ev_lg_rec, 0));
+        // Single-call step without a bias regulariser: the output layer's gradient, its step and the batch cost in ONE launch
+        // (launch_out_grad_step, sbr_misc.hip) instead of the five or six below -- the polling weight-gradient GEMM of the overlapped
+        // tail, next on this stream, then starts with the chain instead of 68 us into it.  SBR_OUT_FUSE=0: as before.
+        h->out_stepped = false;
+        const bool will_step_here = h->in_train_step && !y.n_sparse && !sg && (h->tail_nc == 0 || (h->tail_nc >= 2 && y.L == 1));
+        if (h->out_fuse && will_step_here && y.cfg.regularization == 0.0f && y.D == 1) {
+            hipError_t oe = hipSuccess;
+            float* s1e = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+            if (launch_out_grad_step(so, lg, hl, h->A(y.a_rowcost), h->cost_ptr(), y.cfg.updater, h->P(y.p_WoutT), h->St(0, y.p_WoutT),
+                                     s1e ? s1e + y.p_WoutT : nullptr, h->P(y.p_bout), h->St(0, y.p_bout), s1e ? s1e + y.p_bout : nullptr,
+                                     R, N, Nl, Hp, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1, &oe)) {
+                SBR_LAUNCH(oe);
+                h->out_stepped = true;
+            }
+        }
+        if (!h->out_stepped) {
         SBR_LAUNCH(launch_sum_cost(so, h->A(y.a_rowcost), R, h->cost_ptr()));
         // data-parallel: every rank adds its share of the bias regulariser, shares sum to reg
         const float reg = y.cfg.regularization * (float)R / (float)y.Bg;
         SBR_LAUNCH(launch_colsum_bias(so, lg, R, N, Nl, h->Gd(y.p_bout), h->P(y.p_bout), reg, h->cost_ptr(), h->A(y.a_csum)));
         SBR_LAUNCH(launch_gemm(so, lg, 1, Nl, hl, Hp, 1, h->Gd(y.p_WoutT), Hp, N, Hp, R, nullptr, h->out3 ? h->A(y.a_ws3) : ws2,
                                h->out3 ? y.ws3_floats : y.ws2_floats, sg));
+        }
         SBR_HIP(hipEventRecord(h->ev_og, so)); h->og_recorded = true;   // output-layer gradients + cost complete
         // Single-call step, dense updates: the output layer is stepped right here, beside the BPTT chain (nothing reads W_out
         // any more: dh was computed in front of the record the side stream waited on); sbr_apply_update leaves the range
@@ -1191,6 +1212,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // data parallel -- reduce the gradients first.)
         if (h->in_train_step && !y.n_sparse && h->tail_nc == 0 && !simple_gemm(h)) {
             float* s1e = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+            if (!h->out_stepped)
             SBR_LAUNCH(launch_update(sd, y.cfg.updater, h->P(y.p_split), h->Gd(y.p_split), h->St(0, y.p_split), s1e ? s1e + y.p_split : nullptr,
                                      y.n_params - y.p_split, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
             h->out_early = true;
@@ -1212,15 +1234,25 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, Wc, 1, Hp, act, C, R, C, Hp, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->bpop, h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
                                        y.cfg.loss, y.Bg));
-        SBR_LAUNCH(launch_sum_cost(s, h->A(y.a_rowcost), R, h->cost_ptr()));
-        SBR_LAUNCH(launch_colsum_bias(s, act, R, C, C, dbc, nullptr, 0.0f, nullptr, h->A(y.a_csum)));
-        SBR_LAUNCH(launch_gemm(s, act, 1, C, hl, Hp, 1, dWc, Hp, C, Hp, R, nullptr, nullptr, 0, sg));
-        SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
-        SBR_LAUNCH(launch_scatter_cells(s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
-        SBR_HIP(hipEventRecord(h->ev_og, s)); h->og_recorded = true;
-        h->ev_lg_rec = h->ev_og;
-        if (!fill_needed) {      // the sampled heads keep the main stream: the batch-only side work follows this record
-            SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
+        // Round 5: dh feeds the BPTT chain, everything else here only feeds the optimizer -- cost sum, bias column sums, the dWc GEMM
+        // and the scatter of the cells' gradients (5 launches, ~75 us at C3 beside the side stream's sort) leave the main stream: dh
+        // first, one record, the rest on the side stream beside the chain (as the dense heads always did).  SBR_SAMPLED_SIDE=0: rounds 1 - 4.
+        static const int sampled_side = [] { const char* e = getenv("SBR_SAMPLED_SIDE"); return e ? atoi(e) : 1; }();
+        hipStream_t sg_s = sampled_side ? sd : s;
+        if (sampled_side) {
+            SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
+            h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
+            SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
+        }
+        SBR_LAUNCH(launch_sum_cost(sg_s, h->A(y.a_rowcost), R, h->cost_ptr()));
+        SBR_LAUNCH(launch_colsum_bias(sg_s, act, R, C, C, dbc, nullptr, 0.0f, nullptr, h->A(y.a_csum)));
+        SBR_LAUNCH(launch_gemm(sg_s, act, 1, C, hl, Hp, 1, dWc, Hp, C, Hp, R, nullptr, nullptr, 0, sg));
+        if (!sampled_side) SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
+        SBR_LAUNCH(launch_scatter_cells(sg_s, h->Gd(y.p_WoutT), h->Gd(y.p_bout), dWc, dbc, cells, C, Hp));
+        SBR_HIP(hipEventRecord(h->ev_og, sg_s)); h->og_recorded = true;
+        if (!sampled_side) h->ev_lg_rec = h->ev_og;
+        if (!fill_needed) {      // the batch-only side work follows (the side stream has waited for this phase's record)
+            if (!sampled_side) SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
             const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
         }
         // Single-call step: the head's row-sparse block (W_out^T rows + b_out of the sampled cells) has its complete gradient now
@@ -1230,7 +1262,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         if (h->in_train_step && h->sparse_out_early)
             for (int b = 0; b < y.n_sparse; ++b)
                 if (y.sparse[b].kind == 1 && !h->sp_exchanged[b]) {
-                    SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));
+                    SBR_HIP(hipStreamWaitEvent(sd, h->ev_og, 0));      // (recorded on this very stream unless SBR_SAMPLED_SIDE=0)
                     SBR_LAUNCH(launch_sparse_step_list(sd, sparse_rows(h, b), sparse_upd(h), (const int*)h->A(y.a_cells), nullptr, C, C,
                                                        (int)h->step_count + 1));
                     h->wout_early = true;
@@ -1375,6 +1407,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             // side stream: output layer first (its gradients are complete on this stream: dW_out GEMM, bias sums)
             const bool out_early = upd_here && (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss));
             if (out_early) {
+                if (!h->out_stepped)       // (else: launch_out_grad_step has stepped the output layer with its gradient, sbr_loss_backward_output)
                 SBR_LAUNCH(upd_on(h->out3 ? h->out3_stream : sd, y.p_split, y.n_params));
                 if (h->out3) SBR_HIP(hipEventRecord(h->ev_tail3, h->out3_stream));
             }
@@ -2033,6 +2066,58 @@ extern "C" int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t
                                       ws_floats, false);
     sbr_gemm_set_planes(3);
     SBR_LAUNCH(ge);
+    return SBR_OK;
+}
+
+// the stand-alone scatter-add of layer 0's embedding gradient over the current batch, timed on its own (include/sbr_rnn.h)
+extern "C" int sbr_debug_scatter(sbr_handle* h, int reps, float* us, int64_t* entries, int64_t* rows) {
+    CHECK_ARG(h && us && reps >= 1 && reps <= 1000, "bad argument");
+    const Layout& y = h->lay;
+    if (!h->have_batch || y.E || y.D != 1) { sbr_set_error("sbr_debug_scatter: needs a batch and an index-input, one-direction layer 0"); return SBR_ESTATE; }
+    const LayerLayout& ly = y.layer[0];
+    const int GHp = y.G * ly.Hp;
+    hipStream_t s = h->stream;
+    SBR_HIP(hipDeviceSynchronize());                      // nothing beside it
+    SBR_LAUNCH(launch_scatter_sort(s, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt), (int*)h->A(y.a_soff),
+                                   (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0, 0, 1, nullptr, &h->scnt_zero_n));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SBR_HIP(hipEventCreate(&e0)); SBR_HIP(hipEventCreate(&e1));
+    float* dW = h->Gd(ly.p_Win);
+    const float* dxt = h->A(ly.a_dxt);
+    static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
+    auto one = [&]() -> int {
+        hipError_t se = hipSuccess;
+        if (range_on == 1 && y.a_srpart && GHp <= 1024 &&
+            launch_scatter_range(s, dW, dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
+                                 y.cfg.input_size, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) { SBR_LAUNCH(se); }
+        else if (range_on == 2 && y.a_srpart &&
+                 launch_scatter_wide(s, dW, dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
+                                     y.cfg.input_size, y.T * y.Bp * y.F, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) { SBR_LAUNCH(se); }
+        else SBR_LAUNCH(launch_scatter_reduce(s, dW, dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
+                                              y.cfg.input_size, y.T * y.Bp * y.F, GHp, y.Bp));
+        return SBR_OK;
+    };
+    for (int i = 0; i < 2; ++i) { const int rc = one(); if (rc != SBR_OK) return rc; }
+    SBR_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) { const int rc = one(); if (rc != SBR_OK) return rc; }
+    SBR_HIP(hipEventRecord(e1, s));
+    SBR_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SBR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *us = ms * 1000.0f / (float)reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (entries || rows) {
+        std::vector<int> off((size_t)y.cfg.input_size + 1);
+        SBR_HIP(hipMemcpy(off.data(), h->A(y.a_soff), off.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int64_t nr = 0;
+        for (int i = 0; i < y.cfg.input_size; ++i) nr += off[i + 1] > off[i];
+        if (entries) *entries = off[y.cfg.input_size];
+        if (rows) *rows = nr;
+    }
+    // the gradient block as a step expects it: zero (the rows the scatter-add wrote, i.e. the whole block)
+    SBR_HIP(hipMemsetAsync(dW, 0, (size_t)y.cfg.input_size * GHp * sizeof(float), s));
+    SBR_HIP(hipStreamSynchronize(s));
+    h->tail_sorted = false;
     return SBR_OK;
 }
 

@@ -168,6 +168,8 @@ struct sbr_handle {
     int mark_epoch;
     int head_fuse;       // SBR_HEAD_FUSE (default 1): the full-softmax head in one launch (sbr_head.hip)
     unsigned head_epoch;
+    int out_fuse;        // SBR_OUT_FUSE (default 1): the dense head's gradient and step in one launch (launch_out_grad_step)
+    bool out_stepped;    // this step: done, the output layer's range needs no update launch
     int dh_slabs_n;      // > 0: dh_last of this step sits in the main workspace as that many unreduced split-K slabs
     std::vector<ParamDesc> descs;
     int rpt;             // rows per workgroup for the bf16x6 recurrent kernels
@@ -508,6 +510,10 @@ hipError_t launch_update_rows(hipStream_t s, int updater, float* p, float* g, fl
 // (launch_mark_rows: needs the batch only, not its sort)
 hipError_t launch_update_untouched_rows(hipStream_t s, int updater, float* p, float* s0, float* s1, int n_rows, int row_floats,
                                         const int* offs, const int* mark, int epoch, float lr, float rho, float b1, float b2, long t);
+// the output layer's gradient + its step in one launch (sbr_misc.hip); false: shape not served
+bool launch_out_grad_step(hipStream_t s, const float* dlogits, const float* h_last, const float* rowcost, float* cost, int updater,
+                          float* W, float* Ws0, float* Ws1, float* b, float* bs0, float* bs1, int R, int N, int Nl, int Hp, float lr,
+                          float rho, float b1, float b2, long t, hipError_t* err);
 hipError_t launch_mark_rows(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* mark, int epoch);
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);

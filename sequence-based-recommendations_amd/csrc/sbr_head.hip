@@ -69,29 +69,31 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
     const int wl_floats = max(a.CW * LDW, 64 * HP);
     float* red = lds + wl_floats;                                      // [4][16][2] wave stats, then [CC][16][2] chunk stats
     // ---- 0. W chunk -> LDS (rows beyond the catalogue: zeros), h rows -> registers
-    {
-        constexpr int P = HP / 4;                                      // 16-byte pieces per row
-        const int total = a.CW * P;
-        for (int i0 = tid; i0 < total; i0 += 256 * 6) {
-            f32x4 v[6];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
-                v[u] = (i < total && n_lo + r < a.N) ? *(const f32x4*)(a.W + (size_t)(n_lo + r) * HP + 4 * c4) : f32x4{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
-                if (i < total) *(f32x4*)(Wl + r * LDW + 4 * c4) = v[u];
-            }
-        }
-    }
     const int row = rb * 16 + j;
     f32x4 hb[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) hb[g] = *(const f32x4*)(a.h + (size_t)row * HP + 16 * g + 4 * q);
     const int y = a.tgt[row];
     const float scale = a.inv_Bg / a.pop[row];
+    {
+        // (rounds of 16 pieces per thread in flight: C2's chunk of 240 rows x 128 floats is 30 pieces per thread -- in rounds of 6
+        // the fill was five dependent round trips to L2, ~10 of the kernel's 22 us: profiles/round5_a_c2_timeline.txt)
+        constexpr int P = HP / 4, U = 16;                              // 16-byte pieces per row
+        const int total = a.CW * P;
+        for (int i0 = tid; i0 < total; i0 += 256 * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
+                v[u] = (i < total && n_lo + r < a.N) ? *(const f32x4*)(a.W + (size_t)(n_lo + r) * HP + 4 * c4) : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
+                if (i < total) *(f32x4*)(Wl + r * LDW + 4 * c4) = v[u];
+            }
+        }
+    }
     __syncthreads();
     // ---- 1. logits of this wave's tiles
     f32x4 lg[HEAD_NT];

@@ -1847,6 +1847,101 @@ hipError_t launch_mark_rows(hipStream_t s, const int* X, const int* len, int T, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// The output layer's gradient AND its optimizer step in one launch (round 5; single-call steps of the dense heads, no bias
+// regulariser): dW_out^T[n][k] = sum_rows dlogits[row][n] h[row][k], db[n] = sum_rows dlogits[row][n], cost = sum_rows rowcost
+// (rnn_one_hot.py:65-77 backward + update_manager.py:24-82).  Before: sum_cost, two column-sum kernels, the dW_out GEMM (+ its
+// split-K reduction) and update_kernel -- five to six launches, 50 - 60 us with their gaps on the side stream, IN FRONT of the
+// polling weight-gradient GEMM of the overlapped tail, which therefore started 68 us into a 138 us BPTT chain and ended 39 us
+// behind it (profiles/round4_z_c2_timeline.txt).  Here a workgroup owns 16 items: its four waves split the batch rows, every
+// wave accumulates D[k][item] over its rows on v_mfma_f32_16x16x4_f32 (k slot q = row r0 + q; operands straight from L2: 64
+// contiguous bytes per 16 lanes), the partial sums meet in LDS, and the thread that holds four consecutive k of an item steps
+// W_out^T[item][k .. k + 3] (update_element's arithmetic: scat_step4); the gradient arrays are never written (they stay zero).
+// ---------------------------------------------------------------------------------------
+template <int HP>
+__global__ void __launch_bounds__(256) out_grad_step_kernel(const float* __restrict__ dlog, const float* __restrict__ h,
+                                                            const float* __restrict__ rowcost, float* __restrict__ cost, SbrScatStep st,
+                                                            float* __restrict__ bp, float* __restrict__ bs0, float* __restrict__ bs1,
+                                                            int R, int N, int Nl) {
+    constexpr int KG = HP / 16;
+    __shared__ __attribute__((aligned(16))) f32x4 part[4][KG][64];
+    __shared__ float dbp[4][16];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const bool col_in = n0 + j < N;
+    const int rpw = ((R + 3) / 4 + 3) / 4 * 4;                       // rows per wave, a multiple of 4
+    const int r_lo = wave * rpw, r_hi = min(R, r_lo + rpw);
+    f32x4 acc[KG];
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt) acc[kt] = f32x4{0, 0, 0, 0};
+    float dbv = 0.0f;
+    for (int r0 = r_lo; r0 < r_hi; r0 += 16) {                      // four row groups per round: their 4 + 4 KG loads in flight together
+        float d[4], hv[4][KG];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = r0 + 4 * u + q;
+            const bool in = row < r_hi;
+            d[u] = (in && col_in) ? dlog[(size_t)row * Nl + n0 + j] : 0.0f;
+            const float* hr = h + (size_t)(in ? row : r_lo) * HP + j;
+#pragma unroll
+            for (int kt = 0; kt < KG; ++kt) hv[u][kt] = in ? hr[16 * kt] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dbv += d[u];
+#pragma unroll
+            for (int kt = 0; kt < KG; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][kt], d[u], acc[kt], 0, 0, 0);
+        }
+    }
+    asm volatile("s_nop 15");                                        // MFMA D -> VALU read across the loop exit
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt) part[wave][kt][lane] = acc[kt];
+    dbv += __shfl_xor(dbv, 16); dbv += __shfl_xor(dbv, 32);
+    if (q == 0) dbp[wave][j] = dbv;
+    if (blockIdx.x == 0) {                                           // the batch cost: fixed order
+        float c = 0.0f;
+        for (int r = tid; r < R; r += 256) c += rowcost[r];
+        c = block_sum(c, red);
+        if (tid == 0) *cost = c;
+    }
+    __syncthreads();
+    for (int i = tid; i < KG * 64; i += 256) {
+        const int kt = i >> 6, ln = i & 63, item = n0 + (ln & 15), k = 16 * kt + 4 * (ln >> 4);
+        if (item >= N) continue;
+        const f32x4 g = (part[0][kt][ln] + part[1][kt][ln]) + (part[2][kt][ln] + part[3][kt][ln]);
+        const size_t o = (size_t)item * HP + k;
+        f32x4 pv = *(const f32x4*)(st.p + o), av = *(const f32x4*)(st.s0 + o), bv = st.s1 ? *(const f32x4*)(st.s1 + o) : f32x4{0, 0, 0, 0};
+        scat_step4(st, g, pv, av, bv);
+        *(f32x4*)(st.p + o) = pv; *(f32x4*)(st.s0 + o) = av;
+        if (st.s1) *(f32x4*)(st.s1 + o) = bv;
+    }
+    if (tid < 16 && n0 + tid < N) {
+        const float g = (dbp[0][tid] + dbp[1][tid]) + (dbp[2][tid] + dbp[3][tid]);
+        float pe = bp[n0 + tid], ae = bs0[n0 + tid], be = bs1 ? bs1[n0 + tid] : 0.0f;
+        scat_step1(st, g, pe, ae, be);
+        bp[n0 + tid] = pe; bs0[n0 + tid] = ae;
+        if (bs1) bs1[n0 + tid] = be;
+    }
+}
+
+// W: W_out^T [N][Hp] with its state arrays (s1 NULL: one state array), b: b_out [N] likewise; false: shape not served
+bool launch_out_grad_step(hipStream_t s, const float* dlogits, const float* h_last, const float* rowcost, float* cost, int updater,
+                          float* W, float* Ws0, float* Ws1, float* b, float* bs0, float* bs1, int R, int N, int Nl, int Hp, float lr,
+                          float rho, float b1, float b2, long t, hipError_t* err) {
+    if (!(Hp == 32 || Hp == 64 || Hp == 128) || R < 1 || N < 1) return false;
+    SbrScatStep st; st.p = W; st.s0 = Ws0; st.s1 = Ws1; st.last = nullptr; st.updater = updater; st.t_to = (int)t;
+    st.lr = lr; st.rho = rho; st.b1 = b1; st.b2 = b2; st.a_t = 0.0f;
+    if (updater == SBR_UPD_ADAM)
+        st.a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    const int grid = (N + 15) / 16;
+    if (Hp == 128) out_grad_step_kernel<128><<<grid, 256, 0, s>>>(dlogits, h_last, rowcost, cost, st, b, bs0, bs1, R, N, Nl);
+    else if (Hp == 64) out_grad_step_kernel<64><<<grid, 256, 0, s>>>(dlogits, h_last, rowcost, cost, st, b, bs0, bs1, R, N, Nl);
+    else out_grad_step_kernel<32><<<grid, 256, 0, s>>>(dlogits, h_last, rowcost, cost, st, b, bs0, bs1, R, N, Nl);
+    *err = hipGetLastError();
+    return true;
+}
+
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n, float lr,
                          float rho, float b1, float b2, long t, size_t gap_at, size_t gap_len) {
     if (n == 0) return hipSuccess;

@@ -24,8 +24,10 @@ others instead of silently forking the replicas; tests/test_dp_gloo.py, tests/te
 Where the output layer's all-reduce is issued: small buckets (C2: 1.9 MB) right behind its gradient kernels, on the side stream,
 beside the BPTT chain; buckets above `OUT_EARLY_BYTES` (a 26 744 x 256 W_out is 27 MB: ~0.2 ms on a ring over xGMI) would sit in
 that stream's queue IN FRONT of the weight-gradient kernels `backward_recurrent` enqueues there and hold them back for as long, so
-they are issued behind that work instead, back to back with the recurrent bucket.  The placement relies on this torch (2.10)
-enqueueing a SYNC collective on the current stream; no >1-GPU box was available to the builder to measure either placement.
+they are issued behind that work instead, back to back with the recurrent bucket.  The placement relies on a SYNC collective being
+ordered on the stream it is issued under (this torch, 2.10, enqueues it there): `_side_collectives_are_ordered` verifies that with
+data when a DataParallel with more than one rank is built and otherwise falls back to the fully joined path (`stream_check`); no
+>1-GPU box was available to the builder to measure either placement.
 
 `engine` is anything with the RNNEngine phase methods -- the CPU tests pass an oracle-backed
 stand-in, production passes engine.RNNEngine.
@@ -46,8 +48,15 @@ class DataParallel(object):
             engine.dp_guard = True                       # rank-local flushes of lazily stepped rows now raise (module docstring)
         self.side = self.side2 = None
         self.tail = None
+        self.stream_check = None      # "ordered" / "fallback" / "skipped: ..." once the side-stream placement has been verified
         if hasattr(engine, "side_stream") and getattr(self.grads, "is_cuda", False):
             self.side = engine.side_stream()
+            if self.world > 1 and not self._side_collectives_are_ordered():
+                # this torch / backend does not order a sync collective behind the stream it is issued under: every collective
+                # then runs on the engine's main stream behind a full join (the stand-in path below; correct, nothing overlapped)
+                self.side = None
+                self.stream_check = "fallback"
+                return
             engine.set_deferred_join(True)
             # overlapped step tail (engine.query("tail_chunks") >= 2): dW_in is finished by the engine's second side stream,
             # dW_hid by the first, everything else of the recurrent part by the main stream -- one collective behind each
@@ -57,6 +66,36 @@ class DataParallel(object):
                 self.tail = engine.tail_ranges()
 
     OUT_EARLY_BYTES = 8 << 20      # output-layer buckets up to this size are reduced beside the BPTT chain (module docstring)
+
+    def _side_collectives_are_ordered(self):
+        """The step's placement of its collectives rests on ONE property of torch.distributed: a sync collective issued under
+        `torch.cuda.stream(side)` consumes what `side` has produced so far and is complete for whatever `side` runs next (torch
+        2.10 enqueues it on the current stream; an implementation with a stream of its own must order it by events to the same
+        effect).  Checked once per DataParallel, on the real streams, with data: the side stream is held back by a ~1 ms spin,
+        then fills a buffer, all-reduces it and copies it -- every call returns to the host long before the spin ends, so a
+        collective that did not wait for the side stream would reduce the zeros the buffer still holds.  False -> the caller
+        falls back to the fully joined path."""
+        try:
+            import torch
+            t = torch.zeros(8192, device=self.grads.device)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.side):
+                torch.cuda._sleep(2000000)
+                t.fill_(1.0)
+                self.dist.all_reduce(t, group=self.group)
+                probe = t.clone()
+            torch.cuda.current_stream().wait_stream(self.side)
+            torch.cuda.synchronize()
+            ok = bool((probe == float(self.world)).all().item())
+        except Exception as ex:      # (no such private spin kernel in another torch: nothing verified, nothing changed)
+            self.stream_check = "skipped: %r" % (ex,)
+            return True
+        # every rank must take the same path: one that falls back alone would issue its collectives in another order
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.grads.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        ok = bool(int(flag.item()))
+        self.stream_check = "ordered" if ok else "fallback"
+        return ok
 
     # ---- collectives that bring lazily stepped rows up to date: every rank enters them at the same step
     def _collective(self, name, *a, **kw):

@@ -158,20 +158,66 @@ def _c5_million_item_case(B, T, n, seed, grad_floor=1e-12, recurrent_gain=1.0, t
         Hp = eng.debug_buffer("h_last").size // (((B + 15) // 16) * 16)
         eh = PU.rel_err(eng.debug_buffer("h_last").reshape(-1, Hp)[:B, :layers[-1]], aux["h"])
         assert eh <= tol, eh
-        grads = eng.get_all_grad_values()
-        for nm, g, og in zip(names, grads, ograds):
-            rest = None
-            if nm.startswith("l0.W_in") or nm == "out.b":
-                sub = g[big].copy(); g[big] = 0.0; rest = g
-            elif nm == "out.W":
-                sub = g[:, big].copy(); g[:, big] = 0.0; rest = g
-            else:
-                sub = g
+        def compact(arrays, check_rest=True):
+            """the catalogue-sized arrays reduced to the compact catalogue (rows of l0.W_in, columns of out.W / out.b)"""
+            out = []
+            for nm, g in zip(names, arrays):
+                rest = None
+                if nm.startswith("l0.W_in") or nm == "out.b":
+                    sub = g[big].copy(); g[big] = 0.0; rest = g
+                elif nm == "out.W":
+                    sub = g[:, big].copy(); g[:, big] = 0.0; rest = g
+                else:
+                    sub = g
+                assert not check_rest or rest is None or not rest.any(), nm     # rows no id of the batch names: exactly zero
+                out.append(sub)
+            return out
+
+        g1 = compact(eng.get_all_grad_values())
+        for nm, sub, og in zip(names, g1, ograds):
             assert PU.rel_err(sub, og, grad_floor) <= (tol_g or tol), (nm, PU.rel_err(sub, og, grad_floor))
-            assert rest is None or not rest.any(), nm                           # rows no id of the batch names: exactly zero
-        del grads
         if not optimizer_steps:
             return
+        if optimizer_steps == "twin":
+            # Two row-sparse Adam steps and the ranking where the model's own conditioning keeps the gradients 1e-3 apart (the
+            # reference's initialisation): Adam turns an element whose gradient is ~0 into a step of ~lr whatever the gradient's
+            # size, so parameters cannot be compared with a pure oracle run.  The TWIN separates what is the engine's: the
+            # oracle's updater is fed the ENGINE's gradients step by step (same gradients in -> the optimizer kernels must give the
+            # same parameters out: 2e-5, the bar of parity_util.params_ok), every step's gradients are held against the oracle's
+            # AT THE TWIN'S parameters (tol_g), and the ordered top-10 against the oracle's ranking on the twin's parameters, on
+            # the rows whose logits are further apart than the bar admits.
+            upd_t = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)
+            tparams = [p.astype(np.float64) for p in params]
+            upd_t.apply(tparams, [np.asarray(g, dtype=np.float64) for g in g1])
+            del g1
+            eng.train_step(sync=True)                              # step 1: the gradients above
+            eng.forward_backward()
+            g2 = compact(eng.get_all_grad_values())
+            _, og2, _ = O.cost_and_grads(tparams, cfg, ob)
+            for nm, sub, og in zip(names, g2, og2):
+                assert PU.rel_err(sub, og, grad_floor) <= (tol_g or tol), ("step 2", nm, PU.rel_err(sub, og, grad_floor))
+            upd_t.apply(tparams, [np.asarray(g, dtype=np.float64) for g in g2])
+            del g2, og2
+            eng.train_step(sync=True)                              # step 2
+            new = compact(eng.get_all_param_values(), check_rest=False)
+            for nm, a, t in zip(names, new, tparams):
+                assert PU.rel_err(a, t) <= 2e-5, ("params_twin", nm, PU.rel_err(a, t))
+            del new
+            k = 10
+            ids = eng.test_function((Xb, batch["mask"]), k=k, exclude_seen=True)
+            excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
+            oids = np.array(O.test_function(tparams, cfg, batch["X"], batch["mask"], excl, k=k))
+            _, ologits = O.predict_scores(tparams, cfg, batch["X"], batch["mask"])
+            gap = 6.0 * tol * float(np.abs(ologits).max())            # logits follow the hidden state: tol relative, six times over
+            rows = np.ones(B, dtype=bool)
+            for b in range(B):
+                row = ologits[b].copy(); row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
+                top = -np.sort(-row)[:k + 1]
+                rows[b] = bool(np.all(top[:-1] - top[1:] > gap))
+            assert rows.sum() >= 0.25 * B, rows.sum()
+            assert np.array_equal(ids[rows], big[oids[rows]])
+            return
+        del g1
         upd = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)
         oparams = [p.copy() for p in params]
         upd.apply(oparams, ograds)                     # step 1 of the oracle: the gradients computed above (same parameters)
@@ -245,6 +291,16 @@ def test_c5_as_benched_reference_initialisation_within_the_north_star_bar():
     """... and the model exactly as the reference initialises it is held to north_star's bar: 1e-3 relative on the hidden state that
     feeds the logits and on the cost (measured ~2e-4: the oracle's own sensitivity times the ~200 roundings of a float32 chain),
     3e-3 of the largest entry on every gradient (measured up to 1.2e-3 on layer 2's input weights, the arrays that see both
-    chains' deviations); exact zeros on untouched rows as above.  The optimizer steps and the ranking are compared on the
-    well-conditioned twin: here Adam would turn 1e-4 of gradient difference on near-zero elements into whole steps."""
-    _c5_million_item_case(B=256, T=200, n=40000, seed=31, grad_floor=4e-7, tol=1e-3, tol_g=3e-3, optimizer_steps=False)
+    chains' deviations); exact zeros on untouched rows as above.
+
+    Whose distance that is (round 5, tools/c5_float32_floor.py -> profiles/round5_c5_float32_floor.txt): the SAME case through the
+    independent torch-autograd restatement in plain float32 on the CPU -- every product an f32 FMA, no operand split anywhere --
+    sits 1.1e-4 (hidden state) and up to 3.9e-4 (gradients: l1.W_cell_to_forgetgate, l1.W_in_to_forgetgate) from its own float64
+    run, and 3.9e-7 / 1.4e-6 on the well-conditioned twin: float32 itself leaves 1e-4 .. 4e-4 on this model, whatever computes it;
+    the engine's 2e-4 / 1.2e-3 is the same class (another summation order, a factor of two to three), not a kernel defect, and
+    the bars (1e-3 / 3e-3) stand 2.5x above what was measured.
+
+    Optimizer steps and ranking on THIS model (round 5): through the twin -- the oracle's updater fed the engine's gradients --
+    because Adam would turn 1e-3 of gradient difference on near-zero elements into whole steps in a pure oracle run: see
+    optimizer_steps == "twin" in _c5_million_item_case."""
+    _c5_million_item_case(B=256, T=200, n=40000, seed=31, grad_floor=4e-7, tol=1e-3, tol_g=3e-3, optimizer_steps="twin")

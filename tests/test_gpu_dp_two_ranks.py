@@ -27,6 +27,9 @@ CASES = {
     # ... the counted form of the exchange (one read-back per block; what blocks above DataParallel.INBAND_BYTES take): the
     # other sparse cases travel with their row counts in band, nothing synchronised
     "sparse_counted_gru128_cce_adam": ("GRU", [128], "CCE", 300, 64, 40, 0, "adam"),
+    # the init-time check of the collectives' stream placement says "not ordered" (forced): every collective on the main stream
+    # behind a full join -- same parameters
+    "gru128_cce_adam_join_fallback": ("GRU", [128], "CCE", 300, 64, 70, 0, "adam"),
 }
 SPARSE_FLAG = 32
 
@@ -46,11 +49,17 @@ def _worker(rank, world, port, name, out):
     eng = PU.engine_for(cfg, N, B, T, S=S, updater=updater, local_batch=hi - lo, row_offset=lo, flags=flags)
     try:
         eng.set_all_param_values(params)
+        if "fallback" in name:
+            DataParallel._side_collectives_are_ordered = lambda self: False
         dp = DataParallel(eng, dist)
         if "counted" in name:
             dp.INBAND_BYTES = 0
-        assert dp.side is not None                      # the stream-level path, not the stand-in one
-        assert (dp.tail is not None) == ("overlapped_tail" in name)
+        if "fallback" in name:
+            assert dp.side is None and dp.stream_check == "fallback"
+        else:
+            assert dp.side is not None                      # the stream-level path, not the stand-in one
+            assert dp.stream_check == "ordered", dp.stream_check      # ... verified with data on the real streams
+            assert (dp.tail is not None) == ("overlapped_tail" in name)
         if flags:
             assert len(eng.sparse_blocks()) == (1 if loss == "CCE" else 2)
         smp = batch["samples"] if loss != "CCE" else None
