@@ -638,7 +638,7 @@ def main():
             if mc:
                 keep = {}
                 for k, v in mc.items():
-                    if "rec_fwd" in k or "rec_bwd" in k or "gemm_x6_kernel" in k or "gemm_kernel" in k:
+                    if "rec_fwd" in k or "rec_bwd" in k or "gemm_x6_kernel" in k or "gemm_kernel" in k or "head_cce" in k or "out_grad_step" in k:
                         name = k.split("(")[0].replace("void ", "")[-70:]
                         if "rec_" in k:
                             try:
@@ -650,8 +650,10 @@ def main():
                 result["mfma_counters"] = {"kernels": keep,
                                            "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES child pass of this command (--quick --steps 6, "
                                                    "SBR_TAIL_OVERLAP=2), mean over the launches after the first; mfma_util_of_chip = MFMA_BUSY / (1024 SIMDs x "
-                                                   "SQ_BUSY / 32 SQ instances); the logits projection of this configuration is the gemm_x6_kernel<4, false, 4, "
-                                                   "false, ...> launch, its backward pair the <.., true, ..> ones"}
+                                                   "SQ_BUSY / 32 SQ instances); the output projection: where the one-launch head runs (C1 / C2) logits and dh are "
+                                                   "inside head_cce_kernel and dW_out inside out_grad_step_kernel, both on the exact-f32 matrix instruction; "
+                                                   "elsewhere the logits GEMM is the gemm_x6_kernel<4, false, 4, false, ...> launch, its backward pair the "
+                                                   "<.., true, ..> ones (at C2 the remaining gemm_x6_kernel launch is the polling dW_hid GEMM)"}
         result["phases_us"] = {k: round(v, 2) for k, v in phases.items() if k != "total"}
         result["phases_us"]["note"] = ("%s: HIP events over the timed region; the other phases: survey pass of %d steps with "
                                        "every phase bracketed (those event records lengthen a step, so the phases do not add "
@@ -733,6 +735,8 @@ def main():
             kernels["output_projection"] = {"bound": "mfma", "unit": "TFLOP/s", "us": round(us, 2), "achieved": round(tf, 3),
                                             "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 5),
                                             "shape": "M=%d N=%d K=%d" % (B, n_items, Hl),
+                                            "on_step_path": eng.query("head_fused") == 0,      # (False: the step's head is the one-launch
+                                            # head_cce_kernel -- logits + softmax + dh on the exact-f32 matrix instruction, phases_us.output)
                                             "matrix_pipe": {"issued_tflops": round(proj_terms * tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                                                             "frac": round(proj_terms * tf / BF16_MFMA_PEAK_TFLOPS, 5),
                                                             "terms_per_f32_product": proj_terms}}

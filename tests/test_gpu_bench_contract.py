@@ -142,3 +142,11 @@ def test_counter_passes_sustained_region_and_training_loop_ride_in_the_default_l
     for name, v in oc.items():
         assert "skipped" in v or (v["ms_per_step"] > 0 and 0 < v["roofline"]["frac"] < 1 and v["outside_chains_us"] > 0), (name, v)
     assert "skipped" not in oc["c1"] and "skipped" not in oc["c4"]
+    # round 5: the scatter-add of the embedding gradient on its own (sbr_debug_scatter), and one rank's share of a fixed global
+    # batch of 256 at 2 / 4 / 8 ranks for C2 and C4, measured on this GPU
+    su = d["kernels"]["scatter_unfused"]
+    assert su["bound"] == "hbm" and su["entries"] == 256 * 200 and 0 < su["rows_written"] <= 3706 and 0 < su["frac"] < 1
+    sm = d["strong_scaling_model"]
+    for key, ranks in (("c2_b128", 2), ("c2_b64", 4), ("c2_b32", 8), ("c4_b128", 2), ("c4_b64", 4), ("c4_b32", 8)):
+        assert "skipped" in sm[key] or (sm[key]["ranks_of_global_256"] == ranks and sm[key]["ms_per_step"] > 0), (key, sm[key])
+    assert "skipped" not in sm["c2_b32"]
