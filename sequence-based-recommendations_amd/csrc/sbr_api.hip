@@ -144,8 +144,10 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_ws = take(lay.ws_floats);
     lay.ws2_floats = 4 * lay.ws_floats;          // up to 256 weight-gradient slabs
     lay.a_ws2 = take(lay.ws2_floats);
-    lay.ws3_floats = std::min(lay.ws2_floats, (size_t)16 * lay.N * lay.HLt);      // (the polling weight-gradient GEMM owns ws2 meanwhile)
-    lay.a_ws3 = take(lay.ws3_floats);
+    // the split-K workspace of the dW_out GEMM when SBR_TAIL_OUT_STREAM moves it off the side stream (the polling weight-gradient
+    // GEMM owns ws2 meanwhile): an experiment switch -- taken from the arena only when it is set
+    { const char* e = getenv("SBR_TAIL_OUT_STREAM"); lay.ws3_floats = (e && atoi(e)) ? std::min(lay.ws2_floats, (size_t)16 * lay.N * lay.HLt) : 0; }
+    lay.a_ws3 = lay.ws3_floats ? take(lay.ws3_floats) : 0;
     lay.a_X = take((size_t)Bp * T * lay.F);
     lay.a_len = take(Bp);
     lay.a_tgt = take((size_t)std::max(lay.Bg, Bp) * lay.NT);
@@ -168,9 +170,9 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         lay.sr_slots = wide0 ? std::max(sbr_scatter_wide_slots((size_t)T * Bp * lay.F), 2 * SBR_SCAT_RANGES) : 0;
         lay.a_srpart = wide0 ? take((size_t)lay.sr_slots * ghp0) : 0;
         lay.a_srid = wide0 ? take((size_t)lay.sr_slots * 4 + 8) : 0;
-        lay.a_tmark = wide0 ? take((size_t)cfg.input_size) : 0;      // (dense blocks: which rows the batch touches, without its sort)
+        lay.a_tmark = (wide0 || lay.tail_keys >= 2) ? take((size_t)cfg.input_size) : 0;      // (dense blocks: which rows the batch touches, without its sort)
     }
-    lay.a_hstat = take((size_t)256 * 64);
+    lay.a_hstat = take((size_t)256 * 64 + 64);      // + the head's arrival counter and done flag
     lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, (a gap), the chain's clock words
     lay.a_done = take((size_t)SBR_DONE_COPIES * SBR_DONE_STRIDE);      // the monitor's word, replicated (sbr_common.h SbrPoll)
     // Row-sparse blocks (sbr_sparse.hip): the index-addressed rows of layer 0 (or of the embedding table) and, for the sampled
@@ -424,6 +426,9 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->ev_cells = nullptr; h->mark_epoch = 0;
     { const char* e = getenv("SBR_HEAD_FUSE"); h->head_fuse = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_OUT_FUSE"); h->out_fuse = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_HEAD_GATE"); h->head_gate = e ? atoi(e) : 1; }
+    { const char* e = getenv("SBR_TAIL_WIN_SPLIT"); h->tail_win_split = e ? atoi(e) : 0; }
+    h->win_split_done = false;
     h->out_stepped = false;
     h->head_epoch = 0;
     h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
@@ -989,6 +994,21 @@ extern "C" int sbr_forward(sbr_handle* h) {
                                        h->tail_ch, h->tail_nc, &h->tail_bounds, &h->scnt_zero_n));
         h->tail_sorted = true;
         { const int rc = tail_cost_scan(h); if (rc != SBR_OK) return rc; }
+        // SBR_TAIL_WIN_SPLIT: the dense pass over W_in that ends the scatter-add's stream (12 us behind the chain at C2) split in
+        // time -- the rows this batch does not name take their zero-gradient step NOW, beside the forward chain (which gathers
+        // the OTHER rows), the touched ones behind the scatter-add
+        h->win_split_done = false;
+        if (h->tail_win_split && h->in_train_step && y.a_tmark && !y.n_sparse) {
+            const LayerLayout& l0 = y.layer[0];
+            const int GHp0 = y.G * l0.Hp;
+            h->mark_epoch += 1;
+            SBR_LAUNCH(launch_mark_rows(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_tmark), h->mark_epoch));
+            SBR_LAUNCH(launch_update_untouched_rows(h->side2, y.cfg.updater, h->P(l0.p_Win), h->St(0, l0.p_Win),
+                                                    y.n_state_arrays > 1 ? h->St(1, l0.p_Win) : nullptr, y.cfg.input_size, GHp0, nullptr,
+                                                    (const int*)h->A(y.a_tmark), h->mark_epoch, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
+                                                    y.cfg.beta2, (long)h->step_count + 1));
+            h->win_split_done = true;
+        }
     }
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
@@ -1080,7 +1100,8 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         if (h->tail_nc >= 2) {
             // overlapped tail: the time-chunked sort runs on the SECOND side stream, which consumes it (scatter-add beside the
             // chain); that stream is released by the same record as the first one
-            SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_lg_rec, 0));
+            if (h->ev_lg_rec) SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_lg_rec, 0));      // (NULL: the head's flag form -- the sort ran
+                                                                                        // beside the forward chain, the consumers wait for the chain's progress words)
             if (!h->tail_sorted) {
                 SBR_LAUNCH(launch_scatter_sort(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_scnt),
                                                (int*)h->A(y.a_soff), (int*)h->A(y.a_scur), (int*)h->A(y.a_sid), (int*)h->A(y.a_spos), 0,
@@ -1138,14 +1159,21 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // Round 5: logits, softmax + CCE and dh in ONE launch whose workgroups exchange the row statistics inside the kernel
         // (sbr_head.hip; exact-f32 products); its dh leaves as split-K slabs -- folded into the chain's prologue as above, or
         // reduced here.  Shapes it does not serve (and SBR_HEAD_FUSE=0) keep the three launches below.
-        bool head_done = false;
+        bool head_done = false, head_gated = false;
+        // (the flag form of the release: single-call steps whose side streams need nothing else from this record -- with the
+        // overlapped tail the sort must have run beside the forward chain --, and not while a timing mark shares the record)
+        const bool gate_ok = h->head_gate && h->in_train_step && !fill_needed && !(h->timing && ((h->timing_marks >> 3) & 1)) &&
+                             (h->tail_nc == 0 || (h->tail_sorted && h->tail_overlap == 1 && !h->tail_out_stream));
+        unsigned* head_done_words = (unsigned*)h->A(y.a_hstat) + 256 * 64;
         if (h->head_fuse && y.cfg.loss == SBR_LOSS_CCE && !sg && !bf16p && !(y.cfg.flags & SBR_FLAG_F32_MFMA) && y.D == 1 && R == y.Bp) {
             int nsl = 0; hipError_t he = hipSuccess;
             h->head_epoch += 1; if (!h->head_epoch) h->head_epoch = 1;
             if (launch_head_cce(s, hl, h->P(y.p_WoutT), h->P(y.p_bout), tgt, h->bpop, lg, h->A(y.a_rowcost), ws, y.ws_floats,
-                                (unsigned*)h->A(y.a_hstat), (int*)h->A(y.a_fault), y.Bp, N, Nl, Hp, y.Bg, h->head_epoch, &nsl, &he)) {
+                                (unsigned*)h->A(y.a_hstat), (int*)h->A(y.a_fault), y.Bp, N, Nl, Hp, y.Bg, h->head_epoch, &nsl, &he,
+                                (y.cfg.flags & SBR_FLAG_PROFILE_REC) && (size_t)y.Bp * 16 >= 256 * 8 ? (unsigned long long*)h->A(y.a_prof) : nullptr,
+                                gate_ok ? head_done_words : nullptr)) {
                 SBR_LAUNCH(he);
-                head_done = true;
+                head_done = true; head_gated = gate_ok;
                 if (fold) keep = nsl;
                 else SBR_LAUNCH(launch_splitk_reduce(s, ws, nsl, y.Bp, Hp, h->A(y.a_dhlast), Hp, nullptr));
             }
@@ -1167,8 +1195,13 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         h->dh_slabs_n = keep;
         // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
         // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
-        h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
-        SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
+        if (head_gated) {      // no record on the main stream: the side stream waits for the head kernel's own flag
+            h->ev_lg_rec = nullptr;
+            SBR_LAUNCH(launch_head_gate(sd, head_done_words, h->head_epoch, (int*)h->A(y.a_fault)));
+        } else {
+            h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
+            SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
+        }
         if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
         // Overlapped tail, single-call step: the output layer's gradient kernels and its update (five launches, 50 - 60 us on one
         // stream with its gaps) go to the SECOND side stream, in front of the scatter-add, so that the polling weight-gradient
@@ -1186,7 +1219,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // (launch_out_grad_step, sbr_misc.hip) instead of the five or six below -- the polling weight-gradient GEMM of the overlapped
         // tail, next on this stream, then starts with the chain instead of 68 us into it.  SBR_OUT_FUSE=0: as before.
         h->out_stepped = false;
-        const bool will_step_here = h->in_train_step && !y.n_sparse && !sg && (h->tail_nc == 0 || (h->tail_nc >= 2 && y.L == 1));
+        // (taken WITHOUT the overlapped tail only, unless SBR_OUT_FUSE=2: at C2 the polling GEMM then starts 9 us earlier and ends where
+        // it did -- it is throughput-bound beside the chain -- while the step measured 0.3334 against 0.3294 ms; C1: 0.3156 -> 0.3035
+        // together with the one-launch head: profiles/round5_variants.txt call b)
+        const bool will_step_here = h->in_train_step && !y.n_sparse && !sg && (h->tail_nc == 0 || (h->out_fuse >= 2 && h->tail_nc >= 2 && y.L == 1));
         if (h->out_fuse && will_step_here && y.cfg.regularization == 0.0f && y.D == 1) {
             hipError_t oe = hipSuccess;
             float* s1e = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
@@ -1437,7 +1473,14 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
                                                   0, &h->tail_bounds, h->tail_short_chunks, !serial && h->tail_fence_kb > 0));
-            if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
+            if (upd_here && h->win_split_done) {
+                SBR_LAUNCH(launch_update_touched_rows(s2, y.cfg.updater, h->P(ly.p_Win), h->Gd(ly.p_Win), h->St(0, ly.p_Win),
+                                                      s1a ? s1a + ly.p_Win : nullptr, y.cfg.input_size, GHp, (const int*)h->A(y.a_tmark),
+                                                      h->mark_epoch, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2,
+                                                      (long)h->step_count + 1));
+                h->win_split_done = false;
+            }
+            else if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
             // single-call step: the slab reduction IS the W_hid update (one launch, one pass less behind the chain); phase-by-phase
             // callers (data parallel) need the reduced gradient

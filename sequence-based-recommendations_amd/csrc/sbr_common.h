@@ -168,6 +168,9 @@ struct sbr_handle {
     int mark_epoch;
     int head_fuse;       // SBR_HEAD_FUSE (default 1): the full-softmax head in one launch (sbr_head.hip)
     unsigned head_epoch;
+    int head_gate;       // SBR_HEAD_GATE (default 1): the side stream is released by the head kernel's own flag instead of an event
+    int tail_win_split;  // SBR_TAIL_WIN_SPLIT: overlapped tail, dense W_in: untouched rows stepped beside the forward chain, touched rows behind the scatter-add
+    bool win_split_done; // this step: the untouched rows are stepped (sbr_forward), mark epoch = mark_epoch
     int out_fuse;        // SBR_OUT_FUSE (default 1): the dense head's gradient and step in one launch (launch_out_grad_step)
     bool out_stepped;    // this step: done, the output layer's range needs no update launch
     int dh_slabs_n;      // > 0: dh_last of this step sits in the main workspace as that many unreduced split-K slabs
@@ -479,7 +482,9 @@ bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const 
 bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes);
 bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const float* bout, const int* tgt, const float* pop, float* dlogits,
                      float* rowcost, float* slabs, size_t slab_floats, unsigned* stats, int* fault, int Bp, int N, int Nl, int Hp, int Bglobal,
-                     unsigned epoch, int* n_slabs, hipError_t* err);
+                     unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof = nullptr, unsigned* done = nullptr);
+// side-stream gate on the head launch `epoch` (done = the words handed to launch_head_cce): no event on the main stream
+hipError_t launch_head_gate(hipStream_t s, const unsigned* done, unsigned epoch, int* fault);
 // full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N), row stride ld, in; dlogits out in place
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
                               float* rowcost, int rows, int N, long ld, int Bglobal);
@@ -514,6 +519,8 @@ hipError_t launch_update_untouched_rows(hipStream_t s, int updater, float* p, fl
 bool launch_out_grad_step(hipStream_t s, const float* dlogits, const float* h_last, const float* rowcost, float* cost, int updater,
                           float* W, float* Ws0, float* Ws1, float* b, float* bs0, float* bs1, int R, int N, int Nl, int Hp, float lr,
                           float rho, float b1, float b2, long t, hipError_t* err);
+hipError_t launch_update_touched_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
+                                      const int* mark, int epoch, float lr, float rho, float b1, float b2, long t);
 hipError_t launch_mark_rows(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* mark, int epoch);
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);

@@ -229,16 +229,17 @@ __global__ void gemm_naive(GemmArgs g) {
 }
 
 // SBR_FLAG_F32_MFMA: keep every GEMM on the exact-f32 kernel (set per call by the API layer; a handle is not thread-safe)
-static bool g_gemm_exact_f32 = false;
+// (per host thread: two handles driven from different threads must not steal or leak each other's mode / hint -- ADVICE round 4)
+static thread_local bool g_gemm_exact_f32 = false;
 void sbr_gemm_set_exact_f32(bool on) { g_gemm_exact_f32 = on; }
-static int g_gemm_planes = 3;
+static thread_local int g_gemm_planes = 3;
 void sbr_gemm_set_planes(int planes) { g_gemm_planes = planes == 1 ? 1 : 3; }
 // Hint for the NEXT launch_gemm call only (consumed and cleared by it; a handle is not thread-safe): the operand planes of the
 // tiled kernel -- 2: the two-plane fp16 split (three MFMAs per product instead of bf16x6's six) for operands the caller knows to be
 // bounded: hidden states behind tanh / sigmoid gates, weights, gradients that have passed the clip at +-100, with sa / sb the
 // power-of-two scales that bring A / B into fp16's range (gemm_x6_kernel NP = 2); 1: plain bf16 operands, split-K allowed (the
 // layer GEMMs under SBR_FLAG_BF16_LAYERS).  0: none (bf16x6).
-static int g_hint_planes = 0; static float g_hint_sa = 1.0f, g_hint_sb = 1.0f;
+static thread_local int g_hint_planes = 0; static thread_local float g_hint_sa = 1.0f, g_hint_sb = 1.0f;
 void sbr_gemm_hint(int planes, float sa, float sb) { g_hint_planes = planes; g_hint_sa = sa; g_hint_sb = sb; }
 
 // split-K partial products only: writes exactly `nsplit` slabs [z][M][N] at ws (no reduction)

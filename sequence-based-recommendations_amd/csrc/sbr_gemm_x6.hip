@@ -71,9 +71,11 @@ __device__ __forceinline__ void x6_issue_sc1(const float* __restrict__ p, long s
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[i]) : "v"(r) : "memory");
     }
 }
-template <bool RFAST>
+// YOUNGER: the wave has issued one more stage of 8 loads behind this one (the vector-memory counter retires in order)
+template <bool RFAST, bool YOUNGER = false>
 __device__ __forceinline__ void x6_sc1_landed(f32x4 (&t)[8], float (&v)[4][8]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (YOUNGER) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t[i]));
 #pragma unroll
@@ -133,8 +135,13 @@ __device__ __forceinline__ void x6_load(const float* __restrict__ p, long stride
 // configuration (BASELINE.json configs[4]; SBR_FLAG_BF16_PROJECTION): logits to ~3e-3 of their spread instead of f32
 // rounding, a sixth of the matrix-pipe time and a third of the LDS traffic.
 // PL: consumer of a running BPTT chain (g.poll): both operands through x6_issue_sc1.
+// (PL: one workgroup per CU is what the overlapped tail runs anyway -- 192 of them beside the chain's 64 -- so the polling form may
+// use the registers of two: a second stage of operand loads in flight, X6_PL_STAGES)
+#ifndef X6_PL_STAGES
+#define X6_PL_STAGES 2
+#endif
 template <int VA, bool RA, int VB, bool RB, int TW, int KH, int NP, bool PL = false>
-__global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
+__global__ void __launch_bounds__(256, PL ? 1 : 2) gemm_x6_kernel(GemmX6Args g) {
     constexpr int TM = 32 * TW, TK = 32 * KH, ROW = 64 * KH + 16, PLANE = TM * ROW, KC = 4 * KH;
     using OPV = std::conditional_t<NP == 2, f16x8g, bf16x8>;
     __shared__ __attribute__((aligned(16))) char sA[NP * PLANE];
@@ -157,19 +164,23 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
     char* sdst = (ldB ? sB : sA) + (rg * 4) * ROW + kc * 16;
 
     float v[4][8];
-    f32x4 tq[PL ? 8 : 1];
+    f32x4 tq[8], tq2[8];      // (dead without PL / with one stage)
     int kbeg = 0, kend = 0;
+    // PL: one stage of 8 sc1 loads for the k step at `k0` into t (a k chunk beyond the slab: zeros, no loads -- a wave whose
+    // lanes hold different chunks still executes the 8 load instructions, so the in-order count per stage is the same)
+    auto issue = [&](f32x4 (&t)[8], int k0) {
+        const int nk = max(0, min(8, kend - (k0 + kc * 8)));
+        if (nk < 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = f32x4{0, 0, 0, 0};
+        }
+        else if (ldB) x6_issue_sc1<RB>(src, RB ? sk : srow, t);
+        else x6_issue_sc1<RA>(src, RA ? sk : srow, t);
+        src += kstep;
+    };
     auto load = [&](int k0) {
         const int nk = max(0, min(8, kend - (k0 + kc * 8)));
-        if constexpr (PL) {      // nk is 8 or 0 here (slab bounds and K are multiples of 8: launch_gemm_x6)
-            if (nk < 8) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) tq[i] = f32x4{0, 0, 0, 0};
-            }
-            else if (ldB) x6_issue_sc1<RB>(src, RB ? sk : srow, tq);
-            else x6_issue_sc1<RA>(src, RA ? sk : srow, tq);
-        }
-        else if (ldB) x6_load<VB, RB>(src, RB ? sk : srow, nr, nk, v);
+        if (ldB) x6_load<VB, RB>(src, RB ? sk : srow, nr, nk, v);
         else x6_load<VA, RA>(src, RA ? sk : srow, nr, nk, v);
         src += kstep;
     };
@@ -181,12 +192,11 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
         for (int b = 0; b < TW; ++b) { acc[a][b] = z; if constexpr (NP == 2) acl[a][b] = z; }
     const float opscale = ldB ? g.sb : g.sa;
 
-    auto run_slab = [&]() {                               // acc += A[:, kbeg .. kend) . B[kbeg .. kend, :]
-    src = base + (long)(kbeg + kc * 8) * sk;
-    if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+    // one k step: `t` = the stage that holds its operands (PL), younger = another stage was issued behind it
+    auto k_step = [&](f32x4 (&t)[8], int k0, bool younger) {
         if constexpr (PL) {
-            if (ldB) x6_sc1_landed<RB>(tq, v); else x6_sc1_landed<RA>(tq, v);
+            if (younger) { if (ldB) x6_sc1_landed<RB, true>(t, v); else x6_sc1_landed<RA, true>(t, v); }
+            else { if (ldB) x6_sc1_landed<RB, false>(t, v); else x6_sc1_landed<RA, false>(t, v); }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -215,7 +225,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
             }
         }
         __syncthreads();
-        if (k0 + TK < kend) load(k0 + TK);                 // in flight while this tile's MFMAs run
+        if constexpr (PL && X6_PL_STAGES == 2) { if (k0 + 2 * TK < kend) issue(t, k0 + 2 * TK); }      // this stage's registers are free again
+        else if constexpr (PL) { if (k0 + TK < kend) issue(t, k0 + TK); }
+        else { if (k0 + TK < kend) load(k0 + TK); }        // in flight while this tile's MFMAs run
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
             OPV a[NP][TW], b[NP][TW];
@@ -238,8 +250,24 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(GemmX6Args g) {
 #undef X6_TERL
         }
         __syncthreads();
-    }
-
+    };
+    auto run_slab = [&]() {                               // acc += A[:, kbeg .. kend) . B[kbeg .. kend, :]
+        src = base + (long)(kbeg + kc * 8) * sk;
+        if constexpr (PL && X6_PL_STAGES == 2) {
+            // two k steps of operands in flight: the k loop of a polling group was one exposed round trip to the memory side per
+            // step (sc1 loads, ~3 us against ~1 us of split + MFMAs): 51 200 rows took the launch ~115 us of pure work, 1.2x
+            // the rate at which the chain releases them -- a late start was never caught up (profiles/round5_b_c2_timeline.txt)
+            if (kbeg < kend) issue(tq, kbeg);
+            if (kbeg + TK < kend) issue(tq2, kbeg + TK);
+            for (int k0 = kbeg; k0 < kend; k0 += 2 * TK) {
+                k_step(tq, k0, k0 + TK < kend);
+                if (k0 + TK < kend) k_step(tq2, k0 + TK, k0 + 2 * TK < kend);
+            }
+        } else {
+            if constexpr (PL) { if (kbeg < kend) issue(tq, kbeg); }
+            else { if (kbeg < kend) load(kbeg); }
+            for (int k0 = kbeg; k0 < kend; k0 += TK) k_step(tq, k0, false);
+        }
     };
     if constexpr (PL) {
         // Persistent groups: gridDim.z groups of workgroups (one per N / M tile each) share the nz slabs round-robin in the

@@ -50,10 +50,28 @@ struct HeadArgs {
     int N, Nl, CW, CC, RB, Bp;
     float inv_Bg;
     unsigned epoch;
+    unsigned* done;             // [0] arrival counter, [1] = epoch once every workgroup has finished (head_gate_kernel), or NULL
+    unsigned long long* prof;   // SBR_FLAG_PROFILE_REC: [workgroup][8] stamps of the 100 MHz clock at the phase boundaries (tools/head_prof.py), else NULL
 };
 
 #define HEAD_NT 5          // tiles per wave at most (CW <= 320)
 #define HEAD_LOG2E 1.4426950408889634f
+
+// NTW tiles of one wave (rows 64 i apart in the LDS image) through all of K, NTW independent accumulator chains
+template <int HP, int NTW>
+__device__ __forceinline__ void head_logits(const float* __restrict__ wr, const f32x4 (&hb)[HP / 16], f32x4 (&acc)[HEAD_NT]) {
+    constexpr int LDW = HP + 4, KG = HP / 16;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        f32x4 wv[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) wv[i] = *(const f32x4*)(wr + (size_t)64 * i * LDW + 16 * g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][m], hb[g][m], acc[i], 0, 0, 0);
+    }
+}
 
 template <int HP>
 __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
@@ -65,6 +83,8 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
     if ((a.CC & 7) == 0) { const int x = blockIdx.x & 7, li = blockIdx.x >> 3; cc = x * (a.CC >> 3) + li / a.RB; rb = li % a.RB; }
     else { cc = blockIdx.x / a.RB; rb = blockIdx.x % a.RB; }
     const int n_lo = cc * a.CW, ntiles = a.CW >> 4;
+#define HEAD_STAMP(I) do { if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 8 + (I)] = wall_clock64(); } while (0)
+    HEAD_STAMP(0);
     float* Wl = lds;                                                   // [CW][LDW]  (later: the waves' partial dh [4][16][HP])
     const int wl_floats = max(a.CW * LDW, 64 * HP);
     float* red = lds + wl_floats;                                      // [4][16][2] wave stats, then [CC][16][2] chunk stats
@@ -95,31 +115,42 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
         }
     }
     __syncthreads();
-    // ---- 1. logits of this wave's tiles
+    HEAD_STAMP(1);
+    // ---- 1. logits of this wave's tiles: the tiles advance TOGETHER through k, one accumulator chain each (head_logits<NTW>:
+    // straight-line code per tile count) -- tile after tile the 32 dependent instructions of a tile ran at the f32 matrix
+    // instruction's latency (4.7 us for four tiles against 1.7 us of issue: tools/head_prof.py, profiles/round5_c_head_phases.txt)
     f32x4 lg[HEAD_NT];
     float mx = -INFINITY;
+    {
+        f32x4 acc[HEAD_NT];
 #pragma unroll
-    for (int i = 0; i < HEAD_NT; ++i) {
-        const int t = wave + 4 * i;
-        lg[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (t < ntiles) {                                              // wave-uniform
-            f32x4 acc = {0, 0, 0, 0};
-            const float* wr = Wl + (16 * t + j) * LDW + 4 * q;
+        for (int i = 0; i < HEAD_NT; ++i) acc[i] = f32x4{0, 0, 0, 0};
+        const float* wr = Wl + (16 * wave + j) * LDW + 4 * q;          // tile wave + 4 i: + 64 i rows
+        const int ntw = ntiles > wave ? (ntiles - wave + 3) >> 2 : 0;   // tiles of this wave (wave-uniform)
+        switch (ntw) {
+            case 5: head_logits<HP, 5>(wr, hb, acc); break;
+            case 4: head_logits<HP, 4>(wr, hb, acc); break;
+            case 3: head_logits<HP, 3>(wr, hb, acc); break;
+            case 2: head_logits<HP, 2>(wr, hb, acc); break;
+            case 1: head_logits<HP, 1>(wr, hb, acc); break;
+            default: break;
+        }
+        asm volatile("s_nop 15");                                      // MFMA D -> VALU read (see sbr_gemm.hip)
 #pragma unroll
-            for (int g = 0; g < KG; ++g) {
-                const f32x4 wv = *(const f32x4*)(wr + 16 * g);
+        for (int i = 0; i < HEAD_NT; ++i) {
+            const int t = wave + 4 * i;
+            lg[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < ntiles) {
+                const int c0 = n_lo + 16 * t + 4 * q;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m], hb[g][m], acc, 0, 0, 0);
-            }
-            asm volatile("s_nop 15");                                  // MFMA D -> VALU read (see sbr_gemm.hip)
-            const int c0 = n_lo + 16 * t + 4 * q;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = (c0 + r < a.N) ? acc[r] + a.b[c0 + r] : -INFINITY;
-                lg[i][r] = v; mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (c0 + r < a.N) ? acc[i][r] + a.b[c0 + r] : -INFINITY;
+                    lg[i][r] = v; mx = fmaxf(mx, v);
+                }
             }
         }
     }
+    HEAD_STAMP(2);
     // ---- 2. row statistics: lanes of a row (q = 0..3), waves, chunks
     mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
     float se = 0.0f;
@@ -149,6 +180,7 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
         __hip_atomic_store(p + 3, sb ^ a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                                   // (red is rewritten below)
+    HEAD_STAMP(3);
     if (tid < a.CC * 16) {
         const int c = tid >> 4, r = tid & 15;
         const unsigned* p = a.stats + ((size_t)(rb * a.CC + c) * 16 + r) * 4;
@@ -173,6 +205,7 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
         if (mc > -INFINITY) S += red[(c * 16 + j) * 2 + 1] * __builtin_amdgcn_exp2f((mc - M) * HEAD_LOG2E);
     }
     const float inv = 1.0f / S;
+    HEAD_STAMP(4);
     // ---- 3. dlogits (in the registers of the tile), the row's cost
 #pragma unroll
     for (int i = 0; i < HEAD_NT; ++i) {
@@ -192,6 +225,7 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
             if (c0 < a.N) *(f32x4*)(a.dlog + (size_t)row * a.Nl + c0) = d;
         } else lg[i] = f32x4{0, 0, 0, 0};
     }
+    HEAD_STAMP(5);
     // ---- 4. dh partial of this chunk
     f32x4 da[KG];
 #pragma unroll
@@ -210,6 +244,7 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
     }
     asm volatile("s_nop 15");
     __syncthreads();                                                   // every wave has read its W rows: the image becomes the partials
+    HEAD_STAMP(6);
     float* part = Wl + (size_t)wave * 16 * HP;
 #pragma unroll
     for (int kt = 0; kt < KG; ++kt) *(f32x4*)(part + j * HP + 16 * kt + 4 * q) = da[kt];
@@ -220,6 +255,36 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
         const f32x4 s2 = *(const f32x4*)(Wl + 32 * HP + 4 * i), s3 = *(const f32x4*)(Wl + 48 * HP + 4 * i);
         *(f32x4*)(slab + 4 * i) = (s0 + s1) + (s2 + s3);
     }
+    HEAD_STAMP(7);
+#undef HEAD_STAMP
+    // Release without an event: a hipEventRecord between this kernel and the BPTT chain costs the main stream ~7 - 11 us before the
+    // chain starts (profiles/round5_b_c2_timeline.txt).  Instead every workgroup makes its stores visible device-wide and counts
+    // itself in; the last one raises the launch's epoch in the flag head_gate_kernel waits for on the side stream.
+    if (a.done) {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned arrived = atomicAdd(a.done, 1u);
+            if (arrived == gridDim.x - 1) {
+                atomicExch(a.done, 0u);                                // (every workgroup of this launch has counted itself in)
+                __hip_atomic_store(a.done + 1, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// one workgroup, one lane: returns when the head launch `epoch` has finished everywhere (bounded: fault bit 5)
+__global__ void head_gate_kernel(const unsigned* __restrict__ done, unsigned epoch, int* __restrict__ fault) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(done + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(fault, 32); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+hipError_t launch_head_gate(hipStream_t s, const unsigned* done, unsigned epoch, int* fault) {
+    head_gate_kernel<<<1, 64, 0, s>>>(done, epoch, fault);
+    return hipGetLastError();
 }
 
 // chunks / chunk width for this shape; false: not served
@@ -240,12 +305,13 @@ bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes) {
 // slabs: CC * Bp * Hp floats; stats: (Bp / 16) * CC * 64 unsigned; false: shape not served, nothing launched
 bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const float* bout, const int* tgt, const float* pop, float* dlogits,
                      float* rowcost, float* slabs, size_t slab_floats, unsigned* stats, int* fault, int Bp, int N, int Nl, int Hp, int Bglobal,
-                     unsigned epoch, int* n_slabs, hipError_t* err) {
+                     unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof, unsigned* done) {
     int CC = 0, CW = 0; size_t lds = 0;
     if (!sbr_head_plan(Bp, N, Hp, &CC, &CW, &lds) || (size_t)CC * Bp * Hp > slab_floats || epoch == 0) return false;
     HeadArgs a;
     a.h = h; a.W = WoutT; a.b = bout; a.tgt = tgt; a.pop = pop; a.dlog = dlogits; a.rowcost = rowcost; a.slabs = slabs; a.stats = stats;
     a.fault = fault; a.N = N; a.Nl = Nl; a.CW = CW; a.CC = CC; a.RB = Bp / 16; a.Bp = Bp; a.inv_Bg = 1.0f / (float)Bglobal; a.epoch = epoch;
+    a.prof = prof; a.done = done;
     const int grid = a.RB * CC;
     if (Hp == 128) { SBR_DYN_LDS(head_cce_kernel<128>, lds); head_cce_kernel<128><<<grid, 256, lds, s>>>(a); }
     else if (Hp == 64) { SBR_DYN_LDS(head_cce_kernel<64>, lds); head_cce_kernel<64><<<grid, 256, lds, s>>>(a); }

@@ -126,7 +126,11 @@ __device__ __forceinline__ void sp_step(const SpUpd& u, float& p, float g, float
 // serial chain (64 per wave measured 600 us for C3's 51 200 candidates, the kernel being nothing but 64-deep chains);
 // two 256-float pieces of a row are loaded before the first is used and replayed together (four pieces: 256 VGPRs, one
 // wave per SIMD).
-#define SP_CPW 8
+// (8 until round 4; 2 since round 5: the rows a wave owns are walked one after the other, each a load -> math -> store round trip, and
+// the waves of the sorted list's long tail owned all 8 of theirs -- C3 1.397 -> 1.378 (4) -> 1.373 ms (2): profiles/round5_variants.txt call e)
+#ifndef SP_CPW
+#define SP_CPW 2
+#endif
 #define SP_NV 2
 template <int SRC, bool STEP>
 __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, const int* __restrict__ X, const int* __restrict__ len,

@@ -51,6 +51,20 @@ class RNNBase(object):
                         "item_coverage": {"direction": 1}, "ndcg": {"direction": 1},
                         "blockbuster_share": {"direction": -1}}
         self.engine = None
+        self.dp = None          # parallel.DataParallel around self.engine in a multi-rank driver (attach_data_parallel)
+
+    def attach_data_parallel(self, dp):
+        """A multi-rank training driver hands over its parallel.DataParallel: from then on everything that reads parameters as a
+        whole or ranks with them -- save, test_function / predict_function, the batched validation -- goes through its
+        collectives, which every rank enters at the same step.  With lazily stepped row-sparse blocks the engine refuses those
+        calls when they come from one rank alone (engine.dp_guard: a rank-local flush would fork the replicas by float32
+        roundings); through `dp` they are legal, and every rank must then call save / the tests together (rank 0 may be the only
+        one that keeps the file: see save(write=...))."""
+        self.dp = dp
+
+    def _rd(self):
+        """who answers get_all_param_values / test_function / predict_function: the data-parallel wrapper when there is one"""
+        return self.dp if self.dp is not None else self.engine
 
     # ------------------------------------------------------------------ model construction
     def _n_optional_features(self):
@@ -177,10 +191,10 @@ class RNNBase(object):
 
     def test_function(self, theano_inputs, k=10):
         """ordered top-k ids of the (single) row (rnn_base.py:205-209)."""
-        return self.engine.test_function(theano_inputs, k=k, exclude_seen=self._exclude_mode())[0]
+        return self._rd().test_function(theano_inputs, k=k, exclude_seen=self._exclude_mode())[0]
 
     def predict_function(self, X, mask):
-        return self.engine.predict_function(X, mask)
+        return self._rd().predict_function(X, mask)
 
     def top_k_recommendations(self, sequence, user_id=None, k=10, exclude=None):
         """rnn_base.py:132-159: last max_length items -> scores -> viewed/excluded to -inf -> top k."""
@@ -292,7 +306,7 @@ class RNNBase(object):
         Xs, masks, goals = [], [], []
 
         def flush():
-            ids = self.engine.test_function((np.concatenate(Xs), np.concatenate(masks)), k=k, exclude_seen=self._exclude_mode())
+            ids = self._rd().test_function((np.concatenate(Xs), np.concatenate(masks)), k=k, exclude_seen=self._exclude_mode())
             # a row with fewer than k rankable items carries -1 in the places it cannot fill (include/sbr_rnn.h): drop them
             out = (list(goals), [ids[i][ids[i] >= 0] for i in range(len(goals))])
             del Xs[:], masks[:], goals[:]
@@ -361,14 +375,18 @@ class RNNBase(object):
               " ".join(map(str, [metrics[m][-1] for m in self.metrics])), file=sys.stderr)
 
     # ------------------------------------------------------------------ checkpoints (rnn_base.py:470-515)
-    def save(self, filename):
+    def save(self, filename, write=True):
         """pickle of get_all_param_values(l_out): a plain list of float arrays in Lasagne order.
-        Protocol 2 so that a Python-2 reference install can load it."""
+        Protocol 2 so that a Python-2 reference install can load it.
+        write=False: take part in the export (a collective under data parallelism: every rank calls save at the same step)
+        without keeping the file -- e.g. every rank but 0."""
+        param = self._rd().get_all_param_values()
+        if not write:
+            return
         print("Save model in " + filename)
         d = os.path.dirname(filename)
         if d and not os.path.exists(d):
             os.makedirs(d)
-        param = self.engine.get_all_param_values()
         with open(filename, "wb") as f:
             pickle.dump(param, f, protocol=2)
 

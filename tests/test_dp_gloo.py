@@ -266,3 +266,47 @@ def _worker_guard(rank, world, port):
 def test_rank_local_flush_is_refused_and_the_collective_form_works():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker_guard, args=(2, port), nprocs=2, join=True)
+
+
+def test_models_save_and_rank_through_the_data_parallel_collectives(tmp_path):
+    """with dp_guard set every models.py path that called engine.get_all_param_values / test_function /
+    predict_function directly raised, so a multi-rank driver built on models.py could neither checkpoint nor evaluate.  A model
+    that was handed the DataParallel (attach_data_parallel) routes those three through its collectives (rnn_base.py:476 save,
+    :185-211 the compiled functions)."""
+    import pickle
+    from sbr_amd.models import RNNOneHot
+
+    class GuardedEngine(object):                      # what engine.RNNEngine does under dp_guard with sparse blocks
+        def _no(self, *a, **k):
+            raise RuntimeError("rank-local call: go through DataParallel")
+        get_all_param_values = test_function = predict_function = _no
+
+    class FakeDP(object):
+        def __init__(self):
+            self.calls = []
+
+        def get_all_param_values(self):
+            self.calls.append("get"); return [np.arange(6, dtype=np.float32).reshape(2, 3), np.ones(4, dtype=np.float32)]
+
+        def test_function(self, inputs, k=10, exclude_seen=True):
+            self.calls.append(("test", k)); return [np.zeros((1, k), dtype=np.int32)]
+
+        def predict_function(self, X, mask):
+            self.calls.append("predict"); return np.zeros((1, 5), dtype=np.float32)
+
+    m = RNNOneHot(max_length=8, batch_size=4)
+    m.engine = GuardedEngine()
+    with pytest.raises(RuntimeError):
+        m.save(str(tmp_path / "alone.pkl"))
+    dp = FakeDP()
+    m.attach_data_parallel(dp)
+    f = str(tmp_path / "ckpt" / "model.pkl")
+    m.save(f)
+    m.save(str(tmp_path / "not_kept.pkl"), write=False)      # every other rank: takes part, keeps nothing
+    assert not os.path.exists(str(tmp_path / "not_kept.pkl"))
+    with open(f, "rb") as fh:
+        got = pickle.load(fh)
+    assert len(got) == 2 and np.array_equal(got[0], np.arange(6, dtype=np.float32).reshape(2, 3))
+    m.test_function((None, None), k=7)
+    m.predict_function(None, None)
+    assert dp.calls == ["get", "get", ("test", 7), "predict"]

@@ -208,14 +208,20 @@ def _c5_million_item_case(B, T, n, seed, grad_floor=1e-12, recurrent_gain=1.0, t
             excl = [[int(i) for i in batch["X"][b, :int(batch["mask"][b].sum()), 0]] for b in range(B)]
             oids = np.array(O.test_function(tparams, cfg, batch["X"], batch["mask"], excl, k=k))
             _, ologits = O.predict_scores(tparams, cfg, batch["X"], batch["mask"])
-            gap = 6.0 * tol * float(np.abs(ologits).max())            # logits follow the hidden state: tol relative, six times over
-            rows = np.ones(B, dtype=bool)
+            # per row the longest PREFIX of the ranking whose consecutive logits are further apart than the bar admits (logits
+            # follow the hidden state: tol relative to the largest logit, twice over); eleven ranks that far apart hardly exist
+            # among 40 000 items, a leading few do in most rows
+            gap = 2.0 * tol * float(np.abs(ologits).max())
+            n_cmp, n_rows = 0, 0
             for b in range(B):
                 row = ologits[b].copy(); row[np.asarray(excl[b], dtype=np.int64)] = -np.inf
                 top = -np.sort(-row)[:k + 1]
-                rows[b] = bool(np.all(top[:-1] - top[1:] > gap))
-            assert rows.sum() >= 0.25 * B, rows.sum()
-            assert np.array_equal(ids[rows], big[oids[rows]])
+                far = top[:-1] - top[1:] > gap
+                j = int(np.argmin(far)) if not far.all() else k          # ranks 0 .. j-1 are decided
+                if j > 0:
+                    assert np.array_equal(ids[b, :j], big[oids[b, :j]]), (b, j, ids[b, :j], big[oids[b, :j]])
+                    n_cmp += j; n_rows += 1
+            assert n_rows >= 0.25 * B and n_cmp >= B // 2, (n_rows, n_cmp)
             return
         del g1
         upd = O.Updater("adam", 0.01, rho=0.9, beta1=0.9, beta2=0.999)

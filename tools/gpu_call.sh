@@ -9,6 +9,7 @@
 #   pmc:<cfg>                    FETCH_SIZE / WRITE_SIZE passes + tools/pmc_summary.py       -> <tag>_<cfg>_pmc.json
 #   phases                       in-kernel phase counters of the C2 chains                  -> <tag>_rec_phases.txt
 #   trace                        device-side stamps of the overlapped tail's consumers      -> <tag>_tail_trace.txt
+#   py:<script>[:args,..][:ENV=v,..]   python tools/<script>.py args                          -> <tag>_py_<script>.txt
 #   test:<pytest -k expr|all>[:ENV=v,..][:file]   pytest -m gpu                             -> <tag>_tests_<n>.txt
 #   cmp:<spec>[;<spec>...]     tools/cmp_case.py on each spec (CELL:H[,H2]:B:T:key=value..., ';' between specs) -> <tag>_cmp.txt
 #   bg:<job>                     the job in the background (joined at the end of the call)
@@ -69,6 +70,8 @@ print({k: d.get(k) for k in ('value','ms_per_step','repeats','sustained','train_
            rm -rf $out/${tag}_${a}_pf $out/${tag}_${a}_pw $out/${tag}_${a}_st; head -c 1500 $out/${tag}_${a}_pmc.json ;;
     phases) ( timeout 120 python tools/rec_prof.py c2; timeout 120 python tools/tail_prof.py ) > $out/${tag}_rec_phases.txt 2>&1; cat $out/${tag}_rec_phases.txt | cut -c1-220 ;;
     trace) timeout 120 python tools/tail_trace.py 8 > $out/${tag}_tail_trace.txt 2>&1; tail -30 $out/${tag}_tail_trace.txt ;;
+    py)    envs=$(echo "$c" | tr ',' ' ')
+           env $envs timeout 300 python tools/$a.py $(echo "$b" | tr ',' ' ') > $out/${tag}_py_$a.txt 2>&1; tail -40 $out/${tag}_py_$a.txt | cut -c1-220 ;;
     test)  nt=$((nt+1)); envs=$(echo "$b" | tr ',' ' ')
            if [ "$a" = all ]; then sel=""; else sel="-k"; fi
            env $envs timeout 2700 python -m pytest ${c:-tests} -m gpu -q --durations=8 $sel ${sel:+"$a"} > $out/${tag}_tests_$nt.txt 2>&1

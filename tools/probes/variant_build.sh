@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../../sequence-based-recommendations_amd/csrc" || exit 1
 make -j8 > /dev/null || exit 1
 mkdir -p ../../tools/probes/variants
-OBJS="sbr_api sbr_rec sbr_rec_p sbr_rec_q sbr_rec_cl sbr_batch sbr_gemm sbr_gemm_x6 sbr_misc sbr_sparse sbr_cluster"
+OBJS="sbr_api sbr_rec sbr_rec_p sbr_rec_q sbr_rec_cl sbr_batch sbr_gemm sbr_gemm_x6 sbr_misc sbr_sparse sbr_cluster sbr_head"
 for spec in "$@"; do
   n=${spec%%:*}; r=${spec#*:}; src=${r%%:*}; f=${r#*:}
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize $f -c $src.hip -o /tmp/${src}_$n.o || exit 1

@@ -7,7 +7,7 @@ mkdir -p ../../tools/probes/variants
 for spec in "$@"; do
   n=${spec%%:*}; f=${spec#*:}
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize $f -c sbr_rec_p.hip -o /tmp/sbr_rec_p_$n.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probes/variants/libsbr_$n.so sbr_api.o sbr_rec.o /tmp/sbr_rec_p_$n.o sbr_rec_q.o sbr_rec_cl.o sbr_batch.o sbr_gemm.o sbr_gemm_x6.o sbr_misc.o sbr_sparse.o sbr_cluster.o ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probes/variants/libsbr_$n.so sbr_api.o sbr_rec.o /tmp/sbr_rec_p_$n.o sbr_rec_q.o sbr_rec_cl.o sbr_batch.o sbr_gemm.o sbr_gemm_x6.o sbr_misc.o sbr_sparse.o sbr_cluster.o sbr_head.o ) &
 done
 wait
 ls -la ../../tools/probes/variants/
