@@ -428,6 +428,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_OUT_FUSE"); h->out_fuse = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_HEAD_GATE"); h->head_gate = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_TAIL_WIN_SPLIT"); h->tail_win_split = e ? atoi(e) : 0; }
+    { const char* e = getenv("SBR_ROW_AWARE_UPDATE"); h->row_aware = e ? atoi(e) : 1; }
     h->win_split_done = false;
     h->out_stepped = false;
     h->head_epoch = 0;
@@ -1816,13 +1817,26 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     const size_t p_end = h->out_early ? y.p_split : y.n_params;     // the output layer was stepped beside the BPTT chain
     // [0, hi) of the parameter section; where the untouched rows of W_in were stepped beside the chain (win_early,
     // sbr_backward_recurrent), only the touched rows of that block are left
+    // Single-call step, dense wide index-input block, the step's plain-key sort at hand (a_soff: this batch's segment offsets): the pass
+    // over W_in reads / clears the gradient of the touched rows only (launch_update_rows_aware).  SBR_ROW_AWARE_UPDATE=0: update_kernel.
+    const bool row_aware = h->row_aware && h->in_train_step && y.a_tmark && !y.n_sparse && !y.E && y.D == 1 && h->tail_nc < 2 &&
+                           !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && !simple_gemm(h) && !simple_rec(h) && !h->win_early && !h->win_fused &&
+                           ((y.G * y.layer[0].Hp) & 3) == 0;
     auto upd_front = [&](size_t hi) -> hipError_t {
-        if (!h->win_early && !h->win_fused) return upd(0, hi);
+        if (!h->win_early && !h->win_fused && !row_aware) return upd(0, hi);
         const LayerLayout& l0 = y.layer[0];
         const int GHp0 = y.G * l0.Hp;
         const size_t w_end = l0.p_Win + (size_t)y.cfg.input_size * GHp0;
         hipError_t e = upd(0, l0.p_Win);
         if (e != hipSuccess) return e;
+        if (row_aware) {
+            if (hi < w_end) return hipErrorInvalidValue;      // (callers pass ranges that cover the block)
+            e = launch_update_rows_aware(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
+                                         y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
+                                         y.cfg.beta2, (long)h->step_count);
+            if (e != hipSuccess) return e;
+            return hi > w_end ? upd(w_end, hi) : hipSuccess;
+        }
         if (h->win_fused) return hi > w_end ? upd(w_end, hi) : hipSuccess;      // every row of the block has been stepped (scatter-add + side2)
         e = launch_update_rows(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
                                y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), 1, y.cfg.learning_rate, y.cfg.rho,
@@ -1887,7 +1901,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
             SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
             size_t pos = 0;
             int l_from = 0;
-            if (h->win_early || h->win_fused) {      // layer 0: W_in's touched rows (win_early) / nothing of W_in (win_fused), then b
+            if (h->win_early || h->win_fused || row_aware) {      // layer 0: W_in's touched rows (win_early) / nothing of W_in (win_fused) / the row-aware pass, then b
                 SBR_LAUNCH(upd_front(y.layer[0].p_Whid));
                 pos = y.layer[0].p_peep; l_from = 1;
             }

@@ -169,6 +169,7 @@ struct sbr_handle {
     int head_fuse;       // SBR_HEAD_FUSE (default 1): the full-softmax head in one launch (sbr_head.hip)
     unsigned head_epoch;
     int head_gate;       // SBR_HEAD_GATE (default 1): the side stream is released by the head kernel's own flag instead of an event
+    int row_aware;       // SBR_ROW_AWARE_UPDATE (default 1): the dense pass over a wide index-input block skips the gradient traffic of the rows the batch did not touch
     int tail_win_split;  // SBR_TAIL_WIN_SPLIT: overlapped tail, dense W_in: untouched rows stepped beside the forward chain, touched rows behind the scatter-add
     bool win_split_done; // this step: the untouched rows are stepped (sbr_forward), mark epoch = mark_epoch
     int out_fuse;        // SBR_OUT_FUSE (default 1): the dense head's gradient and step in one launch (launch_out_grad_step)
@@ -521,6 +522,8 @@ bool launch_out_grad_step(hipStream_t s, const float* dlogits, const float* h_la
                           float rho, float b1, float b2, long t, hipError_t* err);
 hipError_t launch_update_touched_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
                                       const int* mark, int epoch, float lr, float rho, float b1, float b2, long t);
+hipError_t launch_update_rows_aware(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
+                                    const int* offs, float lr, float rho, float b1, float b2, long t);
 hipError_t launch_mark_rows(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* mark, int epoch);
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);

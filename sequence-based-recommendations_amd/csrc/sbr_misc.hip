@@ -1862,6 +1862,39 @@ hipError_t launch_update_touched_rows(hipStream_t s, int updater, float* p, floa
     update_touched_rows_kernel<<<grid, 256, 0, s>>>(st, g, n_rows, row_floats / 4, mark, epoch);
     return hipGetLastError();
 }
+// The dense pass over an item-indexed block, aware of which rows the batch touched (offs = the scatter's segment offsets): an
+// untouched row's gradient is zero and stays zero, so its step reads and writes p, s0, s1 only (6 passes instead of 8: C4 touches 40 %
+// of its 26 744 rows per batch); a touched row's gradient is read and cleared as update_kernel does.  One streaming launch, 16
+// bytes per lane, update_element's arithmetic for both kinds of row.
+__global__ void __launch_bounds__(256) update_rows_aware_kernel(SbrScatStep st, float* __restrict__ gr, int n_rows, int R4,
+                                                                const int* __restrict__ offs) {
+    const size_t n4 = (size_t)n_rows * R4;
+    f32x4* __restrict__ p = (f32x4*)st.p; f32x4* __restrict__ s0 = (f32x4*)st.s0; f32x4* __restrict__ s1 = (f32x4*)st.s1;
+    f32x4* __restrict__ g = (f32x4*)gr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (unsigned)R4);
+        const bool touched = offs[r + 1] > offs[r];
+        f32x4 gv = {0, 0, 0, 0};
+        if (touched) { gv = g[i]; g[i] = f32x4{0, 0, 0, 0}; }
+        f32x4 pv = p[i], av = s0[i], bv = s1 ? s1[i] : f32x4{0, 0, 0, 0};
+        scat_step4(st, gv, pv, av, bv);
+        p[i] = pv; s0[i] = av;
+        if (s1) s1[i] = bv;
+    }
+}
+hipError_t launch_update_rows_aware(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
+                                    const int* offs, float lr, float rho, float b1, float b2, long t) {
+    if (n_rows <= 0) return hipSuccess;
+    if ((row_floats & 3) || !offs) return hipErrorInvalidValue;
+    SbrScatStep st; st.p = p; st.s0 = s0; st.s1 = s1; st.last = nullptr; st.updater = updater; st.t_to = (int)t;
+    st.lr = lr; st.rho = rho; st.b1 = b1; st.b2 = b2; st.a_t = 0.0f;
+    if (updater == SBR_UPD_ADAM)
+        st.a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    const size_t n4 = (size_t)n_rows * (row_floats / 4);
+    const int grid = (int)min((size_t)256 * 16, (n4 + 255) / 256);
+    update_rows_aware_kernel<<<grid, 256, 0, s>>>(st, g, n_rows, row_floats / 4, offs);
+    return hipGetLastError();
+}
 // mark[id] = epoch for every id the batch names (X [Bp][T][F], valid while t < len[b]); epochs never repeat, nothing is cleared
 __global__ void mark_rows_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F, int n_ids,
                                  int* __restrict__ mark, int epoch) {
