@@ -291,6 +291,8 @@ def main():
                          "rank holds --batch / N rows")
     ap.add_argument("--brief", action="store_true", help="phase survey + timed regions + roofline only (what the default run starts "
                     "for the other BASELINE configurations): no counter / sustained / train-loop / CPU / side-kernel legs")
+    ap.add_argument("--strong-pieces", action="store_true", help="with --gpus N > 1: rank 0 also measures strong_scaling_model (C2 / C4 at 128 / "
+                    "64 / 32 rows on one GPU) behind the timed regions; the default single-GPU run always carries it")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of BASELINE configs c1 / c3 / c4 / c5")
     ap.add_argument("--other-configs", default="c1,c4,c3,c5,c5_bf16", help="which of them the default run starts (comma-separated, in this order; "
                     "c5_bf16 = C5 with --flags 384: bf16 output projection + bf16 layer GEMMs, the arithmetic BASELINE configs[4] names)")
@@ -852,6 +854,13 @@ def main():
             result["other_configs"] = other_config_lines(log, [n for n in args.other_configs.split(",") if n in ("c1", "c3", "c4", "c5", "c5_bf16")])
         except Exception as ex:
             result["other_configs"] = {"error": repr(ex)[:300]}
+        try:
+            result["strong_scaling_model"] = strong_scaling_pieces(log)
+        except Exception as ex:
+            result["strong_scaling_model"] = {"error": repr(ex)[:300]}
+    elif rank == 0 and world > 1 and args.strong_pieces and not args.quick:
+        # a data-parallel line that carries the single-rank pieces of its own strong-scaling model (the process group is gone by now:
+        # the children are plain one-GPU runs on rank 0's device)
         try:
             result["strong_scaling_model"] = strong_scaling_pieces(log)
         except Exception as ex:

@@ -82,7 +82,9 @@ def test_gpus_2_starts_its_own_ranks():
     # On the one-GPU test box the two ranks share the device, which RCCL refuses: gloo carries the collectives there
     # (--dp-backend gloo); everything else -- rendezvous, row shards, barrier + max-over-ranks timing, rank 0's one line -- is
     # the path the 8-GPU run takes.
-    d = run("--gpus", "2", "--dp-backend", "gloo", "--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0")
+    d = run("--gpus", "2", "--dp-backend", "gloo", "--no-cpu-baseline", "--repeats", "2", "--sustained-seconds", "0", "--strong-pieces")
+    sm = d["strong_scaling_model"]      # (round 5: the two-rank line carries the measured single-rank pieces of its strong-scaling model)
+    assert "skipped" not in sm["c2_b128"] and sm["c2_b128"]["ranks_of_global_256"] == 2 and sm["c2_b128"]["ms_per_step"] > 0
     assert (d["n_gpus"], d["steps"], d["warmup"]) == (2, 6, 2) and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
     assert d["value"] == pytest.approx(512 / (d["ms_per_step"] * 1e-3), rel=2e-3)
