@@ -188,6 +188,10 @@ def strong_scaling_pieces(log, budget_s=150.0):
     (--quick: timed regions only).  The chains are 2 T dependent steps whatever the rows, so these do not shrink like 1 / N."""
     import subprocess
     out, t_all = {}, time.perf_counter()
+    # (a rank of a launcher's job starts these: its children are plain one-GPU runs, not members of that job)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                        "MASTER_ADDR", "MASTER_PORT", "ROLE_NAME", "OMP_NUM_THREADS") and not k.startswith(("TORCHELASTIC_", "PET_"))}
     for name in ("c2", "c4"):
         for bl in (128, 64, 32):
             key = "%s_b%d" % (name, bl)
@@ -196,7 +200,7 @@ def strong_scaling_pieces(log, budget_s=150.0):
                 continue
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--quick", "--batch", str(bl), "--steps", "20",
-                                    "--warmup", "5", "--repeats", "3"], capture_output=True, text=True, timeout=60)
+                                    "--warmup", "5", "--repeats", "3"], capture_output=True, text=True, timeout=60, env=env)
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 out[key] = {"ranks_of_global_256": 256 // bl, "rows_per_rank": bl, "ms_per_step": d["ms_per_step"],
                             "sequences_per_s_per_rank": d["value"]}

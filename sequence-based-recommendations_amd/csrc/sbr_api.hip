@@ -1934,8 +1934,8 @@ static int report_fault(sbr_handle* h, int fault) {
     // bit 3: a consumer of the overlapped tail (or its monitor) waited for the chain for 1.5 s; bit 4: a unit of the LDS-row
     // scatter-add was handed more ids than it has LDS rows for (launch_scatter_lds_poll sizes them: cannot happen)
     if (fault & 32)
-        sbr_set_error("the fused output head (sbr_head.hip) waited 1.5 s for the row statistics of its other workgroups (flag %d, results of "
-                      "this call invalid): its grid was not co-resident; rerun with SBR_HEAD_FUSE=0", fault);
+        sbr_set_error("the side stream's gate waited 1.5 s for the one-launch output head (sbr_head.hip) to finish (flag %d, results of this call "
+                      "invalid); rerun with SBR_HEAD_GATE=0", fault);
     else
     if (fault & 16)
         sbr_set_error("the LDS-row scatter-add of the overlapped tail ran out of rows (flag %d, results of this call invalid); rerun with "

@@ -17,9 +17,11 @@
 //      tile stays in registers.
 //   2. row max / sum of exponentials over the chunk (lanes -> waves through LDS), published as one 16-byte piece per (row block,
 //      chunk, row) whose dwords validate themselves against this launch's epoch (value, value ^ epoch: no ordering needed, a
-//      torn piece is simply not valid yet); every workgroup of the row block polls the CC pieces of its rows (agent-scope loads,
-//      bounded by the wall clock: fault bit 5 instead of a hang) and combines them in chunk order -- every workgroup the same
-//      bits.
+//      torn piece is simply not valid yet); every workgroup of the row block polls the CC pieces of its rows (agent-scope loads)
+//      and combines them in chunk order -- every workgroup the same bits.  A chunk whose workgroup has not published within
+//      60 us is not waited for: its statistics are recomputed by whoever misses them (its W rows through the same LDS image,
+//      the same code), so every workgroup can always finish on its own -- two processes on one GPU can interleave two such
+//      grids so that neither is ever co-resident.
 //   3. dlogits = (softmax - onehot) / (pop B) from the registers, stored once (the output layer's gradient kernels on the side
 //      stream read them); the row's cost by the lane that holds its target column.
 //   4. dh[row][k] = sum_items dlogits[row][item] W[item][k] with the SAME LDS image (item = reduction index: one ds_read_b32 per
@@ -73,53 +75,35 @@ __device__ __forceinline__ void head_logits(const float* __restrict__ wr, const 
     }
 }
 
+#define HEAD_WAIT_TICKS 6000ull      // 60 us of the 100 MHz clock: how long a chunk's statistics are waited for before they are recomputed
+
+// rows [n_lo, n_lo + CW) of W_out^T -> the LDS image (rows beyond the catalogue: zeros).  Rounds of 16 pieces per thread in flight
+// (C2's chunk of 240 rows x 128 floats is 30 pieces per thread; in rounds of 6 the fill was five dependent round trips to L2)
 template <int HP>
-__global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LDW = HP + 4, KG = HP / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-    // workgroups of one chunk share its W rows: keep them on one XCD (workgroup ids go round-robin over the 8 XCDs)
-    int rb, cc;
-    if ((a.CC & 7) == 0) { const int x = blockIdx.x & 7, li = blockIdx.x >> 3; cc = x * (a.CC >> 3) + li / a.RB; rb = li % a.RB; }
-    else { cc = blockIdx.x / a.RB; rb = blockIdx.x % a.RB; }
-    const int n_lo = cc * a.CW, ntiles = a.CW >> 4;
-#define HEAD_STAMP(I) do { if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 8 + (I)] = wall_clock64(); } while (0)
-    HEAD_STAMP(0);
-    float* Wl = lds;                                                   // [CW][LDW]  (later: the waves' partial dh [4][16][HP])
-    const int wl_floats = max(a.CW * LDW, 64 * HP);
-    float* red = lds + wl_floats;                                      // [4][16][2] wave stats, then [CC][16][2] chunk stats
-    // ---- 0. W chunk -> LDS (rows beyond the catalogue: zeros), h rows -> registers
-    const int row = rb * 16 + j;
-    f32x4 hb[KG];
+__device__ __forceinline__ void head_fill(const HeadArgs& a, float* __restrict__ Wl, int n_lo, int tid) {
+    constexpr int LDW = HP + 4, P = HP / 4, U = 16;                    // P: 16-byte pieces per row
+    const int total = a.CW * P;
+    for (int i0 = tid; i0 < total; i0 += 256 * U) {
+        f32x4 v[U];
 #pragma unroll
-    for (int g = 0; g < KG; ++g) hb[g] = *(const f32x4*)(a.h + (size_t)row * HP + 16 * g + 4 * q);
-    const int y = a.tgt[row];
-    const float scale = a.inv_Bg / a.pop[row];
-    {
-        // (rounds of 16 pieces per thread in flight: C2's chunk of 240 rows x 128 floats is 30 pieces per thread -- in rounds of 6
-        // the fill was five dependent round trips to L2, ~10 of the kernel's 22 us: profiles/round5_a_c2_timeline.txt)
-        constexpr int P = HP / 4, U = 16;                              // 16-byte pieces per row
-        const int total = a.CW * P;
-        for (int i0 = tid; i0 < total; i0 += 256 * U) {
-            f32x4 v[U];
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
+            v[u] = (i < total && n_lo + r < a.N) ? *(const f32x4*)(a.W + (size_t)(n_lo + r) * HP + 4 * c4) : f32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
-                v[u] = (i < total && n_lo + r < a.N) ? *(const f32x4*)(a.W + (size_t)(n_lo + r) * HP + 4 * c4) : f32x4{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
-                if (i < total) *(f32x4*)(Wl + r * LDW + 4 * c4) = v[u];
-            }
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 256 * u, r = i / P, c4 = i - r * P;
+            if (i < total) *(f32x4*)(Wl + r * LDW + 4 * c4) = v[u];
         }
     }
-    __syncthreads();
-    HEAD_STAMP(1);
-    // ---- 1. logits of this wave's tiles: the tiles advance TOGETHER through k, one accumulator chain each (head_logits<NTW>:
-    // straight-line code per tile count) -- tile after tile the 32 dependent instructions of a tile ran at the f32 matrix
-    // instruction's latency (4.7 us for four tiles against 1.7 us of issue: tools/head_prof.py, profiles/round5_c_head_phases.txt)
-    f32x4 lg[HEAD_NT];
+}
+
+// this wave's tiles of the chunk whose rows are in the LDS image: logits (+ bias; -inf beyond the catalogue) into lg, the wave's
+// row maximum and sum of exponentials into red_w[wave][row]
+template <int HP>
+__device__ __forceinline__ void head_wave_stats(const HeadArgs& a, const float* __restrict__ Wl, const f32x4 (&hb)[HP / 16], int n_lo, int ntiles,
+                                                int wave, int j, int q, f32x4 (&lg)[HEAD_NT], float* __restrict__ red_w) {
+    constexpr int LDW = HP + 4;
     float mx = -INFINITY;
     {
         f32x4 acc[HEAD_NT];
@@ -127,6 +111,8 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
         for (int i = 0; i < HEAD_NT; ++i) acc[i] = f32x4{0, 0, 0, 0};
         const float* wr = Wl + (16 * wave + j) * LDW + 4 * q;          // tile wave + 4 i: + 64 i rows
         const int ntw = ntiles > wave ? (ntiles - wave + 3) >> 2 : 0;   // tiles of this wave (wave-uniform)
+        // the tiles advance TOGETHER through k, one accumulator chain each; straight-line code per tile count (guards inside the
+        // loops made 160 basic blocks of it: 4.7 -> 24.7 us, profiles/round5_variants.txt call d)
         switch (ntw) {
             case 5: head_logits<HP, 5>(wr, hb, acc); break;
             case 4: head_logits<HP, 4>(wr, hb, acc); break;
@@ -150,9 +136,7 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
             }
         }
     }
-    HEAD_STAMP(2);
-    // ---- 2. row statistics: lanes of a row (q = 0..3), waves, chunks
-    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));      // the lanes of a row: q = 0 .. 3
     float se = 0.0f;
     if (mx > -INFINITY) {
 #pragma unroll
@@ -161,48 +145,117 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
             for (int r = 0; r < 4; ++r) se += __builtin_amdgcn_exp2f((lg[i][r] - mx) * HEAD_LOG2E);      // (-inf -> 0)
     }
     se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
-    if (q == 0) { red[(wave * 16 + j) * 2] = mx; red[(wave * 16 + j) * 2 + 1] = se; }
+    if (q == 0) { red_w[(wave * 16 + j) * 2] = mx; red_w[(wave * 16 + j) * 2 + 1] = se; }
+}
+// the four waves' statistics of row r -> the chunk's (fixed order)
+__device__ __forceinline__ void head_chunk_combine(const float* __restrict__ red_w, int r, float& m, float& s) {
+    m = -INFINITY; s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m = fmaxf(m, red_w[(w * 16 + r) * 2]);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float mw = red_w[(w * 16 + r) * 2];
+        if (mw > -INFINITY) s += red_w[(w * 16 + r) * 2 + 1] * __builtin_amdgcn_exp2f((mw - m) * HEAD_LOG2E);
+    }
+}
+
+template <int HP>
+__global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LDW = HP + 4, KG = HP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    // workgroups of one chunk share its W rows: keep them on one XCD (workgroup ids go round-robin over the 8 XCDs)
+    int rb, cc;
+    if ((a.CC & 7) == 0) { const int x = blockIdx.x & 7, li = blockIdx.x >> 3; cc = x * (a.CC >> 3) + li / a.RB; rb = li % a.RB; }
+    else { cc = blockIdx.x / a.RB; rb = blockIdx.x % a.RB; }
+    const int n_lo = cc * a.CW, ntiles = a.CW >> 4;
+#define HEAD_STAMP(I) do { if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 8 + (I)] = wall_clock64(); } while (0)
+    HEAD_STAMP(0);
+    float* Wl = lds;                                                   // [CW][LDW]  (later: the waves' partial dh [4][16][HP])
+    const int wl_floats = max(a.CW * LDW, 64 * HP);
+    float* red_w = lds + wl_floats;                                    // [4][16][2] the waves' statistics of the chunk in LDS
+    float* cst = red_w + 128;                                          // [CC <= 16][16][2] every chunk's statistics of this row block
+    int* miss = (int*)(cst + 512);                                     // [16] chunks whose workgroup did not publish in time
+    // ---- 0. W chunk -> LDS (rows beyond the catalogue: zeros), h rows -> registers
+    const int row = rb * 16 + j;
+    f32x4 hb[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) hb[g] = *(const f32x4*)(a.h + (size_t)row * HP + 16 * g + 4 * q);
+    const int y = a.tgt[row];
+    const float scale = a.inv_Bg / a.pop[row];
+    if (tid < 16) miss[tid] = 0;
+    head_fill<HP>(a, Wl, n_lo, tid);
     __syncthreads();
-    if (tid < 16) {                                                    // this chunk's (max, sum) of row tid, published
-        float m = -INFINITY, s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) m = fmaxf(m, red[(w * 16 + tid) * 2]);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float mw = red[(w * 16 + tid) * 2];
-            if (mw > -INFINITY) s += red[(w * 16 + tid) * 2 + 1] * __builtin_amdgcn_exp2f((mw - m) * HEAD_LOG2E);
-        }
+    HEAD_STAMP(1);
+    // ---- 1. logits of this wave's tiles, 2. the waves' row statistics
+    f32x4 lg[HEAD_NT];
+    head_wave_stats<HP>(a, Wl, hb, n_lo, ntiles, wave, j, q, lg, red_w);
+    HEAD_STAMP(2);
+    __syncthreads();
+    if (tid < 16) {                                                    // this chunk's (max, sum) of row tid: kept, and published
+        float m, sx;
+        head_chunk_combine(red_w, tid, m, sx);
+        cst[(cc * 16 + tid) * 2] = m; cst[(cc * 16 + tid) * 2 + 1] = sx;
         unsigned* p = a.stats + ((size_t)(rb * a.CC + cc) * 16 + tid) * 4;
-        const unsigned mb = __float_as_uint(m), sb = __float_as_uint(s);
+        const unsigned mb = __float_as_uint(m), sb = __float_as_uint(sx);
         __hip_atomic_store(p + 0, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p + 1, mb ^ a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p + 2, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p + 3, sb ^ a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                                   // (red is rewritten below)
     HEAD_STAMP(3);
-    if (tid < a.CC * 16) {
+    // The other chunks' statistics.  A workgroup that has not published within HEAD_WAIT_TICKS is not waited for: its chunk's
+    // statistics are RECOMPUTED here (below) -- the grid is co-resident on an otherwise idle chip (one workgroup per CU), but two
+    // processes sharing a GPU can interleave two such grids so that neither is ever complete: round 5's first form then spun for
+    // 1.5 s and failed the step (tests/test_gpu_bench_contract.py::test_gpus_2_starts_its_own_ranks, two ranks on one GPU).  Now every
+    // workgroup can always finish on its own.
+    if (tid < a.CC * 16 && (tid >> 4) != cc) {
         const int c = tid >> 4, r = tid & 15;
         const unsigned* p = a.stats + ((size_t)(rb * a.CC + c) * 16 + r) * 4;
         const unsigned long long t0 = wall_clock64();
         unsigned d0, d1, d2, d3;
+        bool ok = false;
         for (;;) {
             d0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((d0 ^ d1) == a.epoch && (d2 ^ d3) == a.epoch) break;
-            if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(a.fault, 32); d0 = __float_as_uint(0.0f); d2 = __float_as_uint(1.0f); break; }
+            if ((d0 ^ d1) == a.epoch && (d2 ^ d3) == a.epoch) { ok = true; break; }
+            if (wall_clock64() - t0 > HEAD_WAIT_TICKS) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        red[(c * 16 + r) * 2] = __uint_as_float(d0); red[(c * 16 + r) * 2 + 1] = __uint_as_float(d2);
+        if (ok) { cst[(c * 16 + r) * 2] = __uint_as_float(d0); cst[(c * 16 + r) * 2 + 1] = __uint_as_float(d2); }
+        else miss[c] = 1;
     }
     __syncthreads();
+    {
+        bool any = false;
+        for (int c = 0; c < a.CC; ++c) {
+            if (!miss[c]) continue;                                    // (LDS word: the same answer in every thread)
+            any = true;
+            __syncthreads();                                           // everyone has read miss[c] / finished with the image
+            head_fill<HP>(a, Wl, c * a.CW, tid);
+            __syncthreads();
+            f32x4 lgx[HEAD_NT];
+            head_wave_stats<HP>(a, Wl, hb, c * a.CW, ntiles, wave, j, q, lgx, red_w);
+            __syncthreads();
+            if (tid < 16) {
+                float m, sx;
+                head_chunk_combine(red_w, tid, m, sx);
+                cst[(c * 16 + tid) * 2] = m; cst[(c * 16 + tid) * 2 + 1] = sx;
+            }
+        }
+        if (any) {                                                     // this chunk's own rows again: phase 4 multiplies with them
+            __syncthreads();
+            head_fill<HP>(a, Wl, n_lo, tid);
+            __syncthreads();
+        }
+    }
     float M = -INFINITY, S = 0.0f;
-    for (int c = 0; c < a.CC; ++c) M = fmaxf(M, red[(c * 16 + j) * 2]);
+    for (int c = 0; c < a.CC; ++c) M = fmaxf(M, cst[(c * 16 + j) * 2]);
     for (int c = 0; c < a.CC; ++c) {                                   // chunk order: the same bits in every workgroup of the row block
-        const float mc = red[(c * 16 + j) * 2];
-        if (mc > -INFINITY) S += red[(c * 16 + j) * 2 + 1] * __builtin_amdgcn_exp2f((mc - M) * HEAD_LOG2E);
+        const float mc = cst[(c * 16 + j) * 2];
+        if (mc > -INFINITY) S += cst[(c * 16 + j) * 2 + 1] * __builtin_amdgcn_exp2f((mc - M) * HEAD_LOG2E);
     }
     const float inv = 1.0f / S;
     HEAD_STAMP(4);
@@ -296,7 +349,7 @@ bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes) {
     if (cc < 1) return false;
     const int cw = ((N + cc - 1) / cc + 15) / 16 * 16;
     if (cw > 16 * 4 * HEAD_NT) return false;
-    const size_t fl = (size_t)std::max(cw * (Hp + 4), 64 * Hp) + 2 * 16 * std::max(4, cc) + 64;
+    const size_t fl = (size_t)std::max(cw * (Hp + 4), 64 * Hp) + 128 + 512 + 32;      // image + wave statistics + chunk statistics + miss flags
     if (fl * 4 > 160 * 1024) return false;
     *CC = cc; *CW = cw; *lds_bytes = fl * 4;
     return true;
