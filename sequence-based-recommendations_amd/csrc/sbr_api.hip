@@ -429,6 +429,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_HEAD_GATE"); h->head_gate = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_TAIL_WIN_SPLIT"); h->tail_win_split = e ? atoi(e) : 0; }
     { const char* e = getenv("SBR_ROW_AWARE_UPDATE"); h->row_aware = e ? atoi(e) : 1; }
+    h->win_untouched_done = false;
     h->win_split_done = false;
     h->out_stepped = false;
     h->head_epoch = 0;
@@ -1659,6 +1660,20 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                         }
                     }
                 }
+                // SBR_ROW_AWARE_UPDATE=2: the zero-gradient step of the rows this batch does not name (6 passes over 60 % of C4's W_in) runs on
+                // the second side stream BESIDE the scatter-add and the weight-gradient GEMM; sbr_apply_update then steps the touched rows only
+                h->win_untouched_done = false;
+                if (h->row_aware == 2 && h->in_train_step && sm == s && y.a_tmark && !y.n_sparse && y.D == 1 && h->tail_nc < 2 && !sg && !simple_rec(h) &&
+                    !h->win_early && (GHp & 3) == 0) {
+                    float* s1w = y.n_state_arrays > 1 ? h->St(1, ly.p_Win) : nullptr;
+                    SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_sort, 0));
+                    if (ev_chain_end) SBR_HIP(hipStreamWaitEvent(h->side2, ev_chain_end, 0));
+                    SBR_LAUNCH(launch_update_untouched_rows(h->side2, y.cfg.updater, h->P(ly.p_Win), h->St(0, ly.p_Win), s1w, y.cfg.input_size, GHp,
+                                                            (const int*)h->A(y.a_soff), nullptr, 0, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
+                                                            y.cfg.beta2, (long)h->step_count + 1));
+                    SBR_HIP(hipEventRecord(h->ev_tail2, h->side2));
+                    h->win_rest_pending = true; h->win_untouched_done = true;
+                }
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
                 // SBR_SCAT_RANGE: 1 (default) = the range form up to 1024-float rows, the atomic kernel beyond (C5: measured 8.35 against
                 // 8.44 - 8.48 ms with either new form); 2 = the segment-parallel form; 0 = the atomic kernel everywhere
@@ -1822,6 +1837,10 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     const bool row_aware = h->row_aware && h->in_train_step && y.a_tmark && !y.n_sparse && !y.E && y.D == 1 && h->tail_nc < 2 &&
                            !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && !simple_gemm(h) && !simple_rec(h) && !h->win_early && !h->win_fused &&
                            ((y.G * y.layer[0].Hp) & 3) == 0;
+    if (h->win_untouched_done && !row_aware) {
+        sbr_set_error("internal: the untouched rows of W_in were stepped (SBR_ROW_AWARE_UPDATE=2) but the update does not take the row-aware pass");
+        return SBR_ESTATE;
+    }
     auto upd_front = [&](size_t hi) -> hipError_t {
         if (!h->win_early && !h->win_fused && !row_aware) return upd(0, hi);
         const LayerLayout& l0 = y.layer[0];
@@ -1829,6 +1848,14 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         const size_t w_end = l0.p_Win + (size_t)y.cfg.input_size * GHp0;
         hipError_t e = upd(0, l0.p_Win);
         if (e != hipSuccess) return e;
+        if (row_aware && h->win_untouched_done) {      // (SBR_ROW_AWARE_UPDATE=2: the untouched rows are done, on side2)
+            if (hi < w_end) return hipErrorInvalidValue;
+            e = launch_update_rows(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
+                                   y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), 1, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2,
+                                   (long)h->step_count);
+            if (e != hipSuccess) return e;
+            return hi > w_end ? upd(w_end, hi) : hipSuccess;
+        }
         if (row_aware) {
             if (hi < w_end) return hipErrorInvalidValue;      // (callers pass ranges that cover the block)
             e = launch_update_rows_aware(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
@@ -1916,7 +1943,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     }
     if (h->win_rest_pending) { SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_tail2, 0)); h->win_rest_pending = false; }
     h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false; h->win_early = false;
-    h->win_fused = false; h->win_rest_done = false; h->wout_early = false;
+    h->win_fused = false; h->win_rest_done = false; h->wout_early = false; h->win_untouched_done = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;

@@ -169,6 +169,7 @@ struct sbr_handle {
     int head_fuse;       // SBR_HEAD_FUSE (default 1): the full-softmax head in one launch (sbr_head.hip)
     unsigned head_epoch;
     int head_gate;       // SBR_HEAD_GATE (default 1): the side stream is released by the head kernel's own flag instead of an event
+    bool win_untouched_done;   // this step (SBR_ROW_AWARE_UPDATE=2): the untouched rows of the dense index-input block were stepped on side2 beside the scatter-add
     int row_aware;       // SBR_ROW_AWARE_UPDATE (default 1): the dense pass over a wide index-input block skips the gradient traffic of the rows the batch did not touch
     int tail_win_split;  // SBR_TAIL_WIN_SPLIT: overlapped tail, dense W_in: untouched rows stepped beside the forward chain, touched rows behind the scatter-add
     bool win_split_done; // this step: the untouched rows are stepped (sbr_forward), mark epoch = mark_epoch
