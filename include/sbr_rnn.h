@@ -297,7 +297,10 @@ int sbr_enable_timing(sbr_handle* h, int on);
  * "adam_table" (entries of the a_t table of the lazy Adam catch-up); what the top layer's recurrent kernels put on the
  * matrix pipe, for roofline reports: "rec_products_fwd" / "rec_products_bwd" (low-precision MFMA terms per f32 product:
  * 6 = bf16x6, 3 = fp16x3, 0 = exact-f32 MFMA kernels), "rec_rows_fwd" / "_bwd" (live batch rows among the 16 columns of an
- * MFMA tile), "rec_workgroups_fwd" / "_bwd" (workgroups of the launch = CUs it can occupy). */
+ * MFMA tile), "rec_workgroups_fwd" / "_bwd" (workgroups of the launch = CUs it can occupy); ABI 9: "head_fused" (column chunks of
+ * the one-launch full-softmax head a full batch of a training step takes, 0 = the three launches: rnn_one_hot.py:65-71 forward +
+ * backward), "scatter_step" (does the scatter-add of a single-call step apply the optimizer to layer 0's index-input rows itself:
+ * 0 no, 1 dense block, 2 row-sparse block -- SBR_SCAT_FUSE). */
 int sbr_query(sbr_handle* h, const char* what, int64_t* value);
 int sbr_phase_times(sbr_handle* h, float us[SBR_N_PHASES]);
 /* Chain-only timing (ABI 8; tooling: bench.py prices the recurrent chain kernels of stacked layers apart from the dense GEMMs
