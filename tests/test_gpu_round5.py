@@ -1,5 +1,5 @@
-"""Round 5 kernels, each against the float64 oracle AND against the form it replaces (every switch is read once per engine /
-process, so the pairs run in children):
+"""Round 5 kernels, each against the float64 oracle AND against the form it replaces (the switches involved are read once per
+engine, in sbr_create, so a pair is two engines of this process built under different environments):
   * the one-launch full-softmax head (csrc/sbr_head.hip: logits + softmax / CCE + dh, rnn_one_hot.py:65-71) -- chunk counts
     that leave whole chunks empty, catalogues that are no multiple of 16, every layer width it serves, one and sixteen row blocks;
   * the scatter-add that steps the rows it completes (launch_scatter_wide_step, sparse_lstm.py:368 + update_manager.py:24-82)
@@ -8,10 +8,7 @@ process, so the pairs run in children):
   * the sampled head's row-sparse block caught up beside the forward chain and stepped beside the BPTT chain;
   *  one kernel family for the forward and the backward launch of a step when the catalogue is too large for the
     fused gather's 32-bit row offsets."""
-import json
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -59,34 +56,43 @@ def test_one_launch_head_is_not_taken_where_it_does_not_fit():
             eng.close()
 
 
-CHILD = r"""
-import sys, json, numpy as np
-sys.path[:0] = [%r, %r]
-import parity_util as PU
-cell, H, loss, N, B, T, S, upd, steps = sys.argv[2:11]
-H, N, B, T, S, steps = int(H), int(N), int(B), int(T), int(S), int(steps)
-r = PU.compare_step(cell, [H], loss, N=N, B=B, T=T, S=S, zipf=True, steps=2, scale=0.03, seed=61, updater=upd,
-                    queries=("head_fused", "scatter_step", "sparse_blocks"))
-params, cfg, batch = PU.build_case(cell, [H], loss, N, B, T, S=S, seed=61, scale=0.03, zipf=True)
-eng = PU.engine_for(cfg, N, B, T, S=S, updater=upd)
-eng.set_all_param_values(params)
-costs = []
-for i in range(steps):
-    bt = PU.make_batch(np.random.default_rng(300 + i %% 2), B, T, N, S=S, zipf=True) if i else batch
-    eng.set_batch(bt["X"], bt["mask"], bt["target"], bt["samples"] if loss != "CCE" else None, bt["pop"])
-    costs.append(eng.train_step(sync=True))
-np.save(sys.argv[1], np.concatenate([p.ravel() for p in eng.get_all_param_values()] + [np.array(costs, dtype=np.float32)]))
-eng.close()
-print(json.dumps({k: float(v) for k, v in r.items() if not k.startswith(("grad:", "pstep:"))}))
-""" % (ROOT, os.path.join(ROOT, "tests"))
+_CACHE = {}
 
 
-def child(tmp_path, name, env, cell, H, loss, N, B, T, S=0, upd="adam", steps=4):
-    out = str(tmp_path / (name + ".npy"))
-    p = subprocess.run([sys.executable, "-c", CHILD, out, cell, str(H), loss, str(N), str(B), str(T), str(S), upd, str(steps)],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-2000:]
-    return json.loads(p.stdout.strip().splitlines()[-1]), np.load(out)
+def variant(env, cell, H, loss, N, B, T, S=0, upd="adam", steps=4, cache_key=None):
+    """One form of the step: the switches of `env` are set while its engines are built (each of them is read per engine in sbr_create:
+    SBR_HEAD_FUSE, SBR_SCAT_FUSE, SBR_WIN_REST, SBR_SPARSE_OUT_EARLY), then (a) parity_util.compare_step against the oracle and (b) a
+    run of `steps` training steps on two alternating batches; returns (compare_step's errors + what sbr_query says the engine
+    selected, the parameters and costs of the run as one vector)."""
+    if cache_key is not None and cache_key in _CACHE:
+        return _CACHE[cache_key]
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        r = PU.compare_step(cell, [H], loss, N=N, B=B, T=T, S=S, zipf=True, steps=2, scale=0.03, seed=61, updater=upd,
+                            queries=("head_fused", "scatter_step", "sparse_blocks"))
+        params, cfg, batch = PU.build_case(cell, [H], loss, N, B, T, S=S, seed=61, scale=0.03, zipf=True)
+        eng = PU.engine_for(cfg, N, B, T, S=S, updater=upd)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        eng.set_all_param_values(params)
+        costs = []
+        for i in range(steps):
+            bt = PU.make_batch(np.random.default_rng(300 + i % 2), B, T, N, S=S, zipf=True) if i else batch
+            eng.set_batch(bt["X"], bt["mask"], bt["target"], bt["samples"] if loss != "CCE" else None, bt["pop"])
+            costs.append(eng.train_step(sync=True))
+        vec = np.concatenate([p.ravel() for p in eng.get_all_param_values()] + [np.array(costs, dtype=np.float32)])
+    finally:
+        eng.close()
+    out = ({k: float(v) for k, v in r.items() if not k.startswith(("grad:", "pstep:"))}, vec)
+    if cache_key is not None:
+        _CACHE[cache_key] = out
+    return out
 
 
 def close(p0, p1, tol=5e-5):
@@ -95,9 +101,9 @@ def close(p0, p1, tol=5e-5):
     assert np.abs(p0 - p1).max() <= tol * np.abs(p0).max(), np.abs(p0 - p1).max() / np.abs(p0).max()
 
 
-def test_one_launch_head_against_the_three_launches(tmp_path):
-    r0, p0 = child(tmp_path, "three", {"SBR_HEAD_FUSE": "0"}, "GRU", 128, "CCE", 3706, 256, 12)
-    r1, p1 = child(tmp_path, "one", {"SBR_HEAD_FUSE": "1"}, "GRU", 128, "CCE", 3706, 256, 12)
+def test_one_launch_head_against_the_three_launches():
+    r0, p0 = variant({"SBR_HEAD_FUSE": "0"}, "GRU", 128, "CCE", 3706, 256, 12)
+    r1, p1 = variant({"SBR_HEAD_FUSE": "1"}, "GRU", 128, "CCE", 3706, 256, 12)
     assert r0["q:head_fused"] == 0 and r1["q:head_fused"] == 16
     bars(r0); bars(r1)
     close(p0, p1)
@@ -107,12 +113,12 @@ def test_one_launch_head_against_the_three_launches(tmp_path):
 # the scatter-add that steps its rows
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rest", ["1", "2", "3"], ids=["rest_behind_chain", "rest_between_chains", "rest_behind_scatter"])
-def test_scatter_add_steps_a_dense_block(tmp_path, rest):
+def test_scatter_add_steps_a_dense_block(rest):
     # LSTM-256 over 4000 items, 64 x 64 positions (>= the catalogue: the dense update is the default): 5.4 M parameters (above the
     # swapped-tail threshold), rows of 1024 floats, Zipf ids -- most rows untouched per batch; four steps on two alternating
     # batches, so rows sit steps out and return
-    r0, p0 = child(tmp_path, "two_pass", {"SBR_SCAT_FUSE": "0"}, "LSTM", 256, "CCE", 4000, 64, 64)
-    r1, p1 = child(tmp_path, "fused", {"SBR_SCAT_FUSE": "1", "SBR_WIN_REST": rest}, "LSTM", 256, "CCE", 4000, 64, 64)
+    r0, p0 = variant({"SBR_SCAT_FUSE": "0"}, "LSTM", 256, "CCE", 4000, 64, 64, cache_key="dense_two_pass")
+    r1, p1 = variant({"SBR_SCAT_FUSE": "1", "SBR_WIN_REST": rest}, "LSTM", 256, "CCE", 4000, 64, 64)
     assert r0["q:sparse_blocks"] == 0 and r1["q:sparse_blocks"] == 0
     assert r0["q:scatter_step"] == 0 and r1["q:scatter_step"] == 1
     bars(r0); bars(r1)
@@ -120,12 +126,12 @@ def test_scatter_add_steps_a_dense_block(tmp_path, rest):
 
 
 @pytest.mark.parametrize("updater", ["adagrad", "adadelta", "rmsprop", "nesterov", "adam"])
-def test_scatter_add_steps_a_row_sparse_block(tmp_path, updater):
+def test_scatter_add_steps_a_row_sparse_block(updater):
     # LSTM-128 rows (512 floats) over 4000 items with a sampled head: both blocks row-sparse; the fused step + the head's block
     # stepped beside the chain against the separate step kernels of round 2 - 4
     old = {"SBR_SCAT_FUSE": "0", "SBR_SPARSE_OUT_EARLY": "0"}
-    r0, p0 = child(tmp_path, "separate", old, "LSTM", 128, "Blackout", 4000, 16, 12, S=8, upd=updater, steps=6)
-    r1, p1 = child(tmp_path, "fused", {"SBR_SCAT_FUSE": "1"}, "LSTM", 128, "Blackout", 4000, 16, 12, S=8, upd=updater, steps=6)
+    r0, p0 = variant(old, "LSTM", 128, "Blackout", 4000, 16, 12, S=8, upd=updater, steps=6)
+    r1, p1 = variant({"SBR_SCAT_FUSE": "1", "SBR_SPARSE_OUT_EARLY": "1"}, "LSTM", 128, "Blackout", 4000, 16, 12, S=8, upd=updater, steps=6)
     assert r0["q:sparse_blocks"] == 2 and r0["q:scatter_step"] == 0 and r1["q:scatter_step"] == 2
     bars(r0); bars(r1)
     # rmsprop turns every gradient into a step of ~lr: roundings flip noise-level elements (tests/test_gpu_sparse_update.py)
