@@ -370,6 +370,7 @@ struct RecArgs {
     const float* dh_slabs;  // rec_bwd_x6p only: dh_last as n_dh_slabs unreduced split-K slabs of [Bp][Hp] (the kernel's prologue
     int n_dh_slabs;         // adds them: one small reduction launch less in front of the BPTT chain), or NULL / 0
     const float* dh_ext;    // [T][Bp][Hp] grad wrt every hid_out[t] (lower layers) or NULL
+    int dhe_on;             // rec_bwd_c16 only (set by its launcher): dh_ext is live (else it points at hs and is only requested)
     float* dxt; float* dhi; // dhi: GRU only, compact [T][Bp][Hp] = candidate-gate slice of grad wrt hid_input (r,u slices == dxt)
     // BPTT in time chunks (so the weight-gradient GEMM of finished chunks runs beside the chain): this launch
     // covers t in [t_lo, t_hi); dh/dc cross launches through `state` [2][Bp][Hp]; part block = chunk*nblocks + block
@@ -405,6 +406,7 @@ struct RecArgs {
                             // run BESIDE the chain and use LDS themselves are placed on other CUs (overlapped step tail)
 };
 #define SBR_CL_ROWS 8       // batch rows per cluster tile
+#define SBR_C16_RING 2      // rec_bwd_c16: slots of the ring of partial-sum blocks (blocks carry the lap's parity: sbr_rec_c16.hip)
 #define SBR_X6P_FUSE_MAX_T 4096      // fused gather of rec_fwd_x6p: 4 rows x T row offsets in LDS
 bool sbr_rec_cluster_ok(const RecArgs& a);
 int sbr_rec_cluster_bwd_rows(const RecArgs& a);

@@ -18,16 +18,19 @@ for _ in range(3):
 raw = eng.debug_buffer("prof").view(np.uint64).reshape(2, -1)
 c16 = eng.query("rec_rows_fwd") == 16      # the 16-row kernels rec_*_c16 (one workgroup per 16 units)
 if c16:
-    names = (("rec_fwd_c16", ("exchange wait", "copy+barrier", "LDS+MFMA", "reduce barrier", "gate math+stores")),
-             ("rec_bwd_c16", ("gate math+publish", "MFMA+block stores", "exchange wait", "reset+barrier", "reduce")))
-    for k, (name, ph) in enumerate(names):
+    # tick indices of sbr_rec_c16.hip (pc[i] -> column 3 + i); the "|" columns exist in counter mode only (an extra wait)
+    names = (("rec_fwd_c16", ((0, "exchange wait"), (1, "requests+MFMA+partials"), (2, "reduce barrier"), (3, "gate math+publish")),
+              (5, "everything since the poll acknowledged")),
+             ("rec_bwd_c16", ((0, "gate math+A planes+barrier"), (1, "MFMA+block stores"), (2, "exchange wait"), (3, "sum+requests"),
+                              (4, "reduce barrier"), (6, "reduce")), (5, "block stores acknowledged")))
+    for k, (name, ph, extra) in enumerate(names):
         p = raw[k][:32 * 4 * 16].reshape(32, 4, 16).astype(np.float64)          # [tile * C + member][wave][16]
         tot, real = p[..., 0], p[..., 1]
         print("%s: kernel %.1f us (realtime), shader clock %.0f MHz, %.0f cycles/step" % (
             name, real.mean() / 100.0, (tot / real * 100.0).mean(), tot.mean() / T))
         for w in range(4):
-            print("   wave%d   polls/step %.2f  " % (w, p[:, w, 2].mean() / T) + "  ".join("%s %5.0f" % (ph[i], p[:, w, 3 + i].mean() / T) for i in range(5))
-                  + "  | own stores acknowledged %5.0f" % (p[:, w, 8].mean() / T))
+            print("   wave%d   polls/step %.2f  " % (w, p[:, w, 2].mean() / T) + "  ".join("%s %5.0f" % (nm, p[:, w, 3 + i].mean() / T) for i, nm in ph)
+                  + "  | %s %5.0f" % (extra[1], p[:, w, 3 + extra[0]].mean() / T))
 else:
   names = (("rec_fwd_cl", ("exchange wait", "publish+barrier", "LDS+MFMA", "reduce barrier", "gate math+stores")),
          ("rec_bwd_cl", ("gate math+stores", "exchange wait", "split+barrier", "LDS+MFMA", "reduce barrier")))
