@@ -30,6 +30,7 @@
 //     RecArgs.g[0..3] (as in rec_*_x6p): one store forward, one load backward instead of four each.
 #include "sbr_rec_cl.h"
 #include <utility>
+#include <cstdlib>
 
 namespace {
 
@@ -498,6 +499,262 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// backward, Hp = 512: the exchange in TWO levels.
+// With the one-level output exchange a member of a 32-member cluster sends and receives 32 KB of partial-sum blocks per step
+// (512 workgroups: 32 MB of stores per step on a memory system that writes every store through): 6 us per step, 1.2 ms per
+// layer where the forward takes 0.57.  Here the cluster is 8 GROUPS of four members:
+//   level 1  the four members of a group share their dhi columns (4 x 64 columns x 16 rows, pre-split fp16 pairs, in the MFMA
+//            operand layout exactly as the forward exchanges h: 4 KB out, 16 KB in per member, staged through LDS);
+//   level 2  member s of a group multiplies the group's K = 256 columns for ITS QUARTER of the destinations (units 128 s ..
+//            128 s + 127: 8 blocks of 16 x 16 partial sums, every block complete over the group's K) and sends them; a member
+//            receives one block per group: 8 KB out, 8 KB in, self-validating as above.
+// 12 KB of stores per member and step instead of 32 (+ no resets), the same 192 MFMAs per workgroup, the same 128 weight
+// registers -- at the price of a second hand-off per step, which two resident workgroups per CU cover for each other.
+// ---------------------------------------------------------------------------------------
+template <int CELL, bool FAST>
+__device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, const int mem, bool dead, char* smem_c) {
+    constexpr bool fast = FAST;
+    constexpr int HP = 512, G = Gates<CELL>::G, C = HP / 16, GHP = G * HP;
+    constexpr int S = 4, NG = C / S;                     // members per group, groups per cluster
+    constexpr int KBL = G == 1 ? 1 : 2;                  // k-blocks of one member's columns (G*16, zero-padded to 32 / 64)
+    constexpr int GP = 2 * KBL;                          // gate slots of a member in the image (the padding slots carry zeros)
+    constexpr int KBG = S * KBL;                         // k-blocks of a group's columns
+    constexpr int IMG1 = KBG * 2048;                     // level-1 image of a group: [KBG][2 planes][4 q][16 rows][16 B]
+    constexpr int NP1 = KBG / 4 * 2;                     // KiB pieces of it a wave polls and stages
+    constexpr int NT2 = 2;                               // destination blocks per wave (8 per member)
+    constexpr int NP2 = NG / 4;                          // incoming blocks per wave
+    constexpr int XRING = 4, RING = SBR_C16_RING;
+    char* stg = smem_c;                                  // the group's image, as exchanged
+    char* red = smem_c + IMG1;                           // [4 waves][64 lanes][16 B]
+    const int ntiles = a.Bp / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rl = 4 * q + wave;
+    const int row = tile * 16 + rl, u = mem * 16 + j;
+    const int gi = mem / S, sm = mem % S;
+    const int T = a.T, Bp = a.Bp;
+    const float clip = a.clip;
+
+    const int mylen = a.len[row];
+    int tmax = 0;
+    for (int i = 0; i < 16; ++i) tmax = max(tmax, a.len[tile * 16 + i]);
+
+    // B operand planes: N tile i of this wave = destination member d = 8 sm + 2 wave + i (units 16 d + j of dh), K = the group's
+    // columns kk = kbg*32 + 8q + e: member kbg / KBL of the group, gate slot 2 (kbg % KBL) + (q >> 1), units (q & 1) * 8 + e
+    f16x8c W1[NT2][KBG], W2[NT2][KBG];
+#pragma unroll
+    for (int i = 0; i < NT2; ++i)
+#pragma unroll
+        for (int kbg = 0; kbg < KBG; ++kbg) {
+            const int g = 2 * (kbg % KBL) + (q >> 1);
+            const int d = 8 * sm + 2 * wave + i;
+            const float* src = a.Whid + (size_t)(d * 16 + j) * GHP + (g < G ? g : 0) * HP + (gi * S + kbg / KBL) * 16 + (q & 1) * 8;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 b1, b2;
+                cl_split2(g < G ? (e < 4 ? lo[e & 3] : hi[e & 3]) : 0.0f, b1, b2);
+                W1[i][kbg][e] = b1; W2[i][kbg][e] = b2;
+            }
+        }
+
+    float dh = 0.f, dc = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
+    if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u];
+    if (CELL == CELL_LSTM) { pi = a.peep[u]; pf = a.peep[HP + u]; po = a.peep[2 * HP + u]; }
+    float sdb[G], sdp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) sdb[g] = 0.f;
+    struct Saved { f32x4 sv; float hprev, cprev, dhe; };
+    const float* const dhe_src = a.dh_ext;               // (never null here: see rec_bwd_c16)
+    const bool dhe_on = a.dhe_on != 0;
+    auto load_saved = [&](int t, Saved& s) {
+        const size_t o = ((size_t)t * Bp + row) * HP + u;
+        s.hprev = a.hs[o];
+        if (CELL != CELL_VANILLA) s.sv = *(const f32x4*)(a.g[0] + o * 4);
+        if (CELL == CELL_LSTM) s.cprev = a.cs[o];
+        s.dhe = dhe_src[o];
+    };
+    Saved cur, nxt;
+    cur.sv = nxt.sv = f32x4{0, 0, 0, 0};
+    cur.hprev = cur.cprev = cur.dhe = nxt.hprev = nxt.cprev = nxt.dhe = 0.f;
+    float cnew = 0.f, hnew = 0.f;
+
+    // level 1: ring[slot][tile][group][IMG1] behind the blocks' ring; this lane's word of gate slot gs: plane j & 1, row rl,
+    // columns (sm*KBL*32 + gs*16 + (j & ~1), + 1) of the group
+    constexpr size_t RING2_BYTES_PER_TILE = (size_t)C * NG * 1024;
+    char* const ring2 = (char*)a.pring;
+    char* const ring1 = ring2 + (size_t)RING * ntiles * RING2_BYTES_PER_TILE;
+    const size_t slot1b = (size_t)ntiles * NG * IMG1;
+    char* const x1 = ring1 + ((size_t)tile * NG + gi) * IMG1;
+    const unsigned xoff1 = (unsigned)(sm * KBL * 2048 + (j & 1) * 1024 + (j >> 3) * 256 + rl * 16 + (j & 6) * 2);   // + (gs >> 1) * 2048 + (gs & 1) * 512
+    const unsigned poff1 = (unsigned)(wave * NP1 * 1024 + lane * 16);
+    // level 2: ring[slot][tile][destination][source group][1 KB as (q, j, 4 rows)]; wave w receives groups w*NP2 .. + NP2 - 1
+    const size_t slot2b = (size_t)ntiles * RING2_BYTES_PER_TILE;
+    const char* const pmine = ring2 + ((size_t)tile * C + mem) * NG * 1024;
+    const unsigned poff2 = (unsigned)(wave * NP2 * 1024 + lane * 16);
+    char* const psend = ring2 + (((size_t)tile * C + 8 * sm + 2 * wave) * NG + gi) * 1024 + lane * 16;   // + i * NG * 1024
+
+    u64 pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, p_c0 = 0, p_r0 = 0, p_t = 0, p_tries = 0;
+    const bool prof = a.prof != nullptr;
+    if (prof) { p_c0 = clock64(); p_r0 = wall_clock64(); }
+    const f32x4 z4 = f32x4{0, 0, 0, 0};
+    __syncthreads();
+
+    float dhx = 0.f;
+    for (int t = T - 1; t >= tmax; --t) {                // whole tile masked: zero rows, nobody waits for them
+        if (dhe_on) dhx += a.dh_ext[((size_t)t * Bp + row) * HP + u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a.dxt[((size_t)t * Bp + row) * GHP + g * HP + u] = 0.f;
+        if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HP + u] = 0.f;
+    }
+    dh += dhx;
+    if (tmax > 0) {
+        load_saved(tmax - 1, cur);
+        load_saved(tmax > 1 ? tmax - 2 : 0, nxt);
+        const size_t o1 = ((size_t)tmax * Bp + row) * HP + u;
+        if (CELL == CELL_LSTM) cnew = a.cs[o1];
+        if (CELL == CELL_VANILLA) hnew = a.hs[o1];
+    }
+    if (prof) p_t = clock64();
+    int n = 0;                                           // steps done
+    size_t o_x = ((size_t)(tmax - 1) * Bp + row) * GHP + u, o_d = ((size_t)(tmax - 1) * Bp + row) * HP + u;   // of step t (used for t >= 0 only)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // (see rec_fwd_c16)
+    for (int t = tmax - 1; t >= 0; --t, ++n) {
+        if (dhe_on) dh += cur.dhe;
+        float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
+        {
+            const float sv[4] = {cur.sv[0], cur.sv[1], cur.sv[2], cur.sv[3]};
+            cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, cur.hprev, cur.cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp, a.relu != 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) sdb[g] += dxi[g];
+        sdp[0] += dp[0]; sdp[1] += dp[1]; sdp[2] += dp[2];
+        if (CELL == CELL_LSTM) cnew = cur.cprev;
+        if (CELL == CELL_VANILLA) hnew = cur.hprev;
+        // level 1: this member's dhi columns to its group (scaled: |dhi| <= clip <= 100, see rec_bwd_x6p); padding slots: zeros
+        {
+            char* const xb = x1 + (size_t)(n & (XRING - 1)) * slot1b + xoff1;
+#pragma unroll
+            for (int gs = 0; gs < GP; ++gs)
+                cl_store1((unsigned*)(xb + (gs >> 1) * 2048 + (gs & 1) * 512), gs < G ? cl_pair_word(dhi[gs < G ? gs : 0] * CL_F16_DSCALE, j) : 0u, fast);
+        }
+        CL_TICK(0);
+        {   // the group's columns, the K quarter this wave stages
+            f32x4 v[NP1];
+            p_tries += c16_poll<NP1, FAST>(v, x1 + (size_t)(n & (XRING - 1)) * slot1b, poff1, dead, a.fault,
+                                           [](const f32x4 (&w)[NP1]) { return c16_no_sentinel<NP1>(w); });
+            CL_TICK(1);
+#pragma unroll
+            for (int i = 0; i < NP1; ++i) *(f32x4*)(stg + poff1 + i * 1024) = v[i];
+        }
+        __syncthreads();                                 // the image complete in LDS; every member of the group has published step n
+        CL_TICK(2);
+        // behind the poll and the barrier: this step's dxt / dhi, the reset of this member's words of the last step's image
+#pragma unroll
+        for (int g = 0; g < G; ++g) a.dxt[o_x + g * HP] = dxi[g];
+        if (CELL == CELL_GRU) a.dhi[o_d] = dhi[2];
+        o_x -= (size_t)Bp * GHP; o_d -= (size_t)Bp * HP;
+        {
+            char* const xb = x1 + (size_t)((n - 1) & (XRING - 1)) * slot1b + xoff1;      // (n = 0: slot 3, a sentinel already)
+#pragma unroll
+            for (int gs = 0; gs < GP; ++gs) cl_store1((unsigned*)(xb + (gs >> 1) * 2048 + (gs & 1) * 512), CL_SENT, fast);
+        }
+        const unsigned par = (unsigned)(n / RING) & 1u;
+        {
+            f32x4 hi[NT2], l1[NT2];
+#pragma unroll
+            for (int i = 0; i < NT2; ++i) { hi[i] = z4; l1[i] = z4; }
+            const char* sb = stg + lane * 16;
+            f16x8c d0 = *(const f16x8c*)(sb), d1 = *(const f16x8c*)(sb + 1024);
+#pragma unroll
+            for (int kbg = 0; kbg < KBG; ++kbg) {
+                const f16x8c c0 = d0, c1 = d1;
+                if (kbg + 1 < KBG) { d0 = *(const f16x8c*)(sb + (kbg + 1) * 2048); d1 = *(const f16x8c*)(sb + (kbg + 1) * 2048 + 1024); }
+#pragma unroll
+                for (int i = 0; i < NT2; ++i) l1[i] = cl_mfma(c1, W1[i][kbg], l1[i]);
+#pragma unroll
+                for (int i = 0; i < NT2; ++i) l1[i] = cl_mfma(c0, W2[i][kbg], l1[i]);
+#pragma unroll
+                for (int i = 0; i < NT2; ++i) hi[i] = cl_mfma(c0, W1[i][kbg], hi[i]);
+            }
+            asm volatile("s_nop 15");
+            char* const dst = psend + (size_t)(n % RING) * slot2b;
+#pragma unroll
+            for (int i = 0; i < NT2; ++i) {
+                f32x4 bv = (hi[i] + l1[i] * (1.0f / CL_F16_LO)) * (1.0f / CL_F16_DSCALE);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = __uint_as_float((__float_as_uint(bv[e]) & ~1u) | par);   // this lap's parity
+                cl_store4((float*)(dst + (size_t)i * NG * 1024), bv, fast);
+            }
+        }
+        CL_TICK(3);
+        if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CL_TICK(5); }      // (counters only: everything issued since the level-1 poll)
+        f32x4 sum = z4;
+        {   // one block per group, addressed to this member
+            f32x4 v[NP2];
+            p_tries += c16_poll<NP2, FAST>(v, pmine + (size_t)(n % RING) * slot2b, poff2, dead, a.fault,
+                                           [par](const f32x4 (&w)[NP2]) { return c16_all_tagged<NP2>(w, par); });
+            CL_TICK(4);
+#pragma unroll
+            for (int i = 0; i < NP2; ++i) sum += v[i];
+        }
+        *(f32x4*)(red + (wave * 64 + lane) * 16) = sum;
+        // behind the poll: the step after next's saved activations
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur.sv[e] = c16_mov(nxt.sv[e]);
+        cur.hprev = c16_mov(nxt.hprev); cur.cprev = c16_mov(nxt.cprev); cur.dhe = c16_mov(nxt.dhe);
+        load_saved(t > 2 ? t - 2 : 0, nxt);
+        __syncthreads();                                 // the four waves' sums visible; every wave is done reading the staged image
+        CL_TICK(6);
+        float add = 0.f;
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) add += *(const float*)(red + (sw * 64 + lane) * 16 + wave * 4);
+        dh += add;
+        CL_TICK(7);
+    }
+    if (prof && lane == 0 && tile * C + mem < 32) {
+        u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 16;
+        o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_tries;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[3 + i] = pc[i];
+    }
+
+    // bias / peephole / initial-state gradient partial sums of this tile: over its 16 rows = over q and over the waves
+    float v[G + 5];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = sdb[g];
+    v[G] = sdp[0]; v[G + 1] = sdp[1]; v[G + 2] = sdp[2]; v[G + 3] = dc; v[G + 4] = dh;
+    __syncthreads();
+    float* redf = (float*)smem_c;                        // [4 waves][G + 5][16 units]
+#pragma unroll
+    for (int k = 0; k < G + 5; ++k) {
+        float sum = v[k];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (q == 0) redf[(wave * (G + 5) + k) * 16 + j] = sum;
+    }
+    __syncthreads();
+    if (wave == 0 && q == 0) {
+        float* part = a.part + (size_t)tile * (GHP + 5 * HP);
+#pragma unroll
+        for (int k = 0; k < G + 5; ++k) {
+            const float sum = redf[k * 16 + j] + redf[((G + 5) + k) * 16 + j] + redf[(2 * (G + 5) + k) * 16 + j] + redf[(3 * (G + 5) + k) * 16 + j];
+            if (k < G) part[k * HP + u] = sum; else part[GHP + (k - G) * HP + u] = sum;
+        }
+    }
+}
+
+template <int CELL>
+__global__ void __launch_bounds__(256, 2) rec_bwd_c16t(RecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    int tile, mem;
+    if (!cl_ids(a, 32, a.Bp / 16, tile, mem)) return;
+    bool dead = false;
+    if (cl_same_xcc(a, 32, tile, mem, (int*)smem_c, dead)) c16_bwd2_body<CELL, true>(a, tile, mem, dead, smem_c);
+    else c16_bwd2_body<CELL, false>(a, tile, mem, dead, smem_c);
+}
+
 template <int CELL, int HP>
 __global__ void __launch_bounds__(256, 2) rec_bwd_c16(RecArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
@@ -511,6 +768,11 @@ __global__ void __launch_bounds__(256, 2) rec_bwd_c16(RecArgs a) {
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+// Hp = 512: the backward exchange in two levels (rec_bwd_c16t); SBR_C16_TWO_LEVEL=0: one level, as at Hp = 256
+static bool c16_two_level() {
+    static const int two = [] { const char* e = getenv("SBR_C16_TWO_LEVEL"); return e ? atoi(e) : 1; }();
+    return two != 0;
+}
 template <int CELL, int HP>
 static hipError_t fwd_c16(hipStream_t s, const RecArgs& a) {
     constexpr int G = Gates<CELL>::G;
@@ -527,6 +789,13 @@ static hipError_t bwd_c16(hipStream_t s, const RecArgs& a_in) {
     RecArgs a = a_in;
     a.dhe_on = a.dh_ext != nullptr;
     if (!a.dh_ext) a.dh_ext = a.hs;                      // requested every step, used only under dhe_on (no pointer select in the kernel)
+    if constexpr (HP == 512) {
+        if (c16_two_level()) {
+            const size_t lds2 = (size_t)4 * (G == 1 ? 1 : 2) * 2048 + 4 * 1024;
+            CL_LAUNCH((rec_bwd_c16t<CELL>), 32, 16, lds2);
+            return hipGetLastError();
+        }
+    }
     CL_LAUNCH((rec_bwd_c16<CELL, HP>), HP / 16, 16, lds);
     return hipGetLastError();
 }
@@ -541,6 +810,9 @@ static hipError_t bwd_c16(hipStream_t s, const RecArgs& a_in) {
 hipError_t launch_rec_forward_c16(hipStream_t s, const RecArgs& a) { C16_DISPATCH(fwd_c16) }
 hipError_t launch_rec_backward_c16(hipStream_t s, const RecArgs& a) { C16_DISPATCH(bwd_c16) }
 // The ring of partial-sum blocks starts a launch with every word's lowest bit set: lap 0 expects it clear (rec_bwd_c16).
+// (two levels: + the sentinel of the level-1 images behind them; 1 MB per tile instead of 2)
 hipError_t sbr_rec_c16_fill(hipStream_t s, const RecArgs& a) {
-    return hipMemsetAsync(a.pring, 0xFF, sbr_rec_c16_ring_floats(a.Bp, a.Hp) * sizeof(float), s);
+    size_t bytes = sbr_rec_c16_ring_floats(a.Bp, a.Hp) * sizeof(float);
+    if (a.Hp == 512 && c16_two_level()) bytes = (size_t)(a.Bp / 16) * (SBR_C16_RING * 32 * 8 * 1024 + 4 * 8 * 16384);
+    return hipMemsetAsync(a.pring, 0xFF, bytes, s);
 }

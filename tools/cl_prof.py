@@ -23,6 +23,9 @@ if c16:
               (5, "everything since the poll acknowledged")),
              ("rec_bwd_c16", ((0, "gate math+A planes+barrier"), (1, "MFMA+block stores"), (2, "exchange wait"), (3, "sum+requests"),
                               (4, "reduce barrier"), (6, "reduce")), (5, "block stores acknowledged")))
+    if max(layers) > 256 and os.environ.get("SBR_C16_TWO_LEVEL", "1") != "0":      # rec_bwd_c16t: two hand-offs per step
+        names = (names[0], ("rec_bwd_c16t", ((0, "gate math+level-1 publish"), (1, "level-1 wait"), (2, "stage+barrier"), (3, "stores+MFMA+blocks"),
+                                             (4, "level-2 wait"), (6, "sum+requests+barrier"), (7, "reduce")), (5, "everything since the level-1 poll acknowledged")))
     for k, (name, ph, extra) in enumerate(names):
         p = raw[k][:32 * 4 * 16].reshape(32, 4, 16).astype(np.float64)          # [tile * C + member][wave][16]
         tot, real = p[..., 0], p[..., 1]
