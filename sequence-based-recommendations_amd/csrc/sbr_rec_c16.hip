@@ -83,6 +83,20 @@ __device__ __forceinline__ float c16_mov(float src) {
     return d;
 }
 
+// A thread's gate gradients of its (row, unit) as fp16 pairs, K-contiguous: the K index of a member's columns is
+// unit * GP + gate slot (GP = 4: i, f, c, o / r, u, c, 0; GP = 2: the one gate, 0), so the GP values one thread holds are GP
+// consecutive K positions -- one 8-byte (4-byte) store per plane, no lane exchange (rounds 2-5 ordered K gate-major and paired
+// neighbouring units through a DPP move: 11 VALU instructions per gate).  Padding slots carry zeros.
+template <int G, int GP>
+__device__ __forceinline__ void c16_pack_gates(const float (&dhi)[G], float scale, f16x4c& p1, f16x4c& p2) {
+#pragma unroll
+    for (int gs = 0; gs < 4; ++gs) {
+        _Float16 a1 = (_Float16)0.0f, a2 = (_Float16)0.0f;
+        if (gs < G && gs < GP) cl_split2(dhi[gs < G ? gs : 0] * scale, a1, a2);
+        p1[gs] = a1; p2[gs] = a2;
+    }
+}
+
 // no word is the NaN sentinel (the largest 32-bit pattern: one v_max3_u32 per two words)
 template <int NP>
 __device__ __forceinline__ bool c16_no_sentinel(const f32x4 (&v)[NP]) {
@@ -303,26 +317,21 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
     int tmax = 0;
     for (int i = 0; i < 16; ++i) tmax = max(tmax, a.len[tile * 16 + i]);
 
-    // B operand planes: N tile n = wave*NT + i (units 16n + j of dh), K = this member's columns kk = kb*32 + 8q + e:
-    // gate kk / 16, unit mem*16 + kk % 16 -- eight consecutive floats of a W_hid row; columns past G*16 are zero
+    // B operand planes: N tile n = wave*NT + i (units 16n + j of dh), K = this member's columns kk = kb*32 + 8q + e =
+    // unit * GP + gate slot (c16_pack_gates); slots past G are zero
+    constexpr int GP = 2 * KBL;
     f16x8c W1[NT][KBL], W2[NT][KBL];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int kb = 0; kb < KBL; ++kb) {
-            const int g = 2 * kb + (q >> 1);
-            const float* src = a.Whid + (size_t)((wave * NT + i) * 16 + j) * GHP + (g < G ? g : 0) * HP + mem * 16 + (q & 1) * 8;
-            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        for (int kb = 0; kb < KBL; ++kb)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                const int kk = kb * 32 + 8 * q + e, gs = kk % GP, ul = kk / GP;
                 _Float16 b1, b2;
-                cl_split2(g < G ? (e < 4 ? lo[e & 3] : hi[e & 3]) : 0.0f, b1, b2);
+                cl_split2(gs < G ? a.Whid[(size_t)((wave * NT + i) * 16 + j) * GHP + (gs < G ? gs : 0) * HP + mem * 16 + ul] : 0.0f, b1, b2);
                 W1[i][kb][e] = b1; W2[i][kb][e] = b2;
             }
-        }
-    if (G * 16 < KBL * 32) {                             // the padding columns of the A planes stay zero
-        for (int i = threadIdx.x; i < 2 * APLANE / 4; i += 256) ((unsigned*)apl)[i] = 0u;
-    }
 
     float dh = 0.f, dc = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
     if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u];
@@ -348,9 +357,9 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
     cur.sv = nxt.sv = f32x4{0, 0, 0, 0};
     cur.hprev = cur.cprev = cur.dhe = nxt.hprev = nxt.cprev = nxt.dhe = 0.f;
     float cnew = 0.f, hnew = 0.f;
-    // this lane's word of a gate's 16 columns in the A planes: plane j & 1, row rl, local columns g*16 + (j & ~1), + 1
-    const unsigned aoff = (unsigned)((j & 1) * APLANE + rl * AROW + (j & 6) * 2);
+    // this thread's GP columns in the A planes: row rl, bytes [2 GP j, 2 GP (j + 1)) of the row, 16-byte chunks swizzled by the row
     const int aswz = (rl / RPB) & (CPR - 1);
+    const unsigned aoff = (unsigned)(rl * AROW + ((((j * GP * 2) >> 4) ^ aswz) << 4) + ((j * GP * 2) & 15));
     // A operand: lane (batch row j, k-group q) reads chunk kb*4 + q of row j
     const char* ab = apl + j * AROW;
     const int rswz = (j / RPB) & (CPR - 1);
@@ -398,9 +407,12 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
         if (CELL == CELL_LSTM) cnew = cur.cprev;
         if (CELL == CELL_VANILLA) hnew = cur.hprev;
         // this member's dhi columns -> the A planes (scaled: |dhi| <= clip <= 100, see rec_bwd_x6p)
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            *(unsigned*)(apl + aoff + (((2 * g + (j >> 3)) ^ aswz) << 4)) = cl_pair_word(dhi[g] * CL_F16_DSCALE, j);
+        {
+            f16x4c p1, p2;
+            c16_pack_gates<G, GP>(dhi, CL_F16_DSCALE, p1, p2);
+            if constexpr (GP == 4) { *(f16x4c*)(apl + aoff) = p1; *(f16x4c*)(apl + aoff + APLANE) = p2; }
+            else { *(f16x2c*)(apl + aoff) = f16x2c{p1[0], p1[1]}; *(f16x2c*)(apl + aoff + APLANE) = f16x2c{p2[0], p2[1]}; }
+        }
         __syncthreads();
         CL_TICK(0);
         const unsigned par = (unsigned)(n / RING) & 1u;
@@ -449,7 +461,15 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
             for (int i = 0; i < NP; ++i) sum += v[i];
         }
         *(f32x4*)(red + (wave * 64 + lane) * 16) = sum;
-        // behind the poll: the step after next's saved activations, this step's dxt / dhi
+        CL_TICK(3);
+        __syncthreads();                                 // the four waves' sums visible; every wave is done reading the A planes
+        CL_TICK(4);
+        float pr[4];
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) pr[sw] = *(const float*)(red + (sw * 64 + lane) * 16 + wave * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // behind the poll, off the path from the blocks to the next gate math (under the reads' latency): the step after next's
+        // saved activations, this step's dxt / dhi
 #pragma unroll
         for (int e = 0; e < 4; ++e) cur.sv[e] = c16_mov(nxt.sv[e]);
         cur.hprev = c16_mov(nxt.hprev); cur.cprev = c16_mov(nxt.cprev); cur.dhe = c16_mov(nxt.dhe);
@@ -458,13 +478,8 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
         for (int g = 0; g < G; ++g) a.dxt[o_x + g * HP] = dxi[g];
         if (CELL == CELL_GRU) a.dhi[o_d] = dhi[2];
         o_x -= (size_t)Bp * GHP; o_d -= (size_t)Bp * HP;
-        CL_TICK(3);
-        __syncthreads();                                 // the four waves' sums visible; every wave is done reading the A planes
-        CL_TICK(4);
-        float add = 0.f;
-#pragma unroll
-        for (int sw = 0; sw < 4; ++sw) add += *(const float*)(red + (sw * 64 + lane) * 16 + wave * 4);
-        dh += add;
+        __builtin_amdgcn_sched_barrier(0);
+        dh += (pr[0] + pr[1]) + (pr[2] + pr[3]);
         CL_TICK(6);
     }
     if (prof && lane == 0 && tile * C + mem < 32) {
@@ -541,23 +556,20 @@ __device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, 
     for (int i = 0; i < 16; ++i) tmax = max(tmax, a.len[tile * 16 + i]);
 
     // B operand planes: N tile i of this wave = destination member d = 8 sm + 2 wave + i (units 16 d + j of dh), K = the group's
-    // columns kk = kbg*32 + 8q + e: member kbg / KBL of the group, gate slot 2 (kbg % KBL) + (q >> 1), units (q & 1) * 8 + e
+    // columns kbg*32 + 8q + e: member kbg / KBL of the group, its column kk = (kbg % KBL)*32 + 8q + e = unit * GP + gate slot
     f16x8c W1[NT2][KBG], W2[NT2][KBG];
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
 #pragma unroll
-        for (int kbg = 0; kbg < KBG; ++kbg) {
-            const int g = 2 * (kbg % KBL) + (q >> 1);
-            const int d = 8 * sm + 2 * wave + i;
-            const float* src = a.Whid + (size_t)(d * 16 + j) * GHP + (g < G ? g : 0) * HP + (gi * S + kbg / KBL) * 16 + (q & 1) * 8;
-            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        for (int kbg = 0; kbg < KBG; ++kbg)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                const int kk = (kbg % KBL) * 32 + 8 * q + e, gs = kk % GP, ul = kk / GP;
+                const int d = 8 * sm + 2 * wave + i;
                 _Float16 b1, b2;
-                cl_split2(g < G ? (e < 4 ? lo[e & 3] : hi[e & 3]) : 0.0f, b1, b2);
+                cl_split2(gs < G ? a.Whid[(size_t)(d * 16 + j) * GHP + (gs < G ? gs : 0) * HP + (gi * S + kbg / KBL) * 16 + ul] : 0.0f, b1, b2);
                 W1[i][kbg][e] = b1; W2[i][kbg][e] = b2;
             }
-        }
 
     float dh = 0.f, dc = 0.f, pi = 0.f, pf = 0.f, po = 0.f;
     if (a.dh_last) dh = a.dh_last[(size_t)row * HP + u];
@@ -587,7 +599,8 @@ __device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, 
     char* const ring1 = ring2 + (size_t)RING * ntiles * RING2_BYTES_PER_TILE;
     const size_t slot1b = (size_t)ntiles * NG * IMG1;
     char* const x1 = ring1 + ((size_t)tile * NG + gi) * IMG1;
-    const unsigned xoff1 = (unsigned)(sm * KBL * 2048 + (j & 1) * 1024 + (j >> 3) * 256 + rl * 16 + (j & 6) * 2);   // + (gs >> 1) * 2048 + (gs & 1) * 512
+    // this thread's GP columns (member-local kk = GP j ..): k-block kk >> 5, k-group (kk >> 3) & 3, bytes 2 (kk & 7) of the lane's 16
+    const unsigned xoff1 = (unsigned)(((sm * KBL + ((j * GP) >> 5)) * 2 * 4 + (((j * GP) >> 3) & 3)) * 256 + rl * 16 + ((j * GP) & 7) * 2);   // + 1024: plane 1
     const unsigned poff1 = (unsigned)(wave * NP1 * 1024 + lane * 16);
     // level 2: ring[slot][tile][destination][source group][1 KB as (q, j, 4 rows)]; wave w receives groups w*NP2 .. + NP2 - 1
     const size_t slot2b = (size_t)ntiles * RING2_BYTES_PER_TILE;
@@ -635,9 +648,15 @@ __device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, 
         // level 1: this member's dhi columns to its group (scaled: |dhi| <= clip <= 100, see rec_bwd_x6p); padding slots: zeros
         {
             char* const xb = x1 + (size_t)(n & (XRING - 1)) * slot1b + xoff1;
-#pragma unroll
-            for (int gs = 0; gs < GP; ++gs)
-                cl_store1((unsigned*)(xb + (gs >> 1) * 2048 + (gs & 1) * 512), gs < G ? cl_pair_word(dhi[gs < G ? gs : 0] * CL_F16_DSCALE, j) : 0u, fast);
+            f16x4c p1, p2;
+            c16_pack_gates<G, GP>(dhi, CL_F16_DSCALE, p1, p2);
+            if constexpr (GP == 4) {
+                union { f16x4c h; f32x2 f; } w1, w2; w1.h = p1; w2.h = p2;
+                cl_store2((float*)xb, w1.f, fast); cl_store2((float*)(xb + 1024), w2.f, fast);
+            } else {
+                union { f16x2c h; unsigned u; } w1, w2; w1.h = f16x2c{p1[0], p1[1]}; w2.h = f16x2c{p2[0], p2[1]};
+                cl_store1((unsigned*)xb, w1.u, fast); cl_store1((unsigned*)(xb + 1024), w2.u, fast);
+            }
         }
         CL_TICK(0);
         {   // the group's columns, the K quarter this wave stages
@@ -657,8 +676,10 @@ __device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, 
         o_x -= (size_t)Bp * GHP; o_d -= (size_t)Bp * HP;
         {
             char* const xb = x1 + (size_t)((n - 1) & (XRING - 1)) * slot1b + xoff1;      // (n = 0: slot 3, a sentinel already)
-#pragma unroll
-            for (int gs = 0; gs < GP; ++gs) cl_store1((unsigned*)(xb + (gs >> 1) * 2048 + (gs & 1) * 512), CL_SENT, fast);
+            if constexpr (GP == 4) {
+                const f32x2 sent = f32x2{__uint_as_float(CL_SENT), __uint_as_float(CL_SENT)};
+                cl_store2((float*)xb, sent, fast); cl_store2((float*)(xb + 1024), sent, fast);
+            } else { cl_store1((unsigned*)xb, CL_SENT, fast); cl_store1((unsigned*)(xb + 1024), CL_SENT, fast); }
         }
         const unsigned par = (unsigned)(n / RING) & 1u;
         {
@@ -700,17 +721,19 @@ __device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, 
             for (int i = 0; i < NP2; ++i) sum += v[i];
         }
         *(f32x4*)(red + (wave * 64 + lane) * 16) = sum;
-        // behind the poll: the step after next's saved activations
+        __syncthreads();                                 // the four waves' sums visible; every wave is done reading the staged image
+        CL_TICK(6);
+        float pr[4];
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) pr[sw] = *(const float*)(red + (sw * 64 + lane) * 16 + wave * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // behind the poll, under the reads' latency: the step after next's saved activations
 #pragma unroll
         for (int e = 0; e < 4; ++e) cur.sv[e] = c16_mov(nxt.sv[e]);
         cur.hprev = c16_mov(nxt.hprev); cur.cprev = c16_mov(nxt.cprev); cur.dhe = c16_mov(nxt.dhe);
         load_saved(t > 2 ? t - 2 : 0, nxt);
-        __syncthreads();                                 // the four waves' sums visible; every wave is done reading the staged image
-        CL_TICK(6);
-        float add = 0.f;
-#pragma unroll
-        for (int sw = 0; sw < 4; ++sw) add += *(const float*)(red + (sw * 64 + lane) * 16 + wave * 4);
-        dh += add;
+        __builtin_amdgcn_sched_barrier(0);
+        dh += (pr[0] + pr[1]) + (pr[2] + pr[3]);
         CL_TICK(7);
     }
     if (prof && lane == 0 && tile * C + mem < 32) {

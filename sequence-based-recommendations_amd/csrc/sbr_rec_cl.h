@@ -109,6 +109,7 @@ __device__ __forceinline__ int cl_fetch(f32x4 (&v)[NP], SRC src, int W, bool fas
 // in [-1, 1] unless the layer rectifies; backward: dhi has passed the reference's gradient clip (<= 100), scaled by 2^9.
 typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4c __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2c __attribute__((ext_vector_type(2)));
 constexpr float CL_F16_LO = 2048.0f, CL_F16_DSCALE = 512.0f;
 __device__ __forceinline__ f32x4 cl_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) { return MFMA_BF16(a, b, c); }
 __device__ __forceinline__ f32x4 cl_mfma(const f16x8c& a, const f16x8c& b, const f32x4& c) {
@@ -144,6 +145,15 @@ __device__ __forceinline__ void cl_publish(const f32x4 (&v)[NP], char* planes, i
     }
 }
 
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 8 bytes to an exchange array (see cl_store4 for `fast`)
+__device__ __forceinline__ void cl_store2(float* p, const f32x2 v, bool fast) {
+    if (fast) { *(f32x2*)p = v; return; }
+    union { float f[2]; u64 u; } a; a.f[0] = v[0]; a.f[1] = v[1];
+    __hip_atomic_store((u64*)p, a.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // SBR_FLAG_PROFILE_REC: cycles per phase of a step (tools/cl_prof.py); the kernels declare pc[], p_t, prof
 #define CL_TICK(i) do { if (prof) { const u64 n_ = clock64(); pc[i] += n_ - p_t; p_t = n_; } } while (0)

@@ -34,14 +34,6 @@ static bool cl_f16_bwd(const RecArgs& a) {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// 8 bytes to an exchange array (see cl_store4 for `fast`)
-__device__ __forceinline__ void cl_store2(float* p, const f32x2 v, bool fast) {
-    if (fast) { *(f32x2*)p = v; return; }
-    union { float f[2]; u64 u; } a; a.f[0] = v[0]; a.f[1] = v[1];
-    __hip_atomic_store((u64*)p, a.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // With R = 8 live rows the MFMA columns 8..15 hold a duplicate of rows 0..7 (the B operand repeats them), so the
 // accumulators of lane (j, q) and lane (j + 8, q) are identical: the lower lane finishes units 0,1 of its four,
