@@ -668,6 +668,11 @@ extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* len
 // ---------------------------------------------------------------------------------------
 // step phases
 // ---------------------------------------------------------------------------------------
+// widest row (floats) the range scatter-add serves (wider: the atomic kernel)
+static int sbr_scat_range_max() {
+    static const int m = [] { const char* e = getenv("SBR_SCAT_RANGE_MAX"); return e ? atoi(e) : 1024; }();
+    return m;
+}
 static RecArgs rec_args(sbr_handle* h, int l) {
     const Layout& y = h->lay; const LayerLayout& ly = y.layer[l];
     RecArgs a; memset(&a, 0, sizeof(a));
@@ -980,6 +985,8 @@ extern "C" int sbr_forward(sbr_handle* h) {
             SBR_LAUNCH(launch_sparse_catch_up_list(h->side, sparse_rows(h, kb), sparse_upd(h), cells, nullptr, y.C, y.C, (int)h->step_count));
             SBR_HIP(hipEventRecord(h->ev_cells, h->side));
             h->cells_early = true;
+            h->side_pending = true;      // (parameters, optimizer state and last[] were written over there: a step abandoned behind
+                                         // sbr_forward -- an error return, a ranking, an export -- joins before it reads them)
         }
     }
     // Overlapped tail, round 3.  Its consumers are throughput-bound once they have the chip's other 192 CUs to themselves (the
@@ -1358,6 +1365,11 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             if (early_on && h->in_train_step && l == 0 && y.L * y.D == 1 && !y.E && !y.n_sparse && !sg && !simple_rec(h) && h->tail_nc < 2 &&
                 !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && (size_t)y.cfg.input_size * GHp >= ((size_t)4 << 20)) {
                 float* s1a = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
+                if (early_on == 2 && (GHp & 3) == 0)      // (experiment) the 16-byte form without the gradient array: 6 passes instead of 8
+                    SBR_LAUNCH(launch_update_untouched_rows(sd, y.cfg.updater, h->P(ly.p_Win), h->St(0, ly.p_Win), s1a ? s1a + ly.p_Win : nullptr,
+                                                            y.cfg.input_size, GHp, (const int*)h->A(y.a_soff), nullptr, 0, y.cfg.learning_rate, y.cfg.rho,
+                                                            y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
+                else
                 SBR_LAUNCH(launch_update_rows(sd, y.cfg.updater, h->P(ly.p_Win), h->Gd(ly.p_Win), h->St(0, ly.p_Win), s1a ? s1a + ly.p_Win : nullptr,
                                               y.cfg.input_size, GHp, (const int*)h->A(y.a_soff), 0, y.cfg.learning_rate, y.cfg.rho,
                                               y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
@@ -1501,6 +1513,9 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                                                   h->Gd(ly.p_cinit), h->Gd(ly.p_hinit)));
             mark(h, 5);
             if (upd_here) {      // b, then (behind the gap that is W_hid) peepholes / initial states, and the output layer unless done
+                // (a sampled head's gradient kernels run on the side stream since round 5 -- SBR_SAMPLED_SIDE -- and this launch reads
+                // and clears their output: order it behind them.  Without the wait the chain's length hid the race.)
+                if (!out_early && h->og_recorded) SBR_HIP(hipStreamWaitEvent(s, h->ev_og, 0));
                 SBR_LAUNCH(upd_on(s, ly.p_b, out_early ? y.p_split : y.n_params, ly.p_Whid - ly.p_b, ly.p_peep - ly.p_Whid));
                 h->tail_updated = true;
             }
@@ -1677,7 +1692,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
                 // SBR_SCAT_RANGE: 1 (default) = the range form up to 1024-float rows, the atomic kernel beyond (C5: measured 8.35 against
                 // 8.44 - 8.48 ms with either new form); 2 = the segment-parallel form; 0 = the atomic kernel everywhere
-                if (range_on == 1 && y.a_srpart && GHp <= 1024 &&
+                if (range_on == 1 && y.a_srpart && GHp <= sbr_scat_range_max() &&
                     launch_scatter_range(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
                                          y.cfg.input_size, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) {
                     SBR_LAUNCH(se);
@@ -2171,7 +2186,7 @@ extern "C" int sbr_debug_scatter(sbr_handle* h, int reps, float* us, int64_t* en
     static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
     auto one = [&]() -> int {
         hipError_t se = hipSuccess;
-        if (range_on == 1 && y.a_srpart && GHp <= 1024 &&
+        if (range_on == 1 && y.a_srpart && GHp <= sbr_scat_range_max() &&
             launch_scatter_range(s, dW, dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
                                  y.cfg.input_size, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) { SBR_LAUNCH(se); }
         else if (range_on == 2 && y.a_srpart &&

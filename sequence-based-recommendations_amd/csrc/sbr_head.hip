@@ -34,6 +34,7 @@
 // else keeps the three launches.  SBR_HEAD_FUSE=0 switches it off.
 #include "sbr_common.h"
 #include "sbr_rec_p.h"
+#include <cstdlib>
 #include <math.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -46,6 +47,7 @@ struct HeadArgs {
     const float* pop;      // [Bp]
     float* dlog;           // [Bp][Nl]
     float* rowcost;        // [Bp]
+    unsigned long long wait_ticks;   // HEAD_WAIT_TICKS, or SBR_HEAD_WAIT_TICKS (tests: 0 = every foreign chunk is recomputed)
     float* slabs;          // [CC][Bp][HP]
     unsigned* stats;       // [RB][CC][16][4]
     int* fault;
@@ -183,6 +185,8 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
     for (int g = 0; g < KG; ++g) hb[g] = *(const f32x4*)(a.h + (size_t)row * HP + 16 * g + 4 * q);
     const int y = a.tgt[row];
     const float scale = a.inv_Bg / a.pop[row];
+    // (a target outside the catalogue hits no column: the row's cost is written here, or last step's value would be summed again)
+    if (cc == 0 && wave == 0 && q == 0 && (unsigned)y >= (unsigned)a.N) a.rowcost[row] = 0.0f;
     if (tid < 16) miss[tid] = 0;
     head_fill<HP>(a, Wl, n_lo, tid);
     __syncthreads();
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
             d2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((d0 ^ d1) == a.epoch && (d2 ^ d3) == a.epoch) { ok = true; break; }
-            if (wall_clock64() - t0 > HEAD_WAIT_TICKS) break;
+            if (wall_clock64() - t0 > a.wait_ticks) break;
             __builtin_amdgcn_s_sleep(2);
         }
         if (ok) { cst[(c * 16 + r) * 2] = __uint_as_float(d0); cst[(c * 16 + r) * 2 + 1] = __uint_as_float(d2); }
@@ -365,6 +369,10 @@ bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const fl
     a.h = h; a.W = WoutT; a.b = bout; a.tgt = tgt; a.pop = pop; a.dlog = dlogits; a.rowcost = rowcost; a.slabs = slabs; a.stats = stats;
     a.fault = fault; a.N = N; a.Nl = Nl; a.CW = CW; a.CC = CC; a.RB = Bp / 16; a.Bp = Bp; a.inv_Bg = 1.0f / (float)Bglobal; a.epoch = epoch;
     a.prof = prof; a.done = done;
+    {   // read per launch: the tests flip it (0: nobody is waited for -- the recompute path serves every foreign chunk)
+        const char* e = getenv("SBR_HEAD_WAIT_TICKS");
+        a.wait_ticks = e ? strtoull(e, nullptr, 10) : HEAD_WAIT_TICKS;
+    }
     const int grid = a.RB * CC;
     if (Hp == 128) { SBR_DYN_LDS(head_cce_kernel<128>, lds); head_cce_kernel<128><<<grid, 256, lds, s>>>(a); }
     else if (Hp == 64) { SBR_DYN_LDS(head_cce_kernel<64>, lds); head_cce_kernel<64><<<grid, 256, lds, s>>>(a); }

@@ -1153,6 +1153,10 @@ bool launch_scatter_wide_step(hipStream_t s, const SbrScatStep& st, const float*
 // equal ids sums the run in slot order) writes those rows.  Every row has exactly one writer and a fixed summation order:
 // the gradient is bit-reproducible.  (sparse_lstm.py:368: the AdvancedIncSubtensor the reference's backward builds.)
 // ---------------------------------------------------------------------------------------
+// (Round 6 measured a software-pipelined walk -- the range's (id, position) pairs staged in LDS, two register sets of SCATR_FLY rows
+// alternating, the flushes counted out of its waits: ALONE on the chip 60.8 against 67.5 us at C4 (4.17 TB/s), but 194 against 112 us
+// in the step, where it runs beside the weight-gradient GEMM: 80 registers instead of 48 halve what fits beside that launch's
+// workgroups.  The two launches together are no faster than one after the other either way -- profiles/round6_variants.txt, calls d, e.)
 #define SCATR_FLY 8
 template <int NV>
 __global__ void __launch_bounds__(256) scat_range_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
@@ -1209,6 +1213,9 @@ __global__ void __launch_bounds__(256) scat_range_kernel(const f32x4* __restrict
     if (tid == 0) { part_id[2 * w] = first_id; part_id[2 * w + 1] = single ? -1 : last_id; }
 }
 
+// The merge of the shared first / last segments.  A hot id's run spans many slots (Zipf: item 0 is ~9 % of C4's entries = ~90 slots of
+// 512 ranges); the leader summed them one dependent load after the other (47 us at C4).  Now: the run's end first (ids only), then
+// its rows SCATR_FLY at a time.
 template <int NV>
 __global__ void __launch_bounds__(256) scat_range_merge_kernel(const f32x4* __restrict__ part, const int* __restrict__ part_id,
                                                                int n_slots, float* __restrict__ dWin, int R4) {
@@ -1220,15 +1227,27 @@ __global__ void __launch_bounds__(256) scat_range_merge_kernel(const f32x4* __re
     if (p & 1) prev = part_id[p - 1];
     else if (p >= 2) prev = part_id[p - 1] >= 0 ? part_id[p - 1] : part_id[p - 2];
     if (prev == id) return;                              // not the leader of its run
+    int qend = p + 1;                                    // one past the run's last slot (empty slots inside a run are skipped below)
+    while (qend < n_slots) { const int iq = part_id[qend]; if (iq >= 0 && iq != id) break; ++qend; }
     f32x4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; acc[v] = f4 < R4 ? part[(size_t)p * R4 + f4] : f32x4{0, 0, 0, 0}; }
-    for (int q = p + 1; q < n_slots; ++q) {
-        const int iq = part_id[q];
-        if (iq < 0) continue;
-        if (iq != id) break;
+    for (int q0 = p + 1; q0 < qend; q0 += SCATR_FLY) {
+        f32x4 val[SCATR_FLY][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) acc[v] += part[(size_t)q * R4 + f4]; }
+        for (int u = 0; u < SCATR_FLY; ++u) {
+            const int q = min(q0 + u, qend - 1);
+            const bool live = q0 + u < qend && part_id[q] == id;       // uniform
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int f4 = tid + 256 * v;
+                val[u][v] = (live && f4 < R4) ? part[(size_t)q * R4 + f4] : f32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SCATR_FLY; ++u)              // slot order: the sum is reproducible
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; if (f4 < R4) ((f32x4*)dWin)[(size_t)id * R4 + f4] = acc[v]; }
@@ -1827,7 +1846,8 @@ hipError_t launch_update_untouched_rows(hipStream_t s, int updater, float* p, fl
     if (updater == SBR_UPD_ADAM)
         st.a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
     const size_t n4 = (size_t)n_rows * (row_floats / 4);
-    const int grid = (int)min((size_t)256 * 16, (n4 + 255) / 256);
+    static const int cap = [] { const char* e = getenv("SBR_UNTOUCHED_WGS"); return e ? atoi(e) : 256 * 16; }();      // (experiment: a throttled pass beside the chain)
+    const int grid = (int)min((size_t)cap, (n4 + 255) / 256);
     update_untouched_rows_kernel<<<grid, 256, 0, s>>>(st, n_rows, row_floats / 4, offs, mark, epoch);
     return hipGetLastError();
 }

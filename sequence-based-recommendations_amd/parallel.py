@@ -55,7 +55,8 @@ class DataParallel(object):
                 # this torch / backend does not order a sync collective behind the stream it is issued under: every collective
                 # then runs on the engine's main stream behind a full join (the stand-in path below; correct, nothing overlapped)
                 self.side = None
-                self.stream_check = "fallback"
+                if not str(self.stream_check or "").startswith("fallback"):
+                    self.stream_check = "fallback"
                 return
             engine.set_deferred_join(True)
             # overlapped step tail (engine.query("tail_chunks") >= 2): dW_in is finished by the engine's second side stream,
@@ -87,14 +88,16 @@ class DataParallel(object):
             torch.cuda.current_stream().wait_stream(self.side)
             torch.cuda.synchronize()
             ok = bool((probe == float(self.world)).all().item())
-        except Exception as ex:      # (no such private spin kernel in another torch: nothing verified, nothing changed)
-            self.stream_check = "skipped: %r" % (ex,)
-            return True
+            note = None
+        except Exception as ex:      # (no such private spin kernel in another torch, a backend error on this rank ...): NOTHING was
+            ok = False               # verified, so the unverified placement is not used -- and this rank still enters the agreement
+            note = "skipped: %r" % (ex,)      # below, so that no rank waits in it alone
         # every rank must take the same path: one that falls back alone would issue its collectives in another order
+        import torch
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.grads.device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
         ok = bool(int(flag.item()))
-        self.stream_check = "ordered" if ok else "fallback"
+        self.stream_check = "ordered" if ok else ("fallback" if note is None else "fallback (%s)" % note)
         return ok
 
     # ---- collectives that bring lazily stepped rows up to date: every rank enters them at the same step

@@ -310,3 +310,29 @@ def test_models_save_and_rank_through_the_data_parallel_collectives(tmp_path):
     m.test_function((None, None), k=7)
     m.predict_function(None, None)
     assert dp.calls == ["get", "get", ("test", 7), "predict"]
+
+
+def test_an_unverifiable_stream_placement_falls_back_and_still_enters_the_agreement():
+    """VERDICT round 5 / ADVICE: a stream check that cannot run (no spin kernel in this torch, a backend error on one rank) must
+    (a) select the fully joined path -- nothing unverified is used -- and (b) still enter the MIN all-reduce of the verdict, so
+    that no other rank waits in it alone.  CPU: torch.cuda.synchronize() raises here, which is exactly the `except` branch."""
+    from sbr_amd.parallel import DataParallel
+
+    class FakeDist:
+        class ReduceOp:
+            MIN = "min"
+        calls = []
+
+        def all_reduce(self, t, op=None, group=None):
+            self.calls.append((tuple(t.shape), op))
+
+    dp = DataParallel.__new__(DataParallel)
+    dp.grads = torch.zeros(4)
+    dp.side = None
+    dp.world = 2
+    dp.group = None
+    dp.dist = FakeDist()
+    dp.stream_check = None
+    assert dp._side_collectives_are_ordered() is False
+    assert dp.stream_check.startswith("fallback (skipped")
+    assert [c[1] for c in dp.dist.calls] == ["min"]            # the agreement was entered exactly once

@@ -109,6 +109,19 @@ def test_one_launch_head_against_the_three_launches():
     close(p0, p1)
 
 
+@pytest.mark.parametrize("N,B,CC", [(3706, 256, 16), (1500, 512, 8)], ids=["16_chunks", "8_chunks"])
+def test_one_launch_head_recompute_path(N, B, CC, monkeypatch):
+    """the timeout / recompute path is what keeps the one-launch head correct when its grid is not co-resident (two
+    processes on one GPU, a busy side stream).  SBR_HEAD_WAIT_TICKS=0: nobody is waited for, EVERY foreign chunk's statistics are
+    recomputed by whoever misses them -- held to the oracle and to the three-launch form, with 16 chunks and (32 row blocks) with 8."""
+    monkeypatch.setenv("SBR_HEAD_WAIT_TICKS", "0")           # read per launch: set for the whole test
+    r0, p0 = variant({"SBR_HEAD_FUSE": "0"}, "GRU", 128, "CCE", N, B, 12)
+    r1, p1 = variant({"SBR_HEAD_FUSE": "1"}, "GRU", 128, "CCE", N, B, 12)
+    assert r0["q:head_fused"] == 0 and r1["q:head_fused"] == CC
+    bars(r0); bars(r1)
+    close(p0, p1)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # the scatter-add that steps its rows
 # ----------------------------------------------------------------------------------------------------------------
