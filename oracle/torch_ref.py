@@ -92,6 +92,68 @@ def layer_forward(layer, cell, inp, mask, index_input):
     return torch.stack(outs, dim=0)
 
 
+# ---------------------------------------------------------------------------------------
+# The same scans with the time loop under torch.jit.script (bench.py's second CPU baseline, "port_scripted"): no Python per step,
+# element-wise chains fused by the profiling executor -- closer to what Theano's compiled scan does than the eager loop above.
+# Gradient clipping (grad_clip nodes at +-100, inactive at the bench's magnitudes) is NOT in it: TorchScript has no custom
+# autograd.Function.  A timing baseline only; parity never runs through it (tests/test_oracle.py holds it to the eager port's cost).
+# ---------------------------------------------------------------------------------------
+@torch.jit.script
+def _lstm_scan(x, m, W_hid, h0, c0, p_i, p_f, p_o):
+    # (unbind / chunk instead of x[t] / gates[:, a:b]: the backward of a select is a zero-filled tensor of the WHOLE input per step --
+    # 200 x 78 MB at C2 --, which is what the eager loop above spends most of its time on)
+    xs = x.unbind(0)
+    ms = m.unbind(0)
+    h, c = h0, c0
+    outs = []
+    for t in range(len(xs)):
+        gi, gf, gg, go = (xs[t] + torch.mm(h, W_hid)).chunk(4, 1)
+        i = torch.sigmoid(gi + c * p_i)
+        f = torch.sigmoid(gf + c * p_f)
+        g = torch.tanh(gg)
+        c_new = f * c + i * g
+        o = torch.sigmoid(go + c_new * p_o)
+        h_new = o * torch.tanh(c_new)
+        c = torch.where(ms[t], c_new, c)
+        h = torch.where(ms[t], h_new, h)
+        outs.append(h)
+    return torch.stack(outs, dim=0)
+
+
+@torch.jit.script
+def _gru_scan(x, m, W_hid, h0):
+    xs = x.unbind(0)
+    ms = m.unbind(0)
+    h = h0
+    outs = []
+    for t in range(len(xs)):
+        hr, hu, hc = torch.mm(h, W_hid).chunk(3, 1)
+        xr, xu, xc = xs[t].chunk(3, 1)
+        r = torch.sigmoid(hr + xr)
+        u = torch.sigmoid(hu + xu)
+        h_new = (1 - u) * h + u * torch.tanh(xc + r * hc)
+        h = torch.where(ms[t], h_new, h)
+        outs.append(h)
+    return torch.stack(outs, dim=0)
+
+
+def layer_forward_scripted(layer, cell, inp, mask, index_input):
+    """layer_forward with the scan under TorchScript (LSTM / GRU; everything else falls back to the eager loop)."""
+    if cell not in ("LSTM", "GRU"):
+        return layer_forward(layer, cell, inp, mask, index_input)
+    W_in, W_hid, b = _stack(layer, cell)
+    H = W_hid.shape[0]
+    x = (W_in[inp.long(), :].sum(dim=-2) + b) if index_input else (inp @ W_in + b)
+    x = x.transpose(0, 1).contiguous()
+    m = mask.transpose(0, 1).bool().unsqueeze(-1)
+    B = x.shape[1]
+    h0 = layer["hid_init"].expand(B, H)
+    if cell == "LSTM":
+        return _lstm_scan(x, m, W_hid, h0, layer["cell_init"].expand(B, H), layer["W_cell_to_ingate"], layer["W_cell_to_forgetgate"],
+                          layer["W_cell_to_outgate"])
+    return _gru_scan(x, m, W_hid, h0)
+
+
 def split_params(params, cell, layers, names_fn, embedding=0, bidirectional=False):
     per, pos = [], (1 if embedding else 0)
     for li, H in enumerate(layers):
@@ -102,8 +164,9 @@ def split_params(params, cell, layers, names_fn, embedding=0, bidirectional=Fals
     return per, params[pos], params[pos + 1]
 
 
-def network_cost(params, cfg, batch, names_fn):
+def network_cost(params, cfg, batch, names_fn, scripted=False):
     """cost tensor of the whole network (rnn_one_hot.py:37-78 / rnn_sampling.py:93-137)."""
+    lf = layer_forward_scripted if scripted else layer_forward
     cell, layers, emb, bi = cfg["cell"], cfg["layers"], cfg.get("embedding", 0), cfg.get("bidirectional", False)
     per, W_out, b_out = split_params(params, cell, layers, names_fn, emb, bi)
     inp = batch["X"]
@@ -116,7 +179,7 @@ def network_cost(params, cfg, batch, names_fn):
         outs, finals = [], []
         for d in range(D):          # --r_bi: second scan over the time-flipped input and mask, outputs flipped back
             src, m = (inp, mask) if d == 0 else (torch.flip(inp, dims=[1]), torch.flip(mask, dims=[1]))
-            hid = layer_forward(per[li * D + d], cell, src, m, index_input=(li == 0 and not emb))
+            hid = lf(per[li * D + d], cell, src, m, index_input=(li == 0 and not emb))
             finals.append(hid[-1])
             outs.append(hid if d == 0 else torch.flip(hid, dims=[0]))
         inp = torch.cat(outs, dim=2).transpose(0, 1)
@@ -165,7 +228,8 @@ def cost_and_grads(np_params, cfg, np_batch, names_fn, dtype=torch.float64):
 class TorchTrainer(object):
     """float32 multi-threaded port used ONLY as bench.py's timed cpu_baseline ("port")."""
 
-    def __init__(self, np_params, cfg, names_fn, updater="adam", lr=1e-3, b1=0.9, b2=0.999, rho=0.9):
+    def __init__(self, np_params, cfg, names_fn, updater="adam", lr=1e-3, b1=0.9, b2=0.999, rho=0.9, scripted=False):
+        self.scripted = scripted
         self.params = [torch.tensor(p, dtype=torch.float32, requires_grad=True) for p in np_params]
         self.cfg, self.names_fn = cfg, names_fn
         self.updater, self.lr, self.b1, self.b2, self.rho = updater, lr, b1, b2, rho
@@ -178,7 +242,7 @@ class TorchTrainer(object):
         for k, v in np_batch.items():
             t = torch.as_tensor(v)
             batch[k] = t.to(torch.float32) if t.is_floating_point() else t
-        cost, _, _ = network_cost(self.params, self.cfg, batch, self.names_fn)
+        cost, _, _ = network_cost(self.params, self.cfg, batch, self.names_fn, scripted=self.scripted)
         grads = torch.autograd.grad(cost, self.params, allow_unused=True)
         with torch.no_grad():
             if self.updater == "adam":

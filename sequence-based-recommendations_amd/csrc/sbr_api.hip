@@ -146,7 +146,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_ws2 = take(lay.ws2_floats);
     // the split-K workspace of the dW_out GEMM when SBR_TAIL_OUT_STREAM moves it off the side stream (the polling weight-gradient
     // GEMM owns ws2 meanwhile): an experiment switch -- taken from the arena only when it is set
-    { const char* e = getenv("SBR_TAIL_OUT_STREAM"); lay.ws3_floats = (e && atoi(e)) ? std::min(lay.ws2_floats, (size_t)16 * lay.N * lay.HLt) : 0; }
+    lay.ws3_floats = 0;      // (the output layer's dW_out GEMM on a stream of its own: measured slower, profiles/round4_variants.txt calls n, q)
     lay.a_ws3 = lay.ws3_floats ? take(lay.ws3_floats) : 0;
     lay.a_X = take((size_t)Bp * T * lay.F);
     lay.a_len = take(Bp);
@@ -170,7 +170,6 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         lay.sr_slots = wide0 ? std::max(sbr_scatter_wide_slots((size_t)T * Bp * lay.F), 2 * SBR_SCAT_RANGES) : 0;
         lay.a_srpart = wide0 ? take((size_t)lay.sr_slots * ghp0) : 0;
         lay.a_srid = wide0 ? take((size_t)lay.sr_slots * 4 + 8) : 0;
-        lay.a_tmark = (wide0 || lay.tail_keys >= 2) ? take((size_t)cfg.input_size) : 0;      // (dense blocks: which rows the batch touches, without its sort)
     }
     lay.a_hstat = take((size_t)256 * 64 + 64);      // + the head's arrival counter and done flag
     lay.a_prog = take((size_t)Bp * 2 + 256);      // per-wave words, (a gap), the chain's clock words
@@ -365,17 +364,14 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         const char* e = getenv("SBR_BWD_CHUNKS");
         const int c = e ? atoi(e) : 1;   // chunking measured neutral-to-slower at C2 (relaunch ~20 us); kept + tested
         h->bwd_chunks = c < 1 ? 1 : (c > SBR_BWD_CHUNKS ? SBR_BWD_CHUNKS : c);
-        const char* w = getenv("SBR_WGRAD_SLICES");
-        h->wgrad_slices = w ? std::max(4, atoi(w)) : 256;
+        h->wgrad_slices = 256;
         const char* cl = getenv("SBR_CLUSTER");
         h->cluster = cl ? atoi(cl) != 0 : 1;
         const char* ln = getenv("SBR_CL_LINEAR");
         h->cl_linear = ln ? atoi(ln) != 0 : 0;
         h->cl_epoch = 0;
-        const char* wx = getenv("SBR_WGRAD_X6");
-        h->wgrad_x6 = wx ? atoi(wx) != 0 : 1;
-        const char* xs = getenv("SBR_X6_SPLIT");
-        h->x6_split = xs ? atoi(xs) != 0 : 1;
+        h->wgrad_x6 = 1;
+        h->x6_split = 1;
         const char* xp = getenv("SBR_X6_PIPE");
         h->x6_pipe = xp ? atoi(xp) : 1;   // 0: barrier kernels (x6s), 1: pipelined without the matrix-pipe gate, 2: with it (rounds 1-3: with
                                           // one sparse instruction per k-block the partner's phase is over long before, the gate only costs its read)
@@ -384,31 +380,23 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     }
     h->n_rows = 0; h->step_count = 0; h->have_batch = false; h->fwd_done = false; h->timing = false;
     h->grads_clean = false; h->timing_marks = 0; h->marks_shared = 0; h->tail_swapped = false;
-    { const char* e = getenv("SBR_SWAP_TAIL"); h->swap_tail = e ? atoi(e) != 0 : true; }
+    h->swap_tail = true;
     { const char* e = getenv("SBR_TAIL_OVERLAP"); h->tail_overlap = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_CHUNKS"); h->tail_chunks_max = e ? std::max(2, atoi(e)) : 8; }
-    { const char* e = getenv("SBR_TAIL_PUBLISH_EVERY"); h->tail_pub_every = e ? std::max(1, atoi(e)) : 2; }
-    { const char* e = getenv("SBR_TAIL_SHORT_CHUNKS"); h->tail_short_chunks = e ? std::max(0, atoi(e)) : 3; }
+    // Tuned constants of the overlapped tail (each was an environment switch while it was being measured -- rounds 2 - 5; the A/B
+    // numbers are in profiles/round2_b_tail_variants.txt, round3_*_variants.txt, round5_variants.txt and DESIGN.md sections 3, 3a, 3d)
+    h->tail_chunks_max = 8; h->tail_pub_every = 2; h->tail_short_chunks = 3;
     // (every switch is read here, once per handle: a test that flips one between two engines of a process gets what it asked for)
     if (getenv("SBR_TAIL_TRACE") && atoi(getenv("SBR_TAIL_TRACE"))) {      // tools/tail_trace.py
         if (hipMalloc(&h->tail_trace, 16384 * sizeof(unsigned long long)) != hipSuccess) h->tail_trace = nullptr;
         else (void)hipMemset(h->tail_trace, 0, 16384 * sizeof(unsigned long long));
     }
-    { const char* e = getenv("SBR_TAIL_FENCE_KB"); h->tail_fence_kb = e ? std::max(0, std::min(160, atoi(e))) : 124; }
-    { const char* e = getenv("SBR_TAIL_EARLY_SORT"); h->tail_early_sort = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_OUT_STREAM"); h->tail_out_stream = e ? atoi(e) : 0; }
-    { const char* e = getenv("SBR_TAIL_FUSE_SLABS"); h->tail_fuse_slabs = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_SLAB_GROWTH"); h->tail_slab_growth = e ? std::max(0.0, atof(e)) : 0.35; }
-    { const char* e = getenv("SBR_TAIL_SCATTER_LDS"); h->tail_scatter_lds = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_GEOM"); h->tail_geom = e ? atof(e) : (h->tail_scatter_lds ? 1.6 : 2.6); }
-    { const char* e = getenv("SBR_TAIL_MONITOR_IN_UNITS"); h->tail_mon_units = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_FIRST"); h->tail_first = e ? std::max(1, atoi(e)) : 6; }
-    { const char* e = getenv("SBR_TAIL_SCATTER_UNITS"); h->tail_scatter_units = e ? std::max(1, std::min(384, atoi(e))) : 192; }
-    { const char* e = getenv("SBR_TAIL_GEMM_GROUPS"); h->tail_gemm_groups = e ? std::max(1, atoi(e)) : 64; }
-    { const char* e = getenv("SBR_TAIL_SLAB_MAX"); h->tail_slab_max = e ? std::max(32, atoi(e) / 32 * 32) : 512; }
-    { const char* e = getenv("SBR_FOLD_DH"); h->fold_dh = e ? atoi(e) != 0 : true; }
+    h->tail_fence_kb = 124; h->tail_early_sort = 1; h->tail_out_stream = 0; h->tail_fuse_slabs = 1; h->tail_slab_growth = 0.35;
+    { const char* e = getenv("SBR_TAIL_SCATTER_LDS"); h->tail_scatter_lds = e ? atoi(e) : 1; }      // 0: the polling range form (also the way out when the LDS rows run out)
+    h->tail_geom = h->tail_scatter_lds ? 1.6 : 2.6;
+    h->tail_mon_units = 1; h->tail_first = 6; h->tail_scatter_units = 192; h->tail_gemm_groups = 64; h->tail_slab_max = 512;
+    h->fold_dh = true;
     { const char* e = getenv("SBR_WGRAD_F16"); h->wgrad_f16 = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_WGRAD_X6_WGS"); h->wgrad_x6_wgs = e ? atoi(e) : 512; }
+    h->wgrad_x6_wgs = 512;
     h->tail_nc = 0; h->tail_ch = 0; h->prog_epoch = 0; h->tail_updated = false; h->ev_tail = nullptr; h->ev_tail2 = nullptr; h->side2 = nullptr; h->ev_lg_rec = nullptr; h->side3 = nullptr; h->ev_tail3 = nullptr; h->tail_sorted = false; h->out3 = false;
     h->step_open = false; h->tail_join_pending = false;
     memset(h->ev, 0, sizeof(h->ev)); h->ring_used = 0; h->ring_cur = 0;
@@ -416,21 +404,14 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr; h->ev_sort = nullptr; h->ev_lg = nullptr; h->ev_fill = nullptr; h->ev_og = nullptr;
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
-    h->out_early = false; h->win_early = false; h->dh_slabs_n = 0;
-    // (default 0: measured no gain -- C4 1.324 -> 1.375, C3 1.484 -> 1.485, C5 equal: the fused kernel's waves hold a row's state
-    // beside its dxt rows and run at 1.5 - 2.3 TB/s where the two-pass form streams the state at 3.6 - 6.2; profiles/round5_a_*)
-    { const char* e = getenv("SBR_SCAT_FUSE"); h->scat_fuse = e ? atoi(e) : 0; }
-    { const char* e = getenv("SBR_WIN_REST"); h->win_rest = e ? atoi(e) : 1; }
+    h->out_early = false; h->dh_slabs_n = 0;
     { const char* e = getenv("SBR_SPARSE_OUT_EARLY"); h->sparse_out_early = e ? atoi(e) : 1; }
-    h->win_fused = false; h->win_rest_pending = false; h->win_rest_done = false; h->cells_early = false; h->wout_early = false;
-    h->ev_cells = nullptr; h->mark_epoch = 0;
+    h->cells_early = false; h->wout_early = false;
+    h->ev_cells = nullptr;
     { const char* e = getenv("SBR_HEAD_FUSE"); h->head_fuse = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_OUT_FUSE"); h->out_fuse = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_HEAD_GATE"); h->head_gate = e ? atoi(e) : 1; }
-    { const char* e = getenv("SBR_TAIL_WIN_SPLIT"); h->tail_win_split = e ? atoi(e) : 0; }
-    { const char* e = getenv("SBR_ROW_AWARE_UPDATE"); h->row_aware = e ? atoi(e) : 1; }
-    h->win_untouched_done = false;
-    h->win_split_done = false;
+    { const char* e = getenv("SBR_OUT_FUSE"); h->out_fuse = e ? atoi(e) != 0 : 1; }
+    h->head_gate = 1;
+    { const char* e = getenv("SBR_ROW_AWARE_UPDATE"); h->row_aware = e ? atoi(e) != 0 : 1; }
     h->out_stepped = false;
     h->head_epoch = 0;
     h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
@@ -668,11 +649,6 @@ extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* len
 // ---------------------------------------------------------------------------------------
 // step phases
 // ---------------------------------------------------------------------------------------
-// widest row (floats) the range scatter-add serves (wider: the atomic kernel)
-static int sbr_scat_range_max() {
-    static const int m = [] { const char* e = getenv("SBR_SCAT_RANGE_MAX"); return e ? atoi(e) : 1024; }();
-    return m;
-}
 static RecArgs rec_args(sbr_handle* h, int l) {
     const Layout& y = h->lay; const LayerLayout& ly = y.layer[l];
     RecArgs a; memset(&a, 0, sizeof(a));
@@ -771,26 +747,6 @@ static int tail_cost_scan(sbr_handle* h) {
         h->tail_cost_scanned = true;
     }
     return SBR_OK;
-}
-
-// Will the scatter-add of this (single-call) step apply the optimizer to the DENSE index-input block of layer 0 itself
-// (launch_scatter_wide_step + a zero-gradient pass over the untouched rows)?  Decided by ONE function: the pass over the untouched
-// rows may run long before the scatter-add (SBR_WIN_REST=2: between the chains), and a step in which one ran without the other
-// would step rows twice or not at all -- sbr_backward_recurrent fails loudly if its own conditions disagree.
-static bool dense_scatter_step_ok(const sbr_handle* h, bool in_step) {
-    const Layout& y = h->lay;
-    static const int early_on = [] { const char* e = getenv("SBR_EARLY_UPDATE"); return e ? atoi(e) : 0; }();
-    static const int scat_first = [] { const char* e = getenv("SBR_SCAT_FIRST"); return e ? atoi(e) : 0; }();
-    static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
-    if (!h->scat_fuse || !h->win_rest || !in_step || early_on || scat_first || range_on == 0) return false;
-    if (y.D != 1 || y.E || !y.a_srpart || !y.a_tmark || h->tail_nc >= 2) return false;
-    if (simple_gemm(h) || simple_rec(h) || (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) return false;
-    for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 0) return false;
-    const int GHp = y.G * y.layer[0].Hp;
-    if ((GHp & 3) || GHp < 512 || GHp > 2048) return false;                       // launch_scatter_wide_step's shapes
-    // small one-layer models may keep the scatter-add on the side stream (swapped tail, sbr_backward_recurrent) and step W_in there
-    if (y.L == 1 && !y.n_sparse && y.n_params <= ((size_t)4 << 20) && h->swap_tail) return false;
-    return true;
 }
 
 // sbr_chain_times: events around one chain launch (dir 0 = forward, 1 = backward); `which` 0 in front of it, 1 behind it
@@ -1003,21 +959,6 @@ extern "C" int sbr_forward(sbr_handle* h) {
                                        h->tail_ch, h->tail_nc, &h->tail_bounds, &h->scnt_zero_n));
         h->tail_sorted = true;
         { const int rc = tail_cost_scan(h); if (rc != SBR_OK) return rc; }
-        // SBR_TAIL_WIN_SPLIT: the dense pass over W_in that ends the scatter-add's stream (12 us behind the chain at C2) split in
-        // time -- the rows this batch does not name take their zero-gradient step NOW, beside the forward chain (which gathers
-        // the OTHER rows), the touched ones behind the scatter-add
-        h->win_split_done = false;
-        if (h->tail_win_split && h->in_train_step && y.a_tmark && !y.n_sparse) {
-            const LayerLayout& l0 = y.layer[0];
-            const int GHp0 = y.G * l0.Hp;
-            h->mark_epoch += 1;
-            SBR_LAUNCH(launch_mark_rows(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_tmark), h->mark_epoch));
-            SBR_LAUNCH(launch_update_untouched_rows(h->side2, y.cfg.updater, h->P(l0.p_Win), h->St(0, l0.p_Win),
-                                                    y.n_state_arrays > 1 ? h->St(1, l0.p_Win) : nullptr, y.cfg.input_size, GHp0, nullptr,
-                                                    (const int*)h->A(y.a_tmark), h->mark_epoch, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
-                                                    y.cfg.beta2, (long)h->step_count + 1));
-            h->win_split_done = true;
-        }
     }
     if (y.D == 2) return forward_bi(h);
     for (int l = 0; l < y.L; ++l) {
@@ -1134,23 +1075,6 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
         const int rc = side_batch_work(); if (rc != SBR_OK) return rc;
     }
-    // SBR_WIN_REST=2: the zero-gradient step of the rows of a dense W_in this batch does not name runs NOW, on the second side
-    // stream beside the head's kernels (which leave HBM idle), from marks that need the batch only (the sort is still running)
-    h->win_rest_done = false;
-    if (h->win_rest == 2 && dense_scatter_step_ok(h, h->in_train_step)) {
-        const LayerLayout& l0 = y.layer[0];
-        const int GHp0 = y.G * l0.Hp;
-        if (!fill_needed) SBR_HIP(hipEventRecord(h->ev_fork, s));
-        SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
-        h->mark_epoch += 1;
-        SBR_LAUNCH(launch_mark_rows(h->side2, h->bX, h->blen, y.T, y.Bp, y.F, y.cfg.input_size, (int*)h->A(y.a_tmark), h->mark_epoch));
-        SBR_LAUNCH(launch_update_untouched_rows(h->side2, y.cfg.updater, h->P(l0.p_Win), h->St(0, l0.p_Win),
-                                                y.n_state_arrays > 1 ? h->St(1, l0.p_Win) : nullptr, y.cfg.input_size, GHp0, nullptr,
-                                                (const int*)h->A(y.a_tmark), h->mark_epoch, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
-                                                y.cfg.beta2, (long)h->step_count + 1));
-        SBR_HIP(hipEventRecord(h->ev_tail2, h->side2));
-        h->win_rest_pending = true; h->win_rest_done = true;
-    }
     if (y.cfg.loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(y.cfg.loss)) {      // dense heads: full softmax, or RNNMargin's linear layer
         float* lg = h->A(y.a_logits);
         const int Nl = (N + 3) & ~3;               // row stride of the logits / dlogits buffer
@@ -1228,10 +1152,10 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // (launch_out_grad_step, sbr_misc.hip) instead of the five or six below -- the polling weight-gradient GEMM of the overlapped
         // tail, next on this stream, then starts with the chain instead of 68 us into it.  SBR_OUT_FUSE=0: as before.
         h->out_stepped = false;
-        // (taken WITHOUT the overlapped tail only, unless SBR_OUT_FUSE=2: at C2 the polling GEMM then starts 9 us earlier and ends where
-        // it did -- it is throughput-bound beside the chain -- while the step measured 0.3334 against 0.3294 ms; C1: 0.3156 -> 0.3035
-        // together with the one-launch head: profiles/round5_variants.txt call b)
-        const bool will_step_here = h->in_train_step && !y.n_sparse && !sg && (h->tail_nc == 0 || (h->out_fuse >= 2 && h->tail_nc >= 2 && y.L == 1));
+        // (taken WITHOUT the overlapped tail only: in front of the polling GEMM of C2 it measured 0.3334 against 0.3294 ms -- that GEMM
+        // then starts 9 us earlier and ends where it did, it is throughput-bound beside the chain; C1: 0.3156 -> 0.3035 together with
+        // the one-launch head: profiles/round5_variants.txt call b)
+        const bool will_step_here = h->in_train_step && !y.n_sparse && !sg && h->tail_nc == 0;
         if (h->out_fuse && will_step_here && y.cfg.regularization == 0.0f && y.D == 1) {
             hipError_t oe = hipSuccess;
             float* s1e = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
@@ -1282,7 +1206,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // Round 5: dh feeds the BPTT chain, everything else here only feeds the optimizer -- cost sum, bias column sums, the dWc GEMM
         // and the scatter of the cells' gradients (5 launches, ~75 us at C3 beside the side stream's sort) leave the main stream: dh
         // first, one record, the rest on the side stream beside the chain (as the dense heads always did).  SBR_SAMPLED_SIDE=0: rounds 1 - 4.
-        static const int sampled_side = [] { const char* e = getenv("SBR_SAMPLED_SIDE"); return e ? atoi(e) : 1; }();
+        const int sampled_side = 1;
         hipStream_t sg_s = sampled_side ? sd : s;
         if (sampled_side) {
             SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
@@ -1353,29 +1277,6 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
         // BPTT in time chunks when the bf16x6 kernel runs: dW_hid of a finished chunk is computed on the side
         // stream (190 idle CUs) while the chain continues
         const size_t slab = (size_t)ly.Hp * GHp;
-        // Dense single-call step of a large index-input layer (C4: 27 M floats of W_in, 139 us of optimizer pass at the HBM roof behind
-        // the scatter-add): the rows this batch does not touch -- two thirds of them with Zipf ids -- have a zero gradient whatever
-        // the chain computes, so their optimizer step runs NOW, on the side stream beside the chain (behind the sort that knows
-        // them); sbr_apply_update then steps only the touched rows.  Same arithmetic per element as the one dense pass.
-        {
-            // MEASURED SLOWER, off by default (profiles/round4_o_c4_timeline.txt): the 0.65 GB the early pass streams through the L2s
-            // beside the chain cost rec_bwd_c16 86 us (512 -> 598: its exchange rings live in those L2s), more than the 90 us the
-            // shorter pass behind the scatter-add saves: C4 1.375 -> 1.41 ms.  SBR_EARLY_UPDATE=1 runs it.
-            static const int early_on = [] { const char* e = getenv("SBR_EARLY_UPDATE"); return e ? atoi(e) : 0; }();
-            if (early_on && h->in_train_step && l == 0 && y.L * y.D == 1 && !y.E && !y.n_sparse && !sg && !simple_rec(h) && h->tail_nc < 2 &&
-                !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && (size_t)y.cfg.input_size * GHp >= ((size_t)4 << 20)) {
-                float* s1a = y.n_state_arrays > 1 ? h->St(1, 0) : nullptr;
-                if (early_on == 2 && (GHp & 3) == 0)      // (experiment) the 16-byte form without the gradient array: 6 passes instead of 8
-                    SBR_LAUNCH(launch_update_untouched_rows(sd, y.cfg.updater, h->P(ly.p_Win), h->St(0, ly.p_Win), s1a ? s1a + ly.p_Win : nullptr,
-                                                            y.cfg.input_size, GHp, (const int*)h->A(y.a_soff), nullptr, 0, y.cfg.learning_rate, y.cfg.rho,
-                                                            y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
-                else
-                SBR_LAUNCH(launch_update_rows(sd, y.cfg.updater, h->P(ly.p_Win), h->Gd(ly.p_Win), h->St(0, ly.p_Win), s1a ? s1a + ly.p_Win : nullptr,
-                                              y.cfg.input_size, GHp, (const int*)h->A(y.a_soff), 0, y.cfg.learning_rate, y.cfg.rho,
-                                              y.cfg.beta1, y.cfg.beta2, (long)h->step_count + 1));
-                h->win_early = true;
-            }
-        }
         int nc = (sbr_rec_bwd_chunkable(a, simple_rec(h)) && y.T >= 64 && !sg) ? h->bwd_chunks : 1;
         int nsl = (int)std::min<size_t>(h->wgrad_slices / nc, y.ws2_floats / (slab * nc));   // K-slices (= workgroups of the wgrad kernel)
         if (nsl < 1) nc = 1;
@@ -1487,14 +1388,7 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             SBR_LAUNCH(launch_scatter_reduce_poll(s2, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
                                                   (const int*)h->A(y.a_soff), y.cfg.input_size, tnc, CH, y.T * y.Bp * y.F, GHp, y.Bp, pl,
                                                   0, &h->tail_bounds, h->tail_short_chunks, !serial && h->tail_fence_kb > 0));
-            if (upd_here && h->win_split_done) {
-                SBR_LAUNCH(launch_update_touched_rows(s2, y.cfg.updater, h->P(ly.p_Win), h->Gd(ly.p_Win), h->St(0, ly.p_Win),
-                                                      s1a ? s1a + ly.p_Win : nullptr, y.cfg.input_size, GHp, (const int*)h->A(y.a_tmark),
-                                                      h->mark_epoch, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2,
-                                                      (long)h->step_count + 1));
-                h->win_split_done = false;
-            }
-            else if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
+            if (upd_here) SBR_LAUNCH(upd_on(s2, ly.p_Win, ly.p_b));
             SBR_HIP(hipEventRecord(h->ev_tail2, s2));
             // single-call step: the slab reduction IS the W_hid update (one launch, one pass less behind the chain); phase-by-phase
             // callers (data parallel) need the reduced gradient
@@ -1535,7 +1429,6 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             h->side_pending = false;
             continue;
         }
-        bool scat_early = false;      // wide rows, tail not swapped: the scatter-add ran on the side stream in FRONT of the weight-gradient GEMM
         hipEvent_t ev_chain_end = nullptr;      // this layer: the main-stream record behind its (last) BPTT launch
         if (nc > 1 || side_wgrad) {
             for (int c = 0; c < nc; ++c) {
@@ -1543,23 +1436,6 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
                 SBR_LAUNCH_CHAIN(1, s, launch_rec_backward(s, a, false));
                 ev_chain_end = record_shared(h, h->ev_chunk[c], (l == 0 && c == nc - 1) ? 4 : -1);
                 SBR_HIP(hipStreamWaitEvent(sd, ev_chain_end, 0));
-                // The scatter-add is the head of the step's critical tail (scatter -> W_in's optimizer pass) and the side stream has
-                // the higher priority: launched on the main stream beside the GEMM it got CUs only as the GEMM's workgroups retired
-                // (C4: 180 us for 50 us of work, profiles/round4_k_c4_timeline.txt).  So it goes first, on the side stream; the main
-                // stream waits for its event, the GEMM follows it.
-                // (SBR_SCAT_FIRST=1; measured no better: the optimizer pass over W_in then shares the chip with the GEMM instead, 139 ->
-                // 239 us at C4: profiles/round4_l_c4_timeline.txt.  Off by default.)
-                static const int scat_first = [] { const char* e = getenv("SBR_SCAT_FIRST"); return e ? atoi(e) : 0; }();
-                if (scat_first && l == 0 && nc == 1 && sw == sd && sm == s && !y.E && y.a_srpart && !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER)) {
-                    hipError_t se = hipSuccess;
-                    if (launch_scatter_wide(sd, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos),
-                                            (const int*)h->A(y.a_soff), y.cfg.input_size, y.T * y.Bp * y.F, GHp,
-                                            h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) {
-                        SBR_LAUNCH(se);
-                        SBR_HIP(hipEventRecord(h->ev_tail, sd));
-                        scat_early = true;
-                    }
-                }
                 // dW_hid [Hp][G*Hp] += hs[t]^T . dhi[t] over the chunk's positions (hs slot t = h_{t-1})
                 const float* hsc = h->A(ly.a_hs) + (size_t)a.t_lo * y.Bp * ly.Hp;
                 const int Kc = (a.t_hi - a.t_lo) * y.Bp;
@@ -1621,78 +1497,12 @@ extern "C" int sbr_backward_recurrent(sbr_handle* h) {
             if (y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) {
                 SBR_LAUNCH(launch_scatter_rows(s, h->Gd(ly.p_Win), a.dxt, h->bX, a.len, y.T, y.Bp, y.F, GHp));
             } else {
-                if (scat_early) { SBR_HIP(hipStreamWaitEvent(s, h->ev_tail, 0)); mark_on(h, 6, sm); continue; }
                 if (sm == s) SBR_HIP(hipStreamWaitEvent(s, h->ev_sort, 0));      // (the sort ran on the side stream)
                 hipError_t se = hipSuccess;
-                // Single-call step, wide index-input rows: the scatter-add steps the rows it completes (launch_scatter_wide_step,
-                // sbr_misc.hip) -- row-sparse blocks (C3 / C5: the separate touched-rows kernel disappears) and dense ones (C4: the
-                // 140 us pass over all of W_in becomes the touched rows' step here + a zero-gradient pass over the others on the
-                // second side stream, beside this kernel and the weight-gradient GEMM).  SBR_SCAT_FUSE=0: scatter-add, then steps.
-                {
-                    int kb0 = -1;
-                    for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 0) kb0 = b;
-                    const bool dense_blk = kb0 < 0;
-                    static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
-                    const bool fuse = dense_blk ? dense_scatter_step_ok(h, h->in_train_step)
-                                                : (h->scat_fuse && h->in_train_step && y.D == 1 && y.a_srpart && !sg && !simple_rec(h) &&
-                                                   range_on != 0 && GHp <= 2048 && !h->sp_exchanged[kb0]);
-                    if (h->win_rest_done && !(fuse && sm == s)) {
-                        sbr_set_error("internal: the untouched rows of W_in were stepped but the scatter-add does not step the others");
-                        return SBR_ESTATE;
-                    }
-                    if (fuse && sm == s) {
-                        SbrScatStep st; memset(&st, 0, sizeof(st));
-                        st.p = h->P(ly.p_Win); st.s0 = h->St(0, ly.p_Win); st.s1 = y.n_state_arrays > 1 ? h->St(1, ly.p_Win) : nullptr;
-                        st.last = dense_blk ? nullptr : (int*)h->A(y.sparse[kb0].a_last);
-                        st.updater = y.cfg.updater; st.t_to = (int)h->step_count + 1;
-                        st.lr = y.cfg.learning_rate; st.rho = y.cfg.rho; st.b1 = y.cfg.beta1; st.b2 = y.cfg.beta2;
-                        st.a_t = y.cfg.updater == SBR_UPD_ADAM
-                                     ? (float)((double)st.lr * sqrt(1.0 - pow((double)st.b2, (double)st.t_to)) / (1.0 - pow((double)st.b1, (double)st.t_to)))
-                                     : 0.0f;
-                        if (!launch_scatter_wide_step(sm, st, a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
-                                                      y.cfg.input_size, y.T * y.Bp * y.F, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), y.sr_slots, &se)) {
-                            sbr_set_error("internal: launch_scatter_wide_step refused a shape dense_scatter_step_ok admits (G*Hp = %d)", GHp);
-                            return SBR_ESTATE;
-                        }
-                        {
-                            SBR_LAUNCH(se);
-                            h->win_fused = true;
-                            if (dense_blk && !h->win_rest_done) {
-                                // the rows this batch does not name: zero-gradient step, no gradient traffic.  On side2 behind the sort
-                                // and the chain (the record the side stream waited on), or (SBR_WIN_REST=3) right here behind the scatter-add
-                                hipStream_t sr = h->win_rest == 3 ? sm : h->side2;
-                                if (sr != sm) {
-                                    SBR_HIP(hipStreamWaitEvent(sr, h->ev_sort, 0));
-                                    if (ev_chain_end) SBR_HIP(hipStreamWaitEvent(sr, ev_chain_end, 0));
-                                }
-                                SBR_LAUNCH(launch_update_untouched_rows(sr, y.cfg.updater, st.p, st.s0, st.s1, y.cfg.input_size, GHp,
-                                                                        (const int*)h->A(y.a_soff), nullptr, 0, st.lr, st.rho, st.b1, st.b2,
-                                                                        (long)st.t_to));
-                                if (sr != sm) { SBR_HIP(hipEventRecord(h->ev_tail2, sr)); h->win_rest_pending = true; }
-                            }
-                            mark_on(h, 6, sm);
-                            continue;
-                        }
-                    }
-                }
-                // SBR_ROW_AWARE_UPDATE=2: the zero-gradient step of the rows this batch does not name (6 passes over 60 % of C4's W_in) runs on
-                // the second side stream BESIDE the scatter-add and the weight-gradient GEMM; sbr_apply_update then steps the touched rows only
-                h->win_untouched_done = false;
-                if (h->row_aware == 2 && h->in_train_step && sm == s && y.a_tmark && !y.n_sparse && y.D == 1 && h->tail_nc < 2 && !sg && !simple_rec(h) &&
-                    !h->win_early && (GHp & 3) == 0) {
-                    float* s1w = y.n_state_arrays > 1 ? h->St(1, ly.p_Win) : nullptr;
-                    SBR_HIP(hipStreamWaitEvent(h->side2, h->ev_sort, 0));
-                    if (ev_chain_end) SBR_HIP(hipStreamWaitEvent(h->side2, ev_chain_end, 0));
-                    SBR_LAUNCH(launch_update_untouched_rows(h->side2, y.cfg.updater, h->P(ly.p_Win), h->St(0, ly.p_Win), s1w, y.cfg.input_size, GHp,
-                                                            (const int*)h->A(y.a_soff), nullptr, 0, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
-                                                            y.cfg.beta2, (long)h->step_count + 1));
-                    SBR_HIP(hipEventRecord(h->ev_tail2, h->side2));
-                    h->win_rest_pending = true; h->win_untouched_done = true;
-                }
                 static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
                 // SBR_SCAT_RANGE: 1 (default) = the range form up to 1024-float rows, the atomic kernel beyond (C5: measured 8.35 against
                 // 8.44 - 8.48 ms with either new form); 2 = the segment-parallel form; 0 = the atomic kernel everywhere
-                if (range_on == 1 && y.a_srpart && GHp <= sbr_scat_range_max() &&
+                if (range_on == 1 && y.a_srpart && GHp <= 1024 &&
                     launch_scatter_range(sm, h->Gd(ly.p_Win), a.dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
                                          y.cfg.input_size, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) {
                     SBR_LAUNCH(se);
@@ -1845,44 +1655,22 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
                              y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
     };
     const size_t p_end = h->out_early ? y.p_split : y.n_params;     // the output layer was stepped beside the BPTT chain
-    // [0, hi) of the parameter section; where the untouched rows of W_in were stepped beside the chain (win_early,
-    // sbr_backward_recurrent), only the touched rows of that block are left
+    // [0, hi) of the parameter section.
     // Single-call step, dense wide index-input block, the step's plain-key sort at hand (a_soff: this batch's segment offsets): the pass
     // over W_in reads / clears the gradient of the touched rows only (launch_update_rows_aware).  SBR_ROW_AWARE_UPDATE=0: update_kernel.
-    const bool row_aware = h->row_aware && h->in_train_step && y.a_tmark && !y.n_sparse && !y.E && y.D == 1 && h->tail_nc < 2 &&
-                           !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && !simple_gemm(h) && !simple_rec(h) && !h->win_early && !h->win_fused &&
-                           ((y.G * y.layer[0].Hp) & 3) == 0;
-    if (h->win_untouched_done && !row_aware) {
-        sbr_set_error("internal: the untouched rows of W_in were stepped (SBR_ROW_AWARE_UPDATE=2) but the update does not take the row-aware pass");
-        return SBR_ESTATE;
-    }
+    const bool row_aware = h->row_aware && h->in_train_step && y.a_srpart && !y.n_sparse && !y.E && y.D == 1 && h->tail_nc < 2 &&
+                           !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && !simple_gemm(h) && !simple_rec(h) && ((y.G * y.layer[0].Hp) & 3) == 0;
     auto upd_front = [&](size_t hi) -> hipError_t {
-        if (!h->win_early && !h->win_fused && !row_aware) return upd(0, hi);
+        if (!row_aware) return upd(0, hi);
         const LayerLayout& l0 = y.layer[0];
         const int GHp0 = y.G * l0.Hp;
         const size_t w_end = l0.p_Win + (size_t)y.cfg.input_size * GHp0;
         hipError_t e = upd(0, l0.p_Win);
         if (e != hipSuccess) return e;
-        if (row_aware && h->win_untouched_done) {      // (SBR_ROW_AWARE_UPDATE=2: the untouched rows are done, on side2)
-            if (hi < w_end) return hipErrorInvalidValue;
-            e = launch_update_rows(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
-                                   y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), 1, y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1, y.cfg.beta2,
-                                   (long)h->step_count);
-            if (e != hipSuccess) return e;
-            return hi > w_end ? upd(w_end, hi) : hipSuccess;
-        }
-        if (row_aware) {
-            if (hi < w_end) return hipErrorInvalidValue;      // (callers pass ranges that cover the block)
-            e = launch_update_rows_aware(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
-                                         y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
-                                         y.cfg.beta2, (long)h->step_count);
-            if (e != hipSuccess) return e;
-            return hi > w_end ? upd(w_end, hi) : hipSuccess;
-        }
-        if (h->win_fused) return hi > w_end ? upd(w_end, hi) : hipSuccess;      // every row of the block has been stepped (scatter-add + side2)
-        e = launch_update_rows(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
-                               y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), 1, y.cfg.learning_rate, y.cfg.rho,
-                               y.cfg.beta1, y.cfg.beta2, (long)h->step_count);
+        if (hi < w_end) return hipErrorInvalidValue;      // (callers pass ranges that cover the block)
+        e = launch_update_rows_aware(h->stream, y.cfg.updater, h->P(l0.p_Win), h->Gd(l0.p_Win), h->St(0, l0.p_Win), s1 ? s1 + l0.p_Win : nullptr,
+                                     y.cfg.input_size, GHp0, (const int*)h->A(y.a_soff), y.cfg.learning_rate, y.cfg.rho, y.cfg.beta1,
+                                     y.cfg.beta2, (long)h->step_count);
         if (e != hipSuccess) return e;
         return hi > w_end ? upd(w_end, hi) : hipSuccess;
     };
@@ -1901,8 +1689,8 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         for (int b = 0; b < y.n_sparse; ++b) {
             const SparseBlockLayout& sb = y.sparse[b];
             const SbrSparseRows rows = sparse_rows(h, b);
-            if ((sb.kind == 0 && h->win_fused) || (sb.kind == 1 && h->wout_early)) {
-                // stepped already: by the scatter-add (sbr_backward_recurrent) / beside the BPTT chain (sbr_loss_backward_output)
+            if (sb.kind == 1 && h->wout_early) {
+                // stepped already, beside the BPTT chain (sbr_loss_backward_output)
             } else
             if (h->sp_exchanged[b]) {
                 SBR_LAUNCH(launch_sparse_step_list(h->stream, rows, sparse_upd(h), (const int*)h->A(sb.a_cand), nullptr, h->sp_ncand[b],
@@ -1943,7 +1731,7 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
             SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_og, 0));
             size_t pos = 0;
             int l_from = 0;
-            if (h->win_early || h->win_fused || row_aware) {      // layer 0: W_in's touched rows (win_early) / nothing of W_in (win_fused) / the row-aware pass, then b
+            if (row_aware) {      // layer 0: the row-aware pass over W_in, then b
                 SBR_LAUNCH(upd_front(y.layer[0].p_Whid));
                 pos = y.layer[0].p_peep; l_from = 1;
             }
@@ -1956,9 +1744,8 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         SBR_LAUNCH(upd_front(p_end));
     }
-    if (h->win_rest_pending) { SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_tail2, 0)); h->win_rest_pending = false; }
-    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false; h->win_early = false;
-    h->win_fused = false; h->win_rest_done = false; h->wout_early = false; h->win_untouched_done = false;
+    h->og_recorded = false; h->tail_swapped = false; h->tail_updated = false; h->out_early = false;
+    h->wout_early = false;
     mark(h, 7);
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;
@@ -2186,7 +1973,7 @@ extern "C" int sbr_debug_scatter(sbr_handle* h, int reps, float* us, int64_t* en
     static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
     auto one = [&]() -> int {
         hipError_t se = hipSuccess;
-        if (range_on == 1 && y.a_srpart && GHp <= sbr_scat_range_max() &&
+        if (range_on == 1 && y.a_srpart && GHp <= 1024 &&
             launch_scatter_range(s, dW, dxt, (const int*)h->A(y.a_sid), (const int*)h->A(y.a_spos), (const int*)h->A(y.a_soff),
                                  y.cfg.input_size, GHp, h->A(y.a_srpart), (int*)h->A(y.a_srid), SBR_SCAT_RANGES, &se)) { SBR_LAUNCH(se); }
         else if (range_on == 2 && y.a_srpart &&
@@ -2231,15 +2018,6 @@ extern "C" int sbr_query(sbr_handle* h, const char* what, int64_t* value) {
         int cc = 0, cw = 0; size_t lds = 0;
         *value = (h->head_fuse && y.cfg.loss == SBR_LOSS_CCE && !simple_gemm(h) && !(y.cfg.flags & (SBR_FLAG_BF16_PROJECTION | SBR_FLAG_F32_MFMA)) &&
                   y.D == 1 && y.B == y.Bp && sbr_head_plan(y.Bp, y.N, y.HLt, &cc, &cw, &lds) && (size_t)cc * y.Bp * y.HLt <= y.ws_floats) ? cc : 0;
-    }
-    else if (w == "scatter_step") {    // sbr_train_step: does the scatter-add step layer 0's index-input block itself? 0 no, 1 dense block, 2 row-sparse block
-        int kb0 = -1;
-        for (int b = 0; b < y.n_sparse; ++b) if (y.sparse[b].kind == 0) kb0 = b;
-        static const int range_on = [] { const char* e = getenv("SBR_SCAT_RANGE"); return e ? atoi(e) : 1; }();
-        const int GHp0 = y.G * y.layer[0].Hp;
-        if (kb0 < 0) *value = dense_scatter_step_ok(h, true) ? 1 : 0;
-        else *value = (h->scat_fuse && y.D == 1 && !y.E && y.a_srpart && !simple_gemm(h) && !simple_rec(h) && range_on != 0 && GHp0 <= 2048 &&
-                       !(y.cfg.flags & SBR_FLAG_ATOMIC_SCATTER) && h->tail_nc < 2) ? 2 : 0;
     }
     else if (w == "cluster") { RecArgs a = rec_args(h, (y.L - 1) * y.D); *value = (!simple_rec(h) && sbr_rec_cluster_ok(a)) ? 1 : 0; }
     else if (w == "rec_kernel") {   // family serving the top layer: 0 triage, 1 cluster, 2 x6p (128 units), 3 x6q (32/64), 4 other

@@ -115,7 +115,6 @@ struct Layout {
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
     size_t a_sP;                          // [input_size + 1] running cost of the ids (launch_scatter_lds_poll)
     size_t a_hstat;                       // [256][16][4] row statistics the chunks of the fused head exchange (sbr_head.hip)
-    size_t a_tmark;                       // [input_size] ints: mark[id] = epoch of the last batch that names id (dense wide index-input block; 0: none)
     size_t a_srpart, a_srid; int sr_slots;   // scatter-add of wide rows: partial rows of the long segments' pieces, counters + records (0: not used)
     int tail_keys;                        // time chunks the sort's key space was sized for (1: no tail overlap possible)
     size_t a_prog;                        // [Bp / 4 * 8] progress words of the running BPTT chain (tail overlap)
@@ -151,28 +150,15 @@ struct sbr_handle {
     bool og_recorded;    // ev_og marks the output-layer gradients of this step complete
     bool fill_done;      // the cluster BPTT sentinel fill of this step was issued on the side stream (ev_fill)
     bool out_early;      // this step's output-layer parameters were stepped on the side stream beside the BPTT chain
-    bool win_early;      // this step's untouched W_in rows were stepped on the side stream beside the BPTT chain (dense, single-call step)
-    // round 5: the scatter-add of a single-call step applies the optimizer to the rows it completes (launch_scatter_wide_step)
-    int scat_fuse;       // SBR_SCAT_FUSE (default 1)
-    int win_rest;        // SBR_WIN_REST: where a DENSE index-input block's untouched rows take their zero-gradient step: 1 (default) behind
-                         // the chain on the second side stream, beside scatter-add and weight-gradient GEMM; 2 between the chains (marks
-                         // instead of the sort's offsets); 3 behind the scatter-add on its own stream; 0: no fused step for dense blocks
-    bool win_fused;      // this step: layer 0's index-input block was stepped by the scatter-add (sbr_apply_update leaves it out)
-    bool win_rest_pending;   // ... and its untouched rows on side2, not yet joined (ev_tail2)
-    bool win_rest_done;  // ... or already, between the chains
     int sparse_out_early;    // SBR_SPARSE_OUT_EARLY (default 1): the sampled head's row-sparse block is caught up beside the forward
                              // chain and stepped beside the BPTT chain (side stream) instead of in front of / behind them
     bool cells_early;    // this step: cells built + their rows caught up on the side stream by sbr_forward (ev_cells)
     bool wout_early;     // this step: the sampled head's rows were stepped beside the BPTT chain
     hipEvent_t ev_cells;
-    int mark_epoch;
     int head_fuse;       // SBR_HEAD_FUSE (default 1): the full-softmax head in one launch (sbr_head.hip)
     unsigned head_epoch;
     int head_gate;       // SBR_HEAD_GATE (default 1): the side stream is released by the head kernel's own flag instead of an event
-    bool win_untouched_done;   // this step (SBR_ROW_AWARE_UPDATE=2): the untouched rows of the dense index-input block were stepped on side2 beside the scatter-add
     int row_aware;       // SBR_ROW_AWARE_UPDATE (default 1): the dense pass over a wide index-input block skips the gradient traffic of the rows the batch did not touch
-    int tail_win_split;  // SBR_TAIL_WIN_SPLIT: overlapped tail, dense W_in: untouched rows stepped beside the forward chain, touched rows behind the scatter-add
-    bool win_split_done; // this step: the untouched rows are stepped (sbr_forward), mark epoch = mark_epoch
     int out_fuse;        // SBR_OUT_FUSE (default 1): the dense head's gradient and step in one launch (launch_out_grad_step)
     bool out_stepped;    // this step: done, the output layer's range needs no update launch
     int dh_slabs_n;      // > 0: dh_last of this step sits in the main workspace as that many unreduced split-K slabs
@@ -320,16 +306,10 @@ bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const in
 // form 2: segment-parallel scatter-add, no atomics on rows; false: not served
 bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos, const int* offs, int n_ids,
                          int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err);
-// ... with the optimizer step applied by the thread that holds a finished gradient row (single-call training steps, round 5): the
-// gradient rows are never written, read back and cleared -- three passes over the touched rows less -- and the separate
-// touched-rows step kernel (sp_rows_kernel<1, true> / the dense pass over W_in) disappears from the end of the step.
-// p / s0 / s1: the block's parameter and optimizer-state rows [n_ids][GHp] (s1 NULL where the updater has one state array);
-// last != NULL: a row-sparse block, last[id] = t_to once the row is stepped (it was caught up through t_to - 1 by the forward
-// pass of the same step: launch_sparse_catch_up_batch); the arithmetic is update_kernel's / sp_step's, element for element
+// arguments of the optimizer step of a block's rows (update_rows_aware_kernel, out_grad_step_kernel): p / s0 / s1 = parameter and
+// optimizer-state rows (s1 NULL where the updater has one state array); the arithmetic is update_kernel's, element for element
 struct SbrScatStep { float* p; float* s0; float* s1; int* last; int updater, t_to; float lr, rho, b1, b2, a_t; };
-bool launch_scatter_wide_step(hipStream_t s, const SbrScatStep& st, const float* dxt, const int* sid, const int* spos, const int* offs,
-                              int n_ids, int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err);
-// partial-row slots launch_scatter_wide(_step) can claim for max_entries sorted entries (the caller's slab has at least as many)
+// partial-row slots launch_scatter_wide can claim for max_entries sorted entries (the caller's slab has at least as many)
 static inline int sbr_scatter_wide_slots(size_t max_entries) { return (int)(max_entries / 64 + max_entries / 65 + 2); }
 // key_lo / accumulate: the entries of the keys [key_lo, key_lo + n_ids) of a time-chunked sort, ADDED to dWin
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
@@ -512,22 +492,12 @@ hipError_t launch_scatter_cells(hipStream_t s, float* dW, float* db, const float
                                 const int* cells, int C, int Hp);
 // optimizers (lasagne.updates.* [3P], update_manager.py:24-82)
 // n elements starting at p / g / s0 / s1, skipping gap_len elements after the first gap_at (two ranges, one launch)
-hipError_t launch_update_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
-                              const int* offs, int touched, float lr, float rho, float b1, float b2, long t);
-// the zero-gradient step of every row the batch does NOT touch, without a pass over the gradient array (it is zero there and stays
-// zero): a row is touched when offs says so (offs != NULL: the scatter's segment offsets) or when mark[row] == epoch
-// (launch_mark_rows: needs the batch only, not its sort)
-hipError_t launch_update_untouched_rows(hipStream_t s, int updater, float* p, float* s0, float* s1, int n_rows, int row_floats,
-                                        const int* offs, const int* mark, int epoch, float lr, float rho, float b1, float b2, long t);
 // the output layer's gradient + its step in one launch (sbr_misc.hip); false: shape not served
 bool launch_out_grad_step(hipStream_t s, const float* dlogits, const float* h_last, const float* rowcost, float* cost, int updater,
                           float* W, float* Ws0, float* Ws1, float* b, float* bs0, float* bs1, int R, int N, int Nl, int Hp, float lr,
                           float rho, float b1, float b2, long t, hipError_t* err);
-hipError_t launch_update_touched_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
-                                      const int* mark, int epoch, float lr, float rho, float b1, float b2, long t);
 hipError_t launch_update_rows_aware(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
                                     const int* offs, float lr, float rho, float b1, float b2, long t);
-hipError_t launch_mark_rows(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* mark, int epoch);
 hipError_t launch_update(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, size_t n,
                          float lr, float rho, float b1, float b2, long t, size_t gap_at = (size_t)-1, size_t gap_len = 0);
 // ... of a block whose gradient is still split-K slabs [nslabs][n] (16-byte aligned, n % 4 == 0): reduction + step in one launch

@@ -315,8 +315,7 @@ hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const 
             return e;
     }
     if (!g_gemm_exact_f32 && a_blk_Bp == 0 && b_blk_Bp == 0 && M >= 48 && N >= 48 && K >= 32) {
-        const char* sb = getenv("SBR_GEMM_SMALL_BELOW");                 // read per call: the tests flip it
-        const int small_below = sb ? atoi(sb) : 128;
+        const int small_below = 128;      // (fewer large tiles than this on the chip: the 64 x 64 x 64 tile -- profiles/round1_j_*)
         auto plan = [&](int tile, int& ns, int& kc) {
             const int t = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
             ns = 1;

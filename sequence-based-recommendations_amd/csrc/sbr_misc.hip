@@ -572,7 +572,7 @@ hipError_t launch_scatter_reduce_poll(hipStream_t s, float* dWin, const float* d
     poll.n_small = std::max(0, std::min(short_chunks, n_tchunks));      // (the field counts the GEMM's short slabs there; here: time chunks cut short)
 
     const int R4 = GHp / 4, nv = (R4 + 63) / 64;
-    const int wgs = getenv("SBR_TAIL_SCATTER_WGS") ? atoi(getenv("SBR_TAIL_SCATTER_WGS")) : 128;   // (round 3: 128 with the short pieces; 64 before)
+    const int wgs = 128;   // (round 3: 128 with the short pieces; 64 before)
     const int grid = std::max(1, std::min(wgs, ((max_entries + 7) / 8 + 3) / 4));
     // (the LDS this launch asks for is a FENCE, not storage: with it a workgroup does not fit beside the BPTT chain's, which claims
     // 124 KB of its CU's 160 for the same purpose -- sbr_rec_p.hip launch_bwd_p)
@@ -977,16 +977,11 @@ bool launch_scatter_wide(hipStream_t s, float* dWin, const float* dxt, const int
 }
 
 // ---------------------------------------------------------------------------------------
-// Form 2 with the optimizer step fused in (round 5; SbrScatStep in sbr_common.h).  In a single-call training step nothing reads
-// the gradient rows of the index-input block but the optimizer, so the wave (short segments) or workgroup (merged long segments)
-// that holds a finished row steps it on the spot: p, s0, s1 of the row are requested BEFORE the segment's dxt rows (one round
-// trip for a one-entry segment, which is what most segments of a large catalogue are), the gradient row never exists in memory.
-// Against scatter-add + touched-rows step kernel that is per touched row 3 row passes less (gradient written, read, cleared) and
-// no second kernel: C3 116 + 35 + 134 us, C5 564 + 354 us before (profiles/round4_z_c{3,5}_timeline.txt).  A row-sparse block's
-// rows were caught up through t_to - 1 by the forward pass of this step (launch_sparse_catch_up_batch: every id of the batch), so
-// the step is the plain one; last[id] = t_to.  Dense blocks (C4): the rows the batch does not touch take their zero-gradient
-// step in launch_update_untouched_rows.  One writer per row (the segment's head), fixed summation order: reproducible.
-// (sparse_lstm.py:368 gather-grad + update_manager.py:24-82.)
+// The optimizer step of one element / one 16-byte piece on registers (SbrScatStep in sbr_common.h): update_element's arithmetic,
+// for the kernels that hold a finished gradient in registers (update_rows_aware_kernel, out_grad_step_kernel).
+// (Round 5 also built a scatter-add that stepped the rows it completed -- launch_scatter_wide_step: correct, 20 % fewer bytes behind
+// the chain, and slower (C4 1.324 -> 1.375 ms): its waves held a row's optimizer state beside the dxt rows of a segment and ran at
+// 1.5 - 2.3 TB/s where the two-pass form streams at 3.6 - 6.2.  Removed in round 6; the numbers are in profiles/round5_a_*.)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void scat_step1(const SbrScatStep& st, float g, float& p, float& s0, float& s1) {
     switch (st.updater) {                                     // update_element's arithmetic (sbr_misc.hip K13), on registers
@@ -1008,134 +1003,6 @@ __device__ __forceinline__ void scat_step1(const SbrScatStep& st, float g, float
 __device__ __forceinline__ void scat_step4(const SbrScatStep& st, const f32x4& g, f32x4& p, f32x4& s0, f32x4& s1) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { float pe = p[e], ae = s0[e], be = s1[e]; scat_step1(st, g[e], pe, ae, be); p[e] = pe; s0[e] = ae; s1[e] = be; }
-}
-
-template <int NV>
-__global__ void __launch_bounds__(256) scat_heads_step_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
-                                                              const int* __restrict__ spos, const int* __restrict__ offs, int n_ids,
-                                                              SbrScatStep st, int R4, int* __restrict__ counters,
-                                                              ScatLong* __restrict__ longs) {
-    const int lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), total = offs[n_ids];
-    if (e >= total) return;
-    const int id = sid[e];
-    if (e > 0 && sid[e - 1] == id) return;               // not the head of its segment
-    const int len = offs[id + 1] - offs[id];
-    if (len > SCATW_SHORT) {
-        if (lane == 0) {
-            const int np = (len + SCATW_SHORT - 1) / SCATW_SHORT;
-            const int slot = atomicAdd(counters, np), k = atomicAdd(counters + 1, 1);
-            longs[k] = ScatLong{id, e, len, slot};
-        }
-        return;
-    }
-    f32x4* __restrict__ prow = (f32x4*)st.p + (size_t)id * R4;
-    f32x4* __restrict__ arow = (f32x4*)st.s0 + (size_t)id * R4;
-    f32x4* __restrict__ brow = st.s1 ? (f32x4*)st.s1 + (size_t)id * R4 : nullptr;
-    f32x4 pv[NV], av[NV], bv[NV], acc[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {                       // the row's state: requested first, used last
-        const int f4 = lane + 64 * v;
-        const bool in = f4 < R4;
-        pv[v] = in ? prow[f4] : f32x4{0, 0, 0, 0};
-        av[v] = in ? arow[f4] : f32x4{0, 0, 0, 0};
-        bv[v] = (in && brow) ? brow[f4] : f32x4{0, 0, 0, 0};
-        acc[v] = f32x4{0, 0, 0, 0};
-    }
-    for (int i = 0; i < len; i += SCATW_FLY) {
-        f32x4 val[SCATW_FLY][NV];
-#pragma unroll
-        for (int u = 0; u < SCATW_FLY; ++u) {
-            if (i + u < len) {                           // uniform
-                const size_t pos = (size_t)spos[e + i + u];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int f4 = lane + 64 * v;
-                    val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) val[u][v] = f32x4{0, 0, 0, 0};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SCATW_FLY; ++u)
-#pragma unroll
-            for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int f4 = lane + 64 * v;
-        if (f4 >= R4) continue;
-        scat_step4(st, acc[v], pv[v], av[v], bv[v]);
-        prow[f4] = pv[v]; arow[f4] = av[v];
-        if (brow) brow[f4] = bv[v];
-    }
-    if (st.last && lane == 0) st.last[id] = st.t_to;
-}
-
-template <int NV>
-__global__ void __launch_bounds__(256) scat_long_merge_step_kernel(const f32x4* __restrict__ part, const int* __restrict__ counters,
-                                                                   const ScatLong* __restrict__ longs, SbrScatStep st, int R4) {
-    const int k = blockIdx.x, tid = threadIdx.x;
-    if (k >= counters[1]) return;
-    const ScatLong L = longs[k];
-    const int np = (L.len + SCATW_SHORT - 1) / SCATW_SHORT;
-    f32x4* __restrict__ prow = (f32x4*)st.p + (size_t)L.id * R4;
-    f32x4* __restrict__ arow = (f32x4*)st.s0 + (size_t)L.id * R4;
-    f32x4* __restrict__ brow = st.s1 ? (f32x4*)st.s1 + (size_t)L.id * R4 : nullptr;
-    f32x4 pv[NV], av[NV], bv[NV], acc[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int f4 = tid + 256 * v;
-        const bool in = f4 < R4;
-        pv[v] = in ? prow[f4] : f32x4{0, 0, 0, 0};
-        av[v] = in ? arow[f4] : f32x4{0, 0, 0, 0};
-        bv[v] = (in && brow) ? brow[f4] : f32x4{0, 0, 0, 0};
-        acc[v] = f32x4{0, 0, 0, 0};
-    }
-    for (int p0 = 0; p0 < np; p0 += 8) {
-        f32x4 val[8][NV];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const size_t sl = (size_t)(L.slot + min(p0 + u, np - 1));
-#pragma unroll
-            for (int v = 0; v < NV; ++v) { const int f4 = tid + 256 * v; val[u][v] = f4 < R4 ? part[sl * R4 + f4] : f32x4{0, 0, 0, 0}; }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (p0 + u < np) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
-            }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int f4 = tid + 256 * v;
-        if (f4 >= R4) continue;
-        scat_step4(st, acc[v], pv[v], av[v], bv[v]);
-        prow[f4] = pv[v]; arow[f4] = av[v];
-        if (brow) brow[f4] = bv[v];
-    }
-    if (st.last && tid == 0) st.last[L.id] = st.t_to;
-}
-
-// part / aux / n_slots as launch_scatter_wide; false: shape not served (the caller scatters and steps in two passes)
-bool launch_scatter_wide_step(hipStream_t s, const SbrScatStep& st, const float* dxt, const int* sid, const int* spos, const int* offs,
-                              int n_ids, int max_entries, int GHp, float* part, int* aux, int n_slots, hipError_t* err) {
-    const int R4 = GHp / 4, nvw = (R4 + 63) / 64;
-    if ((GHp & 3) || GHp < 512 || nvw > 8 || !part || !aux || n_slots < sbr_scatter_wide_slots((size_t)max_entries) || !st.p || !st.s0) return false;
-    if (hipMemsetAsync(aux, 0, 2 * sizeof(int), s) != hipSuccess) { *err = hipGetLastError(); return true; }
-    int* counters = aux; ScatLong* longs = (ScatLong*)(aux + 4);
-    const int gh = (max_entries + 3) / 4;
-#define SWS(NVW, NVB) do { \
-        scat_heads_step_kernel<NVW><<<gh, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, st, R4, counters, longs); \
-        scat_pieces_kernel<NVB><<<n_slots, 256, 0, s>>>((const f32x4*)dxt, spos, counters, longs, (f32x4*)part, R4); \
-        scat_long_merge_step_kernel<NVB><<<n_slots, 256, 0, s>>>((const f32x4*)part, counters, longs, st, R4); } while (0)
-    if (nvw <= 2) SWS(2, 1); else if (nvw <= 4) SWS(4, 1); else SWS(8, 2);
-#undef SWS
-    *err = hipGetLastError();
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1270,7 +1137,7 @@ bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const in
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate, int acc_chunk) {
     const int R4 = GHp / 4;
-    const int chunk_env = getenv("SBR_SCAT_CHUNK") ? atoi(getenv("SBR_SCAT_CHUNK")) : 0;
+    const int chunk_env = 0;
     const int chunk = (accumulate || key_lo) ? (acc_chunk == 16 ? 16 : 32) : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32);
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
@@ -1791,97 +1658,6 @@ hipError_t launch_update_from_slabs(hipStream_t s, int updater, const float* ws,
     return hipGetLastError();
 }
 
-// The dense optimizer pass over an item-indexed block [n_rows][row_floats], for the rows the step's batch touches (touched = 1)
-// or for all the others (0): offs = the scatter's segment offsets (row r has entries iff offs[r + 1] > offs[r]).  A row the batch
-// does not touch has a zero gradient whatever the BPTT chain computes, so its step (Lasagne steps EVERY row: update_manager.py:24-82)
-// can run beside the chain; the arithmetic is update_kernel's, element for element.
-__global__ void update_rows_kernel(int updater, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
-                                   float* __restrict__ s1, int n_rows, int row_floats, const int* __restrict__ offs, int touched,
-                                   float lr, float rho, float b1, float b2, float a_t) {
-    const size_t n = (size_t)n_rows * row_floats;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / (unsigned)row_floats);
-        if ((offs[r + 1] > offs[r]) != (touched != 0)) continue;
-        const float gi = g[i];
-        g[i] = 0.0f;
-        update_element(updater, gi, p, s0, s1, i, lr, rho, b1, b2, a_t);
-    }
-}
-hipError_t launch_update_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
-                              const int* offs, int touched, float lr, float rho, float b1, float b2, long t) {
-    if (n_rows <= 0) return hipSuccess;
-    float a_t = 0.0f;
-    if (updater == SBR_UPD_ADAM)
-        a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
-    const size_t n = (size_t)n_rows * row_floats;
-    const int grid = (int)min((size_t)256 * 16, (n + 255) / 256);
-    update_rows_kernel<<<grid, 256, 0, s>>>(updater, p, g, s0, s1, n_rows, row_floats, offs, touched, lr, rho, b1, b2, a_t);
-    return hipGetLastError();
-}
-
-// The zero-gradient step of the rows of an item-indexed block [n_rows][R4 * 4] the batch does not touch (Lasagne steps EVERY row:
-// update_manager.py:24-82), 16 bytes per lane, without a pass over the gradient array: an untouched row's gradient is zero and
-// stays zero, so the step is update_element's with g = 0 (adagrad: nothing at all) and reads / writes p, s0, s1 only -- 6 instead
-// of 8 passes over two thirds of C4's W_in.  Touched rows belong to the scatter-add's fused step (launch_scatter_wide_step).
-__global__ void __launch_bounds__(256) update_untouched_rows_kernel(SbrScatStep st, int n_rows, int R4, const int* __restrict__ offs,
-                                                                    const int* __restrict__ mark, int epoch) {
-    const size_t n4 = (size_t)n_rows * R4;
-    f32x4* __restrict__ p = (f32x4*)st.p; f32x4* __restrict__ s0 = (f32x4*)st.s0; f32x4* __restrict__ s1 = (f32x4*)st.s1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / (unsigned)R4);
-        const bool touched = offs ? offs[r + 1] > offs[r] : mark[r] == epoch;
-        if (touched) continue;
-        f32x4 pv = p[i], av = s0[i], bv = s1 ? s1[i] : f32x4{0, 0, 0, 0};
-        scat_step4(st, f32x4{0, 0, 0, 0}, pv, av, bv);
-        p[i] = pv; s0[i] = av;
-        if (s1) s1[i] = bv;
-    }
-}
-hipError_t launch_update_untouched_rows(hipStream_t s, int updater, float* p, float* s0, float* s1, int n_rows, int row_floats,
-                                        const int* offs, const int* mark, int epoch, float lr, float rho, float b1, float b2, long t) {
-    if (n_rows <= 0 || updater == SBR_UPD_ADAGRAD) return hipSuccess;      // adagrad with g = 0: acc += 0, p -= 0
-    if ((row_floats & 3) || (!offs && !mark)) return hipErrorInvalidValue;
-    SbrScatStep st; st.p = p; st.s0 = s0; st.s1 = s1; st.last = nullptr; st.updater = updater; st.t_to = (int)t;
-    st.lr = lr; st.rho = rho; st.b1 = b1; st.b2 = b2; st.a_t = 0.0f;
-    if (updater == SBR_UPD_ADAM)
-        st.a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
-    const size_t n4 = (size_t)n_rows * (row_floats / 4);
-    static const int cap = [] { const char* e = getenv("SBR_UNTOUCHED_WGS"); return e ? atoi(e) : 256 * 16; }();      // (experiment: a throttled pass beside the chain)
-    const int grid = (int)min((size_t)cap, (n4 + 255) / 256);
-    update_untouched_rows_kernel<<<grid, 256, 0, s>>>(st, n_rows, row_floats / 4, offs, mark, epoch);
-    return hipGetLastError();
-}
-// ... and the step of the rows the batch DOES touch (mark[row] == epoch), gradient rows read and cleared: the other half of a dense
-// pass split in time (overlapped tail of C2: the untouched rows are stepped beside the forward chain)
-__global__ void __launch_bounds__(256) update_touched_rows_kernel(SbrScatStep st, float* __restrict__ gr, int n_rows, int R4,
-                                                                  const int* __restrict__ mark, int epoch) {
-    const size_t n4 = (size_t)n_rows * R4;
-    f32x4* __restrict__ p = (f32x4*)st.p; f32x4* __restrict__ s0 = (f32x4*)st.s0; f32x4* __restrict__ s1 = (f32x4*)st.s1;
-    f32x4* __restrict__ g = (f32x4*)gr;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / (unsigned)R4);
-        if (mark[r] != epoch) continue;
-        const f32x4 gv = g[i];
-        g[i] = f32x4{0, 0, 0, 0};
-        f32x4 pv = p[i], av = s0[i], bv = s1 ? s1[i] : f32x4{0, 0, 0, 0};
-        scat_step4(st, gv, pv, av, bv);
-        p[i] = pv; s0[i] = av;
-        if (s1) s1[i] = bv;
-    }
-}
-hipError_t launch_update_touched_rows(hipStream_t s, int updater, float* p, float* g, float* s0, float* s1, int n_rows, int row_floats,
-                                      const int* mark, int epoch, float lr, float rho, float b1, float b2, long t) {
-    if (n_rows <= 0) return hipSuccess;
-    if ((row_floats & 3) || !mark) return hipErrorInvalidValue;
-    SbrScatStep st; st.p = p; st.s0 = s0; st.s1 = s1; st.last = nullptr; st.updater = updater; st.t_to = (int)t;
-    st.lr = lr; st.rho = rho; st.b1 = b1; st.b2 = b2; st.a_t = 0.0f;
-    if (updater == SBR_UPD_ADAM)
-        st.a_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
-    const size_t n4 = (size_t)n_rows * (row_floats / 4);
-    const int grid = (int)min((size_t)256 * 16, (n4 + 255) / 256);
-    update_touched_rows_kernel<<<grid, 256, 0, s>>>(st, g, n_rows, row_floats / 4, mark, epoch);
-    return hipGetLastError();
-}
 // The dense pass over an item-indexed block, aware of which rows the batch touched (offs = the scatter's segment offsets): an
 // untouched row's gradient is zero and stays zero, so its step reads and writes p, s0, s1 only (6 passes instead of 8: C4 touches 40 %
 // of its 26 744 rows per batch); a touched row's gradient is read and cleared as update_kernel does.  One streaming launch, 16
@@ -1913,21 +1689,6 @@ hipError_t launch_update_rows_aware(hipStream_t s, int updater, float* p, float*
     const size_t n4 = (size_t)n_rows * (row_floats / 4);
     const int grid = (int)min((size_t)256 * 16, (n4 + 255) / 256);
     update_rows_aware_kernel<<<grid, 256, 0, s>>>(st, g, n_rows, row_floats / 4, offs);
-    return hipGetLastError();
-}
-// mark[id] = epoch for every id the batch names (X [Bp][T][F], valid while t < len[b]); epochs never repeat, nothing is cleared
-__global__ void mark_rows_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F, int n_ids,
-                                 int* __restrict__ mark, int epoch) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Bp * T * F) return;
-    const int b = i / (T * F), t = (i / F) % T;
-    if (t >= len[b]) return;
-    const int id = X[i];
-    if (id >= 0 && id < n_ids) mark[id] = epoch;
-}
-hipError_t launch_mark_rows(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* mark, int epoch) {
-    const int n = Bp * T * F;
-    mark_rows_kernel<<<(n + 255) / 256, 256, 0, s>>>(X, len, T, Bp, F, n_ids, mark, epoch);
     return hipGetLastError();
 }
 

@@ -274,7 +274,7 @@ __device__ __forceinline__ void c16_fwd_body(const RecArgs& a, const int tile, c
         a.hs[o] = h;
         if (CELL == CELL_LSTM) a.cs[o] = c;
     }
-    if (prof && lane == 0 && tile * C + mem < 32) {
+    if (prof && lane == 0 && tile * C + mem < min(32, a.Bp / 8)) {      // (the counters' region: Bp / 16 * 128 words per direction)
         u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 16;
         o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_tries;
 #pragma unroll
@@ -482,7 +482,7 @@ __device__ __forceinline__ void c16_bwd_body(const RecArgs& a, const int tile, c
         dh += (pr[0] + pr[1]) + (pr[2] + pr[3]);
         CL_TICK(6);
     }
-    if (prof && lane == 0 && tile * C + mem < 32) {
+    if (prof && lane == 0 && tile * C + mem < min(32, a.Bp / 8)) {      // (the counters' region: Bp / 16 * 128 words per direction)
         u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 16;
         o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_tries;
 #pragma unroll
@@ -736,7 +736,7 @@ __device__ __forceinline__ void c16_bwd2_body(const RecArgs& a, const int tile, 
         dh += (pr[0] + pr[1]) + (pr[2] + pr[3]);
         CL_TICK(7);
     }
-    if (prof && lane == 0 && tile * C + mem < 32) {
+    if (prof && lane == 0 && tile * C + mem < min(32, a.Bp / 8)) {      // (the counters' region: Bp / 16 * 128 words per direction)
         u64* o = a.prof + (((size_t)tile * C + mem) * 4 + wave) * 16;
         o[0] = clock64() - p_c0; o[1] = wall_clock64() - p_r0; o[2] = p_tries;
 #pragma unroll

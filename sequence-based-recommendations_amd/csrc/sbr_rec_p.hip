@@ -1196,11 +1196,8 @@ static hipError_t launch_bwd_p(hipStream_t s, const RecArgs& a) {
         if (a.progress) X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 1>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, true, 0>));
         return hipGetLastError();
     }
-    const char* re = getenv("SBR_X6_RING");                        // read per launch: the tests flip it
-    // (measured without consumers beside the chain: 194 us through the ring, 189 us with the register prefetch: off by default)
-    const bool ring = (re ? atoi(re) != 0 : false) && f16 && !ext && !a.prof && !a.progress && sbr_rec_x6p_tail_ok(a);
+    // (the LDS ring WITHOUT consumers beside the chain -- WT = 2 -- measured 194 us against 189 with the register prefetch: not launched)
     if (a.progress) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 1>)); }
-    else if (ring) { X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true, 2>)); }
     else if constexpr (CELL == CELL_LSTM) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }
     else if (a.prof) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, true, false>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, true, false>)); }
     else if (f16) { if (ext) X6P_LAUNCH((rec_bwd_x6p<CELL, true, false, true>)); else X6P_LAUNCH((rec_bwd_x6p<CELL, false, false, true>)); }

@@ -75,6 +75,14 @@ def test_cpu_baseline_leg_is_bounded_and_reported():
     assert d["value"] > 100 * c["value"]
     e = c["end_to_end"]        # the same step + reference-style batch packing
     assert 0 < e["value"] < c["value"] and e["packing_s_per_batch"] > 0
+    assert 0 < c["eager_loop"]["value"] <= 1.5 * c["value"]      # the Python-loop form of rounds 1 - 5 beside the scripted scan that is quoted
+
+
+def test_other_configs_carry_a_cpu_number_for_c1():
+    # C1 is the reference's own CPU configuration -- the child run of the default line reports a bounded CPU sample
+    d = run("--config", "c1", "--brief", "--brief-cpu-seconds", "8", "--steps", "5", "--warmup", "2", "--repeats", "1")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and "eager_loop" not in c and d["value"] > 100 * c["value"]
 
 
 def test_gpus_2_starts_its_own_ranks():

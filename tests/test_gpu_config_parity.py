@@ -11,6 +11,7 @@ Bars (north_star): logits / scores 1e-3 relative, gradients 1e-4 relative to the
 ids exact.  The tolerances asserted here are 10x tighter than those bars (measured on MI355X: hidden state and
 gradients ~1e-6, scores ~1e-6, profiles/round2_config_parity.jsonl); parameters after optimizer steps keep the 1e-3
 bar of the other parity tests (Adam turns a 1e-6 gradient difference on a near-zero gradient into a full-size step)."""
+import os
 import numpy as np
 import pytest
 
@@ -144,7 +145,8 @@ def _c5_million_item_case(B, T, n, seed, grad_floor=1e-12, recurrent_gain=1.0, t
             a = np.full(NBIG, fill, dtype=np.float32); a[big] = p32; return a
         return p32
 
-    eng = PU.engine_for(cfg, NBIG, B, T, S=S, updater="adam")
+    # (tools/gpu_r6i.sh: the same case on other arithmetic -- SBR_TEST_FLAGS=16 = exact f32 everywhere -- with SBR_PARITY_LOG set)
+    eng = PU.engine_for(cfg, NBIG, B, T, S=S, updater="adam", flags=int(os.environ.get("SBR_TEST_FLAGS", "0")))
     try:
         assert len(eng.sparse_blocks()) == 2                                   # W_in rows and the W_out / b_out cells step row-sparse
         start = [widen(nm, p, fill=-60.0) for nm, p in zip(names, params)]      # untouched items: logit -60, never ranked
@@ -174,6 +176,15 @@ def _c5_million_item_case(B, T, n, seed, grad_floor=1e-12, recurrent_gain=1.0, t
             return out
 
         g1 = compact(eng.get_all_grad_values())
+        log = os.environ.get("SBR_PARITY_LOG")       # tooling: one JSON line per run of this case
+        if log:
+            import json
+            with open(log, "a") as f:
+                f.write(json.dumps(dict(case="c5_million_items", B=B, T=T, n=n, recurrent_gain=recurrent_gain,
+                                        flags=int(os.environ.get("SBR_TEST_FLAGS", "0")),
+                                        env={k: v for k, v in os.environ.items() if k.startswith("SBR_") and k != "SBR_PARITY_LOG"},
+                                        cost=abs(cost - ocost) / abs(ocost), h_last=eh,
+                                        grads={nm: PU.rel_err(sub, og, grad_floor) for nm, sub, og in zip(names, g1, ograds)})) + "\n")
         for nm, sub, og in zip(names, g1, ograds):
             assert PU.rel_err(sub, og, grad_floor) <= (tol_g or tol), (nm, PU.rel_err(sub, og, grad_floor))
         if not optimizer_steps:

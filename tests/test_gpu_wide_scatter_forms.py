@@ -1,7 +1,6 @@
 """The non-default forms of the step tail of a wide index-input layer (G*Hp >= 512 floats per row: LSTM-128 and wider) -- each a switch
-that is read once per process, so each runs in a child: the atomic scatter-add of rounds 1 - 3 (SBR_SCAT_RANGE=0), the segment-parallel
-form (2), that form in front of the weight-gradient GEMM on the side stream (SBR_SCAT_FIRST=1), and the optimizer pass over W_in split
-in time (SBR_EARLY_UPDATE=1: untouched rows beside the BPTT chain, touched rows behind the scatter-add; needs >= 4 M floats of W_in).
+that is read once per process, so each runs in a child: the atomic scatter-add of rounds 1 - 3 (SBR_SCAT_RANGE=0) -- what rows wider
+than 1024 floats take -- and the segment-parallel form (2), and the plain dense pass over W_in (SBR_ROW_AWARE_UPDATE=0).
 Same bars as the default form (the range scatter-add, every other wide-layer test): cost, hidden state and gradients against the float64
 oracle, parameters after two Adam steps; and after three steps the same parameters as the default form up to what Adam makes of
 summation-order roundings (an element whose gradient is ~0 moves by ~lr whatever the gradient's size: 5e-5 of the largest parameter)."""
@@ -47,19 +46,11 @@ def bars(r):
     assert r["params_twin"] <= 2e-5 and r["topk_mismatch"] == 0, r
 
 
-@pytest.mark.parametrize("env", [{"SBR_SCAT_RANGE": "0"}, {"SBR_SCAT_RANGE": "2"}, {"SBR_SCAT_RANGE": "2", "SBR_SCAT_FIRST": "1"}],
-                         ids=["atomic", "segment_parallel", "segment_parallel_first"])
+@pytest.mark.parametrize("env", [{"SBR_SCAT_RANGE": "0"}, {"SBR_SCAT_RANGE": "2"}, {"SBR_ROW_AWARE_UPDATE": "0"}],
+                         ids=["atomic", "segment_parallel", "plain_dense_pass"])
 def test_scatter_add_forms_of_wide_rows(tmp_path, env):
     r0, p0 = child(tmp_path, "default", {}, 3000, 64, 24)
     r1, p1 = child(tmp_path, "form", env, 3000, 64, 24)
     bars(r0); bars(r1)
     # the atomic-free forms sum in a fixed order; against each other and against the atomic kernel they differ by roundings only
-    assert np.abs(p0 - p1).max() <= 5e-5 * np.abs(p0).max()
-
-
-def test_optimizer_pass_split_in_time(tmp_path):
-    # W_in of 4200 x 1024 floats: above the 4 M-float threshold of the early pass
-    r0, p0 = child(tmp_path, "dense", {"SBR_EARLY_UPDATE": "0"}, 4200, 64, 24)
-    r1, p1 = child(tmp_path, "split", {"SBR_EARLY_UPDATE": "1"}, 4200, 64, 24)
-    bars(r0); bars(r1)
     assert np.abs(p0 - p1).max() <= 5e-5 * np.abs(p0).max()

@@ -48,18 +48,6 @@ def _cfg(E, **kw):
     return c
 
 
-def test_experiment_workspace_is_not_in_every_arena(lib, monkeypatch):
-    # the split-K workspace of SBR_TAIL_OUT_STREAM (up to 4 x the main workspace) was taken from the arena of every
-    # configuration; now only when that experiment switch is set while the layout is built
-    import sbr_amd.engine as E
-    n0, n1 = ctypes.c_size_t(), ctypes.c_size_t()
-    monkeypatch.delenv("SBR_TAIL_OUT_STREAM", raising=False)
-    assert lib.sbr_arena_bytes(ctypes.byref(_cfg(E)), ctypes.byref(n0)) == 0
-    monkeypatch.setenv("SBR_TAIL_OUT_STREAM", "1")
-    assert lib.sbr_arena_bytes(ctypes.byref(_cfg(E)), ctypes.byref(n1)) == 0
-    assert 4e6 <= n1.value - n0.value <= 70e6, (n0.value, n1.value)
-
-
 def test_arena_size_and_config_validation(lib):
     import sbr_amd.engine as E
     n = ctypes.c_size_t()

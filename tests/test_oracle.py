@@ -229,3 +229,25 @@ def test_margin_head_gradients_against_finite_differences(loss):
             if loss == "hinge" and abs(num - grads[pi][idx]) > 1e-6:      # a kink of the hinge inside the step: skip
                 continue
             assert abs(num - grads[pi][idx]) <= 1e-6 * max(1.0, abs(num)), (pi, idx, num, grads[pi][idx])
+
+
+@pytest.mark.parametrize("cell,H", [("LSTM", 20), ("GRU", 32)])
+def test_scripted_cpu_port_equals_the_eager_port(cell, H):
+    """bench.py's cpu_baseline times the torch port with its T-step scan under torch.jit.script (oracle/torch_ref.py,
+    layer_forward_scripted: unbind / chunk instead of per-step selects).  Same arithmetic: costs of three Adam steps on ragged rows
+    equal the eager port's to float32 rounding (no gradient is near the clip the scripted form leaves out)."""
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(5)
+    N, B, T = 50, 16, 12
+    params = O.init_params(cell, [H], N, rng, dtype=np.float32)
+    mask = np.ones((B, T), np.float32)
+    mask[3, 5:] = 0
+    mask[7, 1:] = 0
+    batch = dict(X=rng.integers(0, N, size=(B, T, 1)).astype(np.int32), mask=mask, target=rng.integers(0, N, size=B).astype(np.int32),
+                 pop=np.ones(B, np.float32))
+    cfg = dict(cell=cell, layers=[H], loss="CCE", regularization=0.0)
+    a = R.TorchTrainer(params, cfg, O.recurrent_param_shapes)
+    b = R.TorchTrainer(params, cfg, O.recurrent_param_shapes, scripted=True)
+    for _ in range(3):
+        ca, cb = a.train_function(batch), b.train_function(batch)
+        assert abs(ca - cb) <= 1e-6 * abs(ca), (ca, cb)

@@ -7,7 +7,7 @@ import bench
 from oracle import rnn_oracle as O
 from sbr_amd.engine import RNNEngine
 cell, layers, n_items, loss, ns = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c4"]
-B, T = 256, 200
+B, T = (int(sys.argv[2]) if len(sys.argv) > 2 else 256), 200
 C = 8
 eng = RNNEngine(cell=cell, layers=layers, n_items=n_items, max_length=T, batch_size=B, loss=loss, n_samples=ns, flags=8)
 eng.set_all_param_values(O.init_params(cell, layers, n_items, np.random.default_rng(42), dtype=np.float32))
@@ -27,7 +27,8 @@ if c16:
         names = (names[0], ("rec_bwd_c16t", ((0, "gate math+level-1 publish"), (1, "level-1 wait"), (2, "stage+barrier"), (3, "stores+MFMA+blocks"),
                                              (4, "level-2 wait"), (6, "sum+requests+barrier"), (7, "reduce")), (5, "everything since the level-1 poll acknowledged")))
     for k, (name, ph, extra) in enumerate(names):
-        p = raw[k][:32 * 4 * 16].reshape(32, 4, 16).astype(np.float64)          # [tile * C + member][wave][16]
+        ne = min(32, B // 8)
+        p = raw[k][:ne * 4 * 16].reshape(ne, 4, 16).astype(np.float64)          # [tile * C + member][wave][16]
         tot, real = p[..., 0], p[..., 1]
         print("%s: kernel %.1f us (realtime), shader clock %.0f MHz, %.0f cycles/step" % (
             name, real.mean() / 100.0, (tot / real * 100.0).mean(), tot.mean() / T))
