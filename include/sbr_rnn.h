@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SBR_MAX_LAYERS 4
-#define SBR_ABI_VERSION 9
+#define SBR_ABI_VERSION 10
 
 typedef enum { SBR_OK = 0, SBR_EINVAL = -1, SBR_ENOMEM = -2, SBR_EHIP = -3, SBR_ESTATE = -4,
                SBR_EUNSUPPORTED = -5 } sbr_status;
@@ -316,6 +316,12 @@ int sbr_chain_times(sbr_handle* h, int on, float us[2], int n[2]);
  * them; *us = mean microseconds per launch, *entries = valid (t, b, f) positions, *rows = distinct ids (gradient rows written).
  * dxt holds whatever the last backward pass left; the gradient block is cleared again afterwards.  Index-input layer 0 only. */
 int sbr_debug_scatter(sbr_handle* h, int reps, float* us, int64_t* entries, int64_t* rows);
+/* A FOREIGN kernel that holds part of the chip (ABI 10; test hook): `workgroups` workgroups of 256 threads, each claiming `lds_kb`
+ * KiB of LDS, spin for `milliseconds` on a stream of the library's own (not the engine's) -- asynchronous, returns at once.  What the
+ * tests use to show that a cluster chain whose workgroups cannot all be resident (rnn_base.py has no such notion: one process, one
+ * Theano function) ends in the fault code of sbr_read_cost / sbr_train_step -- never in a wrong gradient -- and that the one-launch
+ * head recomputes what it cannot wait for.  sbr_synchronize(h) does NOT wait for it; sbr_debug_occupy(h, 0, 0, 0) does. */
+int sbr_debug_occupy(sbr_handle* h, int workgroups, int lds_kb, int milliseconds);
 
 /* ------------------------------------------------------------------------------------------------
  * Native batch builder: replaces SequenceGenerator + _gen_mini_batch + _prepare_input

@@ -1764,7 +1764,7 @@ static int report_fault(sbr_handle* h, int fault) {
     // scatter-add was handed more ids than it has LDS rows for (launch_scatter_lds_poll sizes them: cannot happen)
     if (fault & 32)
         sbr_set_error("the side stream's gate waited 1.5 s for the one-launch output head (sbr_head.hip) to finish (flag %d, results of this call "
-                      "invalid); rerun with SBR_HEAD_GATE=0", fault);
+                      "invalid)", fault);
     else
     if (fault & 16)
         sbr_set_error("the LDS-row scatter-add of the overlapped tail ran out of rows (flag %d, results of this call invalid); rerun with "
@@ -1952,6 +1952,26 @@ extern "C" int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t
                                       ws_floats, false);
     sbr_gemm_set_planes(3);
     SBR_LAUNCH(ge);
+    return SBR_OK;
+}
+
+// a foreign kernel that holds CUs for a while (include/sbr_rnn.h: test hook)
+__global__ void __launch_bounds__(256) occupy_kernel(unsigned long long ticks, int* sink) {
+    extern __shared__ int occ_lds[];
+    occ_lds[threadIdx.x] = (int)threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (occ_lds[(threadIdx.x + 1) & 255] == -7) *sink = 1;      // (keeps the LDS claim alive)
+}
+extern "C" int sbr_debug_occupy(sbr_handle* h, int workgroups, int lds_kb, int milliseconds) {
+    CHECK_ARG(h && workgroups >= 0 && workgroups <= 4096 && lds_kb >= 0 && lds_kb <= 160 && milliseconds >= 0 && milliseconds <= 10000, "bad argument");
+    static hipStream_t occ = nullptr;
+    if (!occ) SBR_HIP(hipStreamCreateWithFlags(&occ, hipStreamNonBlocking));
+    if (workgroups == 0) { SBR_HIP(hipStreamSynchronize(occ)); return SBR_OK; }
+    const size_t lds = std::max<size_t>(1024, (size_t)lds_kb * 1024);
+    SBR_DYN_LDS(occupy_kernel, lds);
+    occupy_kernel<<<workgroups, 256, lds, occ>>>((unsigned long long)milliseconds * 100000ull, (int*)h->A(h->lay.a_fault) + 1);
+    SBR_LAUNCH(hipGetLastError());
     return SBR_OK;
 }
 

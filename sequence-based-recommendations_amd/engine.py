@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsbr_rnn.so")
 
 SBR_MAX_LAYERS = 4
-SBR_ABI_VERSION = 9
+SBR_ABI_VERSION = 10
 SBR_N_PHASES = 8
 PHASE_NAMES = ("gather", "rec_fwd", "output", "rec_bwd", "wgrad", "scatter", "update", "total")
 
@@ -62,7 +62,7 @@ EXPORTS = ["sbr_last_error", "sbr_abi_version", "sbr_arena_bytes", "sbr_create",
            "sbr_train_step", "sbr_train_step_lagged", "sbr_lagged_flush", "sbr_zero_grads", "sbr_forward", "sbr_loss_backward_output", "sbr_backward_recurrent",
            "sbr_apply_update", "sbr_read_cost", "sbr_predict_scores", "sbr_topk", "sbr_debug_buffer",
            "sbr_copy_to_host", "sbr_synchronize", "sbr_enable_timing", "sbr_phase_times", "sbr_chain_times", "sbr_query",
-           "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_debug_scatter", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
+           "sbr_set_deferred_join", "sbr_join_side", "sbr_debug_gemm", "sbr_debug_scatter", "sbr_debug_occupy", "sbr_flush_lazy", "sbr_sparse_info", "sbr_sparse_pack",
            "sbr_sparse_unpack_add", "sbr_dense_ranges", "sbr_sparse_pack_device", "sbr_sparse_unpack_add_all",
            "sbr_cluster_create", "sbr_cluster_destroy", "sbr_cluster_set_params", "sbr_cluster_get_params", "sbr_cluster_get_grads",
            "sbr_cluster_set_scale", "sbr_cluster_forward_backward", "sbr_cluster_apply_update", "sbr_cluster_select",
@@ -121,6 +121,7 @@ def load_library(path=None):
     i64p = ctypes.POINTER(ctypes.c_int64)
     lib.sbr_query.argtypes = [vp, ctypes.c_char_p, i64p]
     lib.sbr_debug_scatter.argtypes = [vp, ctypes.c_int, f32p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.sbr_debug_occupy.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.sbr_debug_gemm.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64,
                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, ctypes.c_size_t, ctypes.c_int32]
     lib.sbr_flush_lazy.argtypes = [vp]
@@ -776,6 +777,11 @@ class RNNEngine(object):
         us, n, r = ctypes.c_float(), ctypes.c_int64(), ctypes.c_int64()
         self._check(self.lib.sbr_debug_scatter(self.h, int(reps), ctypes.byref(us), ctypes.byref(n), ctypes.byref(r)))
         return float(us.value), int(n.value), int(r.value)
+
+    def debug_occupy(self, workgroups, lds_kb, milliseconds):
+        """a foreign kernel that holds `workgroups` x `lds_kb` KiB of the chip's LDS for `milliseconds` on a stream of the library's
+        own (sbr_debug_occupy; asynchronous); debug_occupy(0, 0, 0) waits for it"""
+        self._check(self.lib.sbr_debug_occupy(self.h, int(workgroups), int(lds_kb), int(milliseconds)))
 
     def query(self, what):
         v = ctypes.c_int64()

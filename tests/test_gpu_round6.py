@@ -1,0 +1,66 @@
+"""Round 6: the rebuilt 16-row cluster chains (csrc/sbr_rec_c16.hip) beside a FOREIGN kernel that holds part of the chip
+(sbr_debug_occupy), and the one-launch head in the same situation.  VERDICT round 5, items 7 / 14: a grid that is not co-resident must
+end in the fault code (cluster chains: their members wait for each other inside the kernel) or in the recompute path (head) -- never
+in a wrong gradient.  The parity of the kernels themselves is every wide-layer test of tests/test_gpu_parity.py,
+tests/test_gpu_config_parity.py (C3 / C4 / C5 at full length) and tests/test_reference_layers.py."""
+import numpy as np
+import pytest
+
+import parity_util as PU
+from oracle import rnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cell, H, N, B, T, seed):
+    from sbr_amd.engine import RNNEngine, SbrError
+    eng = RNNEngine(cell=cell, layers=[H], n_items=N, max_length=T, batch_size=B, loss="CCE")
+    params = O.init_params(cell, [H], N, np.random.default_rng(seed), dtype=np.float32)
+    batch = PU.make_batch(np.random.default_rng(seed + 1), B, T, N)
+    return eng, params, batch, SbrError
+
+
+def test_cluster_chain_that_cannot_be_resident_fails_loudly():
+    """LSTM-512 at 256 rows: 512 workgroups of 32-member clusters, two per CU.  A foreign kernel holds the LDS of 192 of the 256 CUs
+    for three seconds, so only 128 workgroups -- HALF of the members of the first eight clusters -- get onto the chip; they poll for
+    members that cannot start.  The bounded polls give up (~0.5 s), the step returns the library's error, and after the foreign
+    kernel has gone the same engine computes the same cost as before."""
+    eng, params, batch, SbrError = _engine("LSTM", 512, 500, 256, 12, 5)
+    try:
+        eng.set_all_param_values(params)
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], None, batch["pop"])
+        c0 = eng.forward_backward()
+        assert eng.query("rec_rows_fwd") == 16 and np.isfinite(c0)
+        eng.debug_occupy(192, 160, 3000)
+        with pytest.raises(SbrError, match="bounded wait"):
+            eng.forward_backward()
+        eng.debug_occupy(0, 0, 0)                              # wait for the foreign kernel
+        eng.set_all_param_values(params)
+        c1 = eng.forward_backward()
+        assert abs(c1 - c0) <= 1e-6 * abs(c0), (c0, c1)
+    finally:
+        eng.debug_occupy(0, 0, 0)
+        eng.close()
+
+
+def test_one_launch_head_beside_a_foreign_kernel_recomputes():
+    """C2's head: 256 workgroups of 127 KB LDS, one per CU, that exchange chunk statistics inside the launch.  With 64 CUs held by a
+    foreign kernel a quarter of them start only when others have left: the resident ones stop waiting after 60 us and recompute the
+    missing chunks' statistics themselves.  Same cost, same gradients as on the idle chip."""
+    eng, params, batch, _ = _engine("GRU", 128, 3706, 256, 16, 9)
+    try:
+        eng.set_all_param_values(params)
+        eng.set_batch(batch["X"], batch["mask"], batch["target"], None, batch["pop"])
+        assert eng.query("head_fused") == 16
+        c0 = eng.forward_backward()
+        g0 = [g.copy() for g in eng.get_all_grad_values()]
+        eng.debug_occupy(64, 160, 300)
+        c1 = eng.forward_backward()
+        g1 = eng.get_all_grad_values()
+        eng.debug_occupy(0, 0, 0)
+        assert abs(c1 - c0) <= 1e-6 * abs(c0), (c0, c1)
+        for a, b in zip(g0, g1):
+            assert PU.rel_err(b, a) <= 1e-5
+    finally:
+        eng.debug_occupy(0, 0, 0)
+        eng.close()
