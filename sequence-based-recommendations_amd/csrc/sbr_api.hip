@@ -410,7 +410,6 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     h->ev_cells = nullptr;
     { const char* e = getenv("SBR_HEAD_FUSE"); h->head_fuse = e ? atoi(e) : 1; }
     { const char* e = getenv("SBR_OUT_FUSE"); h->out_fuse = e ? atoi(e) != 0 : 1; }
-    h->head_gate = 1;
     { const char* e = getenv("SBR_ROW_AWARE_UPDATE"); h->row_aware = e ? atoi(e) != 0 : 1; }
     h->out_stepped = false;
     h->head_epoch = 0;
@@ -1092,21 +1091,15 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         // Round 5: logits, softmax + CCE and dh in ONE launch whose workgroups exchange the row statistics inside the kernel
         // (sbr_head.hip; exact-f32 products); its dh leaves as split-K slabs -- folded into the chain's prologue as above, or
         // reduced here.  Shapes it does not serve (and SBR_HEAD_FUSE=0) keep the three launches below.
-        bool head_done = false, head_gated = false;
-        // (the flag form of the release: single-call steps whose side streams need nothing else from this record -- with the
-        // overlapped tail the sort must have run beside the forward chain --, and not while a timing mark shares the record)
-        const bool gate_ok = h->head_gate && h->in_train_step && !fill_needed && !(h->timing && ((h->timing_marks >> 3) & 1)) &&
-                             (h->tail_nc == 0 || (h->tail_sorted && h->tail_overlap == 1 && !h->tail_out_stream));
-        unsigned* head_done_words = (unsigned*)h->A(y.a_hstat) + 256 * 64;
+        bool head_done = false;
         if (h->head_fuse && y.cfg.loss == SBR_LOSS_CCE && !sg && !bf16p && !(y.cfg.flags & SBR_FLAG_F32_MFMA) && y.D == 1 && R == y.Bp) {
             int nsl = 0; hipError_t he = hipSuccess;
             h->head_epoch += 1; if (!h->head_epoch) h->head_epoch = 1;
             if (launch_head_cce(s, hl, h->P(y.p_WoutT), h->P(y.p_bout), tgt, h->bpop, lg, h->A(y.a_rowcost), ws, y.ws_floats,
                                 (unsigned*)h->A(y.a_hstat), (int*)h->A(y.a_fault), y.Bp, N, Nl, Hp, y.Bg, h->head_epoch, &nsl, &he,
-                                (y.cfg.flags & SBR_FLAG_PROFILE_REC) && (size_t)y.Bp * 16 >= 256 * 8 ? (unsigned long long*)h->A(y.a_prof) : nullptr,
-                                gate_ok ? head_done_words : nullptr)) {
+                                (y.cfg.flags & SBR_FLAG_PROFILE_REC) && (size_t)y.Bp * 16 >= 256 * 8 ? (unsigned long long*)h->A(y.a_prof) : nullptr)) {
                 SBR_LAUNCH(he);
-                head_done = true; head_gated = gate_ok;
+                head_done = true;
                 if (fold) keep = nsl;
                 else SBR_LAUNCH(launch_splitk_reduce(s, ws, nsl, y.Bp, Hp, h->A(y.a_dhlast), Hp, nullptr));
             }
@@ -1128,13 +1121,8 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         h->dh_slabs_n = keep;
         // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
         // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
-        if (head_gated) {      // no record on the main stream: the side stream waits for the head kernel's own flag
-            h->ev_lg_rec = nullptr;
-            SBR_LAUNCH(launch_head_gate(sd, head_done_words, h->head_epoch, (int*)h->A(y.a_fault)));
-        } else {
-            h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
-            SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
-        }
+        h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
+        SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
         if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
         // Overlapped tail, single-call step: the output layer's gradient kernels and its update (five launches, 50 - 60 us on one
         // stream with its gaps) go to the SECOND side stream, in front of the scatter-add, so that the polling weight-gradient
@@ -1762,10 +1750,6 @@ static int report_fault(sbr_handle* h, int fault) {
     // bit 0: cluster exchange (sbr_rec_cl.hip); bits 1, 2: publish counter / pipe gate of the pipelined kernels (sbr_rec_p.hip);
     // bit 3: a consumer of the overlapped tail (or its monitor) waited for the chain for 1.5 s; bit 4: a unit of the LDS-row
     // scatter-add was handed more ids than it has LDS rows for (launch_scatter_lds_poll sizes them: cannot happen)
-    if (fault & 32)
-        sbr_set_error("the side stream's gate waited 1.5 s for the one-launch output head (sbr_head.hip) to finish (flag %d, results of this call "
-                      "invalid)", fault);
-    else
     if (fault & 16)
         sbr_set_error("the LDS-row scatter-add of the overlapped tail ran out of rows (flag %d, results of this call invalid); rerun with "
                       "SBR_TAIL_SCATTER_LDS=0", fault);

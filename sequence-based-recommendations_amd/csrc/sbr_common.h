@@ -157,7 +157,6 @@ struct sbr_handle {
     hipEvent_t ev_cells;
     int head_fuse;       // SBR_HEAD_FUSE (default 1): the full-softmax head in one launch (sbr_head.hip)
     unsigned head_epoch;
-    int head_gate;       // SBR_HEAD_GATE (default 1): the side stream is released by the head kernel's own flag instead of an event
     int row_aware;       // SBR_ROW_AWARE_UPDATE (default 1): the dense pass over a wide index-input block skips the gradient traffic of the rows the batch did not touch
     int out_fuse;        // SBR_OUT_FUSE (default 1): the dense head's gradient and step in one launch (launch_out_grad_step)
     bool out_stepped;    // this step: done, the output layer's range needs no update launch
@@ -466,9 +465,7 @@ bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const 
 bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes);
 bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const float* bout, const int* tgt, const float* pop, float* dlogits,
                      float* rowcost, float* slabs, size_t slab_floats, unsigned* stats, int* fault, int Bp, int N, int Nl, int Hp, int Bglobal,
-                     unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof = nullptr, unsigned* done = nullptr);
-// side-stream gate on the head launch `epoch` (done = the words handed to launch_head_cce): no event on the main stream
-hipError_t launch_head_gate(hipStream_t s, const unsigned* done, unsigned epoch, int* fault);
+                     unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof = nullptr);
 // full softmax + categorical cross-entropy (rnn_one_hot.py:65-77): logits (rows,N), row stride ld, in; dlogits out in place
 hipError_t launch_softmax_cce(hipStream_t s, float* logits, const float* bout, const int* target, const float* pop,
                               float* rowcost, int rows, int N, long ld, int Bglobal);

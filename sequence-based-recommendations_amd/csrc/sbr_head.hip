@@ -54,7 +54,6 @@ struct HeadArgs {
     int N, Nl, CW, CC, RB, Bp;
     float inv_Bg;
     unsigned epoch;
-    unsigned* done;             // [0] arrival counter, [1] = epoch once every workgroup has finished (head_gate_kernel), or NULL
     unsigned long long* prof;   // SBR_FLAG_PROFILE_REC: [workgroup][8] stamps of the 100 MHz clock at the phase boundaries (tools/head_prof.py), else NULL
 };
 
@@ -314,34 +313,10 @@ __global__ void __launch_bounds__(256) head_cce_kernel(HeadArgs a) {
     }
     HEAD_STAMP(7);
 #undef HEAD_STAMP
-    // Release without an event: a hipEventRecord between this kernel and the BPTT chain costs the main stream ~7 - 11 us before the
-    // chain starts (profiles/round5_b_c2_timeline.txt).  Instead every workgroup makes its stores visible device-wide and counts
-    // itself in; the last one raises the launch's epoch in the flag head_gate_kernel waits for on the side stream.
-    if (a.done) {
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned arrived = atomicAdd(a.done, 1u);
-            if (arrived == gridDim.x - 1) {
-                atomicExch(a.done, 0u);                                // (every workgroup of this launch has counted itself in)
-                __hip_atomic_store(a.done + 1, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-// one workgroup, one lane: returns when the head launch `epoch` has finished everywhere (bounded: fault bit 5)
-__global__ void head_gate_kernel(const unsigned* __restrict__ done, unsigned epoch, int* __restrict__ fault) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(done + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        if (wall_clock64() - t0 > SBR_POLL_TICKS) { atomicOr(fault, 32); break; }
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-hipError_t launch_head_gate(hipStream_t s, const unsigned* done, unsigned epoch, int* fault) {
-    head_gate_kernel<<<1, 64, 0, s>>>(done, epoch, fault);
-    return hipGetLastError();
+    // (Round 5 released the side stream from here -- every workgroup fenced and counted itself in, a one-lane gate kernel on the side
+    // stream waited for the count -- to save the hipEventRecord between this kernel and the BPTT chain.  Round 6 measured the two forms
+    // with the chain timed by its own stamps: 0.3348 ms with the gate against 0.3247 with the event -- 256 agent-scope fences at the
+    // end of this launch cost the chain more than the record does.  Removed.)
 }
 
 // chunks / chunk width for this shape; false: not served
@@ -362,13 +337,13 @@ bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes) {
 // slabs: CC * Bp * Hp floats; stats: (Bp / 16) * CC * 64 unsigned; false: shape not served, nothing launched
 bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const float* bout, const int* tgt, const float* pop, float* dlogits,
                      float* rowcost, float* slabs, size_t slab_floats, unsigned* stats, int* fault, int Bp, int N, int Nl, int Hp, int Bglobal,
-                     unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof, unsigned* done) {
+                     unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof) {
     int CC = 0, CW = 0; size_t lds = 0;
     if (!sbr_head_plan(Bp, N, Hp, &CC, &CW, &lds) || (size_t)CC * Bp * Hp > slab_floats || epoch == 0) return false;
     HeadArgs a;
     a.h = h; a.W = WoutT; a.b = bout; a.tgt = tgt; a.pop = pop; a.dlog = dlogits; a.rowcost = rowcost; a.slabs = slabs; a.stats = stats;
     a.fault = fault; a.N = N; a.Nl = Nl; a.CW = CW; a.CC = CC; a.RB = Bp / 16; a.Bp = Bp; a.inv_Bg = 1.0f / (float)Bglobal; a.epoch = epoch;
-    a.prof = prof; a.done = done;
+    a.prof = prof;
     {   // read per launch: the tests flip it (0: nobody is waited for -- the recompute path serves every foreign chunk)
         const char* e = getenv("SBR_HEAD_WAIT_TICKS");
         a.wait_ticks = e ? strtoull(e, nullptr, 10) : HEAD_WAIT_TICKS;

@@ -321,7 +321,14 @@ def test_c5_as_benched_reference_initialisation_within_the_north_star_bar():
     the engine's 2e-4 / 1.2e-3 is the same class (another summation order, a factor of two to three), not a kernel defect, and
     the bars (1e-3 / 3e-3) stand 2.5x above what was measured.
 
+    Whether the fp16 split owns the factor of three (round 6; tools/gpu_r6i.sh -> profiles/round6_i_c5_arithmetics.jsonl):
+    the same case on the engine's three arithmetics -- the 2-way fp16 split (default: hidden state 2.2e-4, worst gradient 1.32e-3),
+    bf16x6 everywhere (1.5e-4 / 2.16e-3), and EXACT f32 matrix instructions everywhere (SBR_FLAG_F32_MFMA: 2.9e-4 / 1.22e-3).  The
+    exact-f32 engine sits where the split does: the distance to the CPU port's 3.9e-4 is the summation order of a K-split,
+    tile-ordered GPU reduction against torch's, amplified by this model's conditioning -- not the operand split.  So the bars are
+    twice what the default arithmetic measures: 5e-4 on hidden state and cost, 2.7e-3 on gradients (they were 1e-3 / 3e-3).
+
     Optimizer steps and ranking on THIS model (round 5): through the twin -- the oracle's updater fed the engine's gradients --
     because Adam would turn 1e-3 of gradient difference on near-zero elements into whole steps in a pure oracle run: see
     optimizer_steps == "twin" in _c5_million_item_case."""
-    _c5_million_item_case(B=256, T=200, n=40000, seed=31, grad_floor=4e-7, tol=1e-3, tol_g=3e-3, optimizer_steps="twin")
+    _c5_million_item_case(B=256, T=200, n=40000, seed=31, grad_floor=4e-7, tol=5e-4, tol_g=2.7e-3, optimizer_steps="twin")
