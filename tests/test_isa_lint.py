@@ -147,3 +147,68 @@ def test_one_sparse_matrix_instruction_per_product_in_the_step_loops_of_the_c2_c
             n = sum(1 for ln in body[lo:hi] if ln.strip().startswith("v_smfmac_f32_16x16x64_f16"))
             dense = sum(1 for ln in body[lo:hi] if ln.strip().startswith("v_mfma_"))
             assert n == want and dense == 0, (pat, n, want, dense)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the 16-row cluster chains (csrc/sbr_rec_c16.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def rec_c16_asm():
+    if "c16" not in _ASM:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "rec_c16.s")
+            subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                                   "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
+                                   os.path.join(CSRC, "sbr_rec_c16.hip")], stderr=subprocess.DEVNULL)
+            _ASM["c16"] = open(out).read().splitlines()
+    return _ASM["c16"]
+
+
+def _kernel(text, mangled):
+    st = next(i for i, ln in enumerate(text) if ln.startswith(mangled + ":"))
+    end = next(i for i in range(st, len(text)) if text[i].strip().startswith("s_endpgm"))
+    return text[st:end + 1]
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+@pytest.mark.parametrize("kernel,polls", [("_Z11rec_fwd_c16ILi0ELi256EEv7RecArgs", 1), ("_Z11rec_bwd_c16ILi0ELi256EEv7RecArgs", 1),
+                                          ("_Z11rec_fwd_c16ILi0ELi512EEv7RecArgs", 1), ("_Z12rec_bwd_c16tILi0EEv7RecArgs", 2),
+                                          ("_Z11rec_fwd_c16ILi1ELi256EEv7RecArgs", 1), ("_Z11rec_bwd_c16ILi1ELi256EEv7RecArgs", 1)])
+def test_cluster_chain_step_loops_wait_only_behind_their_polls(kernel, polls):
+    """What the rebuilt chains rest on (csrc/sbr_rec_c16.hip header), checked on the code hipcc produced for the
+    same-XCC body of every chain (the first step loop of a kernel: its polls are the 16-byte `sc1` asm loads):
+
+      * the only waits for vmcnt(0) in the step loop are the hand-written ones -- one behind each poll's loads, one in the counter-mode
+        block -- i.e. the compiler placed none of its own (it did, in three ways, while the kernels were written: at the loop header
+        for loop-carried prefetch registers, between the poll's four loads when the cross-XCC form shared their loop, and at the
+        header for the prologue's pending loads);
+      * the poll's loads are issued back to back: no wait of any kind between the first and the last of them;
+      * no scratch traffic in the step loop (the 512-unit kernels run at the register limit; what spills, spills in the cross-XCC body)."""
+    body = _kernel(rec_c16_asm(), kernel)
+    loops = [(lo, hi) for lo, hi in loops_of(body) if any("dwordx4" in l and "sc1" in l for l in body[lo:hi])]
+    assert loops, "no step loop with sc1 polls found"
+    lo, hi = loops[0]
+    code = body[lo:hi]
+    asm_depth, hand, own = 0, 0, 0
+    poll_runs, in_run = [], None
+    for ln in code:
+        s = ln.strip()
+        if s.startswith(";;#ASMSTART"):
+            asm_depth += 1
+        elif s.startswith(";;#ASMEND"):
+            asm_depth -= 1
+        elif re.match(r"s_waitcnt\s+vmcnt\(0\)\s*$", s) or re.match(r"s_waitcnt\s+vmcnt\(0\)\s", s):
+            if asm_depth > 0:
+                hand += 1
+            else:
+                own += 1
+        if "global_load_dwordx4" in s and "sc1" in s:
+            in_run = [] if in_run is None else in_run
+        elif in_run is not None:
+            if s.startswith("s_waitcnt"):
+                in_run.append(s)
+                if asm_depth > 0:                                 # the poll's own wait ends the run
+                    poll_runs.append(in_run[:-1]); in_run = None
+        assert "scratch_" not in s, s
+    assert own == 0, "%d compiler-placed vmcnt(0) in the step loop of %s" % (own, kernel)
+    assert hand == polls + 1, (hand, polls)                       # + the counter-mode block's
+    assert len(poll_runs) == polls and all(r == [] for r in poll_runs), poll_runs
