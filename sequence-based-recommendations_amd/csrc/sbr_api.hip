@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <math.h>
+#include <atomic>
+#include <chrono>
 
 static thread_local std::string g_err;
 void sbr_set_error(const char* fmt, ...) {
@@ -156,6 +158,11 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
     lay.a_cells = take(std::max(lay.C, 1));
     lay.a_pop = take(Bp);
     lay.a_topk = take((size_t)Bp * 64);
+    lay.a_X2 = take((size_t)Bp * T * lay.F);
+    lay.a_len2 = take(Bp);
+    lay.a_tgt2 = take((size_t)std::max(lay.Bg, Bp) * lay.NT);
+    lay.a_smp2 = take(std::max(lay.S, 1));
+    lay.a_pop2 = take(Bp);
     // tail overlap (sbr_backward_recurrent): the sort's keys carry a time chunk, its counters cover chunks x ids
     lay.tail_keys = 1;
     if (lay.L == 1 && D == 1 && !lay.E && T >= 64 && T < 4096)
@@ -405,6 +412,8 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) h->ev_chunk[c] = nullptr;
     h->in_train_step = false; h->side_pending = false; h->deferred_join = false; h->fill_done = false; h->og_recorded = false;
     h->out_early = false; h->dh_slabs_n = 0;
+    h->s_bb = nullptr; h->ev_bb = nullptr; h->ev_bbw = nullptr; h->bb_set = 0; h->batch_seq = 0; h->set_use[0] = h->set_use[1] = 0;
+    h->lg_seq = 0; h->train_fwd_open = false; h->bb_slow = 0; h->bb_unread = false;
     { const char* e = getenv("SBR_SPARSE_OUT_EARLY"); h->sparse_out_early = e ? atoi(e) : 1; }
     h->cells_early = false; h->wout_early = false;
     h->ev_cells = nullptr;
@@ -413,7 +422,7 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
     { const char* e = getenv("SBR_ROW_AWARE_UPDATE"); h->row_aware = e ? atoi(e) != 0 : 1; }
     h->out_stepped = false;
     h->head_epoch = 0;
-    h->lag_host = nullptr; h->ev_lag[0] = h->ev_lag[1] = nullptr; h->lag_slot = 0; h->lag_pending = -1;
+    h->lag_host = nullptr; h->lag_slot = 0; h->lag_pending = -1; h->lag_counter = 0; h->lag_seq[0] = h->lag_seq[1] = 0;
     // The side stream must not share a hardware queue with the main stream (HIP multiplexes streams onto
     // GPU_MAX_HW_QUEUES = 4 queues; with RCCL's streams alive the side stream landed on the main stream's queue and
     // every "overlapped" kernel serialised: +150 us per step in the data-parallel path).  Streams of another priority
@@ -437,11 +446,19 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
         hipEventCreateWithFlags(&h->ev_chunk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk[3], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_lag[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_lag[1], hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&h->lag_host, 4 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+#if SBR_BB_STREAM
+        hipStreamCreateWithPriority(&h->s_bb, hipStreamNonBlocking, SBR_BB_STREAM == 2 ? prio_lo : prio_hi) != hipSuccess ||
+#endif
+        hipEventCreateWithFlags(&h->ev_bb, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_bbw, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&h->lag_host, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         sbr_set_error("side stream creation failed"); sbr_destroy(h); return SBR_EHIP;
     }
+#if !SBR_BB_STREAM
+    h->s_bb = h->side3;      // (NOT a fifth stream: the device serves four hardware queues per process, a fifth stream shares one with the
+                             //  main stream and the step takes 0.76 ms instead of 0.33 -- profiles/round6_variants.txt, call m)
+#endif
+    memset(h->lag_host, 0, 8 * sizeof(float));
     // parameters, gradients, optimizer state and batch buffers start as zeros
     // (activations too: one-off, keeps every later GEMM operand finite)
     hipError_t e = hipMemsetAsync(h->arena, 0, h->lay.s_end * sizeof(float), h->stream);
@@ -475,11 +492,15 @@ extern "C" void sbr_destroy(sbr_handle* h) {
     if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
     if (h->ev_tail2) (void)hipEventDestroy(h->ev_tail2);
     if (h->side2) (void)hipStreamDestroy(h->side2);
+#if SBR_BB_STREAM
+    if (h->s_bb) (void)hipStreamDestroy(h->s_bb);
+#endif
+    if (h->ev_bb) (void)hipEventDestroy(h->ev_bb);
+    if (h->ev_bbw) (void)hipEventDestroy(h->ev_bbw);
     if (h->side3) (void)hipStreamDestroy(h->side3);
     if (h->ev_tail3) (void)hipEventDestroy(h->ev_tail3);
     if (h->ev_cells) (void)hipEventDestroy(h->ev_cells);
     for (int c = 0; c < SBR_BWD_CHUNKS; ++c) if (h->ev_chunk[c]) (void)hipEventDestroy(h->ev_chunk[c]);
-    for (int c = 0; c < 2; ++c) if (h->ev_lag[c]) (void)hipEventDestroy(h->ev_lag[c]);
     if (h->lag_host) (void)hipHostFree(h->lag_host);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     if (h->tail_trace) (void)hipFree(h->tail_trace);
@@ -620,6 +641,7 @@ extern "C" int sbr_set_batch(sbr_handle* h, const int32_t* X, const int32_t* len
     hipStream_t s = h->stream;
     h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);
     h->bsmp = (const int*)h->A(y.a_smp); h->bpop = h->A(y.a_pop);
+    h->bb_set = 0; h->bb_unread = false;      // (written on the main stream, behind every reader of the set: sbr_build_batch's stream was joined when it built)
     if (on_device && n_rows == y.Bp && (pop || margin)) {
         // device-resident inputs that cover every (padded) row: use them in place, no copies.  The caller
         // keeps them alive and unchanged until the step has run (stream order), as with any device input.
@@ -923,6 +945,9 @@ extern "C" int sbr_forward(sbr_handle* h) {
     const bool training = h->step_open;
     h->step_open = false;
     h->tail_sorted = false;
+    // (sbr_build_batch fills the batch set this forward does not read while the step runs: what it needs to know to do that safely)
+    h->set_use[h->bb_set] = ++h->batch_seq; h->bb_unread = false;
+    if (training) { if (h->train_fwd_open) h->bb_slow = 2; h->train_fwd_open = true; }
     // Sampled heads with lazily stepped W_out rows: which cells the step samples depends on the batch only, and catching their
     // rows up is a chain of dependent replays per row (C3: 81 us, C5: 94 us for 288 rows) that sat on the main stream between the
     // forward chain and the head.  It runs now on the side stream, beside the forward chain; sbr_loss_backward_output waits for
@@ -1121,7 +1146,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         h->dh_slabs_n = keep;
         // beside the BPTT chain: cost, db_out (+ bias regulariser), dW_out^T [N][Hp] = dlogits^T . h.  One record at the end
         // of this phase's main-stream work releases the side stream and is the timing mark in front of rec_bwd.
-        h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
+        h->ev_lg_rec = record_shared(h, h->ev_lg, 3); h->lg_seq = h->batch_seq;
         SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
         if (!fill_needed) { const int rc = side_batch_work(); if (rc != SBR_OK) return rc; }
         // Overlapped tail, single-call step: the output layer's gradient kernels and its update (five launches, 50 - 60 us on one
@@ -1198,7 +1223,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         hipStream_t sg_s = sampled_side ? sd : s;
         if (sampled_side) {
             SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
-            h->ev_lg_rec = record_shared(h, h->ev_lg, 3);
+            h->ev_lg_rec = record_shared(h, h->ev_lg, 3); h->lg_seq = h->batch_seq;
             SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
         }
         SBR_LAUNCH(launch_sum_cost(sg_s, h->A(y.a_rowcost), R, h->cost_ptr()));
@@ -1738,6 +1763,8 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     if (!h->in_train_step && h->timing) h->ring_used += 1;
     h->grads_clean = true;
     h->fwd_done = false;
+    h->train_fwd_open = false;      // the step is complete and its streams are joined: the next batch build may trust main-stream order
+    if (h->side_pending || h->tail_join_pending) h->bb_slow = 2;
     return SBR_OK;
 }
 
@@ -1789,16 +1816,34 @@ extern "C" int sbr_train_step(sbr_handle* h, float* cost_host) {
     return SBR_OK;
 }
 
+// The cost and the fault word of a lagged step reach the host through ONE one-thread kernel that stores them into pinned host memory
+// and then a sequence number (round 6; before: two 4-byte device-to-host copies and an event record on the main stream between two
+// steps, ~10 us of the training loop at C2).  The host reads them one step later: the number is there long before.
+__global__ void lag_report_kernel(const float* cost, const int* fault, volatile float* host, int slot, unsigned seq) {
+    host[slot] = *cost;
+    ((volatile int*)host)[2 + slot] = *fault;
+    __threadfence_system();
+    ((volatile unsigned*)host)[4 + slot] = seq;
+}
+
 static int lagged_collect(sbr_handle* h, float* cost, int* have) {
     *have = 0;
     if (h->lag_pending < 0) return SBR_OK;
     const int s = h->lag_pending;
     h->lag_pending = -1;
-    SBR_HIP(hipEventSynchronize(h->ev_lag[s]));
+    volatile unsigned* q = (volatile unsigned*)&h->lag_host[4 + s];
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *q != h->lag_seq[s]; ++spins) {
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+            SBR_HIP(hipStreamSynchronize(h->stream));      // (a step that long, or a failed one: the stream says which)
+            if (*q != h->lag_seq[s]) { sbr_set_error("lagged step: its report never arrived"); return SBR_EHIP; }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     *cost = h->lag_host[s];
     *have = 1;
     int fault = 0;
-    memcpy(&fault, &h->lag_host[2 + s], sizeof(int));
+    memcpy(&fault, (const void*)&h->lag_host[2 + s], sizeof(int));
     return report_fault(h, fault);
 }
 
@@ -1807,9 +1852,9 @@ extern "C" int sbr_train_step_lagged(sbr_handle* h, float* prev_cost, int* have_
     int rc = sbr_train_step(h, nullptr);
     if (rc != SBR_OK) return rc;
     const int s = h->lag_slot;
-    SBR_HIP(hipMemcpyAsync(&h->lag_host[s], h->cost_ptr(), sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    SBR_HIP(hipMemcpyAsync(&h->lag_host[2 + s], h->A(h->lay.a_fault), sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    SBR_HIP(hipEventRecord(h->ev_lag[s], h->stream));
+    h->lag_seq[s] = ++h->lag_counter;
+    lag_report_kernel<<<1, 1, 0, h->stream>>>(h->cost_ptr(), (const int*)h->A(h->lay.a_fault), h->lag_host, s, h->lag_seq[s]);
+    SBR_LAUNCH(hipGetLastError());
     rc = lagged_collect(h, prev_cost, have_prev);          // the step before this one: normally long finished
     h->lag_pending = s;
     h->lag_slot = s ^ 1;

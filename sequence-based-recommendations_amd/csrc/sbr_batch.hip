@@ -636,7 +636,25 @@ extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uin
     CHECK_ARG(d->batch_size == y.Bg, "the pass was planned for batches of %d rows, the model's global batch is %d", d->batch_size, y.Bg);
     CHECK_ARG(batch >= 0 && batch < d->n_batches, "batch %lld outside the planned pass [0,%lld)", (long long)batch, (long long)d->n_batches);
     CHECK_ARG(d->stream == h->stream, "dataset and engine must share one stream");
-    hipStream_t s = h->stream;
+    // The build runs on a stream of its own into the batch set the step in flight does not read, so that the host can queue
+    // batch i+1 while step i runs and the device packs it beside the step (two small launches, 20 - 30 us that used to sit between
+    // two steps; tools/bench_train_loop.py).  Order: (1) the set it overwrites was read by the step before the one in flight --
+    // every stream of a completed step is joined into the main stream by sbr_apply_update, so any main-stream record made DURING
+    // the step in flight is behind it: the step records one anyway (ev_lg, in front of the BPTT chain), no extra record on the
+    // main stream; (2) without such a record (first batches, evaluation between steps, a step abandoned half way) the build
+    // waits for a fresh record on each of the engine's streams; (3) the main stream waits for the build (long complete by then).
+    // The dataset's own arrays change only inside calls that synchronise d->stream first and last, i.e. behind (3).
+    hipStream_t s = h->s_bb;
+    const int set = h->bb_set ^ 1;
+    if (h->train_fwd_open) h->bb_slow = 2;
+    if (h->bb_unread && h->bb_slow == 0) h->bb_slow = 1;      // two builds and no forward between them: whoever read the first did it outside a step
+    if (h->bb_slow == 0 && h->ev_lg_rec && h->lg_seq > h->set_use[set]) {
+        SBR_HIP(hipStreamWaitEvent(s, h->ev_lg_rec, 0));
+    } else {
+        hipStream_t all[4] = {h->stream, h->side, h->side2, h->side3};
+        for (hipStream_t q : all) { SBR_HIP(hipEventRecord(h->ev_bbw, q)); SBR_HIP(hipStreamWaitEvent(s, h->ev_bbw, 0)); }
+        if (h->bb_slow > 0) --h->bb_slow;
+    }
     if ((size_t)y.Bg > d->cap_rows) {
         (void)hipFree(d->d_split); (void)hipFree(d->d_rowuser); d->d_split = d->d_rowuser = nullptr;
         SBR_HIP(hipMalloc(&d->d_split, (size_t)y.Bg * sizeof(int)));
@@ -656,15 +674,20 @@ extern "C" int sbr_build_batch(sbr_handle* h, sbr_dataset* d, int64_t batch, uin
         bb_split_kernel<<<se - sb, 256, 0, s>>>(d->d_off, len_n, d->d_seg_user, d->d_seg_k, d->d_seg_row0, sb, sd, d->d_split, d->d_rowuser);
         SBR_LAUNCH(hipGetLastError());
     }
+    int *bX = (int*)h->A(set ? y.a_X2 : y.a_X), *blen = (int*)h->A(set ? y.a_len2 : y.a_len), *btgt = (int*)h->A(set ? y.a_tgt2 : y.a_tgt);
+    int* bsmp = (int*)h->A(set ? y.a_smp2 : y.a_smp);
+    float* bpop = h->A(set ? y.a_pop2 : y.a_pop);
     const bool sampled = y.S > 0;
     const int tgt_rows = sampled ? y.Bg : y.B, tgt_offset = sampled ? 0 : y.cfg.row_offset;
     const int extra = (tgt_rows * y.NT + 63) / 64 + (y.S + 63) / 64;
     bb_pack_kernel<<<y.Bp + extra, 64, 0, s>>>(src_items, src_rate, d->d_off, len_n, split, rowuser, d->d_popdb, d->d_cdf, d->n_items, y.T,
-                                                y.F, y.NT, d->shuffle_targets, y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, (int*)h->A(y.a_X),
-                                                (int*)h->A(y.a_len), (int*)h->A(y.a_tgt), h->A(y.a_pop), (int*)h->A(y.a_smp), tgtpos);
+                                                y.F, y.NT, d->shuffle_targets, y.cfg.row_offset, y.B, y.Bp, tgt_rows, tgt_offset, y.S, sd, bX,
+                                                blen, btgt, bpop, bsmp, tgtpos);
     SBR_LAUNCH(hipGetLastError());
-    h->bX = (const int*)h->A(y.a_X); h->blen = (const int*)h->A(y.a_len); h->btgt = (const int*)h->A(y.a_tgt);
-    h->bsmp = (const int*)h->A(y.a_smp); h->bpop = h->A(y.a_pop);
+    SBR_HIP(hipEventRecord(h->ev_bb, s));
+    SBR_HIP(hipStreamWaitEvent(h->stream, h->ev_bb, 0));
+    h->bX = bX; h->blen = blen; h->btgt = btgt; h->bsmp = bsmp; h->bpop = bpop;
+    h->bb_set = set; h->bb_unread = true;
     h->n_rows = y.B; h->have_batch = true; h->fwd_done = false;
     return SBR_OK;
 }

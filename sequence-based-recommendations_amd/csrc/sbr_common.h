@@ -112,6 +112,7 @@ struct Layout {
     size_t a_fault;                       // int: a cluster exchange wait timed out
     size_t a_clx;                         // cluster handshake slots (ints)
     size_t a_X, a_len, a_tgt, a_smp, a_cells, a_pop, a_topk; // batch buffers (ints stored in float slots)
+    size_t a_X2, a_len2, a_tgt2, a_smp2, a_pop2;             // ... second set: sbr_build_batch fills the set the step in flight does not read
     size_t a_scnt, a_soff, a_scur, a_sid, a_spos;            // scatter counting-sort workspace (ints)
     size_t a_sP;                          // [input_size + 1] running cost of the ids (launch_scatter_lds_poll)
     size_t a_hstat;                       // [256][16][4] row statistics the chunks of the fused head exchange (sbr_head.hip)
@@ -171,13 +172,26 @@ struct sbr_handle {
     int sp_exchanged[2]; // data-parallel step: rows of block b were packed / gathered (candidates = a_cand[0 .. sp_ncand[b]))
     int sp_ncand[2];
     int sp_epoch;        // pack epoch
-    float* lag_host;     // pinned: [2] cost, [2] fault flag (sbr_train_step_lagged)
-    hipEvent_t ev_lag[2];
+    float* lag_host;     // pinned: [2] cost, [2] fault flag, [2] sequence number (sbr_train_step_lagged: lag_report_kernel)
+    unsigned lag_seq[2], lag_counter;
     int lag_slot, lag_pending;
     int x6_pipe;         // per-k-block publish counters instead of a workgroup barrier per step (SBR_X6_PIPE, default 1; Hp = 128)
     int wgrad_x6;        // weight gradients through the bf16x6 GEMM instead of the dedicated f32 kernel (SBR_WGRAD_X6, default 1; the f32 kernel serves Hp < 96 and SBR_FLAG_F32_MFMA)
     // current batch: the arena's own buffers, or (device-resident inputs covering all Bp rows) the caller's
     const int *bX, *blen, *btgt, *bsmp; const float* bpop;
+    // sbr_build_batch beside the step in flight (sbr_batch.hip): its own stream, the set the current batch sits in, and what
+    // tells it that the set it is about to overwrite is no longer read
+#ifndef SBR_BB_STREAM
+#define SBR_BB_STREAM 0      // (probe builds: 1 = a stream of its own, 2 = ... at low priority)
+#endif
+    hipStream_t s_bb; hipEvent_t ev_bb, ev_bbw;
+    int bb_set;                 // arena set of the current batch (0: also what sbr_set_batch fills)
+    uint64_t batch_seq;         // sbr_forward calls so far
+    uint64_t set_use[2];        // batch_seq of the last forward that read set i
+    uint64_t lg_seq;            // batch_seq when ev_lg_rec was last recorded (a main-stream record in the middle of a training step)
+    bool bb_unread;             // the current batch was built and no forward has read it yet
+    bool train_fwd_open;        // a training forward whose step has not reached sbr_apply_update
+    int bb_slow;                // builds left that wait for all of the engine's streams (a step was abandoned: its side streams were not joined)
     int n_rows;          // rows of the current batch (<= local_batch)
     int64_t step_count;  // adam t
     bool have_batch, fwd_done;

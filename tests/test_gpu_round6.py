@@ -64,3 +64,55 @@ def test_one_launch_head_beside_a_foreign_kernel_recomputes():
     finally:
         eng.debug_occupy(0, 0, 0)
         eng.close()
+
+
+def test_batches_built_beside_the_step_in_flight_are_the_batches_the_steps_read():
+    """sbr_build_batch packs batch i+1 on a stream of its own, into the second batch set, while step i runs.  Engine A queues
+    build + lagged step back to back (nothing synchronises between them), with a ranking through sbr_set_batch thrown in every
+    few steps and a build that no step reads; engine B builds each batch, copies it to the host, hands it back through
+    sbr_set_batch and steps synchronously.  Same costs, same parameters: a batch overwritten while a step still read it, or read
+    before it was complete, shows up as a different cost at once (the rows of two batches share nothing)."""
+    from sbr_amd.engine import RNNEngine, DeviceDataset
+    rng = np.random.default_rng(11)
+    n_users, N, B, T, H, n = 900, 3706, 256, 30, 128, 14
+    lengths = rng.integers(3, 70, size=n_users)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    items = rng.integers(1, N, size=int(offsets[-1])).astype(np.int32)
+    params = O.init_params("GRU", [H], N, np.random.default_rng(2), dtype=np.float32)
+    probe = PU.make_batch(np.random.default_rng(3), B, T, N)
+
+    def run(overlapped):
+        eng = RNNEngine(cell="GRU", layers=[H], n_items=N, max_length=T, batch_size=B, loss="CCE")
+        ds = DeviceDataset(eng, items, offsets, N)
+        try:
+            eng.set_all_param_values(params)
+            nb = ds.plan_pass(None, B)
+            assert nb >= 4
+            costs, ranks = [], []
+            for i in range(n):
+                if i % 5 == 3:      # evaluation between two steps: another batch through the first set, no training step
+                    if overlapped and i == 8:
+                        eng.build_batch(ds, (i + 2) % nb, seed=999)      # built and never stepped
+                    ranks.append(eng.predict_function(probe["X"], probe["mask"])[:4, :16].copy())
+                eng.build_batch(ds, i % nb, seed=70 + i)
+                if overlapped:
+                    c = eng.train_step_lagged()
+                    if c is not None:
+                        costs.append(c)
+                else:
+                    cur = eng.current_batch()
+                    eng.set_batch(cur["X"], None, cur["target"], None, cur["pop"], lengths=cur["lengths"])
+                    costs.append(eng.train_step())
+            if overlapped:
+                costs.append(eng.flush_lagged())
+            return np.array(costs), np.array(ranks), eng.get_all_param_values()
+        finally:
+            ds.close(); eng.close()
+
+    c0, r0, p0 = run(False)
+    c1, r1, p1 = run(True)
+    assert len(c0) == len(c1) == n
+    assert np.allclose(c0, c1, rtol=1e-5, atol=0), (c0, c1)
+    assert np.allclose(r0, r1, rtol=1e-4, atol=1e-6)
+    assert all(np.allclose(a, b, rtol=1e-4, atol=1e-6) for a, b in zip(p0, p1))
+    assert np.ptp(c0) > 1e-3                   # (the steps did something)
