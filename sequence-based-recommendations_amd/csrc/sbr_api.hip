@@ -1976,9 +1976,12 @@ extern "C" int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t
     CHECK_ARG(A && B && C, "null operand");
     sbr_gemm_set_exact_f32(exact_f32 == 1);
     sbr_gemm_set_planes(exact_f32 == 2 ? 1 : 3);
-    if (exact_f32 == 3) sbr_gemm_hint(2, 1.0f, 1.0f);      // the two-plane fp16 split (three MFMAs): what the step's logits GEMM takes
+    sbr_gemm_set_planes((exact_f32 == 2 || exact_f32 == 5) ? 1 : 3);
+    if (exact_f32 == 3 || exact_f32 == 4) sbr_gemm_hint(2, 1.0f, 1.0f);      // the two-plane fp16 split (three MFMAs): what the step's logits GEMM takes
+    sbr_gemm_x6_no_wide(exact_f32 == 4 || exact_f32 == 5);
     const hipError_t ge = launch_gemm((hipStream_t)stream, A, (long)sam, (long)sak, B, (long)sbk, (long)sbn, C, (long)ldc, M, N, K, bias, ws,
                                       ws_floats, false);
+    sbr_gemm_x6_no_wide(false);
     sbr_gemm_set_planes(3);
     SBR_LAUNCH(ge);
     return SBR_OK;

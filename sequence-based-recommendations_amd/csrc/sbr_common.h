@@ -439,6 +439,7 @@ hipError_t launch_rec_reduce_partials(hipStream_t s, const float* part, int nblk
 hipError_t launch_gemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                        float* C, long ldc, int M, int N, int K, const float* bias, float* ws, size_t ws_floats,
                        bool simple, int a_blk_Bp = 0, int b_blk_Bp = 0, int* keep_slabs = nullptr);
+void sbr_gemm_x6_no_wide(bool on);                       // this thread's next launches stay on the 128-wide tile (parity tests of gemm_x6w_kernel)
 void sbr_gemm_hint(int planes, float sa, float sb);      // operand planes of the NEXT launch_gemm call (sbr_gemm.hip)
 // keep_slabs != NULL: where the split-K form runs, its slabs stay in ws (slab z at ws + z * M * N, row stride N), the
 // reduction is left to the consumer and *keep_slabs = their number; otherwise *keep_slabs = 0 and C holds the result

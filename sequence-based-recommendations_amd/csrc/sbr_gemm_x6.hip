@@ -334,6 +334,222 @@ __global__ void __launch_bounds__(256, PL ? 1 : 2) gemm_x6_kernel(GemmX6Args g) 
     if (PL && g.poll.trace && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g.poll.trace[8 + (blockIdx.z & 7)] = wall_clock64();   // (end of a workgroup)
 }
 
+// Two operand elements -> their fp16 planes, packed (low half = the first): h1 = fp16(x s), h2 = fp16((x s - h1) 2048), three VALU
+// instructions per element (the mixed-precision FMA reads an fp16 half as a source and writes one as a result: no conversion back, no
+// pack) where the C form below takes five or six.  Same values bit for bit: x s is exact (s a power of two), so is x s - h1.
+__device__ __forceinline__ void x6_split_pair(float x0, float x1, float s, float k2048, unsigned& h1, unsigned& h2) {
+    unsigned d1, d2; float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d1) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d1) : "v"(x1), "v"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(s), "v"(d1));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(s), "v"(d1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d2) : "v"(r0), "v"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d2) : "v"(r1), "v"(k2048));
+    h1 = d1; h2 = d2;
+}
+
+// ---------------------------------------------------------------------------------------
+// Wide tile (round 6): 256 x 128 x 32 per workgroup of 512 threads, LDS double-buffered, one barrier per k step.
+// gemm_x6_kernel's 128 x 128 tile is bound by what a k step costs beside its MFMAs -- per loaded element one split (VALU), one LDS
+// write, and the element is used for 128 outputs; two barriers per step keep the split of step k + 1 out of the MFMA phase of step
+// k (the 2:1 ratio: C5's layer-2 input projection 51 200 x 2 048 x 512 runs at 23 % of the fp16 matrix pipe).  Here a workgroup's
+// eight waves own 64 x 64 outputs each: 48 MFMAs (768 cycles of matrix pipe) per wave and k step against 24 loaded elements per
+// thread, the next step's operands are split and written to the OTHER LDS stage while this step's MFMAs run, and the raw f32 of the
+// step after that is in flight in registers.  f32 operands in (same call sites, same arithmetic per product as gemm_x6_kernel NP = 2 /
+// NP = 1, same accumulation order over K inside a slab: results are bitwise those of the 128-wide kernel).
+// Shapes: M % 256 == 0, N % 128 == 0, K and the K slab % 32 == 0, 16-byte aligned rows; everything else stays on gemm_x6_kernel.
+// RA / RB: unit stride along the rows (m / n) instead of k, as above.  grid = (tiles, K slabs).
+template <bool RA, bool RB, int NP>
+__global__ void __launch_bounds__(512, 1) gemm_x6w_kernel(GemmX6Args g) {
+    constexpr int TM = 256, TN = 128, ROW = 80, PA = TM * ROW, PB = TN * ROW, STAGE = NP * (PA + PB);
+    using OPV = std::conditional_t<NP == 2, f16x8g, bf16x8>;
+    using EL = std::conditional_t<NP == 2, _Float16, __bf16>;
+    typedef EL el4 __attribute__((ext_vector_type(4)));
+    typedef EL el2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 15, q = lane >> 4;
+    // tile of this workgroup: consecutive workgroup ids go to different XCDs, so ids that share an XCD walk the n tiles of one m
+    // tile together (its 256 rows of A stay in that XCD's L2)
+    const int tiles_n = g.N / TN, nt = (g.M / TM) * tiles_n;
+    int lin = blockIdx.x;
+    if ((nt & 7) == 0) lin = (lin & 7) * (nt >> 3) + (lin >> 3);
+    const int m0 = (lin / tiles_n) * TM, n0 = (lin % tiles_n) * TN;
+    const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+
+    // loaders: every thread moves 16 elements of the A tile and 8 of the B tile per k step
+    const float* pa; const float* pb; long sa_k, sb_k; int da, db;      // source, its step per k, byte offset inside a plane
+    if (RA) { const int mg = tid & 63, kq = tid >> 6; pa = g.A + (m0 + 4 * mg) + (long)(kbeg + 4 * kq) * g.sak; da = 4 * mg * ROW + kq * 8; }
+    else { const int r = tid >> 1, kh = tid & 1; pa = g.A + (long)(m0 + r) * g.sam + kbeg + 16 * kh; da = r * ROW + kh * 32; }
+    if (RB) { const int ng = tid & 31, kp = tid >> 5; pb = g.B + (n0 + 4 * ng) + (long)(kbeg + 2 * kp) * g.sbk; db = 4 * ng * ROW + kp * 4; }
+    else { const int n = tid >> 2, kq = tid & 3; pb = g.B + (long)(n0 + n) * g.sbn + kbeg + 8 * kq; db = n * ROW + kq * 16; }
+    sa_k = RA ? g.sak : 1; sb_k = RB ? g.sbk : 1;
+    f32x4 ra[4], rb[2];
+    auto load = [&]() {                                    // raw f32 of the next k step (32 k further on)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *(const f32x4*)(RA ? pa + (long)i * sa_k : pa + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *(const f32x4*)(RB ? pb + (long)i * sb_k : pb + 4 * i);
+        pa += 32 * sa_k; pb += 32 * sb_k;
+    };
+    auto conv = [&](float x, float scale, EL& e1, EL& e2) {
+        if constexpr (NP == 2) {
+            x *= scale;
+            asm("" : "+v"(x));                             // one rounding to fp16 for both uses (split2_f16, sbr_rec_p.hip)
+            e1 = (_Float16)x; e2 = (_Float16)((x - (float)e1) * 2048.0f);
+        } else { e1 = (__bf16)x; e2 = e1; }
+    };
+    auto store = [&](char* st) {                           // split + LDS write of what `load` fetched
+        char* A0 = st + da; char* B0 = st + NP * PA + db;
+        if constexpr (RA) {                                // ra[i][e] = A(m = 4 mg + e, k = 4 kq + i): row e gets 4 k = 8 bytes per plane
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                el4 h1, h2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { EL a, b; conv(ra[i][e], g.sa, a, b); h1[i] = a; h2[i] = b; }
+                *(el4*)(A0 + e * ROW) = h1;
+                if constexpr (NP == 2) *(el4*)(A0 + e * ROW + PA) = h2;
+            }
+        } else {                                           // ra[i] = 4 consecutive k of the thread's row: 16 k = 32 bytes per plane
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if constexpr (NP == 2) {
+                    u32x4 w1, w2;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        unsigned p1, p2;
+                        x6_split_pair(ra[2 * hh + (c >> 1)][2 * (c & 1)], ra[2 * hh + (c >> 1)][2 * (c & 1) + 1], g.sa, 2048.0f, p1, p2);
+                        w1[c] = p1; w2[c] = p2;
+                    }
+                    *(u32x4*)(A0 + hh * 16) = w1;
+                    *(u32x4*)(A0 + hh * 16 + PA) = w2;
+                } else {
+                    OPV h1;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { EL a, b; conv(ra[2 * hh + (c >> 2)][c & 3], g.sa, a, b); h1[c] = a; }
+                    *(OPV*)(A0 + hh * 16) = h1;
+                }
+            }
+        }
+        if constexpr (RB) {                                // rb[i][e] = B(k = 2 kp + i, n = 4 ng + e): row e gets 2 k = 4 bytes per plane
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NP == 2) {
+                    unsigned p1, p2;
+                    x6_split_pair(rb[0][e], rb[1][e], g.sb, 2048.0f, p1, p2);
+                    *(unsigned*)(B0 + e * ROW) = p1;
+                    *(unsigned*)(B0 + e * ROW + PB) = p2;
+                } else {
+                    el2 h1;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { EL a, b; conv(rb[i][e], g.sb, a, b); h1[i] = a; }
+                    *(el2*)(B0 + e * ROW) = h1;
+                }
+            }
+        } else {
+            if constexpr (NP == 2) {
+                u32x4 w1, w2;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned p1, p2;
+                    x6_split_pair(rb[c >> 1][2 * (c & 1)], rb[c >> 1][2 * (c & 1) + 1], g.sb, 2048.0f, p1, p2);
+                    w1[c] = p1; w2[c] = p2;
+                }
+                *(u32x4*)B0 = w1;
+                *(u32x4*)(B0 + PB) = w2;
+            } else {
+                OPV h1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { EL a, b; conv(rb[c >> 2][c & 3], g.sb, a, b); h1[c] = a; }
+                *(OPV*)B0 = h1;
+            }
+        }
+    };
+    const f32x4 z = f32x4{0, 0, 0, 0};
+    f32x4 acc[4][4], acl[NP == 2 ? 4 : 1][NP == 2 ? 4 : 1];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { acc[a][b] = z; if constexpr (NP == 2) acl[a][b] = z; }
+    const int fa = (wm * 64 + j) * ROW + q * 16, fb = NP * PA + (wn * 64 + j) * ROW + q * 16;
+    if (kbeg < kend) {
+        load();
+        store(smw);
+        __syncthreads();
+        if (kbeg + 32 < kend) load();
+    }
+    // One k step.  ST: the next step's operands (raw f32 in ra / rb) are split and written to the other LDS stage; LD: the raw f32 of the
+    // step after that is requested.  Everything of a step is ONE scheduling region, and its order is prescribed (sched_group_barrier):
+    // a wave's split instructions go BETWEEN its own MFMAs -- a matrix instruction occupies the pipe for 16 cycles (32 with the SIMD's
+    // other wave taking turns) and the wave issues three to seven VALU instructions meanwhile.  Phases instead of interleaving --
+    // the split of all eight waves, then their MFMAs, or the two waves of a SIMD in opposite order -- cost 4 580 cycles per step
+    // against 1 536 of matrix pipe: a VALU instruction beside the OTHER wave's MFMA stream issues once per matrix instruction
+    // (profiles/round6_variants.txt, call q).
+    int cur = 0;
+    auto step = [&](auto st_tag, auto ld_tag) {
+        constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
+        const char* st = smw + cur * STAGE;
+        OPV a[NP][4], b[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[p][t] = *(const OPV*)(st + fa + p * PA + t * 16 * ROW);
+                b[p][t] = *(const OPV*)(st + fb + p * PB + t * 16 * ROW);
+            }
+#define X6W_TERM(ACC, PA_, PB_) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
+            ACC[mi][ni] = x6_mfma(b[PB_][ni], a[PA_][mi], ACC[mi][ni]);
+        X6W_TERM(acc, 0, 0)                                // (first: needs plane 0 only, the reads of plane 1 land meanwhile)
+        if constexpr (ST) store(smw + (cur ^ 1) * STAGE);
+        if constexpr (NP == 2) { X6W_TERM(acl, 0, 1) }
+        if constexpr (LD) load();
+        if constexpr (NP == 2) { X6W_TERM(acl, 1, 0) }
+#undef X6W_TERM
+        // the prescribed order
+        __builtin_amdgcn_sched_group_barrier(0x100, 8 * NP, 0);                 // fragment reads
+        constexpr int NMF = NP == 2 ? 48 : 16, NFEED = NP == 2 ? 32 : 12, VPER = NP == 2 ? 4 : 8;
+#pragma unroll
+        for (int i = 0; i < NFEED; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (ST) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);
+            if (ST && (i % (NFEED / 6)) == NFEED / 6 - 1) __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);   // 6 x NP LDS writes in all
+        }
+        if (LD) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+#pragma unroll
+        for (int i = NFEED; i < NMF; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __syncthreads();
+        cur ^= 1;
+    };
+    {
+        const int ns = (kend - kbeg) / 32;                 // steps; raw f32 of step 1 is in flight
+        int i = 0;
+        for (; i + 2 < ns; ++i) step(std::true_type{}, std::true_type{});
+        if (i + 1 < ns) { step(std::true_type{}, std::false_type{}); ++i; }
+        if (i < ns) step(std::false_type{}, std::false_type{});
+    }
+    float* out = g.C + (size_t)blockIdx.y * g.slab_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int m = m0 + wm * 64 + mi * 16 + j, n = n0 + wn * 64 + ni * 16 + 4 * q;      // (transposed products: lane (j, q) holds row j, columns 4q..4q+3)
+            f32x4 val = acc[mi][ni];
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[r] = fmaf(acl[mi][ni][r], 1.0f / 2048.0f, val[r]) * g.so;
+            }
+            if (g.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[r] += g.bias[n + r];
+            }
+            *(f32x4*)(out + (long)m * g.ldc + n) = val;
+        }
+}
+
+static thread_local bool g_x6_no_wide = false;
+void sbr_gemm_x6_no_wide(bool on) { g_x6_no_wide = on; }
+
 static inline bool x6_aligned(const float* p, long other_stride) {   // 16-byte loads along the unit-stride dimension
     return ((uintptr_t)p & 15) == 0 && (other_stride & 3) == 0;
 }
@@ -356,6 +572,22 @@ bool launch_gemm_x6(hipStream_t s, const float* A, long sam, long sak, const flo
     if (poll) {      // (interior tiles only: x6_issue_sc1)
         if (small || nsplit < 1 || planes < 2 || (M & 127) || (N & 127) || (K & 7) || !poll->slab_lo || poll->n_slabs < 1) return false;
         g.poll = *poll;
+    }
+    // the wide tile where the shape fills it (see gemm_x6w_kernel); g_x6_no_wide: parity tests of the two kernels against each other
+    // (A with unit stride along m -- the weight-gradient GEMMs, contraction over time -- stays on the 128-wide kernel: eight 8-byte LDS
+    //  writes per thread and step instead of four 16-byte ones, measured slower there: 582 against 476 us for 512 x 2 048 x 51 200)
+    if (!poll && !small && !g_x6_no_wide && !ra && (planes == 1 || planes == 2) && !B2 && (M & 255) == 0 && (N & 127) == 0 && (K & 31) == 0 &&
+        (kchunk & 31) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (slab_stride & 3) == 0 &&
+        (size_t)(M / 256) * (N / 128) * nsplit >= 128) {
+        const dim3 wgrid((M / 256) * (N / 128), nsplit);
+        const size_t lds = (size_t)2 * planes * (256 + 128) * 80;
+#define X6W_GO(NP) do { \
+            if (rb) { SBR_DYN_LDS((gemm_x6w_kernel<false, true, NP>), lds); gemm_x6w_kernel<false, true, NP><<<wgrid, 512, lds, s>>>(g); } \
+            else { SBR_DYN_LDS((gemm_x6w_kernel<false, false, NP>), lds); gemm_x6w_kernel<false, false, NP><<<wgrid, 512, lds, s>>>(g); } } while (0)
+        if (planes == 2) X6W_GO(2); else X6W_GO(1);
+#undef X6W_GO
+        *err = hipGetLastError();
+        return true;
     }
     const int tile = small ? 64 : 128;
     const dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, nsplit);

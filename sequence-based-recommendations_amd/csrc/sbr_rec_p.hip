@@ -73,6 +73,9 @@
 #ifndef X6P_TOK_EARLY
 #define X6P_TOK_EARLY 1  // the pipe gate's token is read together with the step's first operand reads: a separate read was one exposed LDS
 #endif                   // round trip (~140 cycles) per step of waves 0-3, and the token is there long before (profiles/round4_d_rec_phases.txt)
+#ifndef X6P_GATE
+#define X6P_GATE(a) false   // the matrix-pipe gate of rounds 1 - 3 (waves 0-3 wait for their partner's last MFMA): with one sparse instruction per
+#endif                      // k-block it only cost its reads (SBR_X6_PIPE=2 was never faster after round 4); compiled out, -DX6P_GATE(a)=((a).x6_pipe>=2) brings it back
 #ifndef X6P_SYNC
 #define X6P_SYNC 0       // 1: one workgroup barrier per step instead of the counters / the pipe gate / the role split (experiment:
 #endif                   // with two MFMAs per product the matrix phase is short enough for the synchronous schedule to compete)
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         int tokv = 0;                                             // RA: the pipe gate's token, read with the first operands (one LDS
         auto load_half = [&](int half) {                          // round trip instead of two).  Counter first, then planes: the LDS keeps a wave's order
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (X6P_TOK_EARLY && RA && half == 0 && a.x6_pipe >= 2) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (X6P_TOK_EARLY && RA && half == 0 && X6P_GATE(a)) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 2 * half; kb < 2 * half + 2; ++kb) {
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
         // as soon as its own group's k-blocks were there would starve its partner's last MFMAs, whose results
         // everybody waits for: so it holds back until the partner has issued its whole step.  Waves 4-7 need no gate,
         // they only ever get the gaps.
-        if (RA && a.x6_pipe >= 2) {
+        if (RA && X6P_GATE(a)) {
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
             int v = X6P_TOK_EARLY ? tokv : __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
@@ -447,7 +450,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (kb == KB / 2 && RA) ensure_half(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK >= 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK >= 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
                 if (X6P_H1_AT < 0 && kb == 0 && RA) {             // the second operand half: requested in FRONT of the first k-block's instructions
                     load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acc[g][2], 1.0f / F16_LO, acc[g][0]);
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                 if (kb == KB / 2 && RA) ensure_half(1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (PROF && tl && t == 100) tl[1 + kb] = clock64();
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 2) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) { acl[g] = mfma16(hp[kb][0], W2[g][kb], kb == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acl[g]); }
                 if (kb == KB / 2 - 1 && RA) {                     // see the bf16 form below
@@ -480,12 +483,12 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     load_half(1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) { acc[g] = mfma16(hp[kb][0], W1[g][kb], kb == 0 ? biasv[g] : acc[g]); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DEFER && kb == 0 && t > 0) { store_step(off_t - st_h, sv_st, h_st, c_st); __builtin_amdgcn_sched_barrier(0); }
-                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1 && X6P_FWD_TOK == 0) { if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g][0] = fmaf(acc[g][1] + acl[g][0], 1.0f / F16_LO, acc[g][0]);
@@ -505,7 +508,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 X6P_TERL(hp[kb][0], W2[g][kb])
-                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+                if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
                 if (kb == 0) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) acc[g] = mfma16(hp[kb][0], W1[g][kb], biasv[g]);
@@ -537,7 +540,7 @@ __global__ void __launch_bounds__(512) rec_fwd_x6p(RecArgs a) {
             // cycles at GRU) before the last one is issued, so that less of that reaction time is idle matrix pipe.  Not
             // earlier: an older wave that starts while this one still has MFMAs to issue stalls them for its whole first
             // half (measured: 2 G MFMAs early gains nothing in the forward, 3 terms early loses 5 us).
-            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
+            if (!RA && kb == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }
             X6P_TERM(hp[kb][0], W1[g][kb])
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -955,7 +958,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         int tokv = 0;                                             // RA: the pipe gate's token, read with the first flag (see rec_fwd_x6p)
         auto load_flag = [&](int half) {
             fl[half] = __hip_atomic_load(cnt + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (X6P_TOK_EARLY && RA && half == 0 && a.x6_pipe >= 2) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (X6P_TOK_EARLY && RA && half == 0 && X6P_GATE(a)) tokv = __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");
         };
         auto use = [&](int i) { asm volatile("" :: "v"(dpl[i % NS][0]), "v"(dpl[i % NS][1]), "v"(dpl[i % NS][NP - 1])); };
@@ -985,7 +988,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
         if (!RA) load_flag(1);
         ensure_half(0, 0, LA);
         __builtin_amdgcn_s_setprio(0);
-        if (RA && a.x6_pipe >= 2) {                               // the matrix-pipe gate, see rec_fwd_x6p
+        if (RA && X6P_GATE(a)) {                               // the matrix-pipe gate, see rec_fwd_x6p
             unsigned long long w0 = 0;
             if (PROF) w0 = clock64();
             int v = X6P_TOK_EARLY ? tokv : __hip_atomic_load(tok + (wave & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins = 0;
@@ -1010,7 +1013,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SP) {       // acc[0]: {d1 w1, d1 w2, d2 w1, d2 w2}, one dependent chain (full issue rate: smfmac_probe)
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one instruction early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one instruction early
                 acc[0] = smfmac16(dpl[s][0], WS[kb], acc[0], spidx);
                 if (BDEF && i == 1) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1024,7 +1027,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                 }
             } else if constexpr (PK) {       // acc[0][0]: d1 w1, acc[0][1]: d2 w1, acc[1][0]: d1 w2 (acc[1][1] = d2 w2 is dropped)
                 acc[1] = mfma16(dpl[s][0], W2[kb], acc[1]);
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // one MFMA early
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
                 if (BDEF && i == 1) {                               // this step's dxt / dhi, from where the issue slots are free
                     __builtin_amdgcn_sched_barrier(0);
@@ -1037,7 +1040,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if constexpr (F16) {      // acc[0]: d1 w1;  acc[1], acc[2]: the low-order products d2 w1, d1 w2 (/ 2048 at the end)
-                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
+                if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early
                 acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
                 acc[2] = mfma16(dpl[s][0], W2[kb], acc[2]);
                 acc[0] = mfma16(dpl[s][0], W1[kb], acc[0]);
@@ -1045,7 +1048,7 @@ __global__ void __launch_bounds__(512) rec_bwd_x6p(RecArgs a) {
             acc[0] = mfma16(dpl[s][0], W3[kb], acc[0]);
             acc[1] = mfma16(dpl[s][NP - 1], W1[kb], acc[1]);
             acc[2] = mfma16(dpl[s][1], W2[kb], acc[2]);
-            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && a.x6_pipe >= 2) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
+            if (!RA && i == KB - 1) { __builtin_amdgcn_sched_barrier(0); if (!X6P_SYNC && X6P_GATE(a)) lds_inc(lds_tok, one); __builtin_amdgcn_sched_barrier(0); }   // three MFMAs early, see rec_fwd_x6p
             acc[0] = mfma16(dpl[s][0], W2[kb], acc[0]);
             acc[1] = mfma16(dpl[s][1], W1[kb], acc[1]);
             acc[2] = mfma16(dpl[s][0], W1[kb], acc[2]);

@@ -100,3 +100,48 @@ def test_plain_bf16_projection_rows_do_not_depend_on_the_batch():
         assert rc == 0, lib.sbr_last_error()
         outs.append(C.cpu().numpy())
     assert np.array_equal(outs[0][:100], outs[1]) and np.array_equal(outs[0][:1], outs[2])
+
+
+# (M, N, K, b_t, ws): shapes the 256 x 128 tile of gemm_x6w_kernel takes (A k-contiguous, M % 256 == N % 128 == K % 32 == 0, >= 128 workgroups)
+WIDE_SHAPES = [
+    (8192, 2048, 512, False, 0),        # layer-2 input projection (NN), scaled down from 51 200 rows
+    (8192, 512, 2048, True, 0),         # its backward, dx = dxt . W^T (NT)
+    (4096, 1024, 256, False, 0),        # C3-sized projection
+    (2048, 2048, 1024, True, 1 << 24),  # split-K slabs through the wide tile (K >= 512 and a workspace: launch_gemm's plan)
+    (4096, 1024, 96, False, 0),         # three k steps: prologue, one full step, the two peeled ones
+    (4096, 1024, 32, True, 0),          # a single k step
+]
+
+
+@pytest.mark.parametrize("planes", ["f16x3", "bf16"])
+@pytest.mark.parametrize("shape", WIDE_SHAPES)
+def test_wide_tile_equals_the_128_wide_kernel_bit_for_bit(shape, planes):
+    """gemm_x6w_kernel against gemm_x6_kernel on the same operands (sbr_debug_gemm modes 3 / 4 and 2 / 5): the same products in the same
+    order over K, so not a bit differs -- and both inside the f32-rounding class against float64 (fp16 split) or the bf16 bar."""
+    import torch
+    from sbr_amd.engine import load_library
+    lib = load_library()
+    M, N, K, b_t, wsf = shape
+    if planes == "bf16" and wsf:
+        pytest.skip("plain bf16 operands never take split-K")
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.rand((M, K), device=dev, generator=g) * 2 - 1
+    B = (torch.rand((N, K) if b_t else (K, N), device=dev, generator=g) * 2 - 1) * 0.25
+    bias = torch.rand(N, device=dev, generator=g)
+    ws = torch.empty(wsf, device=dev) if wsf else None
+    sbk, sbn = (1, K) if b_t else (N, 1)
+    out = {}
+    for mode in ((3, 4) if planes == "f16x3" else (2, 5)):
+        C = torch.full((M, N), float("nan"), device=dev)
+        rc = lib.sbr_debug_gemm(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), A.data_ptr(), K, 1, B.data_ptr(), sbk, sbn,
+                                C.data_ptr(), N, M, N, K, bias.data_ptr(), ws.data_ptr() if wsf else None, wsf, mode)
+        assert rc == 0, lib.sbr_last_error()
+        torch.cuda.synchronize()
+        out[mode] = C
+    wide, narrow = out.values()
+    assert torch.equal(wide, narrow)
+    rows = torch.arange(0, M, M // 32, device=dev)
+    ref = A[rows].double() @ (B.t() if b_t else B).double() + bias.double()
+    err = ((wide[rows].double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < (2e-6 if planes == "f16x3" else 1e-2), err
