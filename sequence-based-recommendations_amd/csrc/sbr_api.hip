@@ -139,7 +139,7 @@ int sbr_build_layout(const sbr_config& cfg, Layout& lay, std::string& err) {
         lay.a_dWc = take((size_t)lay.C * lay.HLt); lay.a_dbc = take(lay.C);
     }
     lay.a_csum = take((size_t)16 * std::max(lay.N, lay.C));
-    lay.a_prof = take((size_t)2 * (Bp / 16) * 16 * 8 * 2);
+    lay.a_prof = take((size_t)3 * (Bp / 16) * 16 * 8 * 2);      // forward | backward | the one-launch head (tools/rec_prof.py, cl_prof.py, head_prof.py)
     lay.a_fault = take(64);
     lay.a_clx = take((size_t)Bp * 8 + 64);      // handshake slots: up to Bp/4 tiles x 32 members
     lay.ws_floats = std::max((size_t)1 << 20, 64 * maxrec);
@@ -1122,7 +1122,7 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             h->head_epoch += 1; if (!h->head_epoch) h->head_epoch = 1;
             if (launch_head_cce(s, hl, h->P(y.p_WoutT), h->P(y.p_bout), tgt, h->bpop, lg, h->A(y.a_rowcost), ws, y.ws_floats,
                                 (unsigned*)h->A(y.a_hstat), (int*)h->A(y.a_fault), y.Bp, N, Nl, Hp, y.Bg, h->head_epoch, &nsl, &he,
-                                (y.cfg.flags & SBR_FLAG_PROFILE_REC) && (size_t)y.Bp * 16 >= 256 * 8 ? (unsigned long long*)h->A(y.a_prof) : nullptr)) {
+                                (y.cfg.flags & SBR_FLAG_PROFILE_REC) && (size_t)y.Bp * 16 >= 256 * 8 ? (unsigned long long*)h->A(y.a_prof) + (size_t)2 * (y.Bp / 16) * 16 * 8 : nullptr)) {
                 SBR_LAUNCH(he);
                 head_done = true;
                 if (fold) keep = nsl;
@@ -1941,6 +1941,7 @@ extern "C" int sbr_debug_buffer(sbr_handle* h, const char* name, void** dev_ptr,
     if (nm == "batch_pop") { *dev_ptr = (void*)h->bpop; *n_floats = y.Bp; return SBR_OK; }
     if (nm == "batch_samples") { *dev_ptr = (void*)h->bsmp; *n_floats = y.S; return SBR_OK; }
     if (nm == "prof") { *dev_ptr = h->A(y.a_prof); *n_floats = (size_t)2 * (y.Bp / 16) * 16 * 8 * 2; return SBR_OK; }
+    if (nm == "prof_head") { *dev_ptr = h->A(y.a_prof) + (size_t)2 * (y.Bp / 16) * 16 * 8 * 2; *n_floats = (size_t)(y.Bp / 16) * 16 * 8 * 2; return SBR_OK; }
     if (nm == "tail_trace" && h->tail_trace) { *dev_ptr = h->tail_trace; *n_floats = 2 * 16384; return SBR_OK; }
     if (nm == "tail_chain_clock") { *dev_ptr = (int*)h->A(y.a_prog) + (y.Bp / h->rpt) * 8 + 128; *n_floats = 8; return SBR_OK; }
     if (nm == "rowcost") { *dev_ptr = h->A(y.a_rowcost); *n_floats = y.Bp; return SBR_OK; }

@@ -19,7 +19,7 @@ cc = eng.query("head_fused")
 print("head_fused:", cc)
 for _ in range(4):
     eng.train_step(sync=True)
-raw = eng.debug_buffer("prof").view(np.uint64)[:256 * 8].reshape(256, 8).astype(np.int64)
+raw = eng.debug_buffer("prof_head").view(np.uint64)[:256 * 8].reshape(256, 8).astype(np.int64)
 raw = raw[: (B // 16) * cc]
 t0 = raw[:, 0].min()
 names = ["start", "W chunk in LDS", "logits", "stats published", "stats combined", "dlogits stored", "dh MFMAs", "slab stored"]

@@ -20,7 +20,7 @@ SBR_TAIL_OVERLAP=2 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --outpu
 SBR_TAIL_OVERLAP=2 timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_write -o w -- $short > $out/${tag}_pmc_write.log 2>&1
 cd $repo
 python tools/pmc_summary.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_stats > $out/${tag}_pmc.json
-timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 1500 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 tail -c 1500 $out/${tag}_bench.err
 python -c "
 import json; d=json.loads(open('$out/${tag}_bench.json').read().strip().splitlines()[-1])
