@@ -272,7 +272,8 @@ int sbr_topk(sbr_handle* h, int k, int exclude_seen, int32_t* ids_host);
  * C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]); ws: split-K workspace (may be NULL).
  * exact_f32 = 1: v_mfma_f32_16x16x4_f32 kernel; 0: bf16x6 kernel where the shape allows it; 2: plain bf16 operands (the
  * SBR_FLAG_BF16_PROJECTION kernel); 3: the two-plane fp16 split, three MFMAs per product (operands within fp16's range: what the
- * step's logits / layer GEMMs take since ABI 8). */
+ * step's logits / layer GEMMs take since ABI 8); 4 / 5: as 3 / 2 but kept on the 128-wide tile where the library would pick the
+ * 256 x 128 one (gemm_x6w_kernel; the two give the same bits: tests/test_gpu_gemm.py). */
 int sbr_debug_gemm(void* stream, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                    float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, float* ws, size_t ws_floats,
                    int32_t exact_f32);
