@@ -1690,6 +1690,18 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
     if (y.n_sparse) {
         // dense pass over everything outside the sparse blocks, then one row-sparse step per block over the rows this step
         // touched: the scatter's sorted ids / the sampled cells, or (data parallel) the ids gathered from every rank
+        // Single rank: the index-input block's row step goes FIRST, in front of the join -- its gradient rows are this stream's own
+        // work (the scatter-add), so the pass (HBM-bound, 112 us at C3) runs beside the weight-gradient GEMM the side stream is still
+        // busy with instead of behind it (round 6: C3's tail behind the chain 306 -> ~265 us)
+        bool stepped[2] = {false, false};
+        for (int b = 0; b < y.n_sparse; ++b) {
+            const SparseBlockLayout& sb = y.sparse[b];
+            if (sb.kind != 0 || h->sp_exchanged[b] || !h->side_pending || y.D != 1 || y.E) continue;      // (plain index input, one direction: the scatter-add ran on this stream)
+            const int nmax = y.T * y.Bp * y.F;
+            SBR_LAUNCH(launch_sparse_step_list(h->stream, sparse_rows(h, b), sparse_upd(h), (const int*)h->A(y.a_sid),
+                                               (const int*)h->A(y.a_soff) + y.cfg.input_size, 0, nmax, (int)h->step_count));
+            stepped[b] = true;
+        }
         { const int rc = side_join(h); if (rc != SBR_OK) return rc; }
         std::vector<std::pair<size_t, size_t>> skip;
         for (int b = 0; b < y.n_sparse; ++b)
@@ -1702,8 +1714,8 @@ extern "C" int sbr_apply_update(sbr_handle* h) {
         for (int b = 0; b < y.n_sparse; ++b) {
             const SparseBlockLayout& sb = y.sparse[b];
             const SbrSparseRows rows = sparse_rows(h, b);
-            if (sb.kind == 1 && h->wout_early) {
-                // stepped already, beside the BPTT chain (sbr_loss_backward_output)
+            if ((sb.kind == 1 && h->wout_early) || stepped[b]) {
+                // stepped already: beside the BPTT chain (sbr_loss_backward_output) / in front of the join above
             } else
             if (h->sp_exchanged[b]) {
                 SBR_LAUNCH(launch_sparse_step_list(h->stream, rows, sparse_upd(h), (const int*)h->A(sb.a_cand), nullptr, h->sp_ncand[b],
