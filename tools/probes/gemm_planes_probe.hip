@@ -127,6 +127,105 @@ __global__ void __launch_bounds__(256, 2) gemm_pl_kernel(GemmPlArgs g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same on a 256 x 128 x 32 tile (round 6, second probe): 512 threads, eight waves of 64 x 64 outputs, THREE LDS stages of 48 KB
+// ([A1 | A2: 256 rows][B1 | B2: 128 rows] x 64 bytes), the copy of k step i + 2 issued behind the one barrier of step i, each wave six
+// 1 KB pieces per stage.  No split, no operand registers in flight, plane-0 fragments first so that the first sixteen MFMAs start while
+// plane 1 is still being read.
+// ---------------------------------------------------------------------------------------
+#define GPW_STAGE 49152
+__global__ void __launch_bounds__(512, 1) gemm_pl256_kernel(GemmPlArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char sm_pw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 15, q = lane >> 4;
+    const int tiles_n = g.N / 128, nt = (g.M / 256) * tiles_n;
+    int lin = blockIdx.x;
+    if ((nt & 7) == 0) lin = (lin & 7) * (nt >> 3) + (lin >> 3);
+    const int m0 = (lin / tiles_n) * 256, n0 = (lin % tiles_n) * 128;
+    // this wave's six pieces of a stage: piece p = 6 wave + i; p < 16: A1 rows 16 p .., < 32: A2, < 40: B1, else B2
+    const char* pb[6]; unsigned pl[6]; bool isb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int p = wave * 6 + i;
+        const _Float16* src = p < 16 ? g.A1 : p < 32 ? g.A2 : p < 40 ? g.B1 : g.B2;
+        const int rb = p < 16 ? p : p < 32 ? p - 16 : p < 40 ? p - 32 : p - 40;
+        isb[i] = p >= 32;
+        const long ld = isb[i] ? g.ldb : g.lda;
+        pb[i] = (const char*)(src + ((long)(isb[i] ? n0 : m0) + rb * 16) * ld);
+        pl[i] = (unsigned)p * 1024u;
+    }
+    const unsigned swz = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    const unsigned voa = (unsigned)((long)(lane >> 2) * g.lda * 2) + swz, vob = (unsigned)((long)(lane >> 2) * g.ldb * 2) + swz;
+    const unsigned lds0 = (unsigned)(size_t)sm_pw;
+    auto issue = [&](int k0, int stage) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) lds_dma_x4(lds0 + stage * GPW_STAGE + pl[i], pb[i] + (long)k0 * 2, isb[i] ? vob : voa, ~0ull);
+    };
+    unsigned fa[4], fb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ra = wm * 64 + t * 16 + j, rb = wn * 64 + t * 16 + j;
+        fa[t] = (unsigned)(ra * 64 + ((q ^ ((ra >> 2) & 3)) << 4));
+        fb[t] = (unsigned)(32768 + rb * 64 + ((q ^ ((rb >> 2) & 3)) << 4));
+    }
+    const f32x4 z = f32x4{0, 0, 0, 0};
+    f32x4 acc[4][4], acl[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { acc[a][b] = z; acl[a][b] = z; }
+    const int ns = g.K / 32;
+    issue(0, 0);
+    if (ns > 1) issue(32, 1);
+    int st = 0;
+    for (int i = 0; i < ns; ++i) {
+        if (i + 1 < ns) wait_vm<6>(); else wait_vm<0>();          // this wave's pieces of stage i (the counter retires in order)
+        __syncthreads();                                          // ... everybody's; and everybody has read stage i - 1
+        if (i + 2 < ns) issue((i + 2) * 32, st == 0 ? 2 : st - 1);
+        const char* sp = sm_pw + st * GPW_STAGE;
+        f16x8p a1[4], a2[4], b1[4], b2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a1[t] = *(const f16x8p*)(sp + fa[t]); b1[t] = *(const f16x8p*)(sp + fb[t]); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a2[t] = *(const f16x8p*)(sp + 16384 + fa[t]); b2[t] = *(const f16x8p*)(sp + 8192 + fb[t]); }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acl[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2[ni], a1[mi], acl[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acl[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[ni], a2[mi], acl[mi][ni], 0, 0, 0);
+        st = st == 2 ? 0 : st + 1;
+    }
+    float* out = g.C + (long)m0 * g.ldc + n0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = wn * 64 + ni * 16 + 4 * q;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(acl[mi][ni][r], 1.0f / 2048.0f, acc[mi][ni][r]) * g.so;
+            if (g.bias) { const f32x4 bv = *(const f32x4*)(g.bias + n0 + n); v += bv; }
+            *(f32x4*)(out + (long)(wm * 64 + mi * 16 + j) * g.ldc + n) = v;
+        }
+}
+bool launch_gemm_planes256(hipStream_t s, const _Float16* A1, const _Float16* A2, long lda, const _Float16* B1, const _Float16* B2, long ldb,
+                           float* C, long ldc, int M, int N, int K, const float* bias, float so, hipError_t* err) {
+    if ((M & 255) || (N & 127) || (K & 31) || (lda & 7) || (ldb & 7) || (ldc & 3)) return false;
+    if ((long)16 * lda * 2 >= (1l << 31) || (long)16 * ldb * 2 >= (1l << 31)) return false;
+    GemmPlArgs g{A1, A2, lda, B1, B2, ldb, C, ldc, bias, M, N, K, so};
+    (void)hipFuncSetAttribute((const void*)gemm_pl256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GPW_STAGE);
+    gemm_pl256_kernel<<<dim3((M / 256) * (N / 128)), 512, 3 * GPW_STAGE, s>>>(g);
+    *err = hipGetLastError();
+    return true;
+}
+
 // true = launched (err holds the launch status); false: shape / alignment not served
 bool launch_gemm_planes(hipStream_t s, const _Float16* A1, const _Float16* A2, long lda, const _Float16* B1, const _Float16* B2, long ldb,
                         float* C, long ldc, int M, int N, int K, const float* bias, float so, hipError_t* err) {
@@ -195,9 +294,13 @@ int main() {
     launch_split_planes(0, dB, N, K, N, 1.0f, b1, b2, K, true, 0);
     hipError_t e = hipSuccess;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) launch_gemm_planes(0, a1, a2, K, b1, b2, K, dC, N, M, N, K, nullptr, 1.0f, &e);
+    for (int which = 0; which < 2; ++which) {
+    hipMemset(dC, 0, (size_t)M * N * 4);
+    auto go = [&]() { if (which) launch_gemm_planes256(0, a1, a2, K, b1, b2, K, dC, N, M, N, K, nullptr, 1.0f, &e);
+                      else launch_gemm_planes(0, a1, a2, K, b1, b2, K, dC, N, M, N, K, nullptr, 1.0f, &e); };
+    for (int i = 0; i < 3; ++i) go();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) launch_gemm_planes(0, a1, a2, K, b1, b2, K, dC, N, M, N, K, nullptr, 1.0f, &e);
+    for (int i = 0; i < 10; ++i) go();
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     std::vector<float> hC((size_t)N);
@@ -209,7 +312,9 @@ int main() {
             worst = fmax(worst, fabs(s - hC[n])); big = fmax(big, fabs(s));
         }
     }
-    printf("planes GEMM %d x %d x %d: %.1f us, %.1f TFLOP/s f32-equivalent, max error %.2e of the largest entry (%s)\n", M, N, K, ms * 100.0,
+    printf("planes GEMM (%s tile) %d x %d x %d: %.1f us, %.1f TFLOP/s f32-equivalent, max error %.2e of the largest entry (%s)\n",
+           which ? "256 x 128, three stages" : "128 x 128, two stages", M, N, K, ms * 100.0,
            2.0 * M * N * K / (ms * 100.0) / 1e6, worst / big, hipGetErrorString(e));
+    }
     return 0;
 }
