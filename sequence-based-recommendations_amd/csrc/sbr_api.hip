@@ -478,6 +478,12 @@ extern "C" int sbr_create(const sbr_config* cfg, void* arena, size_t arena_bytes
 
 extern "C" void sbr_destroy(sbr_handle* h) {
     if (!h) return;
+    // work still in flight may write into what is freed below (the lagged step's report into pinned memory, a batch build into the
+    // arena's second set): let every stream of the engine drain first
+    (void)hipStreamSynchronize(h->stream);
+    if (h->side) (void)hipStreamSynchronize(h->side);
+    if (h->side2) (void)hipStreamSynchronize(h->side2);
+    if (h->side3) (void)hipStreamSynchronize(h->side3);
     for (int r = 0; r < sbr_handle::kRing; ++r)
         for (int i = 0; i < SBR_N_PHASES; ++i) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
     for (int r = 0; r < sbr_handle::kChain; ++r)
