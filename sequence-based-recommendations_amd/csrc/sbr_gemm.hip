@@ -397,9 +397,12 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const float* __restrict__ hs
         else { bsrc[b] = dxt + n + j; bld[b] = GHp; }
     }
     const float* asrc = hs + m0 + j;
-    // fragments of k-step p+4 are fetched before the MFMAs of k-step p (register double buffer): with one
-    // workgroup per CU nothing else hides the L2/HBM latency of these loads
-    float af[2][MT], bf[2][NT];
+    // fragments of later k-steps (4 positions each) are fetched before the MFMAs of k-step p: with one workgroup per CU nothing
+    // else hides the L2/HBM latency of these loads.  How many k-steps ahead depends on what a step holds: the small layers (C1:
+    // one float of A and two of B per lane and step) were a chain of exposed round trips with one step in flight -- 47 us for
+    // 33 MB at LSTM-20 (profiles/round6_variants.txt, call y); S stages in flight, S - 1 steps ahead.
+    constexpr int S = MT + NT <= 3 ? 8 : MT + NT <= 6 ? 4 : 2;
+    float af[S][MT], bf[S][NT];
     auto fetch = [&](int p, int s) {
         const int pos = p + q;
         const bool ok = pos < pend;
@@ -414,16 +417,16 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const float* __restrict__ hs
 #pragma unroll
             for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][a], bf[s][b], acc[a][b], 0, 0, 0);
     };
-    fetch(pbeg, 0);
-    for (int p = pbeg; p < pend; p += 8) {
-        fetch(p + 4, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(p + 8, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) fetch(pbeg + 4 * s, s);
+    for (int p = pbeg; p < pend; p += 4 * S) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                      // (steps past the slice fetch zeros: their MFMAs add nothing)
+            fetch(p + 4 * (s + S - 1), (s + S - 1) % S);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     asm volatile("s_nop 15");
     float* out = slabs + (size_t)blockIdx.x * Hp * GHp;
