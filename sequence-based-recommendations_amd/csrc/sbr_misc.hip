@@ -448,6 +448,8 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
                                                           const int* __restrict__ spos, const int* __restrict__ offs,
                                                           int n_ids, float* __restrict__ dWin, int R4, int Bp, int key_lo = 0,
                                                           int n_tchunks = 1, SbrTChunks tch = SbrTChunks(), SbrPoll poll = SbrPoll()) {
+    // rows in flight per wave: narrow rows (NV = 1: at most 256 floats, C1's are 128) are latency, not bytes -- 16 of them
+    constexpr int FLY = (NV == 1 && !POLL) ? 16 : SCAT_FLY;
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int total = offs[POLL ? n_ids * n_tchunks : key_lo + n_ids];
@@ -520,11 +522,11 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
             acc[v] = f32x4{0, 0, 0, 0};
         }
     };
-    for (int i = 0; i < cnt; i += SCAT_FLY) {
-        f32x4 val[SCAT_FLY][NV];
-        int ids[SCAT_FLY];
+    for (int i = 0; i < cnt; i += FLY) {
+        f32x4 val[FLY][NV];
+        int ids[FLY];
 #pragma unroll
-        for (int u = 0; u < SCAT_FLY; ++u) {                 // rows in flight
+        for (int u = 0; u < FLY; ++u) {                 // rows in flight
             const int ii = min(i + u, cnt - 1);
             ids[u] = __shfl(my_id, ii);
             const size_t pos = (size_t)__shfl(my_pos, ii);
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
         if constexpr (POLL) {      // (the loads above are invisible to the compiler's waitcnt insertion)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < SCAT_FLY; ++u)
+            for (int u = 0; u < FLY; ++u)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     asm volatile("" : "+v"(val[u][v]));
@@ -547,7 +549,7 @@ __global__ void __launch_bounds__(256) scat_reduce_kernel(const f32x4* __restric
                 }
         }
 #pragma unroll
-        for (int u = 0; u < SCAT_FLY; ++u) {
+        for (int u = 0; u < FLY; ++u) {
             if (i + u < cnt) {                                 // wave-uniform
                 if (ids[u] != cur_id) { flush(cur_id); cur_id = ids[u]; }
 #pragma unroll
@@ -1138,7 +1140,9 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate, int acc_chunk) {
     const int R4 = GHp / 4;
     const int chunk_env = 0;
-    const int chunk = (accumulate || key_lo) ? (acc_chunk == 16 ? 16 : 32) : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : 32);
+    // narrow rows (at most 256 floats): 64 entries per wave -- what the launch waits for there is the float atomics of the chunks that hold
+    // a piece of a hot id (every such chunk adds its partial row onto the same addresses), and twice the entries per chunk is half of them
+    const int chunk = (accumulate || key_lo) ? (acc_chunk == 16 ? 16 : 32) : ((chunk_env == 16 || chunk_env == 32 || chunk_env == 64) ? chunk_env : (R4 <= 64 ? 64 : 32));
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
