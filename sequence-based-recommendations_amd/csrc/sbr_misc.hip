@@ -1136,6 +1136,106 @@ bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const in
     return true;
 }
 
+// The plain scatter-add of rows up to 512 floats (round 6): scat_reduce_kernel's walk, 64 sorted entries per wave, with the partial rows
+// of the segments that cross a wave's chunk COMBINED inside the workgroup before anything is added to memory.  A hot id spans many
+// chunks, and every one of them used to add its partial row onto the same addresses with float atomics -- at C1 (3 706 ids, the hottest
+// with thousands of the step's 51 200 entries) that serialisation was most of the launch (41 us for 26 MB).  Here the W waves of a
+// workgroup take W consecutive chunks, leave at most two open partial rows each (the segment that began before the chunk, the one that
+// goes on behind it) in LDS, and one wave adds up the runs of equal ids: a run that lies inside the workgroup's entries is STORED, only
+// the runs that cross a workgroup boundary are added atomically -- W times fewer atomics on the hot rows.
+template <int NV>
+__global__ void __launch_bounds__(NV == 1 ? 1024 : 512) scat_reduce_comb_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
+                                                                              const int* __restrict__ spos, const int* __restrict__ offs,
+                                                                              int n_ids, float* __restrict__ dWin, int R4) {
+    constexpr int CH = 64, FLY = NV == 1 ? 16 : 8, W = NV == 1 ? 16 : 8;
+    __shared__ f32x4 slot[2 * W][NV * 64];
+    __shared__ int slot_id[2 * W];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2 * W) slot_id[threadIdx.x] = -1;
+    __syncthreads();
+    const int total = offs[n_ids];
+    const int wg_base = blockIdx.x * W * CH, wg_end = min(total, wg_base + W * CH);
+    const int base = wg_base + wave * CH;
+    auto row_out = [&](int key, const f32x4 (&a)[NV], bool store) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f4 = lane + 64 * v;
+            if (f4 < R4) {
+                float* dst = dWin + ((size_t)key * R4 + f4) * 4;
+                if (store) *(f32x4*)dst = a[v];
+                else { atomicAdd(dst, a[v][0]); atomicAdd(dst + 1, a[v][1]); atomicAdd(dst + 2, a[v][2]); atomicAdd(dst + 3, a[v][3]); }
+            }
+        }
+    };
+    if (base < total) {
+        const int cnt = min(CH, total - base);
+        const int e = base + lane;
+        const int my_id = lane < cnt ? sid[e] : -1;
+        const int my_pos = lane < cnt ? spos[e] : 0;
+        f32x4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
+        int cur_id = __shfl(my_id, 0);
+        auto flush = [&](int key) {
+            const int o0 = offs[key], o1 = offs[key + 1];
+            if (o0 >= base && o1 <= base + cnt) row_out(key, acc, true);        // the whole segment inside this chunk
+            else {
+                const int sl = wave * 2 + (o0 < base ? 0 : 1);                  // began before the chunk | goes on behind it
+#pragma unroll
+                for (int v = 0; v < NV; ++v) slot[sl][lane + 64 * v] = acc[v];
+                if (lane == 0) slot_id[sl] = key;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
+        };
+        for (int i = 0; i < cnt; i += FLY) {
+            f32x4 val[FLY][NV];
+            int ids[FLY];
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                const int ii = min(i + u, cnt - 1);
+                ids[u] = __shfl(my_id, ii);
+                const size_t pos = (size_t)__shfl(my_pos, ii);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int f4 = lane + 64 * v;
+                    val[u][v] = f4 < R4 ? dxt[pos * R4 + f4] : f32x4{0, 0, 0, 0};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                if (i + u < cnt) {                                 // wave-uniform
+                    if (ids[u] != cur_id) { flush(cur_id); cur_id = ids[u]; }
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] += val[u][v];
+                }
+            }
+        }
+        flush(cur_id);
+    }
+    __syncthreads();
+    if (wave == 0) {       // runs of equal ids among the open partial rows, in entry order
+        int cur = -1;
+        f32x4 sum[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sum[v] = f32x4{0, 0, 0, 0};
+        auto out = [&](int key) { row_out(key, sum, offs[key] >= wg_base && offs[key + 1] <= wg_end); };
+        for (int sl = 0; sl < 2 * W; ++sl) {
+            const int id = slot_id[sl];                            // (uniform)
+            if (id < 0) continue;
+            if (id != cur) {
+                if (cur >= 0) out(cur);
+                cur = id;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) sum[v] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) sum[v] += slot[sl][lane + 64 * v];
+        }
+        if (cur >= 0) out(cur);
+    }
+}
+
 hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, const int* sid, const int* spos,
                                  const int* offs, int n_ids, int max_entries, int GHp, int Bp, int key_lo, bool accumulate, int acc_chunk) {
     const int R4 = GHp / 4;
@@ -1146,6 +1246,13 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
+    // plain launch, rows of 257 .. 512 floats: the combining form (C2's shape alone on the chip: 43.4 -> 29.4 us).  Rows up to 256 floats
+    // stay on the walk below: alone 26.4 -> 24.5 us with the combining form, but C1's step, where the launch runs beside the weight-gradient
+    // kernel, 0.2981 / 0.2998 -> 0.3020 / 0.3022 ms (profiles/round6_variants.txt, call y)
+    if (!accumulate && !key_lo && nv == 2 && max_entries > 0) {
+        scat_reduce_comb_kernel<2><<<(max_entries + 511) / 512, 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
+        return hipGetLastError();
+    }
 #define SR(NV) do { if ((accumulate || key_lo) && chunk == 16) scat_reduce_kernel<NV, 16, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
                     else if (accumulate || key_lo) scat_reduce_kernel<NV, 32, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
                     else if (chunk == 16) scat_reduce_kernel<NV, 16><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp); \
