@@ -1136,7 +1136,7 @@ bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const in
     return true;
 }
 
-// The plain scatter-add of rows up to 512 floats (round 6): scat_reduce_kernel's walk, 64 sorted entries per wave, with the partial rows
+// The plain scatter-add of rows up to 512 floats (round 6): scat_reduce_kernel's walk, 32 sorted entries per wave, with the partial rows
 // of the segments that cross a wave's chunk COMBINED inside the workgroup before anything is added to memory.  A hot id spans many
 // chunks, and every one of them used to add its partial row onto the same addresses with float atomics -- at C1 (3 706 ids, the hottest
 // with thousands of the step's 51 200 entries) that serialisation was most of the launch (41 us for 26 MB).  Here the W waves of a
@@ -1147,7 +1147,13 @@ template <int NV>
 __global__ void __launch_bounds__(NV == 1 ? 1024 : 512) scat_reduce_comb_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                                               const int* __restrict__ spos, const int* __restrict__ offs,
                                                                               int n_ids, float* __restrict__ dWin, int R4) {
-    constexpr int CH = 64, FLY = NV == 1 ? 16 : 8, W = NV == 1 ? 16 : 8;
+#ifndef COMB_CH
+#define COMB_CH 32      // sorted entries per wave: 64 / 32 / 16 -> 29.3 / 21.5 / 22.6 us at C2 (profiles/round6_variants.txt, call y)
+#endif
+#ifndef COMB_FLY
+#define COMB_FLY 8
+#endif
+    constexpr int CH = COMB_CH, FLY = NV == 1 ? 16 : COMB_FLY, W = NV == 1 ? 16 : 8;
     __shared__ f32x4 slot[2 * W][NV * 64];
     __shared__ int slot_id[2 * W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1250,7 +1256,7 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
     // stay on the walk below: alone 26.4 -> 24.5 us with the combining form, but C1's step, where the launch runs beside the weight-gradient
     // kernel, 0.2981 / 0.2998 -> 0.3020 / 0.3022 ms (profiles/round6_variants.txt, call y)
     if (!accumulate && !key_lo && nv == 2 && max_entries > 0) {
-        scat_reduce_comb_kernel<2><<<(max_entries + 511) / 512, 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
+        scat_reduce_comb_kernel<2><<<(max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH), 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
         return hipGetLastError();
     }
 #define SR(NV) do { if ((accumulate || key_lo) && chunk == 16) scat_reduce_kernel<NV, 16, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
