@@ -1144,7 +1144,7 @@ bool launch_scatter_range(hipStream_t s, float* dWin, const float* dxt, const in
 // goes on behind it) in LDS, and one wave adds up the runs of equal ids: a run that lies inside the workgroup's entries is STORED, only
 // the runs that cross a workgroup boundary are added atomically -- W times fewer atomics on the hot rows.
 template <int NV>
-__global__ void __launch_bounds__(NV == 1 ? 1024 : 512) scat_reduce_comb_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
+__global__ void __launch_bounds__(512) scat_reduce_comb_kernel(const f32x4* __restrict__ dxt, const int* __restrict__ sid,
                                                                               const int* __restrict__ spos, const int* __restrict__ offs,
                                                                               int n_ids, float* __restrict__ dWin, int R4) {
 #ifndef COMB_CH
@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(NV == 1 ? 1024 : 512) scat_reduce_comb_kernel(
 #ifndef COMB_FLY
 #define COMB_FLY 8
 #endif
-    constexpr int CH = COMB_CH, FLY = NV == 1 ? 16 : COMB_FLY, W = NV == 1 ? 16 : 8;
+    constexpr int CH = COMB_CH, FLY = COMB_FLY, W = 8;
     __shared__ f32x4 slot[2 * W][NV * 64];
     __shared__ int slot_id[2 * W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1252,11 +1252,12 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
     const int chunks = (max_entries + chunk - 1) / chunk;
     const int grid = (chunks + 3) / 4;
     const int nv = (R4 + 63) / 64;
-    // plain launch, rows of 257 .. 512 floats: the combining form (C2's shape alone on the chip: 43.4 -> 29.4 us).  Rows up to 256 floats
-    // stay on the walk below: alone 26.4 -> 24.5 us with the combining form, but C1's step, where the launch runs beside the weight-gradient
-    // kernel, 0.2981 / 0.2998 -> 0.3020 / 0.3022 ms (profiles/round6_variants.txt, call y)
-    if (!accumulate && !key_lo && nv == 2 && max_entries > 0) {
-        scat_reduce_comb_kernel<2><<<(max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH), 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
+    // plain launch, rows up to 512 floats: the combining form, 8 waves x 32 entries per workgroup (alone on the chip: C2's shape 43.4 -> 21.5 us,
+    // C1's 26.9 -> 14.8; C1's step 0.298 -> 0.286 ms: profiles/round6_variants.txt, call y).  (16 waves x 64 entries measured slower inside C1's
+    // step than the walk below, which now serves the accumulating / keyed launches and wider rows only.)
+    if (!accumulate && !key_lo && nv <= 2 && max_entries > 0) {
+        if (nv == 1) scat_reduce_comb_kernel<1><<<(max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH), 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
+        else scat_reduce_comb_kernel<2><<<(max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH), 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
         return hipGetLastError();
     }
 #define SR(NV) do { if ((accumulate || key_lo) && chunk == 16) scat_reduce_kernel<NV, 16, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
