@@ -1153,15 +1153,21 @@ __global__ void __launch_bounds__(512) scat_reduce_comb_kernel(const f32x4* __re
 #ifndef COMB_FLY
 #define COMB_FLY 8
 #endif
-    constexpr int CH = COMB_CH, FLY = COMB_FLY, W = 8;
-    __shared__ f32x4 slot[2 * W][NV * 64];
-    __shared__ int slot_id[2 * W];
+    constexpr int CH = COMB_CH, FLY = NV >= 8 ? 2 : NV >= 4 ? 4 : COMB_FLY, W = 8;      // (wide rows: fewer in flight, the pieces stay near 64 registers)
+    extern __shared__ __attribute__((aligned(16))) char comb_lds[];
+    f32x4 (*slot)[NV * 64] = (f32x4 (*)[NV * 64])comb_lds;                         // [2 W][NV * 64]
+    int* slot_id = (int*)(comb_lds + (size_t)2 * W * NV * 64 * sizeof(f32x4));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 2 * W) slot_id[threadIdx.x] = -1;
     __syncthreads();
     const int total = offs[n_ids];
     const int wg_base = blockIdx.x * W * CH, wg_end = min(total, wg_base + W * CH);
     const int base = wg_base + wave * CH;
+    // Whether a segment ends inside a chunk / a run inside the workgroup is read off the NEIGHBOURING entries' ids (the entries are sorted),
+    // two loads per wave up front -- not off offs[key], offs[key + 1] at every flush: with a million ids those were two dependent trips to
+    // HBM per distinct id of the chunk (C5: ~30 per wave), most of the launch.
+    const int wg_prev = (wave == 0 && wg_base > 0 && wg_base < total) ? sid[wg_base - 1] : -1;
+    const int wg_next = (wave == 0 && wg_end < total) ? sid[wg_end] : -1;
     auto row_out = [&](int key, const f32x4 (&a)[NV], bool store) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -1178,15 +1184,15 @@ __global__ void __launch_bounds__(512) scat_reduce_comb_kernel(const f32x4* __re
         const int e = base + lane;
         const int my_id = lane < cnt ? sid[e] : -1;
         const int my_pos = lane < cnt ? spos[e] : 0;
+        const int prev_id = base > 0 ? sid[base - 1] : -1, next_id = base + cnt < total ? sid[base + cnt] : -1;      // (uniform)
         f32x4 acc[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = f32x4{0, 0, 0, 0};
         int cur_id = __shfl(my_id, 0);
         auto flush = [&](int key) {
-            const int o0 = offs[key], o1 = offs[key + 1];
-            if (o0 >= base && o1 <= base + cnt) row_out(key, acc, true);        // the whole segment inside this chunk
+            if (key != prev_id && key != next_id) row_out(key, acc, true);      // the whole segment inside this chunk
             else {
-                const int sl = wave * 2 + (o0 < base ? 0 : 1);                  // began before the chunk | goes on behind it
+                const int sl = wave * 2 + (key == prev_id ? 0 : 1);             // began before the chunk | goes on behind it
 #pragma unroll
                 for (int v = 0; v < NV; ++v) slot[sl][lane + 64 * v] = acc[v];
                 if (lane == 0) slot_id[sl] = key;
@@ -1225,7 +1231,7 @@ __global__ void __launch_bounds__(512) scat_reduce_comb_kernel(const f32x4* __re
         f32x4 sum[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) sum[v] = f32x4{0, 0, 0, 0};
-        auto out = [&](int key) { row_out(key, sum, offs[key] >= wg_base && offs[key + 1] <= wg_end); };
+        auto out = [&](int key) { row_out(key, sum, key != wg_prev && key != wg_next); };      // a run inside the workgroup's entries: stored
         for (int sl = 0; sl < 2 * W; ++sl) {
             const int id = slot_id[sl];                            // (uniform)
             if (id < 0) continue;
@@ -1255,9 +1261,12 @@ hipError_t launch_scatter_reduce(hipStream_t s, float* dWin, const float* dxt, c
     // plain launch, rows up to 512 floats: the combining form, 8 waves x 32 entries per workgroup (alone on the chip: C2's shape 43.4 -> 21.5 us,
     // C1's 26.9 -> 14.8; C1's step 0.298 -> 0.286 ms: profiles/round6_variants.txt, call y).  (16 waves x 64 entries measured slower inside C1's
     // step than the walk below, which now serves the accumulating / keyed launches and wider rows only.)
-    if (!accumulate && !key_lo && nv <= 2 && max_entries > 0) {
-        if (nv == 1) scat_reduce_comb_kernel<1><<<(max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH), 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
-        else scat_reduce_comb_kernel<2><<<(max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH), 512, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4);
+    if (!accumulate && !key_lo && (nv <= 2 || nv == 4 || nv == 8) && max_entries > 0) {
+        const int grid = (max_entries + 8 * COMB_CH - 1) / (8 * COMB_CH);
+#define SRC(NV) do { const size_t lds = (size_t)16 * NV * 64 * sizeof(f32x4) + 64; SBR_DYN_LDS(scat_reduce_comb_kernel<NV>, lds); \
+                     scat_reduce_comb_kernel<NV><<<grid, 512, lds, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4); } while (0)
+        if (nv == 1) SRC(1); else if (nv == 2) SRC(2); else if (nv == 4) SRC(4); else SRC(8);
+#undef SRC
         return hipGetLastError();
     }
 #define SR(NV) do { if ((accumulate || key_lo) && chunk == 16) scat_reduce_kernel<NV, 16, true><<<grid, 256, 0, s>>>((const f32x4*)dxt, sid, spos, offs, n_ids, dWin, R4, Bp, key_lo); \
