@@ -1077,6 +1077,9 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
             }
             SBR_HIP(hipEventRecord(h->ev_fill, sd)); h->fill_done = true;
         }
+        // (round 6, call s3: the sort BEHIND the head's record instead of beside the head lets the one-launch sampled head run in 26 us
+        // instead of 24 .. 72 by workgroup -- the sort's counting kernels are all atomics -- but beside the BPTT chain it costs the chain
+        // more: rec_bwd_c16 375 -> 441 us at C3, 390 -> 404 at C4.  It stays here.)
         if (h->tail_nc >= 2) {
             // overlapped tail: the time-chunked sort runs on the SECOND side stream, which consumes it (scatter-add beside the
             // chain); that stream is released by the same record as the first one
@@ -1219,16 +1222,28 @@ extern "C" int sbr_loss_backward_output(sbr_handle* h) {
         }
         h->cells_early = false;
         SBR_LAUNCH(launch_gather_rows(s, h->P(y.p_WoutT), h->P(y.p_bout), cells, C, Hp, Wc, bc));
+        // Round 6: activations, loss, its gradient and dh in ONE launch where the shape allows it (head_sampled_kernel, sbr_head.hip):
+        // four launches on twenty workgroups each were 113 us between the two chains of C3.  SBR_HEAD_FUSE=0: the launches below.
+        bool head1 = false;
+        if (h->head_fuse && !sg && y.D == 1 && !(y.cfg.flags & SBR_FLAG_F32_MFMA)) {
+            hipError_t he = hipSuccess;
+            head1 = launch_head_sampled(s, hl, Wc, bc, h->bpop, act, h->A(y.a_rowcost), h->A(y.a_dhlast), R, C, Hp, y.Bg, y.S,
+                                        y.cfg.row_offset, y.cfg.loss, y.Bg, &he,
+                                        (y.cfg.flags & SBR_FLAG_PROFILE_REC) ? (unsigned long long*)h->A(y.a_prof) + (size_t)2 * (y.Bp / 16) * 16 * 8 : nullptr);
+            if (head1) SBR_LAUNCH(he);
+        }
+        if (!head1) {
         SBR_LAUNCH(launch_gemm(s, hl, Hp, 1, Wc, 1, Hp, act, C, R, C, Hp, nullptr, nullptr, 0, sg));
         SBR_LAUNCH(launch_sampled_loss(s, act, bc, h->bpop, h->A(y.a_rowcost), R, y.Bg, y.S, y.cfg.row_offset,
                                        y.cfg.loss, y.Bg));
+        }
         // Round 5: dh feeds the BPTT chain, everything else here only feeds the optimizer -- cost sum, bias column sums, the dWc GEMM
         // and the scatter of the cells' gradients (5 launches, ~75 us at C3 beside the side stream's sort) leave the main stream: dh
         // first, one record, the rest on the side stream beside the chain (as the dense heads always did).  SBR_SAMPLED_SIDE=0: rounds 1 - 4.
         const int sampled_side = 1;
         hipStream_t sg_s = sampled_side ? sd : s;
         if (sampled_side) {
-            SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
+            if (!head1) SBR_LAUNCH(launch_gemm(s, act, C, 1, Wc, Hp, 1, h->A(y.a_dhlast), Hp, R, Hp, C, nullptr, nullptr, 0, sg));
             h->ev_lg_rec = record_shared(h, h->ev_lg, 3); h->lg_seq = h->batch_seq;
             SBR_HIP(hipStreamWaitEvent(sd, h->ev_lg_rec, 0));
         }

@@ -478,6 +478,10 @@ bool launch_wgrad_slabs(hipStream_t s, const float* hs, const float* dxt, const 
 
 // sbr_head.hip: logits + softmax / CCE + dh of a full-softmax head in one launch (C1 / C2-class catalogues); false: not served
 bool sbr_head_plan(int Bp, int N, int Hp, int* CC, int* CW, size_t* lds_bytes);
+// the sampled head in one launch (sbr_head.hip: head_sampled_kernel); false: shape not served, nothing launched
+bool launch_head_sampled(hipStream_t s, const float* h, const float* Wc, const float* bc, const float* pop, float* act, float* rowcost,
+                         float* dh, int rows, int C, int Hp, int Bg, int S, int row_offset, int loss, int Bglobal, hipError_t* err,
+                         unsigned long long* prof = nullptr);
 bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const float* bout, const int* tgt, const float* pop, float* dlogits,
                      float* rowcost, float* slabs, size_t slab_floats, unsigned* stats, int* fault, int Bp, int N, int Nl, int Hp, int Bglobal,
                      unsigned epoch, int* n_slabs, hipError_t* err, unsigned long long* prof = nullptr);

@@ -356,3 +356,268 @@ bool launch_head_cce(hipStream_t s, const float* h, const float* WoutT, const fl
     *err = hipGetLastError();
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The SAMPLED head of one training step in one launch (round 6): activations of the C = Bg + S sampled cells, the sampled loss
+// and its gradient, dh -- rnn_sampling.py:52-91 (Blackout / BPR / TOP1), rnn_cluster.py:158-175 (the cluster model's three).
+// Before: four launches on the main stream between the two recurrent chains -- the activations GEMM 256 x 288 x Hp on twenty
+// workgroups (36 us at C3, 58 at C5), sampled_loss_kernel (27 / 9), the dh GEMM (14 / 51), their gaps: 113 us of C3's 1.17 ms.
+// Nothing in that work crosses batch rows, so a workgroup owns 16 rows and ALL cells (C <= 320: five 16-cell tiles per wave):
+//   1. act[item][row] = sum_k Wc[item][k] h[row][k] on v_mfma_f32_16x16x4_f32 (exact f32 products), the gathered rows read straight
+//      from memory: a lane's 16-byte piece holds the k slots of four instructions (head_logits above), one tile's sixteen (Hp = 256)
+//      pieces per lane in flight; h rows in registers.  A lane ends with four consecutive cells of one batch row.
+//   2. the loss row by row: what a row needs from its other cells (maximum, sums, the positive's activation) crosses the lanes of
+//      a row by shuffles and the four waves through LDS, two or three rounds; the gradient replaces the activations in the
+//      registers -- the layout the next phase multiplies with -- and is stored for the side stream's dWc GEMM.
+//   3. dh[row][k] = sum_items dact[row][item] Wc[item][k]: the cell is the reduction index, and the same 16-byte pieces serve
+//      again with the k of a tile PERMUTED (instruction 4 m + s of a lane's piece at 64 m + 4 j holds k = 64 m + 4 i + s for output
+//      row i); the four waves' partial sums meet in LDS and leave as the finished dh rows.
+// Bound by what one CU can pull: the gathered rows (0.3 MB at C3, 0.6 at C5) twice per workgroup.
+// Served: Hp in {128, 256, 512}, full 16-row blocks, C <= 320, one direction.  Everything else keeps the four launches.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SampArgs {
+    const float* h; const float* Wc; const float* bc; const float* pop;
+    float* act;            // [rows][C]  out: d cost / d act
+    float* rowcost;        // [rows]
+    float* dh;             // [rows][HP]
+    int C, Bg, S, row_offset, loss;
+    float inv_Bglobal;
+    unsigned long long* prof;   // SBR_FLAG_PROFILE_REC: [workgroup][8] stamps of the 100 MHz clock (tools/head_prof.py c3), else NULL
+};
+
+// NW waves: eight where the partial dh rows of eight waves fit LDS (Hp <= 256) -- a wave's tiles are a serial chain of (sixteen loads ->
+// 64 MFMAs), and sixteen workgroups are all the launch has: 73 us with four waves at C3 (profiles/round6_variants.txt, call s2)
+template <int HP, int NW>
+__global__ void __launch_bounds__(64 * NW) head_sampled_kernel(SampArgs a) {
+    constexpr int KG = HP / 16, NT = (20 + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) float slds[];       // [NW][16][HP] partial dh | [3][NW][16] row reductions
+    float* part = slds;
+    float* red = slds + NW * 16 * HP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + j, C = a.C, ntiles = (C + 15) >> 4;
+#define SAMP_STAMP(I) do { if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 8 + (I)] = wall_clock64(); } while (0)
+    SAMP_STAMP(0);
+    f32x4 hb[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) hb[g] = *(const f32x4*)(a.h + (size_t)row * HP + 16 * g + 4 * q);
+    // ---- 1. activations of this wave's tiles (tile t = wave + 4 i)
+    f32x4 lg[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = wave + NW * i;
+        f32x4 acc = f32x4{0, 0, 0, 0};
+        if (t < ntiles) {                                              // (wave-uniform)
+            const int item = 16 * t + j;
+            const float* wr = a.Wc + (size_t)min(item, C - 1) * HP + 4 * q;
+            f32x4 wv[KG];
+#pragma unroll
+            for (int g = 0; g < KG; ++g) wv[g] = *(const f32x4*)(wr + 16 * g);
+            if (item >= C) {
+#pragma unroll
+                for (int g = 0; g < KG; ++g) wv[g] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g][m], hb[g][m], acc, 0, 0, 0);
+        }
+        lg[i] = acc;
+    }
+    asm volatile("s_nop 15");                                          // MFMA D -> VALU read
+    SAMP_STAMP(1);
+    // ---- 2. the loss of row j.  A lane holds cells c = 16 (wave + 4 i) + 4 q + r of its row.
+    const int pos = a.row_offset + row;
+    const float scale = a.inv_Bglobal / a.pop[row];
+    bool valid[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (wave + NW * i) + 4 * q + r;
+            valid[i][r] = c < C;
+            if (valid[i][r] && a.bc) lg[i][r] += a.bc[c];
+        }
+    // sums / maxima over a row: its four lanes by shuffles, the four waves through LDS (slot k of `red`)
+    auto row_sum = [&](float v, int k) -> float {
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (q == 0) red[(k * NW + wave) * 16 + j] = v;
+        __syncthreads();
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(k * NW + w) * 16 + j];
+        return t;
+    };
+    auto row_max = [&](float v, int k) -> float {
+        v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
+        if (q == 0) red[(k * NW + wave) * 16 + j] = v;
+        __syncthreads();
+        float t = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t = fmaxf(t, red[(k * NW + w) * 16 + j]);
+        return t;
+    };
+    float ap = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (valid[i][r] && 16 * (wave + NW * i) + 4 * q + r == pos) ap = lg[i][r];
+    const float apos = row_sum(ap, 0);
+    float L;
+    const int loss = a.loss, Bg = a.Bg;
+    if (loss == SBR_LOSS_BLACKOUT || loss == SBR_LOSS_SCCE) {           // rnn_sampling.py:68-72; SCCE: rnn_cluster.py:158-162
+        const bool blackout = loss == SBR_LOSS_BLACKOUT;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (valid[i][r]) mx = fmaxf(mx, lg[i][r]);
+        mx = row_max(mx, 1);
+        float se = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (valid[i][r]) se += expf(lg[i][r] - mx);
+        se = row_sum(se, 2);
+        __syncthreads();                                               // (slot 0 is written again below)
+        const float inv = 1.0f / se;
+        const float ppos = expf(apos - mx) * inv;
+        float dot = 0.0f, lneg = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * (wave + NW * i) + 4 * q + r;
+                if (valid[i][r] && c >= Bg && blackout) { const float p = expf(lg[i][r] - mx) * inv; dot += p / (1.0f - p); lneg -= logf(1.0f - p); }
+            }
+        dot = row_sum(dot, 0) - 1.0f;                                  // positive: (-1 / p_pos) * p_pos
+        lneg = row_sum(lneg, 1);
+        L = -logf(ppos) + lneg;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * (wave + NW * i) + 4 * q + r;
+                float d = 0.0f;
+                if (valid[i][r]) {
+                    const float p = expf(lg[i][r] - mx) * inv;
+                    float dldp = 0.0f;
+                    if (c >= Bg && blackout) dldp = 1.0f / (1.0f - p);
+                    if (c == pos) dldp += -1.0f / p;
+                    d = p * (dldp - dot) * scale;
+                }
+                lg[i][r] = d;
+            }
+    } else {
+        float lsum = 0.0f, dpos = 0.0f;
+        const float fS = (float)a.S;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * (wave + NW * i) + 4 * q + r;
+                float da = 0.0f;
+                if (valid[i][r] && c != pos && c >= Bg) {
+                    const float v = lg[i][r], diff = v - apos;
+                    if (loss == SBR_LOSS_BPR) {                        // :80-84  -log(sigmoid(-diff)) = softplus(diff)
+                        lsum += fmaxf(diff, 0.0f) + log1pf(expf(-fabsf(diff)));
+                        const float dd = (1.0f / (1.0f + expf(-diff))) / fS;
+                        da = dd; dpos += dd;
+                    } else if (loss == SBR_LOSS_BPRELU) {              // rnn_cluster.py:173-175
+                        const float yv = diff + 0.5f;
+                        lsum += yv > 0.0f ? yv : 0.01f * yv;
+                        const float dd = (yv > 0.0f ? 1.0f : 0.01f) / fS;
+                        da = dd; dpos += dd;
+                    } else if (loss == SBR_LOSS_LIN) {                 // rnn_cluster.py:164-167
+                        lsum += v;
+                        da = 1.0f;
+                    } else {                                           // TOP1 :86-91
+                        const float s1 = 1.0f / (1.0f + expf(-diff)), s2 = 1.0f / (1.0f + expf(-v * v));
+                        lsum += s1 + s2;
+                        const float d1 = s1 * (1.0f - s1) / fS;
+                        da = d1 + s2 * (1.0f - s2) * 2.0f * v / fS; dpos += d1;
+                    }
+                }
+                lg[i][r] = da * scale;
+            }
+        lsum = row_sum(lsum, 1);
+        dpos = row_sum(dpos, 2);
+        L = lsum / fS;
+        if (loss == SBR_LOSS_LIN) { L = lsum - apos; dpos = 1.0f; }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (valid[i][r] && 16 * (wave + NW * i) + 4 * q + r == pos) lg[i][r] = -dpos * scale;
+    }
+    SAMP_STAMP(2);
+    if (wave == 0 && q == 0) a.rowcost[row] = L * scale;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int c0 = 16 * (wave + NW * i) + 4 * q;
+        if (c0 + 3 < C && (C & 3) == 0) *(f32x4*)(a.act + (size_t)row * C + c0) = lg[i];
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c0 + r < C) a.act[(size_t)row * C + c0 + r] = lg[i][r];
+        }
+    }
+    SAMP_STAMP(3);
+    // ---- 3. dh: cells are the reduction index; lane (j, q) multiplies its own dact (cell 16 t + 4 q + e of row j)
+    f32x4 da[KG];
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt) da[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = wave + NW * i;
+        if (t < ntiles) {
+            f32x4 w4[4][KG / 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int item = min(16 * t + 4 * q + e, C - 1);       // (a cell past C multiplies a zero gradient)
+#pragma unroll
+                for (int m = 0; m < KG / 4; ++m) w4[e][m] = *(const f32x4*)(a.Wc + (size_t)item * HP + 64 * m + 4 * j);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < KG / 4; ++m)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        da[4 * m + sidx] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[e][m][sidx], lg[i][e], da[4 * m + sidx], 0, 0, 0);
+        }
+    }
+    asm volatile("s_nop 15");
+    SAMP_STAMP(4);
+    // instruction 4 m + s left k = 64 m + 4 (4 q + r) + s of row j in element r
+    float* pw = part + (size_t)(wave * 16 + j) * HP;
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[64 * (kt >> 2) + 16 * q + 4 * r + (kt & 3)] = da[kt][r];
+    __syncthreads();
+    SAMP_STAMP(5);
+    float* out = a.dh + (size_t)blockIdx.x * 16 * HP;
+    for (int i = tid; i < 16 * HP / 4; i += 64 * NW) {
+        f32x4 t = *(const f32x4*)(part + 4 * i);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += *(const f32x4*)(part + (size_t)w * 16 * HP + 4 * i);
+        *(f32x4*)(out + 4 * i) = t;
+    }
+    SAMP_STAMP(6);
+#undef SAMP_STAMP
+}
+
+// false: shape not served, nothing launched (the caller keeps the four launches)
+bool launch_head_sampled(hipStream_t s, const float* h, const float* Wc, const float* bc, const float* pop, float* act, float* rowcost,
+                         float* dh, int rows, int C, int Hp, int Bg, int S, int row_offset, int loss, int Bglobal, hipError_t* err,
+                         unsigned long long* prof) {
+    if (!(Hp == 128 || Hp == 256 || Hp == 512) || rows < 16 || (rows & 15) || C < 1 || C > 320) return false;
+    if (loss == SBR_LOSS_CCE || SBR_LOSS_IS_MARGIN(loss)) return false;
+    SampArgs a{h, Wc, bc, pop, act, rowcost, dh, C, Bg, S, row_offset, loss, 1.0f / (float)Bglobal, prof};
+    const int nw = Hp == 512 ? 4 : 8;
+    const size_t lds = ((size_t)nw * 16 * Hp + 3 * nw * 16) * sizeof(float);
+    const int grid = rows / 16;
+    if (Hp == 512) { SBR_DYN_LDS((head_sampled_kernel<512, 4>), lds); head_sampled_kernel<512, 4><<<grid, 256, lds, s>>>(a); }
+    else if (Hp == 256) { SBR_DYN_LDS((head_sampled_kernel<256, 8>), lds); head_sampled_kernel<256, 8><<<grid, 512, lds, s>>>(a); }
+    else { SBR_DYN_LDS((head_sampled_kernel<128, 8>), lds); head_sampled_kernel<128, 8><<<grid, 512, lds, s>>>(a); }
+    *err = hipGetLastError();
+    return true;
+}

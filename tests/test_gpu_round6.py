@@ -116,3 +116,32 @@ def test_batches_built_beside_the_step_in_flight_are_the_batches_the_steps_read(
     assert np.allclose(r0, r1, rtol=1e-4, atol=1e-6)
     assert all(np.allclose(a, b, rtol=1e-4, atol=1e-6) for a, b in zip(p0, p1))
     assert np.ptp(c0) > 1e-3                   # (the steps did something)
+
+
+@pytest.mark.parametrize("loss", ["Blackout", "BPR", "TOP1"])
+@pytest.mark.parametrize("H", [128, 256])
+def test_one_launch_sampled_head_against_the_oracle_and_the_four_launches(loss, H, monkeypatch):
+    """head_sampled_kernel (activations, sampled loss, its gradient and dh in one launch: full 16-row blocks, Hp in {128, 256, 512},
+    at most 320 cells) against the float64 oracle through the usual step comparison, and against the same engine on the four launches
+    (SBR_HEAD_FUSE=0): costs and every gradient agree to f32 rounding -- both are f32-class, the one launch on exact-f32 products."""
+    from sbr_amd.engine import RNNEngine
+    r = PU.compare_step("LSTM", [H], loss, N=900, B=32, T=9, S=24, scale=0.08)
+    assert r["cost"] <= 2e-6 and r["grad_worst"] <= 5e-6, r
+    params = O.init_params("LSTM", [H], 900, np.random.default_rng(4), dtype=np.float32)
+    batch = PU.make_batch(np.random.default_rng(5), 32, 9, 900)
+    samples = np.random.default_rng(6).integers(1, 900, size=24).astype(np.int32)
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SBR_HEAD_FUSE", fuse)
+        eng = RNNEngine(cell="LSTM", layers=[H], n_items=900, max_length=9, batch_size=32, loss=loss, n_samples=24)
+        try:
+            eng.set_all_param_values(params)
+            eng.set_batch(batch["X"], batch["mask"], batch["target"], samples, batch["pop"])
+            c = eng.forward_backward()
+            out.append((c, [g.copy() for g in eng.get_all_grad_values()]))
+        finally:
+            eng.close()
+    (c1, g1), (c0, g0) = out
+    assert abs(c1 - c0) <= 2e-6 * abs(c0), (c1, c0)
+    for a, b in zip(g1, g0):
+        assert np.abs(a - b).max() <= 5e-6 * max(1e-30, np.abs(b).max()), (np.abs(a - b).max(), np.abs(b).max())
