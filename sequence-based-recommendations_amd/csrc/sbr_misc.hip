@@ -389,6 +389,52 @@ __global__ void scat_fill_kernel(const int* __restrict__ X, const int* __restric
     }
 }
 
+// The counting sort of catalogues beyond the LDS histogram, round 6: one global atomic per DISTINCT id of a workgroup's 1 024 entries
+// instead of one per entry.  The two kernels above send every entry's atomic to cnt[id] / cur[id]; atomics on one address serialise at
+// its L2 channel, and a step's hottest id holds thousands of its 51 200 entries (C5's batch: 3 612) -- ~50 us per kernel, all of it the
+// hot counters, beside the head whose loads wait behind them (profiles/round6_variants.txt, calls s3 / a2).  Here a workgroup first
+// groups its entries in an LDS hash table (id -> count; LDS atomics), then adds each distinct id's count once; the fill takes a base slot
+// per distinct id the same way and every entry adds its rank inside the workgroup.
+#define SCAT_AGG_SLOTS 2048
+__device__ __forceinline__ int scat_agg_insert(int* __restrict__ hkey, int* __restrict__ hcnt, int id, int& rank) {
+    unsigned h = ((unsigned)id * 2654435761u) >> 21;                  // 11 bits
+    for (;;) {
+        const int prev = atomicCAS(&hkey[h], -1, id);
+        if (prev == -1 || prev == id) { rank = atomicAdd(&hcnt[h], 1); return (int)h; }
+        h = (h + 1) & (SCAT_AGG_SLOTS - 1);
+    }
+}
+__global__ void __launch_bounds__(1024) scat_count_agg_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
+                                                              int* __restrict__ cnt) {
+    __shared__ int hkey[SCAT_AGG_SLOTS], hcnt[SCAT_AGG_SLOTS];
+    for (int k = threadIdx.x; k < SCAT_AGG_SLOTS; k += 1024) { hkey[k] = -1; hcnt[k] = 0; }
+    __syncthreads();
+    const int total = T * Bp * F, i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < total) {
+        const int f = i % F, pos = i / F, b = pos % Bp, t = pos / Bp;
+        if (t < len[b]) { int rank; (void)scat_agg_insert(hkey, hcnt, X[((size_t)b * T + t) * F + f], rank); }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SCAT_AGG_SLOTS; k += 1024) if (hkey[k] >= 0) atomicAdd(&cnt[hkey[k]], hcnt[k]);
+}
+__global__ void __launch_bounds__(1024) scat_fill_agg_kernel(const int* __restrict__ X, const int* __restrict__ len, int T, int Bp, int F,
+                                                             int* __restrict__ cur, int* __restrict__ sid, int* __restrict__ spos, int concat) {
+    __shared__ int hkey[SCAT_AGG_SLOTS], hcnt[SCAT_AGG_SLOTS], hbase[SCAT_AGG_SLOTS];
+    for (int k = threadIdx.x; k < SCAT_AGG_SLOTS; k += 1024) { hkey[k] = -1; hcnt[k] = 0; }
+    __syncthreads();
+    const int total = T * Bp * F, i = blockIdx.x * 1024 + threadIdx.x;
+    int id = -1, pos = 0, rank = 0, h = 0;
+    if (i < total) {
+        const int f = i % F; pos = i / F;
+        const int b = pos % Bp, t = pos / Bp;
+        if (t < len[b]) { id = X[((size_t)b * T + t) * F + f]; h = scat_agg_insert(hkey, hcnt, id, rank); }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SCAT_AGG_SLOTS; k += 1024) if (hkey[k] >= 0) hbase[k] = atomicAdd(&cur[hkey[k]], hcnt[k]);
+    __syncthreads();
+    if (id >= 0) { const int slot = hbase[h] + rank; sid[slot] = id; spos[slot] = concat ? i : pos; }
+}
+
 int sbr_scatter_lds_ids() { return SCAT_LDS_IDS; }
 
 hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int T, int Bp, int F, int n_ids, int* cnt,
@@ -419,7 +465,8 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
         scat_fill_lds_kernel<<<grid, SCAT_BLOCK, lds, s>>>(X, len, T, Bp, F, n_ids, per_block, cur, sid, spos, concat, tc, ipc);
     } else {
         const int grid = min(1024, (total + 255) / 256);
-        scat_count_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cnt);
+        const int agrid = (total + 1023) / 1024;
+        scat_count_agg_kernel<<<agrid, 1024, 0, s>>>(X, len, T, Bp, F, cnt);
         const int nb = (n_ids + SCAN_BLK - 1) / SCAN_BLK;
         if (nb <= 1) scat_scan_kernel<false><<<1, 1024, 0, s>>>(cnt, n_ids, offs, cur);
         else {      // block totals in cur[0 .. nb) (rewritten by the add), their prefixes in cnt[0 .. nb) (not read any more)
@@ -427,7 +474,8 @@ hipError_t launch_scatter_sort(hipStream_t s, const int* X, const int* len, int 
             scat_scan_totals_kernel<<<1, 1024, 0, s>>>(cur, nb, cnt, offs + n_ids);
             scat_scan_add_kernel<<<nb, 1024, 0, s>>>(cnt, n_ids, offs, cur);
         }
-        scat_fill_kernel<<<grid, 256, 0, s>>>(X, len, T, Bp, F, cur, sid, spos, concat);
+        (void)grid;
+        scat_fill_agg_kernel<<<agrid, 1024, 0, s>>>(X, len, T, Bp, F, cur, sid, spos, concat);
     }
     return hipGetLastError();
 }
