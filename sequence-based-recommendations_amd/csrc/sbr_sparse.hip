@@ -146,7 +146,13 @@ __global__ void __launch_bounds__(256) sp_rows_kernel(SbrSparseRows r, SpUpd u, 
         int id = -1;
         if (lane < SP_CPW && i < total) {
             if (SRC == 0) { const int b = i / (T * F), t = (i / F) % T; if (t < len[b]) id = X[i]; }
-            else if (SRC == 1) id = list[i];
+            else if (SRC == 1) {
+                id = list[i];
+                // (an entry that repeats its predecessor is that predecessor's business: the step's list is the SORTED entries of the
+                // batch, a hot id fills thousands of consecutive places of it, and every one of them used to send its own atomicMax to
+                // the same last[id] -- round 6, call b2)
+                if (i > 0 && list[i - 1] == id) id = -1;
+            }
             else id = i;
         }
         int old = -1;
