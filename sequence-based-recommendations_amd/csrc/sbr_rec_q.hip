@@ -115,7 +115,6 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
 
     // biases ride in as the C operand of a gate's first MFMA, except for GRU's candidate gate (its recurrent part is
     // multiplied by r before the input part with its bias is added, sparse_lstm.py:786-792)
-    float x[G];
     f32x4 biasv[G];
     float bias_c = 0.f;
 #pragma unroll
@@ -126,24 +125,29 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
         biasv[g] = f32x4{b, b, b, b};
     }
     auto load_id = [&](int t) -> int { return FUSE ? ldi((const char*)a.gX + (size_t)min(t, T - 1) * 4, bo_id) : 0; };
-    auto load_x = [&](int t, int id) {
+    auto load_x = [&](float (&xd)[G], int t, int id) {
         if (FUSE) {
             const unsigned bo = (unsigned)id * (unsigned)(GHP * 4) + (unsigned)u * 4u;   // < 2^32: checked by the launcher
 #pragma unroll
-            for (int g = 0; g < G; ++g) x[g] = ldf(a.gWin, bo, g * HQ * 4);
+            for (int g = 0; g < G; ++g) xd[g] = ldf(a.gWin, bo, g * HQ * 4);
         } else {
             const char* xt_t = (const char*)a.xt + (size_t)min(t, T - 1) * st_x;
 #pragma unroll
-            for (int g = 0; g < G; ++g) x[g] = ldf(xt_t, bo_x, g * HQ * 4);
+            for (int g = 0; g < G; ++g) xd[g] = ldf(xt_t, bo_x, g * HQ * 4);
         }
     };
-    load_x(0, load_id(0));
-    int id_next = load_id(1);
+    // Two register sets for a step's input row, used by the even and the odd steps in turn: the set a step has consumed is refilled for
+    // the step TWO ahead, so its loads have 1.6 steps to land (round 6; one set, refilled at the end of step t for step t + 1, gave them
+    // the 0.6 of a step between the request and the gate math -- ~0.25 us against an L2 round trip of ~0.5: exposed in every step)
+    float xa[G], xb[G];
+    load_x(xa, 0, load_id(0));
+    load_x(xb, 1, load_id(1));
+    int ida = load_id(2), idb = load_id(3);
     __syncthreads();
 
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
     size_t off_t = 0;                                              // t * st_h
-    for (int t = 0; t < tmax; ++t) {
+    auto fstep = [&](int t, float (&x)[G], int& idn) {
         const char* hb = hbuf + (t & 1) * BUFB + lds_rd;
         OPV hp[KB][NPL];
         int fl;
@@ -241,7 +245,12 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
         st_s((const char*)a.hs + off_t + st_h, bo_h, h);
         if (CELL == CELL_LSTM) st_s((const char*)a.cs + off_t + st_h, bo_h, cst);
         off_t += st_h;
-        load_x(t + 1, id_next); id_next = load_id(t + 2);
+        load_x(x, t + 2, idn); idn = load_id(t + 4);
+    };
+    {
+        int t = 0;
+        for (; t + 1 < tmax; t += 2) { fstep(t, xa, ida); fstep(t + 1, xb, idb); }
+        if (t < tmax) fstep(t, xa, ida);
     }
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
@@ -318,15 +327,21 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) sdb[g] = 0.f;
 
-    float sv[4] = {0.f, 0.f, 0.f, 0.f}, hprev = 0.f, cprev = 0.f, cnew = 0.f, hnew = 0.f, dhe = 0.f;
-    auto load_saved = [&](size_t o) {                            // activations of the step at byte offset o = t * st_h
-        hprev = ldf((const char*)a.hs + o, bo_h);
+    // what a step reads of the forward pass; two sets, used by alternating steps and refilled two steps ahead (see rec_fwd_x6q)
+    struct Saved { float sv[4], hprev, cprev, dhe; };
+    Saved SA, SB;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { SA.sv[k] = 0.f; SB.sv[k] = 0.f; }
+    SA.hprev = SA.cprev = SA.dhe = SB.hprev = SB.cprev = SB.dhe = 0.f;
+    float cnew = 0.f, hnew = 0.f;
+    auto load_saved = [&](Saved& S, size_t o) {                  // activations of the step at byte offset o = t * st_h
+        S.hprev = ldf((const char*)a.hs + o, bo_h);
         if (CELL != CELL_VANILLA) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sv[k] = ldf((const char*)a.g[k] + o, bo_g);
+            for (int k = 0; k < 4; ++k) S.sv[k] = ldf((const char*)a.g[k] + o, bo_g);
         }
-        if (CELL == CELL_LSTM) cprev = ldf((const char*)a.cs + o, bo_h);
-        if (EXT) dhe = ldf((const char*)a.dh_ext + o, bo_h);
+        if (CELL == CELL_LSTM) S.cprev = ldf((const char*)a.cs + o, bo_h);
+        if (EXT) S.dhe = ldf((const char*)a.dh_ext + o, bo_h);
     };
     __syncthreads();
 
@@ -338,15 +353,17 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         if (CELL == CELL_GRU) a.dhi[((size_t)t * Bp + row) * HQ + u] = 0.f;
     }
     if (t_live > a.t_lo) {
-        load_saved((size_t)(t_live - 1) * st_h);
+        load_saved(SA, (size_t)(t_live - 1) * st_h);
+        load_saved(SB, (size_t)max(t_live - 2, a.t_lo) * st_h);
         const size_t o1 = (size_t)t_live * Bp * HQ + (size_t)row * HQ + u;
         if (CELL == CELL_LSTM) cnew = a.cs[o1];
         if (CELL == CELL_VANILLA) hnew = a.hs[o1];
     }
     size_t off_h = (size_t)(t_live - 1) * st_h, off_x = (size_t)(t_live - 1) * st_x;   // of step t
     int n = 0;                                                    // steps done
-    for (int t = t_live - 1; t >= a.t_lo; --t, ++n) {
-        if (EXT) dh += dhe;
+    auto bstep = [&](int t, Saved& S) {
+        float (&sv)[4] = S.sv; float& hprev = S.hprev; float& cprev = S.cprev;
+        if (EXT) dh += S.dhe;
         char* lds = dbuf + (n & 1) * BUFB;
         float dxi[G], dhi[G], dp[3] = {0.f, 0.f, 0.f};
         cell_backward<CELL, true>(t < mylen, clip, dh, dc, sv, hprev, cprev, cnew, hnew, pi, pf, po, dxi, dhi, dp, a.relu != 0);
@@ -381,7 +398,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
             if (CELL == CELL_GRU) st_si<0>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_saved(t > a.t_lo ? off_h - st_h : off_h);            // step t-1: unconditional, clamped
+        load_saved(S, t - 2 >= a.t_lo ? off_h - 2 * st_h : (size_t)a.t_lo * st_h);      // step t - 2 into the set this step has consumed: unconditional, clamped
         __builtin_amdgcn_sched_barrier(0);
         off_h -= st_h; off_x -= st_x;
         const char* db = lds + lds_rd;
@@ -434,6 +451,11 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         __builtin_amdgcn_sched_barrier(0);                        // (MFMA D -> VALU read hazard: padded by hipcc, same basic block)
         dh += acc[0][0] + acc[1][0] + acc[2][0];
         }
+    };
+    {
+        int t = t_live - 1;
+        for (; t - 1 >= a.t_lo; t -= 2) { bstep(t, SA); ++n; bstep(t - 1, SB); ++n; }
+        if (t >= a.t_lo) { bstep(t, SA); ++n; }
     }
 
     if (!last) {                                                  // hand dh / dc to the next chunk launch
