@@ -139,10 +139,11 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
     // Two register sets for a step's input row, used by the even and the odd steps in turn: the set a step has consumed is refilled for
     // the step TWO ahead, so its loads have 1.6 steps to land (round 6; one set, refilled at the end of step t for step t + 1, gave them
     // the 0.6 of a step between the request and the gate math -- ~0.25 us against an L2 round trip of ~0.5: exposed in every step)
-    float xa[G], xb[G];
+    float xa[G], xb[G], xc[G];
     load_x(xa, 0, load_id(0));
     load_x(xb, 1, load_id(1));
-    int ida = load_id(2), idb = load_id(3);
+    load_x(xc, 2, load_id(2));
+    int ida = load_id(3), idb = load_id(4), idc = load_id(5);
     __syncthreads();
 
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -245,12 +246,13 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
         st_s((const char*)a.hs + off_t + st_h, bo_h, h);
         if (CELL == CELL_LSTM) st_s((const char*)a.cs + off_t + st_h, bo_h, cst);
         off_t += st_h;
-        load_x(x, t + 2, idn); idn = load_id(t + 4);
+        load_x(x, t + 3, idn); idn = load_id(t + 6);
     };
     {
         int t = 0;
-        for (; t + 1 < tmax; t += 2) { fstep(t, xa, ida); fstep(t + 1, xb, idb); }
+        for (; t + 2 < tmax; t += 3) { fstep(t, xa, ida); fstep(t + 1, xb, idb); fstep(t + 2, xc, idc); }
         if (t < tmax) fstep(t, xa, ida);
+        if (t + 1 < tmax) fstep(t + 1, xb, idb);
     }
     for (int t = tmax; t < T; ++t) {                              // past the tile's longest row: the state is carried
         stf((char*)a.hs + off_t + st_h, bo_h, h);
@@ -329,10 +331,10 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
 
     // what a step reads of the forward pass; two sets, used by alternating steps and refilled two steps ahead (see rec_fwd_x6q)
     struct Saved { float sv[4], hprev, cprev, dhe; };
-    Saved SA, SB;
+    Saved SA, SB, SC;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { SA.sv[k] = 0.f; SB.sv[k] = 0.f; }
-    SA.hprev = SA.cprev = SA.dhe = SB.hprev = SB.cprev = SB.dhe = 0.f;
+    for (int k = 0; k < 4; ++k) { SA.sv[k] = 0.f; SB.sv[k] = 0.f; SC.sv[k] = 0.f; }
+    SA.hprev = SA.cprev = SA.dhe = SB.hprev = SB.cprev = SB.dhe = SC.hprev = SC.cprev = SC.dhe = 0.f;
     float cnew = 0.f, hnew = 0.f;
     auto load_saved = [&](Saved& S, size_t o) {                  // activations of the step at byte offset o = t * st_h
         S.hprev = ldf((const char*)a.hs + o, bo_h);
@@ -355,6 +357,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
     if (t_live > a.t_lo) {
         load_saved(SA, (size_t)(t_live - 1) * st_h);
         load_saved(SB, (size_t)max(t_live - 2, a.t_lo) * st_h);
+        load_saved(SC, (size_t)max(t_live - 3, a.t_lo) * st_h);
         const size_t o1 = (size_t)t_live * Bp * HQ + (size_t)row * HQ + u;
         if (CELL == CELL_LSTM) cnew = a.cs[o1];
         if (CELL == CELL_VANILLA) hnew = a.hs[o1];
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
             if (CELL == CELL_GRU) st_si<0>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_saved(S, t - 2 >= a.t_lo ? off_h - 2 * st_h : (size_t)a.t_lo * st_h);      // step t - 2 into the set this step has consumed: unconditional, clamped
+        load_saved(S, t - 3 >= a.t_lo ? off_h - 3 * st_h : (size_t)a.t_lo * st_h);      // step t - 3 into the set this step has consumed: unconditional, clamped
         __builtin_amdgcn_sched_barrier(0);
         off_h -= st_h; off_x -= st_x;
         const char* db = lds + lds_rd;
@@ -454,8 +457,9 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
     };
     {
         int t = t_live - 1;
-        for (; t - 1 >= a.t_lo; t -= 2) { bstep(t, SA); ++n; bstep(t - 1, SB); ++n; }
+        for (; t - 2 >= a.t_lo; t -= 3) { bstep(t, SA); ++n; bstep(t - 1, SB); ++n; bstep(t - 2, SC); ++n; }
         if (t >= a.t_lo) { bstep(t, SA); ++n; }
+        if (t - 1 >= a.t_lo) { bstep(t - 1, SB); ++n; }
     }
 
     if (!last) {                                                  // hand dh / dc to the next chunk launch
