@@ -136,9 +136,10 @@ __global__ void __launch_bounds__(HQ * 4) rec_fwd_x6q(RecArgs a) {
             for (int g = 0; g < G; ++g) xd[g] = ldf(xt_t, bo_x, g * HQ * 4);
         }
     };
-    // Two register sets for a step's input row, used by the even and the odd steps in turn: the set a step has consumed is refilled for
-    // the step TWO ahead, so its loads have 1.6 steps to land (round 6; one set, refilled at the end of step t for step t + 1, gave them
-    // the 0.6 of a step between the request and the gate math -- ~0.25 us against an L2 round trip of ~0.5: exposed in every step)
+    // THREE register sets for a step's input row, used by the steps in turn: the set a step has consumed is refilled for the step three
+    // ahead, so its loads have 2.6 steps to land (round 6; one set, refilled at the end of step t for step t + 1, gave them the 0.6 of a
+    // step between the request and the gate math -- ~0.25 us against an L2 round trip of ~0.5: exposed in every step.  C1: rec_fwd_x6q
+    // 97.6 us with one set, 87.5 with two, 81.5 with three, 82.9 with four; the backward chain below: 120.8 / 103.1 / 99.3 / 94.9)
     float xa[G], xb[G], xc[G];
     load_x(xa, 0, load_id(0));
     load_x(xb, 1, load_id(1));
@@ -329,12 +330,12 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) sdb[g] = 0.f;
 
-    // what a step reads of the forward pass; two sets, used by alternating steps and refilled two steps ahead (see rec_fwd_x6q)
+    // what a step reads of the forward pass; four sets, used by the steps in turn and refilled four steps ahead (see rec_fwd_x6q)
     struct Saved { float sv[4], hprev, cprev, dhe; };
-    Saved SA, SB, SC;
+    Saved SA, SB, SC, SD;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { SA.sv[k] = 0.f; SB.sv[k] = 0.f; SC.sv[k] = 0.f; }
-    SA.hprev = SA.cprev = SA.dhe = SB.hprev = SB.cprev = SB.dhe = SC.hprev = SC.cprev = SC.dhe = 0.f;
+    for (int k = 0; k < 4; ++k) { SA.sv[k] = 0.f; SB.sv[k] = 0.f; SC.sv[k] = 0.f; SD.sv[k] = 0.f; }
+    SA.hprev = SA.cprev = SA.dhe = SB.hprev = SB.cprev = SB.dhe = SC.hprev = SC.cprev = SC.dhe = SD.hprev = SD.cprev = SD.dhe = 0.f;
     float cnew = 0.f, hnew = 0.f;
     auto load_saved = [&](Saved& S, size_t o) {                  // activations of the step at byte offset o = t * st_h
         S.hprev = ldf((const char*)a.hs + o, bo_h);
@@ -358,6 +359,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
         load_saved(SA, (size_t)(t_live - 1) * st_h);
         load_saved(SB, (size_t)max(t_live - 2, a.t_lo) * st_h);
         load_saved(SC, (size_t)max(t_live - 3, a.t_lo) * st_h);
+        load_saved(SD, (size_t)max(t_live - 4, a.t_lo) * st_h);
         const size_t o1 = (size_t)t_live * Bp * HQ + (size_t)row * HQ + u;
         if (CELL == CELL_LSTM) cnew = a.cs[o1];
         if (CELL == CELL_VANILLA) hnew = a.hs[o1];
@@ -401,7 +403,7 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
             if (CELL == CELL_GRU) st_si<0>((const char*)a.dhi + off_h, bo_h, dhi[G - 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_saved(S, t - 3 >= a.t_lo ? off_h - 3 * st_h : (size_t)a.t_lo * st_h);      // step t - 3 into the set this step has consumed: unconditional, clamped
+        load_saved(S, t - 4 >= a.t_lo ? off_h - 4 * st_h : (size_t)a.t_lo * st_h);      // step t - 4 into the set this step has consumed: unconditional, clamped
         __builtin_amdgcn_sched_barrier(0);
         off_h -= st_h; off_x -= st_x;
         const char* db = lds + lds_rd;
@@ -457,9 +459,10 @@ __global__ void __launch_bounds__(HQ * 4) rec_bwd_x6q(RecArgs a) {
     };
     {
         int t = t_live - 1;
-        for (; t - 2 >= a.t_lo; t -= 3) { bstep(t, SA); ++n; bstep(t - 1, SB); ++n; bstep(t - 2, SC); ++n; }
+        for (; t - 3 >= a.t_lo; t -= 4) { bstep(t, SA); ++n; bstep(t - 1, SB); ++n; bstep(t - 2, SC); ++n; bstep(t - 3, SD); ++n; }
         if (t >= a.t_lo) { bstep(t, SA); ++n; }
         if (t - 1 >= a.t_lo) { bstep(t - 1, SB); ++n; }
+        if (t - 2 >= a.t_lo) { bstep(t - 2, SC); ++n; }
     }
 
     if (!last) {                                                  // hand dh / dc to the next chunk launch
